@@ -1,0 +1,389 @@
+"""ctypes binding of libgeograster (include/geograster.h) and the device backend the mesh class drives.
+
+The library is the product: there is no CPU fallback.  Importing this module is cheap; the first use of
+`HipRaster` loads `csrc/libgeograster.so` and raises `RuntimeError` when the shared object or a GPU is missing.
+PyTorch-ROCm supplies device memory (tensors), streams and `torch.distributed`; no torch type crosses the C ABI,
+only `tensor.data_ptr()` and the raw `hipStream_t` of the current torch stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+from typing import Optional, Tuple
+
+import numpy as np
+
+_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libgeograster.so"
+_lib = None
+
+GR_OK = 0
+GR_EOVERFLOW = -6
+GR_FLAG_NEG1_IS_LAST_FACE = 1
+GR_CAM_FLOATS = 16
+
+# every symbol include/geograster.h declares (tests check that the library exports each of them)
+EXPORTED_SYMBOLS = (
+    "gr_version",
+    "gr_ctx_create",
+    "gr_ctx_destroy",
+    "gr_last_error",
+    "gr_set_profiling",
+    "gr_get_stage_times",
+    "gr_mesh_upload",
+    "gr_raster_face_ids",
+    "gr_raster_status",
+    "gr_gather_texture_f64",
+    "gr_project_labels_u8",
+    "gr_project_values_f64",
+    "gr_project_view_f64",
+    "gr_raster_project_labels_u8",
+    "gr_finalize_votes",
+    "gr_finalize_sums_f64",
+    "gr_argmax_nonzero_f64",
+)
+
+
+class StageTimes(ctypes.Structure):
+    _fields_ = [
+        ("setup_ms", ctypes.c_float),
+        ("scan_ms", ctypes.c_float),
+        ("fill_ms", ctypes.c_float),
+        ("raster_ms", ctypes.c_float),
+        ("project_ms", ctypes.c_float),
+        ("vote_ms", ctypes.c_float),
+        ("gather_ms", ctypes.c_float),
+        ("raster_launches", ctypes.c_int32),
+        ("views", ctypes.c_int32),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class RasterStats(ctypes.Structure):
+    _fields_ = [
+        ("records", ctypes.c_int64),
+        ("entries", ctypes.c_int64),
+        ("max_entries", ctypes.c_int64),
+        ("entry_cap", ctypes.c_int64),
+        ("overflow", ctypes.c_int32),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+def library_path() -> Path:
+    return _LIB_PATH
+
+
+def load_library() -> ctypes.CDLL:
+    """Load libgeograster.so (built in-tree by `__graft_entry__.build()` / `geograypher_amd.build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.is_file():
+        raise RuntimeError(
+            f"HIP extension missing: {_LIB_PATH} not found. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "geograypher_amd has no CPU fallback for the projection path."
+        )
+    lib = ctypes.CDLL(str(_LIB_PATH))
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    lib.gr_version.restype = i32
+    lib.gr_version.argtypes = []
+    lib.gr_ctx_create.restype = i32
+    lib.gr_ctx_create.argtypes = [i32, ctypes.POINTER(vp)]
+    lib.gr_ctx_destroy.restype = i32
+    lib.gr_ctx_destroy.argtypes = [vp]
+    lib.gr_last_error.restype = ctypes.c_char_p
+    lib.gr_last_error.argtypes = [vp]
+    lib.gr_set_profiling.restype = i32
+    lib.gr_set_profiling.argtypes = [vp, i32]
+    lib.gr_get_stage_times.restype = i32
+    lib.gr_get_stage_times.argtypes = [vp, ctypes.POINTER(StageTimes)]
+    lib.gr_mesh_upload.restype = i32
+    lib.gr_mesh_upload.argtypes = [vp, vp, vp, i64, i64, vp]
+    lib.gr_raster_face_ids.restype = i32
+    lib.gr_raster_face_ids.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.gr_raster_status.restype = i32
+    lib.gr_raster_status.argtypes = [vp, ctypes.POINTER(RasterStats)]
+    lib.gr_gather_texture_f64.restype = i32
+    lib.gr_gather_texture_f64.argtypes = [vp, vp, i64, vp, i64, i32, vp, vp]
+    lib.gr_project_labels_u8.restype = i32
+    lib.gr_project_labels_u8.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
+    lib.gr_project_values_f64.restype = i32
+    lib.gr_project_values_f64.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
+    lib.gr_project_view_f64.restype = i32
+    lib.gr_project_view_f64.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, vp]
+    lib.gr_raster_project_labels_u8.restype = i32
+    lib.gr_raster_project_labels_u8.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp]
+    lib.gr_finalize_votes.restype = i32
+    lib.gr_finalize_votes.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp]
+    lib.gr_finalize_sums_f64.restype = i32
+    lib.gr_finalize_sums_f64.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
+    lib.gr_argmax_nonzero_f64.restype = i32
+    lib.gr_argmax_nonzero_f64.argtypes = [vp, vp, i64, i32, vp, vp]
+    _lib = lib
+    return lib
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+class HipRaster:
+    """Device backend: one libgeograster context on one GPU, operating on torch tensors.
+
+    All methods take and return torch tensors that live on `self.device`; the Python mesh class converts to the
+    numpy arrays the reference API promises only at its own boundary.
+    """
+
+    def __init__(self, device: Optional[int] = None):
+        torch = _torch()
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                "geograypher_amd: no ROCm GPU visible (torch.cuda.is_available() is False). "
+                "The projection path runs on MI355X only; there is no CPU fallback."
+            )
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        handle = ctypes.c_void_p()
+        rc = self.lib.gr_ctx_create(self.device_index, ctypes.byref(handle))
+        if rc != GR_OK:
+            raise RuntimeError(f"gr_ctx_create(device={device}) failed with code {rc}")
+        self._ctx = handle
+        self._verts = None
+        self._faces = None
+        self.n_faces = 0
+        self.n_verts = 0
+
+    # -- plumbing ------------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self.lib.gr_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        torch = _torch()
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, rc: int, what: str):
+        if rc == GR_OK:
+            return
+        msg = self.lib.gr_last_error(self._ctx)
+        msg = msg.decode("utf-8", "replace") if msg else ""
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        if rc == -5:
+            raise IndexError(f"{what}: {msg}")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+    def _dev(self, array, dtype):
+        """numpy / tensor -> contiguous tensor of `dtype` on this device (no copy when already there)."""
+        torch = _torch()
+        if isinstance(array, torch.Tensor):
+            return array.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(array)).to(device=self.device, dtype=dtype).contiguous()
+
+    def set_profiling(self, enabled: bool):
+        self._check(self.lib.gr_set_profiling(self._ctx, 1 if enabled else 0), "gr_set_profiling")
+
+    def stage_times(self) -> dict:
+        st = StageTimes()
+        self._check(self.lib.gr_get_stage_times(self._ctx, ctypes.byref(st)), "gr_get_stage_times")
+        return st.as_dict()
+
+    # -- mesh ----------------------------------------------------------------------------------------------------
+    def upload_mesh(self, verts, faces):
+        """verts (V,3) float, faces (F,3) int in the cameras' local frame (meshes.py:1641-1676 output)."""
+        torch = _torch()
+        v = self._dev(verts, torch.float32)
+        f = self._dev(faces, torch.int32)
+        if v.ndim != 2 or v.shape[1] != 3 or f.ndim != 2 or f.shape[1] != 3:
+            raise ValueError(f"mesh must be (V,3) vertices and (F,3) faces, got {tuple(v.shape)} and {tuple(f.shape)}")
+        with torch.cuda.device(self.device):
+            rc = self.lib.gr_mesh_upload(self._ctx, v.data_ptr(), f.data_ptr(), v.shape[0], f.shape[0], self._stream())
+        self._check(rc, "gr_mesh_upload")
+        self._verts, self._faces = v, f  # borrowed by the library: keep alive
+        self.n_verts, self.n_faces = int(v.shape[0]), int(f.shape[0])
+
+    # -- pix2face ------------------------------------------------------------------------------------------------
+    def raster_face_ids(self, cams, h: int, w: int, out=None, want_depth: bool = False, check: bool = True):
+        """cams (N,16) camera records -> ids (N,h,w) int32 tensor [, depth (N,h,w) float32]."""
+        torch = _torch()
+        cams_t = self._dev(cams, torch.float32)
+        if cams_t.ndim != 2 or cams_t.shape[1] != GR_CAM_FLOATS:
+            raise ValueError(f"camera records must be (N,{GR_CAM_FLOATS}), got {tuple(cams_t.shape)}")
+        n = int(cams_t.shape[0])
+        if out is None:
+            out = torch.empty((n, h, w), dtype=torch.int32, device=self.device)
+        elif tuple(out.shape) != (n, h, w) or out.dtype != torch.int32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous int32 tensor of shape (N,h,w)")
+        depth = torch.empty((n, h, w), dtype=torch.float32, device=self.device) if want_depth else None
+        for attempt in range(3):
+            with torch.cuda.device(self.device):
+                rc = self.lib.gr_raster_face_ids(
+                    self._ctx, cams_t.data_ptr(), n, h, w, out.data_ptr(),
+                    depth.data_ptr() if depth is not None else None, self._stream(),
+                )
+            self._check(rc, "gr_raster_face_ids")
+            if not check:
+                break
+            st = RasterStats()
+            rc = self.lib.gr_raster_status(self._ctx, ctypes.byref(st))
+            if rc == GR_EOVERFLOW and attempt < 2:
+                continue  # the library has recorded the exact need; the retry re-allocates the bin lists
+            self._check(rc, "gr_raster_status")
+            self.last_stats = st.as_dict()
+            break
+        return (out, depth) if want_depth else out
+
+    def raster_status(self) -> dict:
+        st = RasterStats()
+        self._check(self.lib.gr_raster_status(self._ctx, ctypes.byref(st)), "gr_raster_status")
+        return st.as_dict()
+
+    # -- render_flat gather --------------------------------------------------------------------------------------
+    def gather_texture(self, ids, face_texture):
+        """ids (...,) int32 tensor, face_texture (F,C) -> (..., C) float64 tensor, NaN where ids == -1."""
+        torch = _torch()
+        ids_t = self._dev(ids, torch.int32)
+        tex = self._dev(face_texture, torch.float64)
+        F, C = int(tex.shape[0]), int(tex.shape[1])
+        out = torch.empty(tuple(ids_t.shape) + (C,), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gr_gather_texture_f64(
+                self._ctx, ids_t.data_ptr(), ids_t.numel(), tex.data_ptr(), F, C, out.data_ptr(), self._stream()
+            )
+        self._check(rc, "gr_gather_texture_f64")
+        return out
+
+    # -- projection / aggregation --------------------------------------------------------------------------------
+    def new_vote_buffers(self, C: int):
+        torch = _torch()
+        votes = torch.zeros((self.n_faces, C), dtype=torch.int32, device=self.device)  # uint32 payload
+        counts = torch.zeros((self.n_faces,), dtype=torch.int32, device=self.device)
+        return votes, counts
+
+    def project_labels(self, ids, labels, C: int, votes, counts, neg1_is_last_face: bool = True):
+        """ids (N,h,w) int32, labels (N,h,w) uint8 class indices; accumulates into votes (F,C), counts (F,)."""
+        torch = _torch()
+        ids_t = self._dev(ids, torch.int32)
+        lab_t = self._dev(labels, torch.uint8)
+        if ids_t.ndim == 2:
+            ids_t, lab_t = ids_t[None], lab_t[None]
+        if ids_t.shape != lab_t.shape:
+            raise ValueError(f"ids {tuple(ids_t.shape)} and labels {tuple(lab_t.shape)} differ in shape")
+        n, h, w = (int(x) for x in ids_t.shape)
+        flags = GR_FLAG_NEG1_IS_LAST_FACE if neg1_is_last_face else 0
+        with torch.cuda.device(self.device):
+            rc = self.lib.gr_project_labels_u8(
+                self._ctx, ids_t.data_ptr(), lab_t.data_ptr(), n, h, w, C, votes.data_ptr(), counts.data_ptr(), flags,
+                self._stream(),
+            )
+        self._check(rc, "gr_project_labels_u8")
+
+    def project_values(self, ids, img, sums, counts, neg1_is_last_face: bool = True):
+        """ids (N,h,w) int32, img (N,h,w,C) float64; accumulates nansum into sums (F,C) and counts (F,)."""
+        torch = _torch()
+        ids_t = self._dev(ids, torch.int32)
+        img_t = self._dev(img, torch.float64)
+        if ids_t.ndim == 2:
+            ids_t, img_t = ids_t[None], img_t[None]
+        n, h, w = (int(x) for x in ids_t.shape)
+        C = int(img_t.shape[-1])
+        if tuple(img_t.shape) != (n, h, w, C):
+            raise ValueError(f"img {tuple(img_t.shape)} does not match ids {tuple(ids_t.shape)}")
+        flags = GR_FLAG_NEG1_IS_LAST_FACE if neg1_is_last_face else 0
+        with torch.cuda.device(self.device):
+            rc = self.lib.gr_project_values_f64(
+                self._ctx, ids_t.data_ptr(), img_t.data_ptr(), n, h, w, C, sums.data_ptr(), counts.data_ptr(), flags,
+                self._stream(),
+            )
+        self._check(rc, "gr_project_values_f64")
+
+    def project_view(self, ids, img, neg1_is_last_face: bool = True):
+        """One view of project_images: ids (h,w) int32, img (h,w,C) float64 -> (F,C) float64, NaN for unseen faces."""
+        torch = _torch()
+        ids_t = self._dev(ids, torch.int32)
+        img_t = self._dev(img, torch.float64)
+        h, w = (int(x) for x in ids_t.shape)
+        C = int(img_t.shape[-1])
+        if tuple(img_t.shape) != (h, w, C):
+            raise ValueError(f"img {tuple(img_t.shape)} does not match ids {tuple(ids_t.shape)}")
+        tex = torch.empty((self.n_faces, C), dtype=torch.float64, device=self.device)
+        flags = GR_FLAG_NEG1_IS_LAST_FACE if neg1_is_last_face else 0
+        with torch.cuda.device(self.device):
+            rc = self.lib.gr_project_view_f64(
+                self._ctx, ids_t.data_ptr(), img_t.data_ptr(), h, w, C, tex.data_ptr(), flags, self._stream()
+            )
+        self._check(rc, "gr_project_view_f64")
+        return tex
+
+    def raster_project_labels(self, cams, labels, C: int, votes, counts, ids_out=None, neg1_is_last_face: bool = True):
+        """Fused pix2face + label projection for N views (aggregate_projected_images fast path)."""
+        torch = _torch()
+        cams_t = self._dev(cams, torch.float32)
+        lab_t = self._dev(labels, torch.uint8)
+        n, h, w = (int(x) for x in lab_t.shape)
+        if ids_out is None:
+            ids_out = torch.empty((n, h, w), dtype=torch.int32, device=self.device)
+        flags = GR_FLAG_NEG1_IS_LAST_FACE if neg1_is_last_face else 0
+        with torch.cuda.device(self.device):
+            rc = self.lib.gr_raster_project_labels_u8(
+                self._ctx, cams_t.data_ptr(), lab_t.data_ptr(), n, h, w, C, votes.data_ptr(), counts.data_ptr(),
+                ids_out.data_ptr(), flags, self._stream(),
+            )
+        self._check(rc, "gr_raster_project_labels_u8")
+        return ids_out
+
+    def finalize_votes(self, votes, counts):
+        """(votes, counts) -> average (F,C), summed (F,C), counts (F,) float64 tensors (meshes.py:2069-2082)."""
+        torch = _torch()
+        F, C = int(votes.shape[0]), int(votes.shape[1])
+        avg = torch.empty((F, C), dtype=torch.float64, device=self.device)
+        summed = torch.empty((F, C), dtype=torch.float64, device=self.device)
+        cnt = torch.empty((F,), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gr_finalize_votes(
+                self._ctx, votes.data_ptr(), counts.data_ptr(), F, C, avg.data_ptr(), summed.data_ptr(), cnt.data_ptr(),
+                self._stream(),
+            )
+        self._check(rc, "gr_finalize_votes")
+        return avg, summed, cnt
+
+    def finalize_sums(self, sums, counts):
+        torch = _torch()
+        F, C = int(sums.shape[0]), int(sums.shape[1])
+        avg = torch.empty((F, C), dtype=torch.float64, device=self.device)
+        cnt = torch.empty((F,), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gr_finalize_sums_f64(
+                self._ctx, sums.data_ptr(), counts.data_ptr(), F, C, avg.data_ptr(), cnt.data_ptr(), self._stream()
+            )
+        self._check(rc, "gr_finalize_sums_f64")
+        return avg, sums, cnt
+
+    def argmax_nonzero(self, array):
+        """utils/indexing.py:9-32 on device: (F,C) float64 -> (F,) float64."""
+        torch = _torch()
+        arr = self._dev(array, torch.float64)
+        F, C = int(arr.shape[0]), int(arr.shape[1])
+        out = torch.empty((F,), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gr_argmax_nonzero_f64(self._ctx, arr.data_ptr(), F, C, out.data_ptr(), self._stream())
+        self._check(rc, "gr_argmax_nonzero_f64")
+        return out

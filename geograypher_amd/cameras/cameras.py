@@ -1,0 +1,378 @@
+"""Camera records of the projection path: `PhotogrammetryCamera` and `PhotogrammetryCameraSet`.
+
+Host-side mirror of geograypher/cameras/cameras.py (same names, arguments and error behaviour) restricted to what
+`pix2face` / `render_flat` / `project_images` / `aggregate_projected_images` touch.  No pyvista: where the reference
+builds a `pv.Camera` (cameras.py:446-477) this module exposes the same view parameters as plain numbers and packs
+them into the 16-float record the HIP rasterizer consumes (`include/geograster.h`).
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+from copy import deepcopy
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple, Union
+
+import numpy as np
+
+from geograypher_amd.constants import EXAMPLE_INTRINSICS, PATH_TYPE
+
+
+def _imread(filename) -> np.ndarray:
+    """Image file -> numpy array (the reference uses skimage.io.imread, cameras.py:157)."""
+    from PIL import Image
+
+    with Image.open(filename) as im:
+        return np.asarray(im)
+
+
+def _resize_bilinear(image: np.ndarray, out_hw: Tuple[int, int]) -> np.ndarray:
+    """Float resize with half-pixel centres (stands in for skimage.transform.resize, cameras.py:168-172)."""
+    import torch
+
+    t = torch.as_tensor(np.ascontiguousarray(image), dtype=torch.float64)
+    squeeze = t.ndim == 2
+    if squeeze:
+        t = t[..., None]
+    t = t.permute(2, 0, 1)[None]
+    down = out_hw[0] < image.shape[0] or out_hw[1] < image.shape[1]
+    t = torch.nn.functional.interpolate(t, size=out_hw, mode="bilinear", align_corners=False, antialias=down)
+    t = t[0].permute(1, 2, 0)
+    return (t[..., 0] if squeeze else t).numpy()
+
+
+def vtk_like_near_plane(cam_to_world: np.ndarray, bounds: np.ndarray, tolerance: float = 0.001) -> float:
+    """Near clipping distance the reference's renderer would pick for this camera and mesh bounds.
+
+    The pyvista path never sets a clipping range (cameras.py:446-477), so VTK derives one from the actor bounds
+    (`vtkRenderer::ResetCameraClippingRange`): the range of the 8 bounding-box corners along the view direction,
+    widened by 1 % plus half its extent, with the near plane kept at >= `tolerance` x far (0.001 for depth buffers
+    deeper than 16 bit).  Restated from the published VTK algorithm; VTK is not runnable here (parity unpinned).
+    bounds: (xmin, xmax, ymin, ymax, zmin, zmax) in the cameras' local frame.
+    """
+    forward = cam_to_world[:3, 2]
+    position = cam_to_world[:3, 3]
+    xs, ys, zs = bounds[0:2], bounds[2:4], bounds[4:6]
+    dists = [float(np.dot(forward, np.array([x, y, z]) - position)) for x in xs for y in ys for z in zs]
+    near, far = min(dists), max(max(dists), 1e-18)
+    near = max(near, 0.0)
+    expansion = 0.5
+    near = 0.99 * near - (far - near) * expansion
+    far = 1.01 * far + (far - near) * expansion
+    if near >= far:
+        near = 0.01 * far
+    if near < tolerance * far:
+        near = tolerance * far
+    return float(near)
+
+
+class PhotogrammetryCamera:
+    def __init__(
+        self,
+        image_filename: PATH_TYPE,
+        cam_to_world_transform: np.ndarray,
+        f: float,
+        cx: float,
+        cy: float,
+        image_width: int,
+        image_height: int,
+        distortion_params: Dict[str, float] = {},
+        lon_lat: Union[None, Tuple[float, float]] = None,
+        local_to_epsg_4978_transform: Union[np.ndarray, None] = None,
+    ):
+        """One camera pose + intrinsics as determined by photogrammetry (reference: cameras.py:55-102).
+
+        Args:
+            image_filename: the image used for reconstruction (may be None for synthetic cameras)
+            cam_to_world_transform: 4x4 camera-to-world (chunk-local) transform; camera frame +X right, +Y down,
+                +Z forward
+            f: focal length in pixels
+            cx, cy: principal point in pixels from the image centre
+            image_width, image_height: sensor size in pixels
+            distortion_params: lens distortion coefficients (Metashape names)
+            lon_lat: optional (lon, lat)
+            local_to_epsg_4978_transform: 4x4 chunk-local -> EPSG:4978
+        """
+        self.image_filename = image_filename
+        self.cam_to_world_transform = cam_to_world_transform
+        self.world_to_cam_transform = np.linalg.inv(cam_to_world_transform)
+        self.f = f
+        self.cx = cx
+        self.cy = cy
+        self.image_width = image_width
+        self.image_height = image_height
+        self.distortion_params = distortion_params
+        self._local_to_epsg_4978_transform = local_to_epsg_4978_transform
+        self.lon_lat = (None, None) if lon_lat is None else lon_lat
+        self.image_size = (image_height, image_width)
+        self.image = None
+        self.cache_image = False
+
+    # -- identity ------------------------------------------------------------------------------------------------
+    def get_camera_hash(self, include_image_hash: bool = False):
+        """sha256 of the camera geometry (reference: cameras.py:104-134; same JSON layout, same digest)."""
+        camera_settings = {
+            "transform": np.asarray(self.cam_to_world_transform).tolist(),
+            "f": self.f,
+            "cx": self.cx,
+            "cy": self.cy,
+            "image_width": self.image_width,
+            "image_height": self.image_height,
+            "distortion_params": self.distortion_params,
+            "lon_lat": self.lon_lat,
+        }
+        if include_image_hash:
+            camera_settings["image_filename"] = str(self.image_filename)
+        data = json.dumps(camera_settings, sort_keys=True)
+        return hashlib.sha256(data.encode("utf-8")).hexdigest()
+
+    def get_camera_properties(self):
+        """reference: cameras.py:136-152"""
+        return {
+            "focal_length": self.f,
+            "principal_point_x": self.cx,
+            "principal_point_y": self.cy,
+            "image_height": self.image_height,
+            "image_width": self.image_width,
+            "distortion_params": self.distortion_params,
+            "world_to_cam_transform": self.world_to_cam_transform,
+        }
+
+    # -- image access --------------------------------------------------------------------------------------------
+    def get_image(self, image_scale: float = 1.0) -> np.ndarray:
+        """reference: cameras.py:154-174 (uint8 images are returned as float in [0, 1])."""
+        if self.image is None:
+            image = _imread(self.image_filename)
+            if image.dtype == np.uint8:
+                image = image / 255.0
+            if self.cache_image:
+                self.image = image
+        else:
+            image = self.image
+        if image_scale != 1.0:
+            image = _resize_bilinear(image, (int(image.shape[0] * image_scale), int(image.shape[1] * image_scale)))
+        return image
+
+    def get_image_filename(self):
+        return self.image_filename
+
+    def get_image_size(self, image_scale=1.0):
+        """(h, w) in pixels, truncated like the reference (cameras.py:179-200)."""
+        if self.image_size is not None:
+            pass
+        elif self.image is not None:
+            self.image_size = self.image.shape[:2]
+        else:
+            self.image_size = self.get_image().shape[:2]
+        return (int(self.image_size[0] * image_scale), int(self.image_size[1] * image_scale))
+
+    def get_local_to_epsg_4978_transform(self) -> np.ndarray:
+        """reference: cameras.py:311-326"""
+        return self._local_to_epsg_4978_transform
+
+    # -- view ----------------------------------------------------------------------------------------------------
+    def get_view_parameters(self, focal_dist: float = 10) -> dict:
+        """The numbers the reference loads into a pyvista camera (cameras.py:446-477): position, focal point,
+        view-up and the VERTICAL field of view in degrees.  The principal point is not part of this view."""
+        T = np.asarray(self.cam_to_world_transform, dtype=np.float64)
+        position = T[:3, 3]
+        focal_point = position + T[:3, :3] @ np.array((0, 0, focal_dist), dtype=np.float64)
+        up = T[:3, :3] @ np.array((0, -1, 0), dtype=np.float64)
+        view_angle = np.rad2deg(2 * np.arctan((self.image_height / 2) / self.f))
+        return {"position": position, "focal_point": focal_point, "up": up, "view_angle": view_angle}
+
+    def get_raster_record(
+        self, image_scale: float = 1.0, near: float = 1e-3, principal_point: str = "center"
+    ) -> np.ndarray:
+        """Pack this view into the 16-float record of include/geograster.h.
+
+        The pinhole that a pyvista camera with the parameters above realises in an (h, w) window is
+        u = w/2 + f_eff X/Z, v = h/2 + f_eff Y/Z with f_eff = (h/2)/tan(view_angle/2) = f*h/image_height
+        (cameras.py:469-475, meshes.py:1801, 1820-1822).  principal_point="center" reproduces that (cx, cy ignored
+        exactly as the reference's pyvista path does); "intrinsics" places it at (w/2 + cx*s, h/2 + cy*s), the
+        convention of the reference's PyTorch3D plugin (derived_meshes.py:772-780) scaled to the window.
+        """
+        h, w = self.get_image_size(image_scale)
+        T = np.asarray(self.cam_to_world_transform, dtype=np.float64)
+        f_eff = float(self.f) * h / float(self.image_height)
+        if principal_point == "center":
+            cxp, cyp = w / 2.0, h / 2.0
+        elif principal_point == "intrinsics":
+            cxp = w / 2.0 + float(self.cx) * h / float(self.image_height)
+            cyp = h / 2.0 + float(self.cy) * h / float(self.image_height)
+        else:
+            raise ValueError(f"principal_point must be 'center' or 'intrinsics', not {principal_point!r}")
+        rec = np.empty(16, dtype=np.float32)
+        rec[0:9] = T[:3, :3].reshape(9)
+        rec[9:12] = T[:3, 3]
+        rec[12] = f_eff
+        rec[13] = cxp
+        rec[14] = cyp
+        rec[15] = near
+        return rec
+
+
+class PhotogrammetryCameraSet:
+    def __init__(
+        self,
+        cameras: Union[None, PhotogrammetryCamera, List[PhotogrammetryCamera]] = None,
+        cam_to_world_transforms: Optional[List[np.ndarray]] = None,
+        intrinsic_params_per_sensor_type: Dict[int, Dict[str, float]] = {0: EXAMPLE_INTRINSICS},
+        image_filenames: Optional[List[PATH_TYPE]] = None,
+        lon_lats: Optional[List[Union[None, Tuple[float, float]]]] = None,
+        image_folder: Optional[PATH_TYPE] = None,
+        sensor_IDs: Optional[List[int]] = None,
+        validate_images: bool = False,
+        local_to_epsg_4978_transform: np.ndarray = np.eye(4),
+    ):
+        """A set of cameras in one chunk-local frame (reference: cameras.py:661-781, same arguments).
+
+        Raises:
+            ValueError: if the number of sensor IDs differs from the number of transforms.
+        """
+        self._local_to_epsg_4978_transform = local_to_epsg_4978_transform
+        self._maps_ideal_to_warped = {}
+        self._maps_warped_to_ideal = {}
+
+        if cameras is not None:
+            if isinstance(cameras, PhotogrammetryCamera):
+                self.image_folder = None if cameras.image_filename is None else Path(cameras.image_filename).parent
+                cameras = [cameras]
+            else:
+                names = [str(cam.image_filename) for cam in cameras if cam.image_filename is not None]
+                self.image_folder = Path(os.path.commonpath(names)) if len(names) == len(cameras) and names else None
+            self.cameras = cameras
+            return
+
+        n_transforms = len(cam_to_world_transforms)
+        if image_filenames is None:
+            image_filenames = [None] * n_transforms
+        if sensor_IDs is None and len(intrinsic_params_per_sensor_type) == 1:
+            sensor_IDs = [list(intrinsic_params_per_sensor_type.keys())[0]] * n_transforms
+        elif len(sensor_IDs) != n_transforms:
+            raise ValueError(
+                f"Number of sensor_IDs ({len(sensor_IDs)}) is different than the number of transforms ({n_transforms})"
+            )
+        if lon_lats is None:
+            lon_lats = [None] * n_transforms
+
+        self.cam_to_world_transforms = cam_to_world_transforms
+        self.intrinsic_params_per_sensor_type = intrinsic_params_per_sensor_type
+        self.image_filenames = image_filenames
+        self.lon_lats = lon_lats
+        self.sensor_IDs = sensor_IDs
+        self.image_folder = image_folder
+
+        if validate_images:
+            missing_images, invalid_mask = self.find_missing_images()
+            if len(missing_images) > 0:
+                print(f"Deleting {len(missing_images)} missing images")
+                keep = [i for i, bad in enumerate(invalid_mask) if not bad]
+                self.image_filenames = [self.image_filenames[i] for i in keep]
+                self.cam_to_world_transforms = [self.cam_to_world_transforms[i] for i in keep]
+                self.sensor_IDs = [self.sensor_IDs[i] for i in keep]
+                self.lon_lats = [self.lon_lats[i] for i in keep]
+
+        self.cameras = []
+        for image_filename, cam_to_world_transform, sensor_ID, lon_lat in zip(
+            self.image_filenames, self.cam_to_world_transforms, self.sensor_IDs, self.lon_lats
+        ):
+            sensor_params = self.intrinsic_params_per_sensor_type[sensor_ID]
+            if sensor_params is None:  # sensor without a full calibration
+                continue
+            self.cameras.append(
+                PhotogrammetryCamera(
+                    image_filename,
+                    cam_to_world_transform,
+                    lon_lat=lon_lat,
+                    local_to_epsg_4978_transform=local_to_epsg_4978_transform,
+                    **sensor_params,
+                )
+            )
+
+    # -- container -----------------------------------------------------------------------------------------------
+    def __len__(self):
+        return self.n_cameras()
+
+    def __getitem__(self, slice):
+        subset_cameras = self.cameras[slice]
+        if isinstance(subset_cameras, PhotogrammetryCamera):
+            return subset_cameras
+        return PhotogrammetryCameraSet(
+            subset_cameras, local_to_epsg_4978_transform=self._local_to_epsg_4978_transform
+        )
+
+    def get_image_folder(self):
+        return self.image_folder
+
+    def find_missing_images(self):
+        invalid_mask = [not Path(image_file).is_file() for image_file in self.image_filenames]
+        invalid_images = [f for f, bad in zip(self.image_filenames, invalid_mask) if bad]
+        return invalid_images, invalid_mask
+
+    def n_cameras(self) -> int:
+        return len(self.cameras)
+
+    def n_image_channels(self) -> int:
+        return 3
+
+    def get_subset_cameras(self, inds: List[int]):
+        """reference: cameras.py:861-864 (a copy of the set holding only `inds`; IndexError when out of range)."""
+        subset_camera_set = deepcopy(self)
+        subset_camera_set.cameras = [subset_camera_set[i] for i in inds]
+        return subset_camera_set
+
+    def get_image_by_index(self, index: int, image_scale: float = 1.0) -> np.ndarray:
+        return self[index].get_image(image_scale=image_scale)
+
+    def get_image_filename(self, index: Union[int, None], absolute=True):
+        """reference: cameras.py:883-909"""
+        if index is None:
+            return [self.get_image_filename(i, absolute=absolute) for i in range(len(self.cameras))]
+        filename = self.cameras[index].get_image_filename()
+        if absolute:
+            return Path(filename)
+        return Path(filename).relative_to(self.get_image_folder())
+
+    def get_local_to_epsg_4978_transform(self):
+        """reference: cameras.py:911-926"""
+        return self._local_to_epsg_4978_transform
+
+    def get_raster_records(
+        self, image_scale: float = 1.0, near: Union[float, List[float]] = 1e-3, principal_point: str = "center"
+    ) -> np.ndarray:
+        """(N,16) float32 records for the HIP rasterizer; all cameras must share one image size."""
+        nears = [near] * len(self.cameras) if np.isscalar(near) else list(near)
+        sizes = {cam.get_image_size(image_scale) for cam in self.cameras}
+        if len(sizes) > 1:
+            raise ValueError("Not all cameras have the same image size")
+        return np.stack(
+            [cam.get_raster_record(image_scale, nr, principal_point) for cam, nr in zip(self.cameras, nears)], axis=0
+        )
+
+    # -- distortion (the warp stage itself is the "next" row f1 of SURVEY.md section 8) -------------------------------
+    def distortion_key(self, parameters: Dict[str, float], image_scale: float = 1.0) -> str:
+        """reference: cameras.py:968-993 (8-decimal repeatable key)"""
+        keys = sorted(parameters.keys())
+        strings = [f"{key}:{parameters[key]:.8f}" for key in keys] + [f"image_scale:{image_scale:.8f}"]
+        return "|".join(strings)
+
+    def ideal_to_warped(self, camera: PhotogrammetryCamera, xpix: np.ndarray, ypix: np.ndarray):
+        """reference: cameras.py:1064-1090 -- only derived sets know a distortion model."""
+        raise NotImplementedError(f"ideal_to_warped not implemented for {self.__class__}.")
+
+    def warp_dewarp_image(
+        self,
+        camera: PhotogrammetryCamera,
+        input_image: np.ndarray,
+        fill_value: float = 0.0,
+        inversion_downsample: int = 8,
+        interpolation_order: int = 1,
+        warped_to_ideal: bool = True,
+        image_scale: float = 1.0,
+    ) -> np.ndarray:
+        """reference: cameras.py:1092-1156.  The base set has no distortion model, so -- exactly like the reference
+        (pinned by tests/test_derived_cameras.py:318-337) -- asking for a warp raises NotImplementedError."""
+        self.ideal_to_warped(camera, np.zeros(1), np.zeros(1))
+        raise NotImplementedError("distortion warp is not part of the round-1 scope (SURVEY.md section 8, row f1)")

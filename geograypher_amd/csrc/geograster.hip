@@ -1,0 +1,968 @@
+// geograypher_amd/csrc/geograster.hip -- hand-written CDNA4 (gfx950, wave64) kernels + the C ABI of include/geograster.h.
+//
+// Hot path of geograypher re-designed for MI355X (reference lines in include/geograster.h and DESIGN.md):
+//   pix2face            k_setup_cull -> k_scan_tiles -> k_fill_bins -> k_raster_tile     (meshes.py:1776-1836)
+//   project/aggregate   k_winner_*   -> k_vote_*                                          (meshes.py:1987-2002, 2057-2067)
+//   render_flat gather  k_gather_texture                                                  (meshes.py:1921-1937)
+// No MFMA anywhere: there is no dense contraction on this path.  The work is integer edge functions, an
+// LDS-resident depth|id tile per workgroup, wave ballot/popcount compaction of surviving faces and global
+// atomicMax/atomicAdd for bins and per-face winners.
+//
+// Rule-set R0-R6 is implemented here independently of oracle/oracle_raster.c; tests demand equality.
+// Compile with -ffp-contract=off: every floating-point operation below is individually rounded on purpose.
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "geograster.h"
+
+// ------------------------------------------------------------------------------------------------------------------
+// constants
+// ------------------------------------------------------------------------------------------------------------------
+#define GR_TILE 64          // tile edge in pixels (one workgroup rasterizes one 64x64 tile out of LDS)
+#define GR_TILE_LOG2 6
+#define GR_RASTER_THREADS 256
+#define GR_MAX_BATCH 16     // views per launch group (amortises kernel boundaries)
+#define GR_CTRL_HDR 4       // ctrl words before the tile arrays: rec_count, total_entries, overflow, pad
+#define GR_MAX_DIM 16384    // h, w limit (guard band and 16-bit bbox packing)
+
+namespace {
+
+struct BinArgs {
+  uint32_t *ctrl;        // [slot][GR_CTRL_HDR + 3*Tcap]   rec_count,total,overflow,pad | count[T] | offset[T] | cursor[T]
+  int4 *rec;             // [slot][3][F]  plane0 {X0,Y0,X1,Y1} plane1 {X2,Y2,iz0,face} plane2 {A,B,jmin|jmax<<16,imin|imax<<16}
+  uint32_t *entries;     // [slot][ent_cap]  record indices grouped by tile
+  unsigned long long *stats;  // [4] records, entries, max_entries, overflow (accumulated over the call)
+  int64_t ctrl_stride;   // words per slot
+  int64_t rec_stride;    // int4 per slot (= 3*F)
+  int64_t ent_cap;       // entries per slot
+  int64_t F;
+  int T, TX, TY, Tcap;
+  int h, w;
+};
+
+__device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b, c)); }
+__device__ __forceinline__ int imax3(int a, int b, int c) { return max(a, max(b, c)); }
+
+struct Vtx {
+  int X, Y;
+  float iz;
+  bool valid;
+};
+
+// R1 -- vertex transform, fp32, each operation individually rounded
+__device__ __forceinline__ Vtx project_vertex(const float *__restrict__ p, const float *__restrict__ cam) {
+  Vtx v;
+  const float dx = p[0] - cam[9];
+  const float dy = p[1] - cam[10];
+  const float dz = p[2] - cam[11];
+  float m0, m1, m2;
+  m0 = cam[0] * dx; m1 = cam[3] * dy; m2 = cam[6] * dz;
+  const float qx = (m0 + m1) + m2;
+  m0 = cam[1] * dx; m1 = cam[4] * dy; m2 = cam[7] * dz;
+  const float qy = (m0 + m1) + m2;
+  m0 = cam[2] * dx; m1 = cam[5] * dy; m2 = cam[8] * dz;
+  const float qz = (m0 + m1) + m2;
+  v.valid = qz > cam[15];
+  const float iz = 1.0f / qz;  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
+  const float fx = cam[12] * qx;
+  const float fy = cam[12] * qy;
+  const float sx = cam[13] + fx * iz;
+  const float sy = cam[14] + fy * iz;
+  v.valid = v.valid && (fabsf(sx) < 16384.0f) && (fabsf(sy) < 16384.0f);
+  v.X = (int)floorf(sx * 256.0f + 0.5f);
+  v.Y = (int)floorf(sy * 256.0f + 0.5f);
+  v.iz = iz;
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K1  transform + cull + compact record + per-tile counts.   grid (ceil(F/256), views)
+//     faces (F,3) int32 read coalesced; vertices gathered (12 B each, L2-resident for mesh-local face order);
+//     survivors compacted with wave ballot + popcount, ONE atomicAdd per wave; record planes written as
+//     consecutive 16-byte slots (full-rate coalesced stores).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ verts, const int32_t *__restrict__ faces,
+                                                    const float *__restrict__ cams, BinArgs a) {
+  const int slot = blockIdx.y;
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
+  uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+
+  bool keep = false;
+  int4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0};
+  int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+  if (f < a.F) {
+    const int i0 = faces[3 * f + 0], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+    Vtx v0 = project_vertex(verts + 3 * (int64_t)i0, cam);
+    Vtx v1 = project_vertex(verts + 3 * (int64_t)i1, cam);
+    Vtx v2 = project_vertex(verts + 3 * (int64_t)i2, cam);
+    if (v0.valid && v1.valid && v2.valid) {
+      long long area2 = (long long)(v1.X - v0.X) * (long long)(v2.Y - v0.Y) -
+                        (long long)(v2.X - v0.X) * (long long)(v1.Y - v0.Y);
+      if (area2 != 0) {
+        if (area2 < 0) {  // both windings are drawn: normalise to positive area
+          Vtx s = v1; v1 = v2; v2 = s;
+          area2 = -area2;
+        }
+        const int Xmin = imin3(v0.X, v1.X, v2.X), Xmax = imax3(v0.X, v1.X, v2.X);
+        const int Ymin = imin3(v0.Y, v1.Y, v2.Y), Ymax = imax3(v0.Y, v1.Y, v2.Y);
+        int jmin = (Xmin - 128 + 255) >> 8, jmax = (Xmax - 128) >> 8;  // R2: pixel centres inside the bbox
+        int imin = (Ymin - 128 + 255) >> 8, imax = (Ymax - 128) >> 8;
+        jmin = max(jmin, 0); imin = max(imin, 0);
+        jmax = min(jmax, a.w - 1); imax = min(imax, a.h - 1);
+        if (jmin <= jmax && imin <= imax) {
+          keep = true;
+          // R4: gradients of 1/z in double, rounded once to float
+          const double d1 = (double)v1.iz - (double)v0.iz;
+          const double d2 = (double)v2.iz - (double)v0.iz;
+          const double a2 = (double)area2;
+          double n1, n2;
+          n1 = d1 * (double)(v2.Y - v0.Y); n2 = d2 * (double)(v1.Y - v0.Y);
+          const float A = (float)((n1 - n2) / a2);
+          n1 = d2 * (double)(v1.X - v0.X); n2 = d1 * (double)(v2.X - v0.X);
+          const float B = (float)((n1 - n2) / a2);
+          r0 = make_int4(v0.X, v0.Y, v1.X, v1.Y);
+          r1 = make_int4(v2.X, v2.Y, __float_as_int(v0.iz), (int)f);
+          r2 = make_int4(__float_as_int(A), __float_as_int(B), jmin | (jmax << 16), imin | (imax << 16));
+          tx0 = jmin >> GR_TILE_LOG2; tx1 = jmax >> GR_TILE_LOG2;
+          ty0 = imin >> GR_TILE_LOG2; ty1 = imax >> GR_TILE_LOG2;
+        }
+      }
+    }
+  }
+  // wave-level compaction of survivors
+  const unsigned long long m = __ballot(keep);
+  if (m == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  const int n = __popcll(m);
+  const int prefix = __popcll(m & ((1ull << lane) - 1ull));
+  const int leader = __ffsll((long long)m) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(&ctrl[0], (uint32_t)n);
+  base = __shfl(base, leader);
+  if (keep) {
+    int4 *rec = a.rec + slot * a.rec_stride;
+    const int64_t s = (int64_t)base + prefix;
+    rec[s] = r0;
+    rec[a.F + s] = r1;
+    rec[2 * a.F + s] = r2;
+    uint32_t *cnt = ctrl + GR_CTRL_HDR;
+    for (int ty = ty0; ty <= ty1; ++ty)
+      for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&cnt[ty * a.TX + tx], 1u);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K2  exclusive scan of the per-tile counts of one view.  grid (views), 1024 threads
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan_tiles(BinArgs a) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s;
+  const int slot = blockIdx.x;
+  uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  const uint32_t *cnt = ctrl + GR_CTRL_HDR;
+  uint32_t *off = ctrl + GR_CTRL_HDR + a.Tcap;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < a.T; base += 1024) {
+    const int t = base + tid;
+    const uint32_t c = (t < a.T) ? cnt[t] : 0u;
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int k = 0; k < wv; ++k) wbase += wave_tot[k];
+    const uint32_t carry = carry_s;
+    if (t < a.T) off[t] = carry + wbase + incl - c;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + wbase + incl;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const uint32_t total = carry_s;
+    ctrl[1] = total;
+    const bool ovf = (int64_t)total > a.ent_cap;
+    ctrl[2] = ovf ? 1u : 0u;
+    atomicAdd(&a.stats[0], (unsigned long long)ctrl[0]);
+    atomicAdd(&a.stats[1], (unsigned long long)total);
+    atomicMax(&a.stats[2], (unsigned long long)total);
+    if (ovf) atomicMax(&a.stats[3], 1ull);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K3  scatter record indices into their tiles' lists.  grid (G, views), grid-stride over the surviving records
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fill_bins(BinArgs a) {
+  const int slot = blockIdx.y;
+  uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  const uint32_t n_rec = ctrl[0];
+  const uint32_t *off = ctrl + GR_CTRL_HDR + a.Tcap;
+  uint32_t *cur = ctrl + GR_CTRL_HDR + 2 * a.Tcap;
+  const int4 *rec2 = a.rec + slot * a.rec_stride + 2 * a.F;
+  uint32_t *ent = a.entries + slot * a.ent_cap;
+  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n_rec; r += gridDim.x * 256) {
+    const int4 q = rec2[r];
+    const int tx0 = (q.z & 0xFFFF) >> GR_TILE_LOG2, tx1 = (int)((uint32_t)q.z >> 16) >> GR_TILE_LOG2;
+    const int ty0 = (q.w & 0xFFFF) >> GR_TILE_LOG2, ty1 = (int)((uint32_t)q.w >> 16) >> GR_TILE_LOG2;
+    for (int ty = ty0; ty <= ty1; ++ty)
+      for (int tx = tx0; tx <= tx1; ++tx) {
+        const int t = ty * a.TX + tx;
+        const int64_t idx = (int64_t)off[t] + atomicAdd(&cur[t], 1u);
+        if (idx < a.ent_cap) ent[idx] = r;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K4  tile rasterizer (the dominant kernel).  grid (T, views), 256 threads = 4 waves, one 64x64 tile per workgroup.
+//     depth|id keys (u64: 1/z bits << 32 | ~face) live in 32 KiB of LDS; each wave takes every 4th triangle of the
+//     tile's list, walks its bounding box in 8x8 stamps (lane = pixel) and resolves visibility with ds_max_u64, so
+//     the result is independent of list order.  LDS column index is XOR-swizzled by (row & 3) << 3 so the four
+//     rows serviced together by one 32-lane group land on 64 distinct banks.  Epilogue: one coalesced 256-byte row
+//     store per wave-instruction.
+// ------------------------------------------------------------------------------------------------------------------
+struct RasterOut {
+  int32_t *ids;    // [slot][h][w] or null
+  float *depth;    // [slot][h][w] or null
+};
+
+__device__ __forceinline__ int lds_index(int row, int col) { return row * GR_TILE + (col ^ ((row & 3) << 3)); }
+
+__global__ __launch_bounds__(GR_RASTER_THREADS) void k_raster_tile(BinArgs a, RasterOut out) {
+  __shared__ unsigned long long keys[GR_TILE * GR_TILE];
+  const int slot = blockIdx.y;
+  const int tile = blockIdx.x;
+  const int tx = tile % a.TX, ty = tile / a.TX;
+  const int px0 = tx * GR_TILE, py0 = ty * GR_TILE;
+  const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  const int tid = threadIdx.x;
+
+  for (int i = tid; i < GR_TILE * GR_TILE; i += GR_RASTER_THREADS) keys[i] = 0ull;
+  __syncthreads();
+
+  uint32_t cnt = ctrl[GR_CTRL_HDR + tile];
+  const int64_t beg = ctrl[GR_CTRL_HDR + a.Tcap + tile];
+  if (beg >= a.ent_cap) cnt = 0;
+  else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
+
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, lx = lane & 7, ly = lane >> 3;
+  const int4 *rec0 = a.rec + slot * a.rec_stride;
+  const int4 *rec1 = rec0 + a.F;
+  const int4 *rec2 = rec1 + a.F;
+  const uint32_t *ent = a.entries + slot * a.ent_cap + beg;
+  // lane-constant part of the swizzled LDS index: row ly, column lx, swizzle (ly & 3) << 3
+  const int lds_lane = ly * GR_TILE + lx;
+  const int swz = (ly & 3) << 3;
+
+  for (uint32_t e = wave; e < cnt; e += GR_RASTER_THREADS / 64) {
+    const uint32_t r = __builtin_amdgcn_readfirstlane(ent[e]);
+    const int4 p0 = rec0[r], p1 = rec1[r], p2 = rec2[r];
+    const int X0 = p0.x, Y0 = p0.y, X1 = p0.z, Y1 = p0.w, X2 = p1.x, Y2 = p1.y;
+    const float iz0 = __int_as_float(p1.z);
+    const uint32_t face = (uint32_t)p1.w;
+    const float A = __int_as_float(p2.x), B = __int_as_float(p2.y);
+    // bounding box of pixel centres, intersected with this tile, in tile-local pixels
+    const int jlo = max((p2.z & 0xFFFF) - px0, 0), jhi = min((int)((uint32_t)p2.z >> 16) - px0, GR_TILE - 1);
+    const int ilo = max((p2.w & 0xFFFF) - py0, 0), ihi = min((int)((uint32_t)p2.w >> 16) - py0, GR_TILE - 1);
+    // R3 edges k: (v0->v1), (v1->v2), (v2->v0); covered <=> E_k + bias_k >= 0 with bias = owns ? 0 : -1
+    const int dx0 = X1 - X0, dy0 = Y1 - Y0;
+    const int dx1 = X2 - X1, dy1 = Y2 - Y1;
+    const int dx2 = X0 - X2, dy2 = Y0 - Y2;
+    const int b0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;
+    const int b1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
+    const int b2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
+    const int ext = max(imax3(X0, X1, X2) - imin3(X0, X1, X2), imax3(Y0, Y1, Y2) - imin3(Y0, Y1, Y2));
+    const unsigned long long key_lo = (unsigned long long)(~face);
+
+    if (ext < 16384) {
+      // small triangle (< 64 px): every product fits 32 bits, operands fit 24 bits (full-rate v_mul_i32_i24)
+      const int L0 = __mul24(dx0, ly * 256) - __mul24(dy0, lx * 256);
+      const int L1 = __mul24(dx1, ly * 256) - __mul24(dy1, lx * 256);
+      const int L2 = __mul24(dx2, ly * 256) - __mul24(dy2, lx * 256);
+      for (int sy = ilo & ~7; sy <= ihi; sy += 8) {
+        const int Pys = (py0 + sy) * 256 + 128;  // stamp-origin pixel centre (wave-uniform)
+        for (int sx = jlo & ~7; sx <= jhi; sx += 8) {
+          const int Pxs = (px0 + sx) * 256 + 128;
+          const int E0 = dx0 * (Pys - Y0) - dy0 * (Pxs - X0) + b0;
+          const int E1 = dx1 * (Pys - Y1) - dy1 * (Pxs - X1) + b1;
+          const int E2 = dx2 * (Pys - Y2) - dy2 * (Pxs - X2) + b2;
+          const bool inside = (((E0 + L0) | (E1 + L1) | (E2 + L2)) >= 0);
+          if (__ballot(inside) == 0ull) continue;
+          if (inside) {
+            const float fx = (float)((Pxs - X0) + lx * 256);
+            const float fy = (float)((Pys - Y0) + ly * 256);
+            const float m0 = A * fx;
+            const float m1 = B * fy;
+            const float s = m0 + m1;
+            const float z = iz0 + s;
+            const int zb = max(__float_as_int(z), 1);
+            const unsigned long long key = ((unsigned long long)(uint32_t)zb << 32) | key_lo;
+            atomicMax(&keys[sy * GR_TILE + lds_lane + (sx ^ swz)], key);
+          }
+        }
+      }
+    } else {
+      // large triangle: exact 64-bit edge functions
+      for (int sy = ilo & ~7; sy <= ihi; sy += 8) {
+        for (int sx = jlo & ~7; sx <= jhi; sx += 8) {
+          const long long Px = (long long)(px0 + sx + lx) * 256 + 128;
+          const long long Py = (long long)(py0 + sy + ly) * 256 + 128;
+          const long long E0 = (long long)dx0 * (Py - Y0) - (long long)dy0 * (Px - X0) + b0;
+          const long long E1 = (long long)dx1 * (Py - Y1) - (long long)dy1 * (Px - X1) + b1;
+          const long long E2 = (long long)dx2 * (Py - Y2) - (long long)dy2 * (Px - X2) + b2;
+          const bool inside = ((E0 | E1 | E2) >= 0);
+          if (inside) {
+            const float fx = (float)((int)Px - X0);
+            const float fy = (float)((int)Py - Y0);
+            const float m0 = A * fx;
+            const float m1 = B * fy;
+            const float s = m0 + m1;
+            const float z = iz0 + s;
+            const int zb = max(__float_as_int(z), 1);
+            const unsigned long long key = ((unsigned long long)(uint32_t)zb << 32) | key_lo;
+            atomicMax(&keys[sy * GR_TILE + lds_lane + (sx ^ swz)], key);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // epilogue: wave w writes rows w*16 .. w*16+15, one 64-pixel row (256 B) per wave-instruction
+  const int col = lane;
+  const int gx = px0 + col;
+  if (gx < a.w) {
+    const int64_t plane = (int64_t)slot * a.h * a.w;
+#pragma unroll 4
+    for (int k = 0; k < GR_TILE / 4; ++k) {
+      const int row = (tid >> 6) * (GR_TILE / 4) + k;
+      const int gy = py0 + row;
+      if (gy >= a.h) break;
+      const unsigned long long key = keys[lds_index(row, col)];
+      const int64_t p = plane + (int64_t)gy * a.w + gx;
+      if (out.ids) out.ids[p] = key ? (int32_t)(~(uint32_t)key) : -1;
+      if (out.depth) out.depth[p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K5  last-writer-wins winners.  One thread per pixel.  A pixel can only be its face's LAST pixel in row-major
+//     order if neither its right nor its lower neighbour shows the same face, so only those candidates issue the
+//     global atomicMax (~1-3 per visible face instead of ~80).  key = (pixel+1) << LB | label  (LB = 0: pixel+1).
+// ------------------------------------------------------------------------------------------------------------------
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_winner(const int32_t *__restrict__ ids, const uint8_t *__restrict__ labels,
+                                                KeyT *__restrict__ winner, int64_t F, int h, int w, int C, int LB,
+                                                int compat) {
+  const int slot = blockIdx.y;
+  const int64_t P = (int64_t)h * w;
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int32_t *im = ids + slot * P;
+  const int y = (int)(p / w), x = (int)(p - (int64_t)y * w);
+  int f = im[p];
+  int fr = (x + 1 < w) ? im[p + 1] : -2;
+  int fb = (y + 1 < h) ? im[p + w] : -2;
+  if (compat) {  // meshes.py:1998-2001: index -1 aliases the last face
+    const int last = (int)F - 1;
+    if (f == -1) f = last;
+    if (fr == -1) fr = last;
+    if (fb == -1) fb = last;
+  }
+  if (f < 0 || f >= F) return;
+  if (fr == f || fb == f) return;  // a later pixel of the same face exists
+  KeyT key = (KeyT)(p + 1);
+  if (LB) {
+    const int l = labels[slot * P + p];
+    key = (key << LB) | (KeyT)min(l, C);
+  }
+  atomicMax(&winner[slot * F + f], key);
+}
+
+// K6  per-face vote: one thread per face walks the views of the batch IN ORDER (deterministic, no atomics needed:
+//     a face belongs to exactly one thread).  votes[f][label] += 1, counts[f] += 1; winners are cleared for reuse.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_vote_labels(KeyT *__restrict__ winner, int n_views, int64_t F, int C, int LB,
+                                                     uint32_t *__restrict__ votes, uint32_t *__restrict__ counts) {
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  const KeyT mask = (((KeyT)1) << LB) - 1;
+  uint32_t c = 0;
+  for (int v = 0; v < n_views; ++v) {
+    const KeyT key = winner[v * F + f];
+    if (key == 0) continue;
+    winner[v * F + f] = 0;
+    const int l = (int)(key & mask);
+    if (l < C) votes[f * C + l] += 1u;
+    ++c;
+  }
+  if (c) counts[f] += c;
+}
+
+__global__ __launch_bounds__(256) void k_vote_values(uint32_t *__restrict__ winner, const double *__restrict__ img,
+                                                     int n_views, int64_t F, int64_t P, int C,
+                                                     double *__restrict__ sums, uint32_t *__restrict__ counts) {
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  uint32_t c = 0;
+  for (int v = 0; v < n_views; ++v) {
+    const uint32_t key = winner[v * F + f];
+    if (key == 0) continue;
+    winner[v * F + f] = 0;
+    const double *row = img + ((int64_t)v * P + (key - 1)) * C;
+    bool any_finite = false;
+    for (int ch = 0; ch < C; ++ch) {
+      const double x = row[ch];
+      if (isfinite(x)) any_finite = true;
+      if (!isnan(x)) sums[f * C + ch] += x;  // nansum: NaN counts as 0 (meshes.py:2060-2062)
+    }
+    if (any_finite) ++c;
+  }
+  if (c) counts[f] += c;
+}
+
+__global__ __launch_bounds__(256) void k_project_view(uint32_t *__restrict__ winner, const double *__restrict__ img,
+                                                      int64_t F, int C, double *__restrict__ tex) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= F * C) return;
+  const int64_t f = i / C;
+  const int ch = (int)(i - f * C);
+  const uint32_t key = winner[f];
+  tex[i] = key ? img[(int64_t)(key - 1) * C + ch] : __longlong_as_double(0x7FF8000000000000ll);
+}
+
+__global__ __launch_bounds__(256) void k_clear_u32(uint32_t *p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
+// K7  render_flat gather: out[p][c] = tex[ids[p]][c] or NaN
+__global__ __launch_bounds__(256) void k_gather_texture(const int32_t *__restrict__ ids, int64_t n_pix,
+                                                        const double *__restrict__ tex, int64_t F, int C,
+                                                        double *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_pix * C) return;
+  const int64_t p = i / C;
+  const int ch = (int)(i - p * C);
+  const int f = ids[p];
+  out[i] = (f >= 0 && f < F) ? tex[(int64_t)f * C + ch] : __longlong_as_double(0x7FF8000000000000ll);
+}
+
+__global__ __launch_bounds__(256) void k_finalize_votes(const uint32_t *__restrict__ votes,
+                                                        const uint32_t *__restrict__ counts, int64_t F, int C,
+                                                        double *__restrict__ average, double *__restrict__ summed,
+                                                        double *__restrict__ counts_f64) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= F * C) return;
+  const int64_t f = i / C;
+  const uint32_t c = counts[f];
+  const double nan = __longlong_as_double(0x7FF8000000000000ll);
+  const double s = c ? (double)votes[i] : nan;
+  summed[i] = s;
+  average[i] = c ? s / (double)c : nan;  // numpy: nan / 0 = nan
+  if (i == f * C) counts_f64[f] = (double)c;
+}
+
+__global__ __launch_bounds__(256) void k_finalize_sums(double *__restrict__ sums, const uint32_t *__restrict__ counts,
+                                                       int64_t F, int C, double *__restrict__ average,
+                                                       double *__restrict__ counts_f64) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= F * C) return;
+  const int64_t f = i / C;
+  const uint32_t c = counts[f];
+  const double nan = __longlong_as_double(0x7FF8000000000000ll);
+  const double s = c ? sums[i] : nan;
+  sums[i] = s;
+  average[i] = c ? s / (double)c : nan;
+  if (i == f * C) counts_f64[f] = (double)c;
+}
+
+// utils/indexing.py:9-32
+__global__ __launch_bounds__(256) void k_argmax_nonzero(const double *__restrict__ arr, int64_t F, int C,
+                                                        double *__restrict__ out) {
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  const double *row = arr + f * C;
+  double best = row[0], sum = 0.0;
+  int arg = 0;
+  bool bad = false;
+  // np.argmax: first maximum; a NaN is "maximal" and the first NaN wins
+  bool best_nan = isnan(best);
+  for (int c = 0; c < C; ++c) {
+    const double x = row[c];
+    if (!isfinite(x)) bad = true;
+    sum += x;
+    if (c > 0 && !best_nan) {
+      if (isnan(x)) { best_nan = true; arg = c; }
+      else if (x > best) { best = x; arg = c; }
+    }
+  }
+  out[f] = (bad || sum == 0.0) ? __longlong_as_double(0x7FF8000000000000ll) : (double)arg;
+}
+
+__global__ __launch_bounds__(256) void k_validate_faces(const int32_t *__restrict__ faces, int64_t n, int64_t V,
+                                                        int *__restrict__ bad) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int v = faces[i];
+  if (v < 0 || v >= V) atomicOr(bad, 1);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side: context, scratch, C ABI
+// ------------------------------------------------------------------------------------------------------------------
+struct gr_ctx {
+  int device = 0;
+  const float *verts = nullptr;
+  const int32_t *faces = nullptr;
+  int64_t V = 0, F = 0;
+  // bin scratch
+  uint32_t *ctrl = nullptr;
+  int4 *rec = nullptr;
+  uint32_t *entries = nullptr;
+  unsigned long long *stats = nullptr;
+  int *flag = nullptr;
+  int64_t ctrl_stride = 0, rec_stride = 0, ent_cap = 0, ent_cap_request = 0;
+  int Tcap = 0, slots = 0;
+  int64_t rec_F = 0;
+  // winner scratch
+  void *winner = nullptr;
+  size_t winner_bytes = 0;
+  hipStream_t last_stream = nullptr;
+  // profiling
+  bool profiling = false;
+  struct Span { hipEvent_t a, b; int stage; };
+  std::vector<Span> spans;
+  std::vector<hipEvent_t> pool;
+  int prof_views = 0, prof_raster_launches = 0;
+  char err[512] = {0};
+};
+
+namespace {
+
+int fail(gr_ctx *c, int code, const char *fmt, ...) {
+  if (c) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof(c->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define GR_HIP(ctx, call)                                                                          \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess) return fail(ctx, GR_EHIP, "%s: %s", #call, hipGetErrorString(e_));       \
+  } while (0)
+
+enum { ST_SETUP = 0, ST_SCAN, ST_FILL, ST_RASTER, ST_PROJECT, ST_VOTE, ST_GATHER, ST_N };
+
+hipEvent_t take_event(gr_ctx *c) {
+  hipEvent_t e;
+  if (!c->pool.empty()) { e = c->pool.back(); c->pool.pop_back(); return e; }
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+struct Timed {  // RAII span around a kernel group when profiling is on
+  gr_ctx *c; hipStream_t s; int stage; hipEvent_t a = nullptr, b = nullptr;
+  Timed(gr_ctx *c_, hipStream_t s_, int st) : c(c_), s(s_), stage(st) {
+    if (c->profiling) { a = take_event(c); b = take_event(c); if (a) (void)hipEventRecord(a, s); }
+  }
+  ~Timed() {
+    if (c->profiling && a && b) { (void)hipEventRecord(b, s); c->spans.push_back({a, b, stage}); }
+  }
+};
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+int ensure_bins(gr_ctx *c, int n_slots, int T) {
+  const int64_t F = c->F;
+  int64_t want_cap = c->ent_cap_request > 0 ? c->ent_cap_request : (2 * F + 65536);
+  if (c->ctrl && c->slots >= n_slots && c->Tcap >= T && c->rec_F == F && c->ent_cap >= want_cap) return GR_OK;
+  (void)hipDeviceSynchronize();
+  if (c->ctrl) (void)hipFree(c->ctrl);
+  if (c->rec) (void)hipFree(c->rec);
+  if (c->entries) (void)hipFree(c->entries);
+  c->ctrl = nullptr; c->rec = nullptr; c->entries = nullptr;
+  const int slots = n_slots > c->slots ? n_slots : c->slots;
+  const int Tcap = T > c->Tcap ? T : c->Tcap;
+  const int64_t cap = want_cap > c->ent_cap ? want_cap : c->ent_cap;
+  const int64_t ctrl_stride = ((GR_CTRL_HDR + 3 * (int64_t)Tcap) + 63) / 64 * 64;
+  if (hipMalloc(&c->ctrl, sizeof(uint32_t) * ctrl_stride * slots) != hipSuccess ||
+      hipMalloc(&c->rec, sizeof(int4) * 3 * (F > 0 ? F : 1) * slots) != hipSuccess ||
+      hipMalloc(&c->entries, sizeof(uint32_t) * cap * slots) != hipSuccess) {
+    c->slots = 0; c->Tcap = 0; c->ent_cap = 0;
+    return fail(c, GR_ENOMEM, "bin scratch allocation failed (slots=%d F=%lld cap=%lld)", slots, (long long)F,
+                (long long)cap);
+  }
+  c->slots = slots; c->Tcap = Tcap; c->ent_cap = cap; c->ctrl_stride = ctrl_stride; c->rec_stride = 3 * F;
+  c->rec_F = F;
+  return GR_OK;
+}
+
+int ensure_winner(gr_ctx *c, size_t bytes) {
+  if (c->winner && c->winner_bytes >= bytes) return GR_OK;
+  (void)hipDeviceSynchronize();
+  if (c->winner) (void)hipFree(c->winner);
+  c->winner = nullptr; c->winner_bytes = 0;
+  if (hipMalloc(&c->winner, bytes) != hipSuccess) return fail(c, GR_ENOMEM, "winner scratch allocation failed");
+  if (hipMemset(c->winner, 0, bytes) != hipSuccess) return fail(c, GR_EHIP, "winner memset failed");
+  c->winner_bytes = bytes;
+  return GR_OK;
+}
+
+BinArgs make_args(gr_ctx *c, int h, int w) {
+  BinArgs a;
+  a.ctrl = c->ctrl; a.rec = c->rec; a.entries = c->entries; a.stats = c->stats;
+  a.ctrl_stride = c->ctrl_stride; a.rec_stride = c->rec_stride; a.ent_cap = c->ent_cap; a.F = c->F;
+  a.TX = (w + GR_TILE - 1) / GR_TILE; a.TY = (h + GR_TILE - 1) / GR_TILE; a.T = a.TX * a.TY; a.Tcap = c->Tcap;
+  a.h = h; a.w = w;
+  return a;
+}
+
+// bin + rasterize `nb` views starting at camera `cams`, results into out (already offset to the first view)
+int raster_batch(gr_ctx *c, const float *cams, int nb, int h, int w, RasterOut out, hipStream_t s) {
+  BinArgs a = make_args(c, h, w);
+  GR_HIP(c, hipMemsetAsync(c->ctrl, 0, sizeof(uint32_t) * c->ctrl_stride * nb, s));
+  {
+    Timed t(c, s, ST_SETUP);
+    hipLaunchKernelGGL(k_setup_cull, dim3((unsigned)ceil_div(c->F, 256), nb), dim3(256), 0, s, c->verts, c->faces, cams,
+                       a);
+  }
+  {
+    Timed t(c, s, ST_SCAN);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(nb), dim3(1024), 0, s, a);
+  }
+  {
+    Timed t(c, s, ST_FILL);
+    const unsigned g = (unsigned)std::min<int64_t>(ceil_div(c->F, 256), 1024);
+    hipLaunchKernelGGL(k_fill_bins, dim3(g, nb), dim3(256), 0, s, a);
+  }
+  {
+    Timed t(c, s, ST_RASTER);
+    hipLaunchKernelGGL(k_raster_tile, dim3(a.T, nb), dim3(GR_RASTER_THREADS), 0, s, a, out);
+    c->prof_raster_launches += 1;
+  }
+  c->prof_views += nb;
+  GR_HIP(c, hipGetLastError());
+  return GR_OK;
+}
+
+int check_common(gr_ctx *c, int n_views, int h, int w) {
+  if (!c) return GR_EINVAL;
+  if (n_views < 0 || h <= 0 || w <= 0 || h > GR_MAX_DIM || w > GR_MAX_DIM)
+    return fail(c, GR_EINVAL, "bad shape n_views=%d h=%d w=%d (limit %d)", n_views, h, w, GR_MAX_DIM);
+  return GR_OK;
+}
+
+int label_bits(int C) {
+  int lb = 1;
+  while ((1 << lb) < C + 1) ++lb;
+  return lb;
+}
+
+template <typename KeyT>
+int project_labels_t(gr_ctx *c, const int32_t *ids, const uint8_t *labels, int n_views, int h, int w, int C, int LB,
+                     uint32_t *votes, uint32_t *counts, int flags, hipStream_t s) {
+  const int64_t P = (int64_t)h * w, F = c->F;
+  const int B = n_views < GR_MAX_BATCH ? n_views : GR_MAX_BATCH;
+  int rc = ensure_winner(c, sizeof(KeyT) * (size_t)F * B);
+  if (rc) return rc;
+  KeyT *win = (KeyT *)c->winner;
+  for (int v0 = 0; v0 < n_views; v0 += B) {
+    const int nb = (n_views - v0) < B ? (n_views - v0) : B;
+    {
+      Timed t(c, s, ST_PROJECT);
+      hipLaunchKernelGGL(k_winner<KeyT>, dim3((unsigned)ceil_div(P, 256), nb), dim3(256), 0, s, ids + v0 * P,
+                         labels + v0 * P, win, F, h, w, C, LB, (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0);
+    }
+    {
+      Timed t(c, s, ST_VOTE);
+      hipLaunchKernelGGL(k_vote_labels<KeyT>, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s, win, nb, F, C, LB,
+                         votes, counts);
+    }
+  }
+  GR_HIP(c, hipGetLastError());
+  return GR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gr_version(void) { return GR_VERSION; }
+
+int gr_ctx_create(int device, gr_ctx **out) {
+  if (!out) return GR_EINVAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return GR_ENODEVICE;
+  if (hipSetDevice(device) != hipSuccess) return GR_ENODEVICE;
+  gr_ctx *c = new (std::nothrow) gr_ctx();
+  if (!c) return GR_ENOMEM;
+  c->device = device;
+  if (hipMalloc(&c->stats, sizeof(unsigned long long) * 4) != hipSuccess ||
+      hipMalloc(&c->flag, sizeof(int)) != hipSuccess) {
+    delete c;
+    return GR_ENOMEM;
+  }
+  (void)hipMemset(c->stats, 0, sizeof(unsigned long long) * 4);
+  *out = c;
+  return GR_OK;
+}
+
+int gr_ctx_destroy(gr_ctx *c) {
+  if (!c) return GR_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  for (auto &sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+  for (auto e : c->pool) (void)hipEventDestroy(e);
+  if (c->ctrl) (void)hipFree(c->ctrl);
+  if (c->rec) (void)hipFree(c->rec);
+  if (c->entries) (void)hipFree(c->entries);
+  if (c->winner) (void)hipFree(c->winner);
+  if (c->stats) (void)hipFree(c->stats);
+  if (c->flag) (void)hipFree(c->flag);
+  delete c;
+  return GR_OK;
+}
+
+const char *gr_last_error(const gr_ctx *c) { return c ? c->err : "null context"; }
+
+int gr_set_profiling(gr_ctx *c, int enabled) {
+  if (!c) return GR_EINVAL;
+  c->profiling = enabled != 0;
+  for (auto &sp : c->spans) { c->pool.push_back(sp.a); c->pool.push_back(sp.b); }
+  c->spans.clear();
+  c->prof_views = 0; c->prof_raster_launches = 0;
+  return GR_OK;
+}
+
+int gr_get_stage_times(gr_ctx *c, gr_stage_times *o) {
+  if (!c || !o) return GR_EINVAL;
+  float acc[ST_N] = {0};
+  for (auto &sp : c->spans) {
+    GR_HIP(c, hipEventSynchronize(sp.b));
+    float ms = 0.f;
+    GR_HIP(c, hipEventElapsedTime(&ms, sp.a, sp.b));
+    acc[sp.stage] += ms;
+  }
+  o->setup_ms = acc[ST_SETUP]; o->scan_ms = acc[ST_SCAN]; o->fill_ms = acc[ST_FILL]; o->raster_ms = acc[ST_RASTER];
+  o->project_ms = acc[ST_PROJECT]; o->vote_ms = acc[ST_VOTE]; o->gather_ms = acc[ST_GATHER];
+  o->raster_launches = c->prof_raster_launches; o->views = c->prof_views;
+  for (auto &sp : c->spans) { c->pool.push_back(sp.a); c->pool.push_back(sp.b); }
+  c->spans.clear();
+  c->prof_views = 0; c->prof_raster_launches = 0;
+  return GR_OK;
+}
+
+int gr_mesh_upload(gr_ctx *c, const float *verts, const int32_t *faces, int64_t V, int64_t F, void *stream) {
+  if (!c) return GR_EINVAL;
+  if (!verts || !faces || V <= 0 || F <= 0 || V > 0x7FFFFFFFll || F > 0x7FFFFFF0ll)
+    return fail(c, GR_EINVAL, "bad mesh V=%lld F=%lld", (long long)V, (long long)F);
+  hipStream_t s = (hipStream_t)stream;
+  GR_HIP(c, hipSetDevice(c->device));
+  GR_HIP(c, hipMemsetAsync(c->flag, 0, sizeof(int), s));
+  hipLaunchKernelGGL(k_validate_faces, dim3((unsigned)ceil_div(3 * F, 256)), dim3(256), 0, s, faces, 3 * F, V, c->flag);
+  int bad = 0;
+  GR_HIP(c, hipMemcpyAsync(&bad, c->flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  GR_HIP(c, hipStreamSynchronize(s));
+  if (bad) return fail(c, GR_EINDEX, "face index outside [0, %lld)", (long long)V);
+  c->verts = verts; c->faces = faces; c->V = V; c->F = F;
+  return GR_OK;
+}
+
+int gr_raster_face_ids(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_t *ids, float *depth,
+                       void *stream) {
+  int rc = check_common(c, n_views, h, w);
+  if (rc) return rc;
+  if (!c->verts) return fail(c, GR_ENOMESH, "gr_mesh_upload has not been called");
+  if (!cams || (!ids && !depth)) return fail(c, GR_EINVAL, "null cams / outputs");
+  if (n_views == 0) return GR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  GR_HIP(c, hipSetDevice(c->device));
+  const int B = n_views < GR_MAX_BATCH ? n_views : GR_MAX_BATCH;
+  const int T = ((w + GR_TILE - 1) / GR_TILE) * ((h + GR_TILE - 1) / GR_TILE);
+  rc = ensure_bins(c, B, T);
+  if (rc) return rc;
+  c->last_stream = s;
+  GR_HIP(c, hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 4, s));
+  const int64_t P = (int64_t)h * w;
+  for (int v0 = 0; v0 < n_views; v0 += B) {
+    const int nb = (n_views - v0) < B ? (n_views - v0) : B;
+    RasterOut out;
+    out.ids = ids ? ids + v0 * P : nullptr;
+    out.depth = depth ? depth + v0 * P : nullptr;
+    rc = raster_batch(c, cams + (int64_t)v0 * GR_CAM_FLOATS, nb, h, w, out, s);
+    if (rc) return rc;
+  }
+  return GR_OK;
+}
+
+int gr_raster_status(gr_ctx *c, gr_raster_stats *o) {
+  if (!c || !o) return GR_EINVAL;
+  unsigned long long st[4] = {0, 0, 0, 0};
+  GR_HIP(c, hipMemcpyAsync(st, c->stats, sizeof(st), hipMemcpyDeviceToHost, c->last_stream));
+  GR_HIP(c, hipStreamSynchronize(c->last_stream));
+  o->records = (int64_t)st[0]; o->entries = (int64_t)st[1]; o->max_entries = (int64_t)st[2];
+  o->entry_cap = c->ent_cap; o->overflow = (int32_t)st[3];
+  if (st[3]) {
+    // grow on the next call: exact need is known
+    c->ent_cap_request = (int64_t)st[2] + (int64_t)st[2] / 8 + 65536;
+    return fail(c, GR_EOVERFLOW, "bin list overflow: a view needs %llu entries, capacity %lld; retry the call",
+                st[2], (long long)c->ent_cap);
+  }
+  return GR_OK;
+}
+
+int gr_gather_texture_f64(gr_ctx *c, const int32_t *ids, int64_t n_pix, const double *face_tex, int64_t F, int C,
+                          double *out, void *stream) {
+  if (!c || !ids || !face_tex || !out || n_pix < 0 || F <= 0 || C <= 0) return fail(c, GR_EINVAL, "bad gather args");
+  if (n_pix == 0) return GR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  GR_HIP(c, hipSetDevice(c->device));
+  Timed t(c, s, ST_GATHER);
+  hipLaunchKernelGGL(k_gather_texture, dim3((unsigned)ceil_div(n_pix * C, 256)), dim3(256), 0, s, ids, n_pix, face_tex,
+                     F, C, out);
+  GR_HIP(c, hipGetLastError());
+  return GR_OK;
+}
+
+int gr_project_labels_u8(gr_ctx *c, const int32_t *ids, const uint8_t *labels, int n_views, int h, int w, int C,
+                         uint32_t *votes, uint32_t *counts, int flags, void *stream) {
+  int rc = check_common(c, n_views, h, w);
+  if (rc) return rc;
+  if (c->F <= 0) return fail(c, GR_ENOMESH, "gr_mesh_upload has not been called");
+  if (!ids || !labels || !votes || !counts || C <= 0 || C > 255) return fail(c, GR_EINVAL, "bad project args C=%d", C);
+  if (n_views == 0) return GR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  GR_HIP(c, hipSetDevice(c->device));
+  const int LB = label_bits(C);
+  const int64_t P = (int64_t)h * w;
+  if (((P + 1) << LB) <= 0xFFFFFFFFll)
+    return project_labels_t<uint32_t>(c, ids, labels, n_views, h, w, C, LB, votes, counts, flags, s);
+  return project_labels_t<unsigned long long>(c, ids, labels, n_views, h, w, C, LB, votes, counts, flags, s);
+}
+
+int gr_project_values_f64(gr_ctx *c, const int32_t *ids, const double *img, int n_views, int h, int w, int C,
+                          double *sums, uint32_t *counts, int flags, void *stream) {
+  int rc = check_common(c, n_views, h, w);
+  if (rc) return rc;
+  if (c->F <= 0) return fail(c, GR_ENOMESH, "gr_mesh_upload has not been called");
+  if (!ids || !img || !sums || !counts || C <= 0) return fail(c, GR_EINVAL, "bad project args");
+  if (n_views == 0) return GR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  GR_HIP(c, hipSetDevice(c->device));
+  const int64_t P = (int64_t)h * w, F = c->F;
+  const int B = n_views < GR_MAX_BATCH ? n_views : GR_MAX_BATCH;
+  rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F * B);
+  if (rc) return rc;
+  uint32_t *win = (uint32_t *)c->winner;
+  for (int v0 = 0; v0 < n_views; v0 += B) {
+    const int nb = (n_views - v0) < B ? (n_views - v0) : B;
+    {
+      Timed t(c, s, ST_PROJECT);
+      hipLaunchKernelGGL(k_winner<uint32_t>, dim3((unsigned)ceil_div(P, 256), nb), dim3(256), 0, s, ids + v0 * P,
+                         (const uint8_t *)nullptr, win, F, h, w, C, 0, (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0);
+    }
+    {
+      Timed t(c, s, ST_VOTE);
+      hipLaunchKernelGGL(k_vote_values, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s, win, img + v0 * P * C, nb, F,
+                         P, C, sums, counts);
+    }
+  }
+  GR_HIP(c, hipGetLastError());
+  return GR_OK;
+}
+
+int gr_project_view_f64(gr_ctx *c, const int32_t *ids, const double *img, int h, int w, int C, double *tex, int flags,
+                        void *stream) {
+  int rc = check_common(c, 1, h, w);
+  if (rc) return rc;
+  if (c->F <= 0) return fail(c, GR_ENOMESH, "gr_mesh_upload has not been called");
+  if (!ids || !img || !tex || C <= 0) return fail(c, GR_EINVAL, "bad project args");
+  hipStream_t s = (hipStream_t)stream;
+  GR_HIP(c, hipSetDevice(c->device));
+  const int64_t P = (int64_t)h * w, F = c->F;
+  rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F);
+  if (rc) return rc;
+  uint32_t *win = (uint32_t *)c->winner;
+  {
+    Timed t(c, s, ST_PROJECT);
+    hipLaunchKernelGGL(k_winner<uint32_t>, dim3((unsigned)ceil_div(P, 256), 1), dim3(256), 0, s, ids,
+                       (const uint8_t *)nullptr, win, F, h, w, C, 0, (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0);
+  }
+  {
+    Timed t(c, s, ST_VOTE);
+    hipLaunchKernelGGL(k_project_view, dim3((unsigned)ceil_div(F * C, 256)), dim3(256), 0, s, win, img, F, C, tex);
+    hipLaunchKernelGGL(k_clear_u32, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s, win, F);
+  }
+  GR_HIP(c, hipGetLastError());
+  return GR_OK;
+}
+
+int gr_raster_project_labels_u8(gr_ctx *c, const float *cams, const uint8_t *labels, int n_views, int h, int w, int C,
+                                uint32_t *votes, uint32_t *counts, int32_t *ids_or_null, int flags, void *stream) {
+  // Round-1 form: materialise the ids of one batch in caller- or context-owned memory, then project.  (A later
+  // round folds the winner pass into k_raster_tile's epilogue so the ids never leave LDS.)
+  if (!ids_or_null) return fail(c, GR_EINVAL, "ids buffer required in this version");
+  int rc = gr_raster_face_ids(c, cams, n_views, h, w, ids_or_null, nullptr, stream);
+  if (rc) return rc;
+  return gr_project_labels_u8(c, ids_or_null, labels, n_views, h, w, C, votes, counts, flags, stream);
+}
+
+int gr_finalize_votes(gr_ctx *c, const uint32_t *votes, const uint32_t *counts, int64_t F, int C, double *average,
+                      double *summed, double *counts_f64, void *stream) {
+  if (!c || !votes || !counts || !average || !summed || !counts_f64 || F <= 0 || C <= 0)
+    return fail(c, GR_EINVAL, "bad finalize args");
+  hipStream_t s = (hipStream_t)stream;
+  GR_HIP(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_finalize_votes, dim3((unsigned)ceil_div(F * C, 256)), dim3(256), 0, s, votes, counts, F, C,
+                     average, summed, counts_f64);
+  GR_HIP(c, hipGetLastError());
+  return GR_OK;
+}
+
+int gr_finalize_sums_f64(gr_ctx *c, double *sums, const uint32_t *counts, int64_t F, int C, double *average,
+                         double *counts_f64, void *stream) {
+  if (!c || !sums || !counts || !average || !counts_f64 || F <= 0 || C <= 0)
+    return fail(c, GR_EINVAL, "bad finalize args");
+  hipStream_t s = (hipStream_t)stream;
+  GR_HIP(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_finalize_sums, dim3((unsigned)ceil_div(F * C, 256)), dim3(256), 0, s, sums, counts, F, C,
+                     average, counts_f64);
+  GR_HIP(c, hipGetLastError());
+  return GR_OK;
+}
+
+int gr_argmax_nonzero_f64(gr_ctx *c, const double *array, int64_t F, int C, double *out, void *stream) {
+  if (!c || !array || !out || F <= 0 || C <= 0) return fail(c, GR_EINVAL, "bad argmax args");
+  hipStream_t s = (hipStream_t)stream;
+  GR_HIP(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_argmax_nonzero, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s, array, F, C, out);
+  GR_HIP(c, hipGetLastError());
+  return GR_OK;
+}
+
+}  // extern "C"

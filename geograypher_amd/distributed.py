@@ -1,0 +1,44 @@
+"""Multi-GPU layer of the projection path: views shard, votes reduce.
+
+One process per GPU (torchrun).  `project_images` for a view depends only on (mesh, camera_i, image_i)
+(reference: meshes.py:1977-2002) and the cross-view state is a commutative integer sum (meshes.py:2057-2067), so
+views are dealt round-robin to ranks with the mesh replicated, and the ONLY exchange is one all-reduce(sum) of the
+per-face vote tensor [F x C] + counts [F] at the end (backend "nccl" is RCCL over xGMI on ROCm; "gloo" on CPU for
+tests).  uint32 votes travel as int32: sums stay below 2^31 for any realistic number of views.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+
+def rank_world() -> Tuple[int, int]:
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_views(n_views: int, rank: int, world: int) -> List[int]:
+    """Indices of the views rank `rank` processes: i with i % world == rank."""
+    return list(range(rank, n_views, world))
+
+
+def all_reduce_votes(votes, counts, group=None):
+    """Sum the per-face votes and counts of all ranks in place with ONE collective.
+
+    votes (F,C) and counts (F,) are packed into a single [F x (C+1)] int32 buffer so that exactly one all-reduce
+    crosses xGMI (24 MB for 1.2 M faces x 4 classes)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return votes, counts
+    F, C = votes.shape
+    packed = torch.empty((F, C + 1), dtype=torch.int32, device=votes.device)
+    packed[:, :C] = votes
+    packed[:, C] = counts
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    votes.copy_(packed[:, :C])
+    counts.copy_(packed[:, C])
+    return votes, counts

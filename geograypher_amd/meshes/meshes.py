@@ -1,0 +1,541 @@
+"""`TexturedPhotogrammetryMesh`: the image<->mesh projection path of geograypher on MI355X.
+
+Host-side mirror of the hot-path slice of geograypher/meshes/meshes.py (1631-2084): same method names, arguments,
+return types and error behaviour, so `render_labels` / `aggregate_images`-style callers run unchanged.  All per-pixel
+and per-face work happens in hand-written HIP kernels behind the C ABI of include/geograster.h:
+
+    pix2face                     -> gr_raster_face_ids           (replaces the VTK render of meshes.py:1776-1836)
+    render_flat                  -> + gr_gather_texture_f64      (meshes.py:1921-1937)
+    project_images               -> + gr_project_view_f64        (meshes.py:1987-2002)
+    aggregate_projected_images   -> + gr_project_labels_u8 / gr_project_values_f64 + gr_finalize_*  (2044-2084)
+
+There is no CPU implementation in this package: without the HIP extension or a GPU the constructor of the backend
+raises.  (`backend=` exists so tests can drive this host logic against the CPU oracle; the product never does.)
+"""
+from __future__ import annotations
+
+import hashlib
+import logging
+import sys
+import typing
+from pathlib import Path
+
+import numpy as np
+
+from geograypher_amd.cameras.cameras import PhotogrammetryCamera, PhotogrammetryCameraSet, vtk_like_near_plane
+from geograypher_amd.constants import CACHE_FOLDER, EARTH_CENTERED_EARTH_FIXED_CRS, PATH_TYPE
+
+try:  # tqdm is optional: the reference wraps its view loops in it (meshes.py:2049-2053)
+    from tqdm import tqdm
+except Exception:  # pragma: no cover
+
+    def tqdm(it, **_):
+        return it
+
+
+class LocalMesh:
+    """A mesh expressed in the cameras' chunk-local frame: what `get_mesh_in_cameras_coords` returns in place of
+    the reference's transformed `pv.PolyData` (meshes.py:1641-1676)."""
+
+    def __init__(self, points: np.ndarray, faces: np.ndarray, key: typing.Optional[str] = None):
+        self.points = points
+        self.faces = faces
+        self.key = key
+
+    @property
+    def n_faces(self):
+        return int(self.faces.shape[0])
+
+    def bounds(self) -> np.ndarray:
+        lo, hi = self.points.min(axis=0), self.points.max(axis=0)
+        return np.array([lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]], dtype=np.float64)
+
+
+def _parse_mesh(mesh) -> typing.Tuple[np.ndarray, np.ndarray]:
+    """Accept (points, faces), a pyvista-like object (.points/.faces), or a .npz file with those two arrays."""
+    if isinstance(mesh, (str, Path)):
+        path = Path(mesh)
+        if path.suffix != ".npz":
+            raise NotImplementedError(
+                f"Mesh file loading is limited to .npz (points, faces) here; {path.suffix} readers (pyvista) are "
+                "outside the projection path (SURVEY.md section 8)"
+            )
+        with np.load(path) as data:
+            return _parse_mesh((data["points"], data["faces"]))
+    if isinstance(mesh, (tuple, list)) and len(mesh) == 2:
+        points, faces = mesh
+    elif hasattr(mesh, "points") and hasattr(mesh, "faces"):
+        points, faces = mesh.points, mesh.faces
+    else:
+        raise TypeError("mesh must be (points, faces), an object with .points/.faces, or a .npz path")
+    points = np.asarray(points)
+    faces = np.asarray(faces)
+    if faces.ndim == 1:  # pyvista's padded layout [3, a, b, c, 3, ...]
+        faces = faces.reshape(-1, 4)
+        if not np.all(faces[:, 0] == 3):
+            raise ValueError("only triangular faces are supported")
+        faces = faces[:, 1:4]
+    if points.ndim != 2 or points.shape[1] != 3 or faces.ndim != 2 or faces.shape[1] != 3:
+        raise ValueError(f"expected (V,3) points and (F,3) faces, got {points.shape} and {faces.shape}")
+    return points, faces.astype(np.int64, copy=True)
+
+
+class TexturedPhotogrammetryMesh:
+    def __init__(
+        self,
+        mesh,
+        input_CRS=EARTH_CENTERED_EARTH_FIXED_CRS,
+        downsample_target: float = 1.0,
+        texture: typing.Union[PATH_TYPE, np.ndarray, None] = None,
+        texture_column_name: typing.Union[PATH_TYPE, None] = None,
+        IDs_to_labels: typing.Union[PATH_TYPE, dict, None] = None,
+        shift: typing.Union[np.ndarray, None] = None,
+        ROI=None,
+        ROI_buffer_meters: float = 0,
+        log_level: str = "INFO",
+        device: typing.Optional[int] = None,
+        backend=None,
+        neg1_is_last_face: bool = True,
+    ):
+        """A textured mesh that renders to / aggregates from camera views on an MI355X.
+
+        Same leading arguments as the reference constructor (meshes.py:55-156).  `mesh` is `(points (V,3), faces
+        (F,3))`, any object with `.points`/`.faces` (pyvista layout accepted) or a `.npz` path.  The coordinates are
+        interpreted in `input_CRS`; only EPSG:4978 (the frame the reference reprojects every mesh into,
+        meshes.py:1659) is accepted because CRS reprojection is outside the projection path.  Decimation, ROI
+        cropping and vector/raster texture files are likewise outside it and raise NotImplementedError.
+
+        Extra keyword arguments (defaults keep reference behaviour):
+            device: GPU index for the HIP backend (default: current torch device).
+            backend: test hook -- an object with the `HipRaster` interface.
+            neg1_is_last_face: reproduce meshes.py:1998-2001, where background pixels (-1) index the LAST face
+                during projection.  True matches the reference's aggregated textures on every face.
+        """
+        if downsample_target != 1.0:
+            raise NotImplementedError("mesh decimation is outside the projection path (meshes.py:215-226)")
+        if ROI is not None:
+            raise NotImplementedError("ROI cropping is outside the projection path (meshes.py:646-731)")
+        if input_CRS is not None and str(input_CRS).upper().replace(" ", "") not in ("EPSG:4978",):
+            raise NotImplementedError(
+                f"input_CRS={input_CRS!r}: only EPSG:4978 meshes are accepted (CRS reprojection needs pyproj and is "
+                "outside the projection path)"
+            )
+        self.downsample_target = downsample_target
+        self.CRS = input_CRS
+        self.texture = None
+        self.vertex_texture = None
+        self.face_texture = None
+        self.IDs_to_labels = None
+        self.neg1_is_last_face = neg1_is_last_face
+
+        self.logger = logging.getLogger(f"mesh_{id(self)}")
+        self.logger.setLevel(log_level)
+        if not self.logger.hasHandlers():
+            self.logger.addHandler(logging.StreamHandler(stream=sys.stdout))
+
+        self.logger.info("Loading mesh")
+        points, faces = _parse_mesh(mesh)
+        if shift is not None:
+            points = points + np.asarray(shift).reshape(1, 3)
+        self.points = points
+        self.faces = faces
+
+        self._device_index = device
+        self._backend = backend
+        self._uploaded_key = None
+
+        self.logger.info("Loading texture")
+        if isinstance(IDs_to_labels, (str, Path)):
+            import json
+
+            with open(IDs_to_labels, "r") as file:
+                IDs_to_labels = {int(k): v for k, v in json.load(file).items()}
+        self.IDs_to_labels = IDs_to_labels
+        if isinstance(texture, (str, Path)):
+            if Path(texture).suffix != ".npy":
+                raise NotImplementedError("only .npy texture files are read here (meshes.py:533-644 is out of scope)")
+            texture = np.load(texture)
+        if texture is not None:
+            self.set_texture(np.asarray(texture))
+
+    # -- backend -------------------------------------------------------------------------------------------------
+    @property
+    def backend(self):
+        if self._backend is None:
+            from geograypher_amd._hip import HipRaster
+
+            self._backend = HipRaster(self._device_index)  # raises when the extension or the GPU is missing
+        return self._backend
+
+    # -- texture (reference: meshes.py:325-531) ------------------------------------------------------------------
+    def standardize_texture(self, texture_array: np.ndarray):
+        if texture_array.ndim == 1:
+            texture_array = np.expand_dims(texture_array, axis=1)
+        elif texture_array.ndim != 2:
+            raise ValueError(f"Input texture should have 1 or 2 dimensions but instead has {texture_array.ndim}")
+        return texture_array
+
+    def is_discrete_texture(self):
+        return self.IDs_to_labels is not None
+
+    def get_IDs_to_labels(self):
+        return self.IDs_to_labels
+
+    def set_texture(self, texture_array, is_vertex_texture: typing.Union[bool, None] = None, delete_existing=True):
+        """reference: meshes.py:476-531 (same inference rules and errors)."""
+        texture_array = self.standardize_texture(np.asarray(texture_array))
+        if is_vertex_texture is None:
+            n_values = texture_array.shape[0]
+            n_faces = self.faces.shape[0]
+            n_verts = self.points.shape[0]
+            if n_verts == n_faces:
+                raise ValueError(
+                    "Cannot infer whether texture should be applied to vertices of faces because the number is the same"
+                )
+            elif n_values == n_verts:
+                is_vertex_texture = True
+            elif n_values == n_faces:
+                is_vertex_texture = False
+            else:
+                raise ValueError(
+                    f"The number of elements in the texture ({n_values}) did not match the number of faces "
+                    f"({n_faces}) or vertices ({n_verts})"
+                )
+        if is_vertex_texture:
+            self.vertex_texture = texture_array
+            if delete_existing:
+                self.face_texture = None
+        else:
+            self.face_texture = texture_array
+            if delete_existing:
+                self.vertex_texture = None
+
+    def vert_to_face_texture(self, vert_IDs, discrete=True):
+        """reference: meshes.py:947-987.  Continuous textures: mean of the three vertex rows.  The discrete branch
+        of the reference votes with an UNSEEDED random tie-break (utils/numeric.py:622-659); here ties go to the
+        smallest value so results are reproducible."""
+        if vert_IDs is None:
+            raise ValueError("None")
+        vert_IDs = np.squeeze(vert_IDs)
+        if vert_IDs.ndim != 1 and discrete:
+            raise ValueError(
+                f"Can only perform discrete conversion with one dimensional array but instead had {vert_IDs.ndim}"
+            )
+        values_per_face = vert_IDs[self.faces]
+        if not discrete:
+            return np.mean(values_per_face, axis=1)
+        a, b, c = values_per_face[:, 0], values_per_face[:, 1], values_per_face[:, 2]
+        out = np.where((b == c) & np.isfinite(b), b, np.fmin(np.fmin(a, b), c))
+        out = np.where(((a == b) | (a == c)) & np.isfinite(a), a, out)
+        return out
+
+    def get_texture(self, request_vertex_texture: typing.Union[bool, None] = None, try_verts_faces_conversion=True):
+        """reference: meshes.py:337-378"""
+        if self.vertex_texture is None and self.face_texture is None:
+            return
+        if request_vertex_texture is None:
+            if self.vertex_texture is not None and self.face_texture is not None:
+                raise ValueError("Ambigious which texture is requested, set request_vertex_texture appropriately")
+            request_vertex_texture = self.vertex_texture is not None
+        if request_vertex_texture:
+            if self.vertex_texture is not None:
+                return self.standardize_texture(self.vertex_texture)
+            raise NotImplementedError("face -> vertex texture conversion is outside the projection path")
+        if self.face_texture is not None:
+            return self.standardize_texture(self.face_texture)
+        elif try_verts_faces_conversion:
+            face_texture = self.vert_to_face_texture(self.vertex_texture, discrete=self.is_discrete_texture())
+            self.set_texture(face_texture, is_vertex_texture=False)
+            return self.face_texture
+        raise ValueError("Face texture not present and conversion was not requested")
+
+    # -- geometry ------------------------------------------------------------------------------------------------
+    def get_mesh_hash(self):
+        """sha256 over the vertex bytes and pyvista's padded int64 face layout (reference: meshes.py:1631-1639)."""
+        hasher = hashlib.sha256()
+        hasher.update(np.ascontiguousarray(self.points).tobytes())
+        padded = np.concatenate([np.full((self.faces.shape[0], 1), 3, dtype=np.int64), self.faces], axis=1)
+        hasher.update(np.ascontiguousarray(padded).tobytes())
+        return hasher.hexdigest()
+
+    def get_mesh_in_cameras_coords(self, cameras, inplace: bool = False) -> typing.Optional[LocalMesh]:
+        """Mesh in the chunk-local frame of `cameras` (reference: meshes.py:1641-1676): x_local = inv(T) x_ecef in
+        float64, with T = cameras.get_local_to_epsg_4978_transform()."""
+        T = cameras.get_local_to_epsg_4978_transform()
+        T = np.eye(4) if T is None else np.asarray(T, dtype=np.float64)
+        epsg_4978_to_camera = np.linalg.inv(T)
+        pts = np.asarray(self.points, dtype=np.float64)
+        local = pts @ epsg_4978_to_camera[:3, :3].T + epsg_4978_to_camera[:3, 3]
+        mesh = LocalMesh(local, self.faces, key=hashlib.sha1(T.tobytes()).hexdigest())
+        if inplace:
+            self.points = local
+            self.CRS = None
+            return None
+        return mesh
+
+    def _ensure_uploaded(self, mesh: LocalMesh):
+        key = (id(self.faces), mesh.key if mesh.key is not None else id(mesh.points))
+        if self._uploaded_key != key:
+            self.backend.upload_mesh(mesh.points.astype(np.float32), mesh.faces.astype(np.int32))
+            self._uploaded_key = key
+
+    # -- pix2face ------------------------------------------------------------------------------------------------
+    def _pix2face_device(self, cameras, mesh, render_img_scale, near=None, principal_point="center"):
+        """(N,h,w) int32 device tensor of face ids for a camera or camera set."""
+        if isinstance(cameras, PhotogrammetryCamera):
+            cameras = PhotogrammetryCameraSet([cameras], local_to_epsg_4978_transform=cameras._local_to_epsg_4978_transform)
+        if mesh is None:
+            mesh = self.get_mesh_in_cameras_coords(cameras)
+        elif not isinstance(mesh, LocalMesh):
+            pts, fcs = _parse_mesh(mesh)
+            mesh = LocalMesh(np.asarray(pts, dtype=np.float64), fcs)
+        self._ensure_uploaded(mesh)
+        if near is None:
+            bounds = mesh.bounds()
+            near = [vtk_like_near_plane(np.asarray(c.cam_to_world_transform, dtype=np.float64), bounds) for c in cameras.cameras]
+        records = cameras.get_raster_records(render_img_scale, near=near, principal_point=principal_point)
+        h, w = cameras.cameras[0].get_image_size(render_img_scale)
+        return self.backend.raster_face_ids(records, h, w)
+
+    def pix2face(
+        self,
+        cameras: typing.Union[PhotogrammetryCamera, PhotogrammetryCameraSet],
+        mesh=None,
+        render_img_scale: float = 1,
+        save_to_cache: bool = False,
+        cache_folder: typing.Union[None, PATH_TYPE] = CACHE_FOLDER,
+        distortion_set: typing.Optional[PhotogrammetryCameraSet] = None,
+        apply_distortion: bool = True,
+        return_tensor: bool = False,
+        near: typing.Union[None, float, typing.List[float]] = None,
+        principal_point: str = "center",
+    ):
+        """Face hit by the ray through each pixel, per camera (reference: meshes.py:1678-1856).
+
+        Returns an int64 numpy array of shape (h, w) for a single camera or (n_cameras, h, w) for a camera set, with
+        -1 where no face is visible and (h, w) = (int(H*scale), int(W*scale)).  With `return_tensor=True` the int32
+        device tensor is returned instead (no host copy).  `save_to_cache` / `cache_folder` are accepted for API
+        compatibility and unused, as in the reference's own GPU plugin (derived_meshes.py:665-668): rasterizing on
+        the GPU is faster than reading a cached array from disk.
+        """
+        if distortion_set is None and apply_distortion:
+            self.logger.warning("Distortion requested but no distortion parameters provided. Skipping")
+            apply_distortion = False
+        single = isinstance(cameras, PhotogrammetryCamera)
+        if not single and not isinstance(cameras, PhotogrammetryCameraSet):
+            raise TypeError()
+        ids = self._pix2face_device(cameras, mesh, render_img_scale, near=near, principal_point=principal_point)
+        if apply_distortion:
+            # reference: meshes.py:1842-1854.  A base camera set raises NotImplementedError here, as the reference does
+            cams = [cameras] if single else cameras.cameras
+            warped = [
+                distortion_set.warp_dewarp_image(
+                    camera=cam,
+                    input_image=ids[i].cpu().numpy().astype(np.int64),
+                    warped_to_ideal=False,
+                    fill_value=-1,
+                    interpolation_order=0,
+                    image_scale=render_img_scale,
+                )
+                for i, cam in enumerate(cams)
+            ]
+            out = np.stack(warped, axis=0)
+            return out[0] if single else out
+        if return_tensor:
+            return ids[0] if single else ids
+        out = ids.cpu().numpy().astype(np.int64)
+        return out[0] if single else out
+
+    # -- render_flat ---------------------------------------------------------------------------------------------
+    def render_flat(
+        self,
+        cameras: typing.Union[PhotogrammetryCamera, PhotogrammetryCameraSet],
+        batch_size: int = 1,
+        render_img_scale: float = 1,
+        return_camera: bool = False,
+        **pix2face_kwargs,
+    ):
+        """Generator: the face texture seen from each camera, (h, w, C) float64 with NaN where no face is visible
+        (reference: meshes.py:1858-1942, including its batch arithmetic)."""
+        mesh = self.get_mesh_in_cameras_coords(cameras)
+        if isinstance(cameras, PhotogrammetryCamera):
+            cameras = PhotogrammetryCameraSet([cameras], local_to_epsg_4978_transform=cameras._local_to_epsg_4978_transform)
+        elif not isinstance(cameras, PhotogrammetryCameraSet):
+            raise TypeError()
+        face_texture = self.get_texture(request_vertex_texture=False, try_verts_faces_conversion=True)
+        face_texture = np.asarray(face_texture, dtype=np.float64)
+        tex_dev = None
+
+        batch_stop = max(len(cameras) - batch_size + 1, 1)
+        for batch_start in range(0, batch_stop, batch_size):
+            batch_cameras = cameras[batch_start : batch_start + batch_size]
+            batch_pix2face = self.pix2face(
+                cameras=batch_cameras, mesh=mesh, render_img_scale=render_img_scale, return_tensor=True,
+                **pix2face_kwargs,
+            )
+            if isinstance(batch_pix2face, np.ndarray):  # distortion applied on the host
+                batch_pix2face = self.backend._dev(batch_pix2face.astype(np.int32), _torch().int32)
+            if tex_dev is None:
+                tex_dev = self.backend._dev(face_texture, _torch().float64)
+            rendered = self.backend.gather_texture(batch_pix2face, tex_dev).cpu().numpy()
+            for i in range(rendered.shape[0]):
+                if return_camera:
+                    yield (rendered[i], batch_cameras[i])
+                else:
+                    yield rendered[i]
+
+    # -- project_images ------------------------------------------------------------------------------------------
+    def _iter_view_inputs(self, cameras, batch_size, aggregate_img_scale, check_null_image, pix2face_kwargs):
+        """Shared view loop of project_images / aggregate_projected_images (reference: meshes.py:1970-1996):
+        yields (view index, ids (h,w) int32 device tensor, image (h,w,C) float64 numpy or None for a null image,
+        n_channels).  Trailing cameras that do not fill a batch are dropped, as in the reference (1976-1977)."""
+        mesh = self.get_mesh_in_cameras_coords(cameras)
+        torch = _torch()
+        batch_stop = max(len(cameras) - batch_size + 1, 1)
+        for batch_start in range(0, batch_stop, batch_size):
+            batch_inds = list(range(batch_start, batch_start + batch_size))
+            batch_cameras = cameras.get_subset_cameras(batch_inds)
+            batch_pix2face = self.pix2face(
+                cameras=batch_cameras, mesh=mesh, render_img_scale=aggregate_img_scale, return_tensor=True,
+                **pix2face_kwargs,
+            )
+            if isinstance(batch_pix2face, np.ndarray):  # distortion applied on the host
+                batch_pix2face = self.backend._dev(batch_pix2face.astype(np.int32), torch.int32)
+            for i in range(batch_pix2face.shape[0]):
+                img = np.asarray(cameras.get_image_by_index(batch_start + i, aggregate_img_scale))
+                n_channels = 1 if img.ndim == 2 else img.shape[-1]
+                if check_null_image and not np.any(np.isfinite(img)):
+                    yield batch_start + i, batch_pix2face[i], None, n_channels
+                    continue
+                flat = np.reshape(img, (img.shape[0], img.shape[1], -1)).astype(np.float64)
+                yield batch_start + i, batch_pix2face[i], flat, n_channels
+
+    def project_images(
+        self,
+        cameras: typing.Union[PhotogrammetryCamera, PhotogrammetryCameraSet],
+        batch_size: int = 1,
+        aggregate_img_scale: float = 1,
+        check_null_image: bool = False,
+        **pix2face_kwargs,
+    ):
+        """Generator: per-face projection of each camera's image, (F, C) float64 with NaN for unseen faces
+        (reference: meshes.py:1944-2002).  Per view the LAST pixel (row-major) mapped to a face provides its value;
+        with `neg1_is_last_face` background pixels address the last face exactly like numpy's index -1 does."""
+        n_faces = self.faces.shape[0]
+        for _, ids, img, n_channels in self._iter_view_inputs(
+            cameras, batch_size, aggregate_img_scale, check_null_image, pix2face_kwargs
+        ):
+            if img is None:
+                yield np.full((n_faces, n_channels), fill_value=np.nan)
+            else:
+                yield self.backend.project_view(ids, img, neg1_is_last_face=self.neg1_is_last_face).cpu().numpy()
+
+    # -- aggregate_projected_images ------------------------------------------------------------------------------
+    def aggregate_projected_images(
+        self,
+        cameras: typing.Union[PhotogrammetryCamera, PhotogrammetryCameraSet],
+        batch_size: int = 1,
+        aggregate_img_scale: float = 1,
+        return_all: bool = False,
+        distributed: bool = False,
+        **kwargs,
+    ):
+        """Average the images of many cameras per face (reference: meshes.py:2004-2084).
+
+        Returns `(average (F,C), {"projection_counts": (F,), "summed_projections": (F,C)[, "all_projections"]})`,
+        all float64, NaN for faces no view observed.
+
+        Fast path: when `cameras` can supply class-index images (`get_label_index_image`, e.g. a
+        `SegmentorPhotogrammetryCameraSet`) and `return_all` is False, face ids and vote histograms stay on the GPU:
+        per view one winner pass + one vote pass in uint32 (bit-exact, order independent), one finalize at the end.
+        `distributed=True` (inside an initialised torch.distributed job): this rank handles views rank::world and the
+        per-face votes are summed with ONE all-reduce (RCCL over xGMI) before finalising.
+        """
+        from geograypher_amd import distributed as dist_utils
+
+        if len(cameras) == 0 or batch_size > len(cameras):
+            raise IndexError("list index out of range")  # what the reference's get_subset_cameras raises here
+        rank, world = dist_utils.rank_world() if distributed else (0, 1)
+        torch = _torch()
+        n_faces = self.faces.shape[0]
+        check_null_image = bool(kwargs.pop("check_null_image", False))
+
+        batch_stop = max(len(cameras) - batch_size + 1, 1)
+        view_inds = [i for s in range(0, batch_stop, batch_size) for i in range(s, s + batch_size)]
+
+        label_fn = getattr(cameras, "get_label_index_image", None) if not return_all else None
+        first_label = label_fn(view_inds[0], aggregate_img_scale) if label_fn is not None else None
+
+        if first_label is not None:
+            # ---- index-label fast path: uint32 votes on device --------------------------------------------------------
+            my_inds = view_inds[rank::world]
+            mesh = self.get_mesh_in_cameras_coords(cameras)
+            C = int(cameras.n_image_channels())
+            self._ensure_uploaded(mesh)
+            votes, counts = self.backend.new_vote_buffers(C)
+            chunk = max(int(batch_size), 8)
+            for c0 in tqdm(range(0, len(my_inds), chunk), total=(len(my_inds) + chunk - 1) // chunk,
+                           desc="Aggregating projected viewpoints"):
+                inds = my_inds[c0 : c0 + chunk]
+                sub = cameras.get_subset_cameras(inds)
+                ids = self._pix2face_device(sub, mesh, aggregate_img_scale, **_raster_kwargs(kwargs))
+                labels = [first_label if i == view_inds[0] else label_fn(i, aggregate_img_scale) for i in inds]
+                if isinstance(labels[0], torch.Tensor):
+                    lab = torch.stack([l.to(self.backend.device, torch.uint8) for l in labels], dim=0)
+                else:
+                    lab = np.stack([np.asarray(l).astype(np.uint8) for l in labels], axis=0)
+                self.backend.project_labels(ids, lab, C, votes, counts, neg1_is_last_face=self.neg1_is_last_face)
+            if distributed and world > 1:
+                dist_utils.all_reduce_votes(votes, counts)
+            avg, summed, cnt = self.backend.finalize_votes(votes, counts)
+            return avg.cpu().numpy(), {
+                "projection_counts": cnt.cpu().numpy(),
+                "summed_projections": summed.cpu().numpy(),
+            }
+
+        # ---- general path: float images; nansum + finite-row counts accumulate on device (meshes.py:2057-2067) ----------
+        if distributed and world > 1:
+            raise NotImplementedError("distributed aggregation is implemented for class-index label images")
+        all_projections = [] if return_all else None
+        single_view = len(view_inds) == 1
+        sums = counts = first = None
+        gen = self._iter_view_inputs(cameras, batch_size, aggregate_img_scale, check_null_image, kwargs)
+        for _, ids, img, n_channels in tqdm(gen, total=len(cameras), desc="Aggregating projected viewpoints"):
+            if sums is None:
+                sums = torch.zeros((n_faces, n_channels), dtype=torch.float64, device=self.backend.device)
+                counts = torch.zeros((n_faces,), dtype=torch.int32, device=self.backend.device)
+            if return_all or single_view:
+                if img is None:
+                    proj = np.full((n_faces, n_channels), fill_value=np.nan)
+                else:
+                    proj = self.backend.project_view(ids, img, neg1_is_last_face=self.neg1_is_last_face).cpu().numpy()
+                if return_all:
+                    all_projections.append(proj)
+                first = proj if first is None else first
+            if img is not None:
+                self.backend.project_values(ids, img, sums, counts, neg1_is_last_face=self.neg1_is_last_face)
+        avg, summed, cnt = self.backend.finalize_sums(sums, counts)
+        avg, summed, cnt = avg.cpu().numpy(), summed.cpu().numpy(), cnt.cpu().numpy()
+        if single_view:
+            # the reference keeps the first projection as is (meshes.py:2057-2058): a NaN channel of a seen face survives
+            summed = first.astype(float)
+            summed[cnt == 0] = np.nan
+            with np.errstate(divide="ignore", invalid="ignore"):
+                avg = np.divide(summed, np.expand_dims(cnt, 1))
+        info = {"projection_counts": cnt, "summed_projections": summed}
+        if return_all:
+            info["all_projections"] = all_projections
+        return avg, info
+
+    # the north star's name for the same method
+    aggregate_viewpoints = aggregate_projected_images
+
+
+def _raster_kwargs(kwargs: dict) -> dict:
+    return {k: kwargs[k] for k in ("near", "principal_point") if k in kwargs}
+
+
+def _torch():
+    import torch
+
+    return torch

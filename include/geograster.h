@@ -1,0 +1,145 @@
+/*
+ * include/geograster.h -- C ABI of libgeograster (MI355X / gfx950 HIP implementation of geograypher's
+ * image<->mesh projection hot path).
+ *
+ * This is the drop-in boundary.  The reference (pure Python) has no FFI for this path; the seam it offers is the
+ * subclass-override plugin `pix2face` (geograypher/meshes/derived_meshes.py:642-650, precedent
+ * TexturedPhotogrammetryMeshPyTorch3dRendering) plus the numpy stages that consume its output.  Each entry point
+ * below names the reference lines it replaces; INTEGRATION.md shows the ctypes stub a reference maintainer adds.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer (hipMalloc / torch tensor .data_ptr()) unless its name ends in _h.
+ *  - The caller allocates and owns all inputs and outputs.  The library allocates only per-context scratch
+ *    (bin lists, per-face winners), grown lazily, freed by gr_ctx_destroy.
+ *  - All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream) and is
+ *    asynchronous.  No hidden synchronisation except: gr_ctx_destroy, gr_mesh_upload (index validation) and
+ *    scratch growth (hipMalloc/hipFree when a larger batch, image or mesh is first seen).
+ *  - Return value: 0 (GR_OK) or a negative GR_E* code; text via gr_last_error().  No C++ exception crosses the ABI.
+ *  - A context belongs to one (device, host thread); distinct contexts are independent.
+ */
+#ifndef GEOGRASTER_H
+#define GEOGRASTER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GR_VERSION 100 /* 0.1.0 */
+
+enum {
+  GR_OK = 0,
+  GR_EINVAL = -1,    /* bad argument / shape                                                  */
+  GR_EHIP = -2,      /* HIP runtime error (text in gr_last_error)                             */
+  GR_ENOMEM = -3,    /* scratch allocation failed                                             */
+  GR_ENOMESH = -4,   /* no mesh uploaded                                                      */
+  GR_EINDEX = -5,    /* face index outside [0, V) found by gr_mesh_upload                     */
+  GR_EOVERFLOW = -6, /* bin-list capacity exceeded: call gr_raster_status, then retry         */
+  GR_ENODEVICE = -7  /* no usable gfx950 device                                               */
+};
+
+/* flags for the projection / aggregation entry points */
+enum {
+  GR_FLAG_NEG1_IS_LAST_FACE = 1 /* reproduce meshes.py:1998-2001: pix2face == -1 writes the LAST face */
+};
+
+/* camera record: 16 floats per view, see DESIGN.md R0.
+ *  [0..8]  R   cam_to_world rotation, row-major       (cameras.py:84, 446-477)
+ *  [9..11] t   camera position (chunk-local frame)
+ *  [12]    f_eff   focal length in pixels of the RENDERED image  = f * h / image_height
+ *  [13,14] cxp,cyp principal point in pixels of the rendered image (pyvista path: w/2, h/2)
+ *  [15]    near    faces with any vertex at camera depth <= near are discarded                 */
+#define GR_CAM_FLOATS 16
+
+typedef struct gr_ctx gr_ctx;
+
+/* per-stage device times of the most recent profiled call, milliseconds (see gr_set_profiling) */
+typedef struct gr_stage_times {
+  float setup_ms;   /* k_setup_cull : transform + cull + record + tile counts      */
+  float scan_ms;    /* k_scan_tiles                                                */
+  float fill_ms;    /* k_fill_bins                                                 */
+  float raster_ms;  /* k_raster_tile (the dominant kernel)                         */
+  float project_ms; /* k_winner_* : last-writer-wins pixel -> face                 */
+  float vote_ms;    /* k_vote_*   : per-face accumulate                            */
+  float gather_ms;  /* k_gather_texture                                            */
+  int32_t raster_launches;
+  int32_t views;
+} gr_stage_times;
+
+typedef struct gr_raster_stats {
+  int64_t records;      /* faces that survived culling, summed over the views of the last call */
+  int64_t entries;      /* (face, tile) pairs, summed over views                               */
+  int64_t max_entries;  /* largest per-view entry count seen (capacity needed)                 */
+  int64_t entry_cap;    /* current per-view capacity                                           */
+  int32_t overflow;     /* != 0: some view exceeded entry_cap, output incomplete               */
+} gr_raster_stats;
+
+int gr_version(void);
+
+/* context -------------------------------------------------------------------------------------------------- */
+int gr_ctx_create(int device, gr_ctx **out);
+int gr_ctx_destroy(gr_ctx *ctx);
+const char *gr_last_error(const gr_ctx *ctx);
+
+/* Turn per-stage hipEvent timing on (1) or off (0).  When on, events are recorded on `stream` around every
+ * kernel group; gr_get_stage_times synchronises on them. */
+int gr_set_profiling(gr_ctx *ctx, int enabled);
+int gr_get_stage_times(gr_ctx *ctx, gr_stage_times *out_h);
+
+/* mesh -- replaces the per-view mesh + colour upload of meshes.py:1776-1817 (plotter.clear/add_mesh) and the
+ * coordinate hand-over of meshes.py:1641-1676.  verts: V x 3 fp32 in the cameras' local frame; faces: F x 3 int32.
+ * Borrowed: the caller keeps both alive until the next upload or gr_ctx_destroy.  Validates 0 <= index < V. */
+int gr_mesh_upload(gr_ctx *ctx, const float *verts, const int32_t *faces, int64_t V, int64_t F, void *stream);
+
+/* pix2face -- replaces meshes.py:1776-1836 (encode ids, VTK render, decode, background mask) for n_views
+ * cameras of equal image size.  ids: n_views x h x w int32, background -1.  depth (may be NULL): n_views x h x w
+ * fp32 camera-space depth of the visible face, +inf for background.  Rule-set: DESIGN.md R0-R6. */
+int gr_raster_face_ids(gr_ctx *ctx, const float *cams, int n_views, int h, int w, int32_t *ids, float *depth,
+                       void *stream);
+int gr_raster_status(gr_ctx *ctx, gr_raster_stats *out_h); /* synchronises `stream` of the last raster call */
+
+/* render_flat gather -- replaces meshes.py:1921-1937: out[p,:] = face_tex[ids[p],:] where ids[p] != -1 else NaN.
+ * ids: n_pix int32; face_tex: F x C f64; out: n_pix x C f64. */
+int gr_gather_texture_f64(gr_ctx *ctx, const int32_t *ids, int64_t n_pix, const double *face_tex, int64_t F, int C,
+                          double *out, void *stream);
+
+/* project_images + aggregate step for index labels -- replaces meshes.py:1987-2002 and 2057-2067 for the
+ * one-hot label images of cameras/segmentor.py:33-42 + predictors/segmentor.py:37-69.
+ * ids: n_views x h x w int32; labels: n_views x h x w uint8 class indices (>= C: all-zero one-hot row, still an
+ * observation).  Per view the LAST pixel (row-major) of each face wins; votes[f*C + label] += 1 and counts[f] += 1
+ * are ACCUMULATED into the caller's buffers (zero them before the first call). */
+int gr_project_labels_u8(gr_ctx *ctx, const int32_t *ids, const uint8_t *labels, int n_views, int h, int w, int C,
+                         uint32_t *votes, uint32_t *counts, int flags, void *stream);
+
+/* same for continuous images (cameras.py:154-177 float images): img n_views x h x w x C f64 (NaN allowed).
+ * sums[f*C+c] += value (NaN counts as 0, meshes.py:2060-2062); counts[f] += any(isfinite(row)) (2064-2067). */
+int gr_project_values_f64(gr_ctx *ctx, const int32_t *ids, const double *img, int n_views, int h, int w, int C,
+                          double *sums, uint32_t *counts, int flags, void *stream);
+
+/* project_images for ONE view, materialised like the reference generator yields it (meshes.py:1991-2002):
+ * tex: F x C f64, NaN for faces no pixel maps to.  img: h x w x C f64. */
+int gr_project_view_f64(gr_ctx *ctx, const int32_t *ids, const double *img, int h, int w, int C, double *tex,
+                        int flags, void *stream);
+
+/* fused pix2face + project_labels (ids never leave the chip unless ids_or_null != NULL): the
+ * aggregate_projected_images fast path, meshes.py:2004-2084 over n_views cameras. */
+int gr_raster_project_labels_u8(gr_ctx *ctx, const float *cams, const uint8_t *labels, int n_views, int h, int w,
+                                int C, uint32_t *votes, uint32_t *counts, int32_t *ids_or_null, int flags,
+                                void *stream);
+
+/* finalise -- meshes.py:2069-2082: summed[counts==0] = NaN; average = summed / counts.
+ * votes_u32 (F x C) is converted to f64 `summed`; average and summed are F x C f64, counts_f64 is F f64. */
+int gr_finalize_votes(gr_ctx *ctx, const uint32_t *votes, const uint32_t *counts, int64_t F, int C, double *average,
+                      double *summed, double *counts_f64, void *stream);
+int gr_finalize_sums_f64(gr_ctx *ctx, double *sums_inout, const uint32_t *counts, int64_t F, int C, double *average,
+                         double *counts_f64, void *stream);
+
+/* find_argmax_nonzero_value -- utils/indexing.py:9-32 on an F x C f64 array: argmax per row as f64, NaN when the
+ * row sums to zero or holds a non-finite value. */
+int gr_argmax_nonzero_f64(gr_ctx *ctx, const double *array, int64_t F, int C, double *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEOGRASTER_H */

@@ -1,0 +1,264 @@
+/*
+ * oracle/oracle_raster.c -- TEST INFRASTRUCTURE ONLY (CPU oracle, never shipped, never on the product path).
+ *
+ * Plain-C restatement of the face-ID rasterization stage of the reference hot path:
+ *   geograypher/meshes/meshes.py:1678-1856   TexturedPhotogrammetryMesh.pix2face (single-camera branch)
+ *   geograypher/cameras/cameras.py:446-477   PhotogrammetryCamera.get_pyvista_camera (view parameters)
+ *   geograypher/cameras/cameras.py:179-200   get_image_size  (h, w) = (int(H*s), int(W*s))
+ *
+ * The arithmetic of that stage lives in a third-party dependency that is absent from /root/reference and
+ * from this image: vtk==9.2.6 driven through pyvista==0.42.2 (poetry.lock:3361-3362, 2342-2343), i.e. an
+ * OpenGL polygon rasterizer.  What is restated here is the *published* algorithm of that stage (OpenGL 4.6
+ * core spec 14.6.1 "Basic Polygon Rasterization": point sampling at pixel centres, a consistent
+ * shared-edge fill rule, nearest-depth-wins with window-space-linear depth) as the fixed rule-set R0-R6 of
+ * DESIGN.md.  The HIP kernels implement the same rule-set independently; tests require bit equality.
+ *
+ * PARITY STATUS: pinned to the reference's own known-answer tests for this stage
+ * (tests/test_derived_meshes.py:23-76 pixel colours; tests/test_derived_cameras.py:339-415 shape/dtype/range
+ * properties), restated in tests/test_reference_kats.py.  Exact per-pixel face ids versus a real VTK/OpenGL
+ * stack are PARITY UNPINNED: the reference holds no golden pix2face array and VTK cannot run here.
+ *
+ * Two entry points compute the same function:
+ *   orc_raster_spec  -- literal rule-set, every pixel of the bounding box evaluated from the closed forms.
+ *   orc_raster_fast  -- same results, incremental integer edge stepping (exact), used for timing the CPU
+ *                       baseline and for full-size parity runs.  tests/ check fast == spec.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: no FMA contraction, SSE2 scalar IEEE arithmetic).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_SUB 256          /* sub-pixel units per pixel (8 fractional bits)                  R1 */
+#define ORC_HALF 128         /* pixel centre offset                                             R2 */
+#define ORC_GUARD 16384.0f   /* |screen coordinate| must be below this many pixels              R1 */
+
+typedef struct {
+  int32_t X, Y; /* snapped window coordinates, sub-pixel units */
+  float iz;     /* 1 / camera-space depth                      */
+  int valid;
+} orc_vtx;
+
+/* R1: vertex transform, fp32, every operation individually rounded (no fused multiply-add).
+ * cam[0..8]  R = cam_to_world rotation (row-major), cam[9..11] t = camera position,
+ * cam[12] f_eff (pixels), cam[13] cxp, cam[14] cyp (principal point in pixels of the rendered image),
+ * cam[15] near.   q = R^T (p - t); camera frame +X right, +Y down, +Z forward (cameras.py:446-477). */
+static orc_vtx orc_project(const float *p, const float *cam) {
+  orc_vtx v;
+  float dx = p[0] - cam[9];
+  float dy = p[1] - cam[10];
+  float dz = p[2] - cam[11];
+  float m0, m1, m2;
+  m0 = cam[0] * dx; m1 = cam[3] * dy; m2 = cam[6] * dz;
+  float qx = (m0 + m1) + m2;
+  m0 = cam[1] * dx; m1 = cam[4] * dy; m2 = cam[7] * dz;
+  float qy = (m0 + m1) + m2;
+  m0 = cam[2] * dx; m1 = cam[5] * dy; m2 = cam[8] * dz;
+  float qz = (m0 + m1) + m2;
+  v.valid = (qz > cam[15]) ? 1 : 0; /* false for NaN */
+  v.X = 0; v.Y = 0; v.iz = 0.0f;
+  if (!v.valid) return v;
+  float iz = 1.0f / qz;
+  float fx = cam[12] * qx;
+  float fy = cam[12] * qy;
+  float sx = cam[13] + fx * iz;
+  float sy = cam[14] + fy * iz;
+  if (!(fabsf(sx) < ORC_GUARD) || !(fabsf(sy) < ORC_GUARD)) { v.valid = 0; return v; }
+  v.X = (int32_t)floorf(sx * 256.0f + 0.5f);
+  v.Y = (int32_t)floorf(sy * 256.0f + 0.5f);
+  v.iz = iz;
+  return v;
+}
+
+typedef struct {
+  int32_t X[3], Y[3];
+  float iz0, A, B;
+  int32_t jmin, jmax, imin, imax; /* inclusive pixel bounding box, clamped to the image */
+} orc_tri;
+
+static inline int32_t orc_min3(int32_t a, int32_t b, int32_t c) { int32_t m = a < b ? a : b; return m < c ? m : c; }
+static inline int32_t orc_max3(int32_t a, int32_t b, int32_t c) { int32_t m = a > b ? a : b; return m > c ? m : c; }
+
+/* R2 + R4 setup. Returns 0 when the face is discarded. */
+static int orc_setup(const float *verts, const int32_t *face, const float *cam, int h, int w, orc_tri *t) {
+  orc_vtx v0 = orc_project(verts + 3 * (int64_t)face[0], cam);
+  orc_vtx v1 = orc_project(verts + 3 * (int64_t)face[1], cam);
+  orc_vtx v2 = orc_project(verts + 3 * (int64_t)face[2], cam);
+  if (!(v0.valid && v1.valid && v2.valid)) return 0;
+  int64_t area2 = (int64_t)(v1.X - v0.X) * (int64_t)(v2.Y - v0.Y) - (int64_t)(v2.X - v0.X) * (int64_t)(v1.Y - v0.Y);
+  if (area2 == 0) return 0;
+  if (area2 < 0) { orc_vtx s = v1; v1 = v2; v2 = s; area2 = -area2; } /* both windings are drawn */
+  t->X[0] = v0.X; t->X[1] = v1.X; t->X[2] = v2.X;
+  t->Y[0] = v0.Y; t->Y[1] = v1.Y; t->Y[2] = v2.Y;
+  int32_t Xmin = orc_min3(v0.X, v1.X, v2.X), Xmax = orc_max3(v0.X, v1.X, v2.X);
+  int32_t Ymin = orc_min3(v0.Y, v1.Y, v2.Y), Ymax = orc_max3(v0.Y, v1.Y, v2.Y);
+  /* pixel j has its centre at 256*j+128: keep j with Xmin <= 256j+128 <= Xmax (arithmetic shifts = floor) */
+  int32_t jmin = (Xmin - ORC_HALF + (ORC_SUB - 1)) >> 8;
+  int32_t jmax = (Xmax - ORC_HALF) >> 8;
+  int32_t imin = (Ymin - ORC_HALF + (ORC_SUB - 1)) >> 8;
+  int32_t imax = (Ymax - ORC_HALF) >> 8;
+  if (jmin < 0) jmin = 0;
+  if (imin < 0) imin = 0;
+  if (jmax > w - 1) jmax = w - 1;
+  if (imax > h - 1) imax = h - 1;
+  if (jmin > jmax || imin > imax) return 0;
+  t->jmin = jmin; t->jmax = jmax; t->imin = imin; t->imax = imax;
+  /* R4: plane of 1/z over the window, gradients in double then rounded to float */
+  double d1 = (double)v1.iz - (double)v0.iz;
+  double d2 = (double)v2.iz - (double)v0.iz;
+  double a2 = (double)area2;
+  double n1, n2;
+  n1 = d1 * (double)(v2.Y - v0.Y); n2 = d2 * (double)(v1.Y - v0.Y);
+  double Ad = (n1 - n2) / a2;
+  n1 = d2 * (double)(v1.X - v0.X); n2 = d1 * (double)(v2.X - v0.X);
+  double Bd = (n1 - n2) / a2;
+  t->iz0 = v0.iz; t->A = (float)Ad; t->B = (float)Bd;
+  return 1;
+}
+
+/* R3: edge k runs from vertex a=k to b=(k+1)%3; returns 1 when pixel centre (Px,Py) is covered */
+static inline int64_t orc_edge(const orc_tri *t, int k, int64_t Px, int64_t Py) {
+  int a = k, b = (k + 1) % 3;
+  int64_t dx = (int64_t)t->X[b] - t->X[a], dy = (int64_t)t->Y[b] - t->Y[a];
+  return dx * (Py - t->Y[a]) - dy * (Px - t->X[a]);
+}
+static inline int orc_owns(const orc_tri *t, int k) { /* top-left rule, y down */
+  int a = k, b = (k + 1) % 3;
+  int32_t dx = t->X[b] - t->X[a], dy = t->Y[b] - t->Y[a];
+  return (dy < 0) || (dy == 0 && dx > 0);
+}
+
+/* R4: fragment depth key */
+static inline int32_t orc_zbits(const orc_tri *t, int32_t Px, int32_t Py) {
+  float fx = (float)(Px - t->X[0]);
+  float fy = (float)(Py - t->Y[0]);
+  float m0 = t->A * fx;
+  float m1 = t->B * fy;
+  float s = m0 + m1;
+  float z = t->iz0 + s;
+  int32_t zb;
+  memcpy(&zb, &z, 4);
+  if (zb < 1) zb = 1;
+  return zb;
+}
+
+/* R5: nearest (largest 1/z) wins, equal depth -> lower face id */
+static inline void orc_resolve(int32_t *zbuf, int32_t *ids, int64_t p, int32_t zb, int32_t f) {
+  if (zb > zbuf[p] || (zb == zbuf[p] && f < ids[p])) { zbuf[p] = zb; ids[p] = f; }
+}
+
+static void orc_finish(const int32_t *zbuf, const int32_t *ids, float *depth, int64_t n) {
+  if (!depth) return;
+  for (int64_t p = 0; p < n; ++p) {
+    if (ids[p] < 0) { depth[p] = INFINITY; continue; }
+    float iz; memcpy(&iz, &zbuf[p], 4);
+    depth[p] = 1.0f / iz;
+  }
+}
+
+/* Literal rule-set. ids: int32 [h*w], background -1. depth (optional): camera-space Z, +inf background.
+ * zbuf: caller scratch int32 [h*w]. */
+int orc_raster_spec(const float *verts, const int32_t *faces, int64_t V, int64_t F, const float *cam, int h, int w,
+                    int32_t *ids, float *depth, int32_t *zbuf) {
+  (void)V;
+  int64_t n = (int64_t)h * w;
+  for (int64_t p = 0; p < n; ++p) { ids[p] = -1; zbuf[p] = 0; }
+  for (int64_t f = 0; f < F; ++f) {
+    orc_tri t;
+    if (!orc_setup(verts, faces + 3 * f, cam, h, w, &t)) continue;
+    int own[3] = {orc_owns(&t, 0), orc_owns(&t, 1), orc_owns(&t, 2)};
+    for (int32_t i = t.imin; i <= t.imax; ++i) {
+      for (int32_t j = t.jmin; j <= t.jmax; ++j) {
+        int32_t Px = j * ORC_SUB + ORC_HALF, Py = i * ORC_SUB + ORC_HALF;
+        int inside = 1;
+        for (int k = 0; k < 3; ++k) {
+          int64_t e = orc_edge(&t, k, Px, Py);
+          if (!(e > 0 || (e == 0 && own[k]))) inside = 0;
+        }
+        if (!inside) continue;
+        orc_resolve(zbuf, ids, (int64_t)i * w + j, orc_zbits(&t, Px, Py), (int32_t)f);
+      }
+    }
+  }
+  orc_finish(zbuf, ids, depth, n);
+  return 0;
+}
+
+/* Same function, incremental (exact integer) edge stepping along rows. */
+int orc_raster_fast(const float *verts, const int32_t *faces, int64_t V, int64_t F, const float *cam, int h, int w,
+                    int32_t *ids, float *depth, int32_t *zbuf) {
+  (void)V;
+  int64_t n = (int64_t)h * w;
+  for (int64_t p = 0; p < n; ++p) { ids[p] = -1; zbuf[p] = 0; }
+  for (int64_t f = 0; f < F; ++f) {
+    orc_tri t;
+    if (!orc_setup(verts, faces + 3 * f, cam, h, w, &t)) continue;
+    int64_t bias[3], stepx[3], e_row[3];
+    int32_t Px0 = t.jmin * ORC_SUB + ORC_HALF;
+    for (int k = 0; k < 3; ++k) {
+      int a = k, b = (k + 1) % 3;
+      /* covered  <=>  e > 0 || (e == 0 && owns)  <=>  e + (owns ? 0 : -1) >= 0 */
+      bias[k] = orc_owns(&t, k) ? 0 : -1;
+      stepx[k] = -(int64_t)(t.Y[b] - t.Y[a]) * ORC_SUB;
+      (void)a;
+    }
+    for (int32_t i = t.imin; i <= t.imax; ++i) {
+      int32_t Py = i * ORC_SUB + ORC_HALF;
+      for (int k = 0; k < 3; ++k) e_row[k] = orc_edge(&t, k, Px0, Py) + bias[k];
+      int64_t e0 = e_row[0], e1 = e_row[1], e2 = e_row[2];
+      int64_t p = (int64_t)i * w + t.jmin;
+      for (int32_t j = t.jmin; j <= t.jmax; ++j, ++p, e0 += stepx[0], e1 += stepx[1], e2 += stepx[2]) {
+        if ((e0 | e1 | e2) < 0) continue;
+        orc_resolve(zbuf, ids, p, orc_zbits(&t, j * ORC_SUB + ORC_HALF, Py), (int32_t)f);
+      }
+    }
+  }
+  orc_finish(zbuf, ids, depth, n);
+  return 0;
+}
+
+/* n_views cameras (cams: n_views x 16), ids: n_views x h x w. Views are independent; with OpenMP they run
+ * on separate threads (each with its own z-buffer). Returns the number of threads used. */
+int orc_raster_views(const float *verts, const int32_t *faces, int64_t V, int64_t F, const float *cams, int n_views,
+                     int h, int w, int32_t *ids, int n_threads) {
+  int64_t n = (int64_t)h * w;
+  int used = 1;
+#ifdef _OPENMP
+  if (n_threads < 1) n_threads = 1;
+  used = n_threads;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+#endif
+  for (int v = 0; v < n_views; ++v) {
+    int32_t *zbuf = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    orc_raster_fast(verts, faces, V, F, cams + 16 * (int64_t)v, h, w, ids + (int64_t)v * n, NULL, zbuf);
+    free(zbuf);
+  }
+  (void)n_threads;
+  return used;
+}
+
+/* ---- aggregation stage restated in C (meshes.py:1987-2002, 2044-2084) for uint8 index labels ---------------
+ * Per view: textured_faces[pix2face.flatten()] = one_hot(label)  => the LAST pixel in row-major order wins per
+ * face; a pix2face of -1 indexes the LAST face (reference's own TODO, meshes.py:1998-2001) when compat != 0.
+ * Across views: votes[f][c] += one_hot, counts[f] += 1 for every face touched.
+ * labels >= C (e.g. 255 = ignore) give an all-zero one-hot row that still counts (predictors/segmentor.py:37-69).
+ * winner: caller scratch int64 [F]. */
+int orc_project_labels(const int32_t *ids, const uint8_t *labels, int h, int w, int64_t F, int C, int compat,
+                       uint32_t *votes, uint32_t *counts, int64_t *winner) {
+  int64_t n = (int64_t)h * w;
+  for (int64_t f = 0; f < F; ++f) winner[f] = -1;
+  for (int64_t p = 0; p < n; ++p) {
+    int64_t f = ids[p];
+    if (f < 0) { if (!compat) continue; f = F + f; }
+    if (f < 0 || f >= F) return -1;
+    winner[f] = p; /* row-major sweep: later pixels overwrite earlier ones */
+  }
+  for (int64_t f = 0; f < F; ++f) {
+    if (winner[f] < 0) continue;
+    uint8_t l = labels[winner[f]];
+    if ((int)l < C) votes[f * C + l] += 1;
+    counts[f] += 1;
+  }
+  return 0;
+}

@@ -1,0 +1,92 @@
+"""tests/oracle_backend.py -- the CPU oracle dressed in the `HipRaster` interface.
+
+Lets the `-m "not gpu"` suite drive the product's HOST logic (generators, batching, API shapes, error behaviour of
+geograypher_amd.meshes) without a GPU.  Test-only: nothing under geograypher_amd/ imports this.
+"""
+import numpy as np
+import torch
+
+from oracle import oracle_c, oracle_np
+
+
+class OracleBackend:
+    device = torch.device("cpu")
+
+    def __init__(self):
+        self.verts = None
+        self.faces = None
+        self.n_faces = 0
+        self.uploads = 0
+
+    def _dev(self, array, dtype):
+        if isinstance(array, torch.Tensor):
+            return array.to(dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(array)).to(dtype=dtype).contiguous()
+
+    def upload_mesh(self, verts, faces):
+        self.verts = np.ascontiguousarray(np.asarray(verts), dtype=np.float32)
+        self.faces = np.ascontiguousarray(np.asarray(faces), dtype=np.int32)
+        if self.faces.min() < 0 or self.faces.max() >= self.verts.shape[0]:
+            raise IndexError("face index outside [0, V)")
+        self.n_faces = self.faces.shape[0]
+        self.uploads += 1
+
+    def raster_face_ids(self, cams, h, w, out=None, want_depth=False, check=True):
+        cams = np.asarray(cams, dtype=np.float32).reshape(-1, 16)
+        ids, _ = oracle_c.raster_views(self.verts, self.faces, cams, h, w, n_threads=1)
+        return torch.from_numpy(ids)
+
+    def gather_texture(self, ids, face_texture):
+        ids = np.asarray(ids)
+        tex = np.asarray(face_texture, dtype=np.float64)
+        flat = oracle_np.render_flat_gather(ids.reshape(-1, 1).astype(np.int64), tex)
+        return torch.from_numpy(flat.reshape(ids.shape + (tex.shape[1],)))
+
+    def new_vote_buffers(self, C):
+        return torch.zeros((self.n_faces, C), dtype=torch.int32), torch.zeros((self.n_faces,), dtype=torch.int32)
+
+    def project_labels(self, ids, labels, C, votes, counts, neg1_is_last_face=True):
+        ids = np.asarray(ids)
+        labels = np.asarray(labels)
+        if ids.ndim == 2:
+            ids, labels = ids[None], labels[None]
+        v = votes.numpy().view(np.uint32)
+        c = counts.numpy().view(np.uint32)
+        for k in range(ids.shape[0]):
+            oracle_c.project_labels(ids[k], labels[k], self.n_faces, C, v, c, neg1_is_last_face)
+
+    def project_view(self, ids, img, neg1_is_last_face=True):
+        tex = oracle_np.project_image(np.asarray(ids).astype(np.int64), np.asarray(img), self.n_faces,
+                                      neg1_is_last_face=neg1_is_last_face)
+        return torch.from_numpy(tex)
+
+    def project_values(self, ids, img, sums, counts, neg1_is_last_face=True):
+        ids = np.asarray(ids)
+        img = np.asarray(img)
+        if ids.ndim == 2:
+            ids, img = ids[None], img[None]
+        for k in range(ids.shape[0]):
+            proj = oracle_np.project_image(ids[k].astype(np.int64), img[k], self.n_faces,
+                                           neg1_is_last_face=neg1_is_last_face)
+            sums += torch.from_numpy(np.where(np.isnan(proj), 0.0, proj))
+            counts += torch.from_numpy(np.any(np.isfinite(proj), axis=1).astype(np.int32))
+
+    def finalize_votes(self, votes, counts):
+        v = votes.numpy().view(np.uint32).astype(np.float64)
+        c = counts.numpy().view(np.uint32).astype(np.float64)
+        summed = v.copy()
+        summed[c == 0] = np.nan
+        with np.errstate(divide="ignore", invalid="ignore"):
+            avg = summed / c[:, None]
+        return torch.from_numpy(avg), torch.from_numpy(summed), torch.from_numpy(c)
+
+    def finalize_sums(self, sums, counts):
+        s = sums.numpy().copy()
+        c = counts.numpy().astype(np.float64)
+        s[c == 0] = np.nan
+        with np.errstate(divide="ignore", invalid="ignore"):
+            avg = s / c[:, None]
+        return torch.from_numpy(avg), torch.from_numpy(s), torch.from_numpy(c)
+
+    def argmax_nonzero(self, array):
+        return torch.from_numpy(oracle_np.find_argmax_nonzero_value(np.asarray(array)))

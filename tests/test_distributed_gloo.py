@@ -1,0 +1,75 @@
+"""N > 1 path on CPU: two gloo ranks shard the views, accumulate votes with the oracle, and ONE all-reduce gives the
+same per-face votes as the unsharded run (integer sums: bit-identical for any world size)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from geograypher_amd import distributed as gdist
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _scene():
+    rng = np.random.default_rng(7)
+    F, N, h, w, C = 300, 9, 24, 32, 5
+    ids = rng.integers(-1, F, size=(N, h, w)).astype(np.int32)
+    labels = rng.integers(0, C + 1, size=(N, h, w)).astype(np.uint8)
+    labels[labels == C] = 255
+    return F, N, h, w, C, ids, labels
+
+
+def _votes_for(view_inds, scene):
+    from oracle import oracle_c
+
+    F, N, h, w, C, ids, labels = scene
+    votes = np.zeros((F, C), dtype=np.uint32)
+    counts = np.zeros(F, dtype=np.uint32)
+    for v in view_inds:
+        oracle_c.project_labels(ids[v], labels[v], F, C, votes, counts)
+    return votes, counts
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        scene = _scene()
+        assert gdist.rank_world() == (rank, world)
+        mine = gdist.shard_views(scene[1], rank, world)
+        votes, counts = _votes_for(mine, scene)
+        tv = torch.from_numpy(votes.view(np.int32).copy())
+        tc = torch.from_numpy(counts.view(np.int32).copy())
+        gdist.all_reduce_votes(tv, tc)
+        np.save(os.path.join(out_dir, f"votes_{rank}.npy"), tv.numpy())
+        np.save(os.path.join(out_dir, f"counts_{rank}.npy"), tc.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_views_partition():
+    for n in (0, 1, 7, 50, 2000):
+        for world in (1, 2, 4, 8):
+            parts = [gdist.shard_views(n, r, world) for r in range(world)]
+            assert sorted(i for p in parts for i in p) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gloo_all_reduce_equals_single_process(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    scene = _scene()
+    want_votes, want_counts = _votes_for(range(scene[1]), scene)
+    for r in range(world):
+        np.testing.assert_array_equal(np.load(tmp_path / f"votes_{r}.npy").view(np.uint32), want_votes)
+        np.testing.assert_array_equal(np.load(tmp_path / f"counts_{r}.npy").view(np.uint32), want_counts)

@@ -1,0 +1,236 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs -- bit-exact for face
+ids / depth bits / integer votes, 1e-12 relative for float64 sums (tolerance of north_star: 1e-5) -- plus golden
+fixtures of the real reference and size-independent properties at BASELINE.json's full size."""
+import numpy as np
+import pytest
+import torch
+
+from geograypher_amd.cameras import SegmentorPhotogrammetryCameraSet
+from geograypher_amd.meshes import TexturedPhotogrammetryMesh
+from geograypher_amd.predictors import ArrayLabelSegmentor
+from geograypher_amd.utils import synthetic
+from oracle import oracle_c, oracle_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+    np.testing.assert_array_equal(np.nan_to_num(a, nan=-7.0), np.nan_to_num(b, nan=-7.0))
+
+
+def _records(cams, scale=1.0, near=0.05):
+    return cams.get_raster_records(scale, near=near)
+
+
+def _check_views(hip, points, faces, recs, h, w, depth=False):
+    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+    if depth:
+        ids, dep = hip.raster_face_ids(recs, h, w, want_depth=True)
+        dep = dep.cpu().numpy()
+    else:
+        ids = hip.raster_face_ids(recs, h, w)
+    ids = ids.cpu().numpy()
+    for v in range(recs.shape[0]):
+        if depth:
+            want, wdep = oracle_c.raster(points, faces, recs[v], h, w, want_depth=True)
+            np.testing.assert_array_equal(dep[v].view(np.int32), wdep.view(np.int32), err_msg=f"depth view {v}")
+        else:
+            want = oracle_c.raster(points, faces, recs[v], h, w)
+        bad = np.argwhere(ids[v] != want)
+        assert bad.size == 0, f"view {v}: {bad.shape[0]} pixels differ, first {bad[:5].tolist()}"
+    return ids
+
+
+def test_config1_all_views_bit_exact(hip):
+    (points, faces), cams = synthetic.config1_scene()
+    ids = _check_views(hip, points, faces, _records(cams), 480, 640, depth=True)
+    assert ids.shape == (8, 480, 640)
+    assert (ids >= 0).mean() > 0.5
+
+
+@pytest.mark.parametrize("scale", [0.25, 0.37, 1.0])
+def test_ragged_sizes_and_scales(hip, scale):
+    """h, w not multiples of the 64-pixel tile, and the int(H*s) truncation of cameras.py:179-200."""
+    (points, faces), cams = synthetic.config1_scene()
+    for c in cams.cameras:
+        c.image_width, c.image_height, c.image_size = 613, 457, (457, 613)
+    h, w = cams[0].get_image_size(scale)
+    _check_views(hip, points, faces, _records(cams, scale), h, w)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_triangle_soup_occlusion_degenerates_behind_camera(hip, seed):
+    """Random overlapping triangles of every size: sub-pixel slivers, triangles larger than a tile (64-bit edge path),
+    coincident depths, zero-area faces, faces behind / straddling the camera plane."""
+    rng = np.random.default_rng(seed)
+    n = 3000
+    centers = rng.uniform(-30, 30, (n, 1, 3)) * np.array([1, 1, 0.3])
+    size = np.exp(rng.uniform(np.log(0.02), np.log(40.0), (n, 1, 1)))
+    tri = centers + rng.normal(0, 1, (n, 3, 3)) * size
+    tri[:50, :, 2] = 45.0                       # behind the camera (camera at z = 40 looking down)
+    tri[50:100, 0, 2] = 45.0                    # straddling the camera plane -> discarded as a whole
+    tri[100:120, 2] = tri[100:120, 1]           # zero area
+    tri[120:140] = tri[140:160]                 # coincident faces: lower id wins
+    points = tri.reshape(-1, 3)
+    faces = np.arange(3 * n).reshape(n, 3)
+    poses = [synthetic.nadir_pose(0, 0, 40.0, yaw_deg=17.0 * seed, tilt_x_deg=3.0 * seed),
+             synthetic.look_at((60, 10, 25), (0, 0, 0), up_hint=(0, 0, 1))]
+    cams = synthetic.camera_set_from_poses(poses, f=300.0, width=333, height=251)
+    ids = _check_views(hip, points, faces, _records(cams, near=0.5), 251, 333, depth=True)
+    assert len(np.unique(ids)) > 100
+
+
+def test_empty_view_and_single_face(hip):
+    points = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float64)
+    faces = np.array([[0, 1, 2]])
+    look_away = synthetic.nadir_pose(500, 500, 10.0)
+    look_at = synthetic.nadir_pose(0.3, 0.3, 2.0)
+    cams = synthetic.camera_set_from_poses([look_away, look_at], f=200.0, width=130, height=70)
+    ids = _check_views(hip, points, faces, _records(cams), 70, 130)
+    assert np.all(ids[0] == -1) and set(np.unique(ids[1])) == {-1, 0}
+
+
+def test_many_views_in_one_call_cross_batch_boundary(hip):
+    """More views than the library batches per launch group (16): results must not depend on the batching."""
+    (points, faces), cams = synthetic.config1_scene()
+    poses = [synthetic.nadir_pose(3.0 * k - 30, 2.0 * k - 20, 35.0 + k, yaw_deg=11.0 * k) for k in range(21)]
+    cams = synthetic.camera_set_from_poses(poses, f=260.0, width=320, height=200)
+    _check_views(hip, points, faces, _records(cams), 200, 320)
+
+
+def test_bin_overflow_is_detected_and_retried(hip):
+    """40 stacked faces that each cover every tile of a 4000 x 3000 view: 40 x 2961 bin entries exceed the initial
+    list capacity (2F + 65536); the library reports the exact need and the retry must reproduce the oracle."""
+    n = 40
+    base = np.array([[-50, -50, 0], [50, -50, 0], [0, 60, 0]], dtype=np.float64)
+    points = np.concatenate([base + np.array([0, 0, -0.05 * k]) for k in range(n)], axis=0)
+    faces = np.arange(3 * n).reshape(n, 3)
+    cams = synthetic.camera_set_from_poses([synthetic.nadir_pose(0, 0, 5.0)], f=4000.0, width=4000, height=3000)
+    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+    recs = _records(cams)
+    ids = hip.raster_face_ids(recs, 3000, 4000).cpu().numpy()
+    assert hip.last_stats["overflow"] == 0 and hip.last_stats["entries"] == n * 47 * 63
+    assert hip.last_stats["entry_cap"] >= n * 47 * 63
+    want = oracle_c.raster(points, faces, recs[0], 3000, 4000)
+    np.testing.assert_array_equal(ids[0], want)
+    assert np.all(ids[0] == 0)
+
+
+# ---- aggregation ---------------------------------------------------------------------------------------------------------
+def test_projection_kernels_against_reference_golden(hip, golden):
+    """Kernels fed the golden pix2face images: outputs must equal the REAL reference's (tests/golden)."""
+    ids, F = golden["ids"].astype(np.int32), int(golden["F"])
+    hip.upload_mesh(np.zeros((F + 3, 3), dtype=np.float32), np.zeros((F, 3), dtype=np.int32))
+    C = golden["onehot"].shape[-1]
+    votes, counts = hip.new_vote_buffers(C)
+    hip.project_labels(ids, golden["label_inds"], C, votes, counts)
+    avg, summed, cnt = (t.cpu().numpy() for t in hip.finalize_votes(votes, counts))
+    _same(avg, golden["agg_onehot_average"])
+    _same(summed, golden["agg_onehot_summed"])
+    _same(cnt, golden["agg_onehot_counts"])
+    for kind in ("rgb", "scalar", "onehot"):
+        imgs = golden[kind].astype(np.float64).reshape(ids.shape + (-1,))
+        for v in range(ids.shape[0]):
+            _same(hip.project_view(ids[v], imgs[v]).cpu().numpy(), golden[f"project_{kind}"][v])
+        sums = torch.zeros((F, imgs.shape[-1]), dtype=torch.float64, device=hip.device)
+        cn = torch.zeros((F,), dtype=torch.int32, device=hip.device)
+        hip.project_values(ids, imgs, sums, cn)
+        avg, summed, cnt = (t.cpu().numpy() for t in hip.finalize_sums(sums, cn))
+        np.testing.assert_allclose(avg, golden[f"agg_{kind}_average"], rtol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(summed, golden[f"agg_{kind}_summed"], rtol=1e-12, equal_nan=True)
+        _same(cnt, golden[f"agg_{kind}_counts"])
+    _same(hip.gather_texture(ids, golden["face_texture"]).cpu().numpy(), golden["render_flat"])
+    _same(hip.argmax_nonzero(golden["argmax_in"]).cpu().numpy(), golden["argmax_out_flat"])
+
+
+@pytest.mark.parametrize("compat", [True, False])
+def test_label_votes_bit_exact_vs_oracle(hip, compat):
+    (points, faces), cams = synthetic.config1_scene()
+    F = faces.shape[0]
+    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+    recs = _records(cams)
+    ids = hip.raster_face_ids(recs, 480, 640)
+    ids_np = ids.cpu().numpy()
+    C = 4
+    labels = np.stack([synthetic.synthetic_labels(ids_np[v], v, C) for v in range(len(cams))])
+    votes, counts = hip.new_vote_buffers(C)
+    hip.project_labels(ids, labels, C, votes, counts, neg1_is_last_face=compat)
+    want_v = np.zeros((F, C), dtype=np.uint32)
+    want_c = np.zeros(F, dtype=np.uint32)
+    for v in range(len(cams)):
+        oracle_c.project_labels(ids_np[v], labels[v], F, C, want_v, want_c, neg1_is_last_face=compat)
+    np.testing.assert_array_equal(votes.cpu().numpy().view(np.uint32), want_v)
+    np.testing.assert_array_equal(counts.cpu().numpy().view(np.uint32), want_c)
+    assert want_c.max() > 1 and (want_v.sum(axis=1) <= want_c).all()
+    # fused entry point gives the same votes
+    v2, c2 = hip.new_vote_buffers(C)
+    hip.raster_project_labels(recs, labels, C, v2, c2, neg1_is_last_face=compat)
+    assert torch.equal(v2, votes) and torch.equal(c2, counts)
+
+
+def test_end_to_end_api_matches_oracle_pipeline(hip, oracle_backend_cls):
+    """TexturedPhotogrammetryMesh on HIP vs the same class on the oracle backend: pix2face, render_flat,
+    project_images, aggregate (index-label fast path and float path)."""
+    (points, faces), cams = synthetic.config1_scene()
+    F = faces.shape[0]
+    tex = np.random.default_rng(0).random((F, 3))
+    m_hip = TexturedPhotogrammetryMesh((points, faces), texture=tex, log_level="ERROR", backend=hip)
+    m_orc = TexturedPhotogrammetryMesh((points, faces), texture=tex, log_level="ERROR", backend=oracle_backend_cls())
+    sub = cams[0:3]
+    a, b = m_hip.pix2face(sub, render_img_scale=0.5, apply_distortion=False), m_orc.pix2face(sub, render_img_scale=0.5, apply_distortion=False)
+    assert a.dtype == np.int64 and a.shape == (3, 240, 320)
+    np.testing.assert_array_equal(a, b)
+    for ra, rb in zip(m_hip.render_flat(sub, render_img_scale=0.5, apply_distortion=False),
+                      m_orc.render_flat(sub, render_img_scale=0.5, apply_distortion=False)):
+        _same(ra, rb)
+    labels = [synthetic.synthetic_labels(a[v], v, 4) for v in range(3)]
+    seg = ArrayLabelSegmentor(labels, 4, filenames=[c.image_filename for c in sub.cameras])
+    out_h = m_hip.aggregate_projected_images(SegmentorPhotogrammetryCameraSet(sub, seg), aggregate_img_scale=0.5)
+    out_o = m_orc.aggregate_projected_images(SegmentorPhotogrammetryCameraSet(sub, seg), aggregate_img_scale=0.5)
+    _same(out_h[0], out_o[0])
+    _same(out_h[1]["projection_counts"], out_o[1]["projection_counts"])
+    for pa, pb in zip(m_hip.project_images(SegmentorPhotogrammetryCameraSet(sub, seg), aggregate_img_scale=0.5),
+                      m_orc.project_images(SegmentorPhotogrammetryCameraSet(sub, seg), aggregate_img_scale=0.5)):
+        _same(pa, pb)
+
+
+# ---- full size (BASELINE.json config 2/3 shapes): properties + sampled oracle views --------------------------------------
+@pytest.fixture(scope="module")
+def terrain():
+    return synthetic.terrain_mesh()
+
+
+def test_full_size_views_bit_exact_and_properties(hip, terrain):
+    points, faces = terrain
+    assert faces.shape[0] == 1_201_250
+    cams = synthetic.config2_cameras(50)
+    recs = _records(cams, near=1.0)
+    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+    pick = [0, 23, 49]
+    ids = hip.raster_face_ids(recs[pick], 3000, 4000)
+    ids_np = ids.cpu().numpy()
+    for k, v in enumerate(pick[:2]):
+        want = oracle_c.raster(points, faces, recs[v], 3000, 4000)
+        assert np.array_equal(ids_np[k], want), f"view {v} differs in {(ids_np[k] != want).sum()} pixels"
+    # properties that hold at any size: ids in range, rerun idempotent, a single-view call equals the batched call,
+    # votes conserve observations (every visible face is counted exactly once per view)
+    assert ids_np.min() >= -1 and ids_np.max() < faces.shape[0]
+    again = hip.raster_face_ids(recs[pick], 3000, 4000)
+    assert torch.equal(ids, again)
+    single = hip.raster_face_ids(recs[pick[2]:pick[2] + 1], 3000, 4000)
+    assert torch.equal(single[0], ids[2])
+    C = 4
+    labels = torch.from_numpy(np.stack([synthetic.synthetic_labels(ids_np[k], k, C) for k in range(3)])).to(hip.device)
+    votes, counts = hip.new_vote_buffers(C)
+    hip.project_labels(ids, labels, C, votes, counts, neg1_is_last_face=False)
+    n_visible = sum(len(np.setdiff1d(np.unique(ids_np[k]), [-1])) for k in range(3))
+    assert int(counts.sum()) == n_visible
+    assert int(votes.sum()) <= n_visible
+    want_v = np.zeros((faces.shape[0], C), dtype=np.uint32)
+    want_c = np.zeros(faces.shape[0], dtype=np.uint32)
+    lab_np = labels.cpu().numpy()
+    for k in range(3):
+        oracle_c.project_labels(ids_np[k], lab_np[k], faces.shape[0], C, want_v, want_c, neg1_is_last_face=False)
+    np.testing.assert_array_equal(votes.cpu().numpy().view(np.uint32), want_v)
+    np.testing.assert_array_equal(counts.cpu().numpy().view(np.uint32), want_c)

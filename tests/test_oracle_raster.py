@@ -1,0 +1,162 @@
+"""Rule-set checks for the C rasterizer oracle: fast == spec, and coverage == the exact geometric predicate on the
+snapped vertices (evaluated with Python integers / fractions, independent of the C code)."""
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+from geograypher_amd.utils import synthetic
+from oracle import oracle_c
+
+
+def _cam(h, w, f=None, pos=(0, 0, 5.0), near=1e-3):
+    T = synthetic.downward_view(1, pos[2], 1)  # looks down from z = pos[2]
+    T[:3, 3] = pos
+    rec = np.zeros(16, dtype=np.float32)
+    rec[0:9] = T[:3, :3].reshape(9)
+    rec[9:12] = T[:3, 3]
+    rec[12] = f if f is not None else h
+    rec[13], rec[14], rec[15] = w / 2, h / 2, near
+    return rec
+
+
+def _project_f32(p, cam):
+    """R1 in numpy float32, op for op."""
+    f32 = np.float32
+    d = [f32(p[i]) - cam[9 + i] for i in range(3)]
+    q = []
+    for c in range(3):
+        m0, m1, m2 = cam[c] * d[0], cam[3 + c] * d[1], cam[6 + c] * d[2]
+        q.append(f32(f32(m0 + m1) + m2))
+    if not q[2] > cam[15]:
+        return None
+    iz = f32(1.0) / q[2]
+    sx = cam[13] + f32(f32(cam[12] * q[0]) * iz)
+    sy = cam[14] + f32(f32(cam[12] * q[1]) * iz)
+    if not (abs(sx) < 16384 and abs(sy) < 16384):
+        return None
+    return int(np.floor(f32(sx * f32(256.0)) + f32(0.5))), int(np.floor(f32(sy * f32(256.0)) + f32(0.5))), iz
+
+
+def _spec_python(verts, faces, cam, h, w):
+    """Exact coverage + top-left rule + R4 depth, straight from DESIGN.md, with Python ints."""
+    f32 = np.float32
+    ids = np.full((h, w), -1, dtype=np.int64)
+    zb = np.zeros((h, w), dtype=np.int64)
+    for f, tri in enumerate(faces):
+        v = [_project_f32(verts[i], cam) for i in tri]
+        if any(x is None for x in v):
+            continue
+        (X0, Y0, z0), (X1, Y1, z1), (X2, Y2, z2) = v
+        area2 = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0)
+        if area2 == 0:
+            continue
+        if area2 < 0:
+            (X1, Y1, z1), (X2, Y2, z2) = (X2, Y2, z2), (X1, Y1, z1)
+            area2 = -area2
+        d1, d2 = float(z1) - float(z0), float(z2) - float(z0)
+        A = f32((d1 * float(Y2 - Y0) - d2 * float(Y1 - Y0)) / float(area2))
+        B = f32((d2 * float(X1 - X0) - d1 * float(X2 - X0)) / float(area2))
+        P = [(X0, Y0), (X1, Y1), (X2, Y2)]
+        for i in range(h):
+            for j in range(w):
+                px, py = 256 * j + 128, 256 * i + 128
+                ok = True
+                for k in range(3):
+                    (xa, ya), (xb, yb) = P[k], P[(k + 1) % 3]
+                    dx, dy = xb - xa, yb - ya
+                    e = dx * (py - ya) - dy * (px - xa)
+                    owns = dy < 0 or (dy == 0 and dx > 0)
+                    if not (e > 0 or (e == 0 and owns)):
+                        ok = False
+                if not ok:
+                    continue
+                z = f32(z0 + f32(f32(A * f32(px - X0)) + f32(B * f32(py - Y0))))
+                bits = int(np.array(z, dtype=np.float32).view(np.int32))
+                bits = max(bits, 1)
+                if bits > zb[i, j] or (bits == zb[i, j] and f < ids[i, j]):
+                    zb[i, j], ids[i, j] = bits, f
+    return ids
+
+
+def _random_soup(rng, n_tri, spread=3.0, zspread=1.5):
+    verts = rng.uniform(-spread, spread, (3 * n_tri, 3))
+    verts[:, 2] = rng.uniform(-zspread, zspread, 3 * n_tri)
+    faces = np.arange(3 * n_tri).reshape(n_tri, 3)
+    return verts.astype(np.float32), faces.astype(np.int32)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_c_oracle_equals_python_spec(seed):
+    rng = np.random.default_rng(seed)
+    verts, faces = _random_soup(rng, 25)
+    h, w = 20, 28
+    cam = _cam(h, w, f=18.0)
+    got = oracle_c.raster(verts, faces, cam, h, w, spec=True)
+    want = _spec_python(verts, faces, cam, h, w)
+    np.testing.assert_array_equal(got, want)
+    assert (got >= 0).sum() > 50
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fast_equals_spec(seed):
+    rng = np.random.default_rng(100 + seed)
+    verts, faces = _random_soup(rng, 400, spread=6.0)
+    h, w = 97, 131
+    cam = _cam(h, w, f=60.0 + 10 * seed)
+    a, da = oracle_c.raster(verts, faces, cam, h, w, want_depth=True, spec=True)
+    b, db = oracle_c.raster(verts, faces, cam, h, w, want_depth=True, spec=False)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(da, db)
+
+
+def test_shared_edges_are_watertight_and_exclusive():
+    """A nadir view of a jittered grid: every pixel inside the footprint gets exactly one face, no holes on edges."""
+    (points, faces), cams = synthetic.config1_scene()
+    cam = cams[0]
+    h, w = cam.get_image_size(1.0)
+    ids = oracle_c.raster(points, faces, cam.get_raster_record(1.0, near=0.1), h, w)
+    assert ids.min() >= 0 and ids.max() < faces.shape[0]  # the 100 m plane covers the 51 x 38 m footprint entirely
+
+
+def test_pixel_centres_on_edges_follow_top_left_rule():
+    """Two triangles of one square whose diagonal passes exactly through pixel centres (the situation of the
+    reference's own simple-mesh fixture): every pixel is claimed exactly once and the split is the top-left rule."""
+    verts = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], dtype=np.float32)
+    faces = np.array([[0, 1, 2], [0, 2, 3]], dtype=np.int32)
+    h = w = 8
+    cam = _cam(h, w, f=20.0)  # 4 px per unit at depth 5: the square fills the 8 x 8 window, diagonal on centres
+    ids = oracle_c.raster(verts, faces, cam, h, w, spec=True)
+    assert ids.min() >= 0
+    # each pixel centre on the shared diagonal belongs to exactly one triangle, and both triangles own pixels
+    assert set(np.unique(ids)) == {0, 1}
+
+
+def test_background_degenerate_and_behind_camera():
+    h, w = 16, 16
+    cam = _cam(h, w, f=8.0)
+    verts = np.array(
+        [[0, 0, 0], [1, 0, 0], [2, 0, 0],  # collinear -> zero area
+         [0, 0, 6], [1, 0, 6], [0, 1, 6],  # behind the camera (camera at z=5 looking down)
+         [-0.4, -0.4, 0], [0.4, -0.4, 0], [0, 0.4, 0]],
+        dtype=np.float32,
+    )
+    faces = np.array([[0, 1, 2], [3, 4, 5], [6, 7, 8]], dtype=np.int32)
+    ids, depth = oracle_c.raster(verts, faces, cam, h, w, want_depth=True)
+    assert set(np.unique(ids)) <= {-1, 2}
+    assert (ids == 2).sum() > 0
+    assert np.all(np.isinf(depth[ids == -1]))
+    np.testing.assert_allclose(depth[ids == 2], 5.0, rtol=1e-6)
+
+
+def test_nearest_face_wins_and_ties_go_to_lower_id():
+    h, w = 12, 12
+    cam = _cam(h, w, f=6.0)
+    big = [[-3, -3], [3, -3], [0, 4]]
+    verts = np.array([[x, y, 0.0] for x, y in big] + [[x, y, 1.0] for x, y in big] + [[x, y, 0.0] for x, y in big],
+                     dtype=np.float32)
+    faces = np.array([[0, 1, 2], [3, 4, 5], [6, 7, 8]], dtype=np.int32)
+    ids = oracle_c.raster(verts, faces, cam, h, w)
+    assert set(np.unique(ids)) <= {-1, 1}  # z = 1 is nearer to the camera at z = 5
+    ids2 = oracle_c.raster(verts, faces[[0, 2]], cam, h, w)  # two coincident faces: lower id
+    assert set(np.unique(ids2)) <= {-1, 0}
