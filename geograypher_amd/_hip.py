@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = (
     "gr_ctx_destroy",
     "gr_last_error",
     "gr_set_profiling",
+    "gr_set_option",
     "gr_get_stage_times",
     "gr_mesh_upload",
     "gr_raster_face_ids",
@@ -101,6 +102,8 @@ def load_library() -> ctypes.CDLL:
     lib.gr_last_error.argtypes = [vp]
     lib.gr_set_profiling.restype = i32
     lib.gr_set_profiling.argtypes = [vp, i32]
+    lib.gr_set_option.restype = i32
+    lib.gr_set_option.argtypes = [vp, i32, i32]
     lib.gr_get_stage_times.restype = i32
     lib.gr_get_stage_times.argtypes = [vp, ctypes.POINTER(StageTimes)]
     lib.gr_mesh_upload.restype = i32
@@ -200,6 +203,10 @@ class HipRaster:
 
     def set_profiling(self, enabled: bool):
         self._check(self.lib.gr_set_profiling(self._ctx, 1 if enabled else 0), "gr_set_profiling")
+
+    def set_option(self, key: int, value: int):
+        """Tuning knobs of include/geograster.h (GR_OPT_*): 1 raster kernel, 2 tile height log2, 3 batch."""
+        self._check(self.lib.gr_set_option(self._ctx, int(key), int(value)), "gr_set_option")
 
     def stage_times(self) -> dict:
         st = StageTimes()

@@ -36,8 +36,12 @@
 namespace {
 
 struct BinArgs {
-  uint32_t *ctrl;        // [slot][GR_CTRL_HDR + 3*Tcap]   rec_count,total,overflow,pad | count[T] | offset[T] | cursor[T]
-  int4 *rec;             // [slot][3][F]  plane0 {X0,Y0,X1,Y1} plane1 {X2,Y2,iz0,face} plane2 {A,B,jmin|jmax<<16,imin|imax<<16}
+  uint32_t *ctrl;        // [slot][GR_CTRL_HDR + 4*Tcap]  rec_count,total,overflow,pad | cntS[T] | cntB[T] | offset[T] | curB[T]
+                         //   cntS: entries whose list position was handed out in k_setup_cull (faces touching <= 2x2 tiles)
+                         //   cntB: entries of larger faces, placed by k_fill_bins behind the cntS block of their tile
+  int4 *rec;             // [slot][4][F]  plane0 {X0,Y0,X1,Y1} plane1 {X2,Y2,iz0,face} plane2 {A,B,jmin|jmax<<16,imin|imax<<16}
+                         //               plane3 {list position in up to 4 tiles}
+  const float4 *blk;     // [ceil(F/256)] bounding sphere (centre, radius) of each block of 256 faces, local frame
   uint32_t *entries;     // [slot][ent_cap]  record indices grouped by tile
   unsigned long long *stats;  // [4] records, entries, max_entries, overflow (accumulated over the call)
   int64_t ctrl_stride;   // words per slot
@@ -46,6 +50,8 @@ struct BinArgs {
   int64_t F;
   int T, TX, TY, Tcap;
   int h, w;
+  int twl, thl;          // log2 of the tile width / height in pixels
+  int dbg;               // timing-only ablation mask (GR_OPT_DEBUG): 1 skip scanline loop, 2 skip id stores, 4 skip triangles
 };
 
 __device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b, c)); }
@@ -84,17 +90,93 @@ __device__ __forceinline__ Vtx project_vertex(const float *__restrict__ p, const
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K1  transform + cull + compact record + per-tile counts.   grid (ceil(F/256), views)
-//     faces (F,3) int32 read coalesced; vertices gathered (12 B each, L2-resident for mesh-local face order);
-//     survivors compacted with wave ballot + popcount, ONE atomicAdd per wave; record planes written as
-//     consecutive 16-byte slots (full-rate coalesced stores).
+// K0  (once per mesh upload) bounding sphere of every block of 256 consecutive faces.  Photogrammetry meshes keep
+//     neighbouring faces close in index order, so a view's frustum rejects most blocks with one sphere test.
 // ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_block_bounds(const float *__restrict__ verts, const int32_t *__restrict__ faces,
+                                                      int64_t F, float4 *__restrict__ blk) {
+  __shared__ float red[6][4];
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  if (f < F) {
+    for (int k = 0; k < 3; ++k) {
+      const float *p = verts + 3 * (int64_t)faces[3 * f + k];
+      for (int d = 0; d < 3; ++d) { lo[d] = fminf(lo[d], p[d]); hi[d] = fmaxf(hi[d], p[d]); }
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int d = 0; d < 3; ++d) {
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[d] = fminf(lo[d], __shfl_xor(lo[d], o));
+      hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o));
+    }
+    if (lane == 0) { red[d][wv] = lo[d]; red[3 + d][wv] = hi[d]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float c[3], r2 = 0.f;
+    for (int d = 0; d < 3; ++d) {
+      const float l = fminf(fminf(red[d][0], red[d][1]), fminf(red[d][2], red[d][3]));
+      const float h = fmaxf(fmaxf(red[3 + d][0], red[3 + d][1]), fmaxf(red[3 + d][2], red[3 + d][3]));
+      c[d] = 0.5f * (l + h);
+      const float e = 0.5f * (h - l);
+      r2 += e * e;
+    }
+    // NaN / inf vertices give a NaN radius: the cull test below is written so that NaN never culls
+    blk[blockIdx.x] = make_float4(c[0], c[1], c[2], sqrtf(r2) * 1.0001f + 1e-6f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K1  transform + cull + compact record + per-tile counts.   grid (ceil(F/256), views)
+//     (a) block cull: the 256-face block's bounding sphere against the view frustum (2-pixel margin) -- wave-uniform,
+//         rejects ~85 % of a survey mesh per view before a single face is read;
+//     (b) faces (F,3) int32 read coalesced; vertices gathered (12 B each, L2-resident for mesh-local face order);
+//     (c) survivors compacted with wave ballot + popcount, ONE atomicAdd per wave; record planes written as
+//         consecutive 16-byte slots (full-rate coalesced stores);
+//     (d) tile counting is aggregated per wave as well: lanes that hit the same tile share one returning atomicAdd
+//         and receive consecutive list positions, which k_fill_bins later uses without any atomic.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_count_tile(uint32_t *cnt, int t, int lane) {
+  // every lane with t >= 0 receives a unique position in tile t's list; one atomic per distinct tile in the wave
+  uint32_t pos = 0;
+  unsigned long long rem = __ballot(t >= 0);
+  while (rem) {
+    const int leader = __ffsll((long long)rem) - 1;
+    const int tl = __shfl(t, leader);
+    const unsigned long long m = __ballot(t == tl);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&cnt[tl], (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    if (t == tl) pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    rem &= ~m;
+  }
+  return pos;
+}
+
 __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ verts, const int32_t *__restrict__ faces,
                                                     const float *__restrict__ cams, BinArgs a) {
   const int slot = blockIdx.y;
   const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
   uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+
+  {  // (a) sphere vs frustum, camera space.  Planes carry a 2-pixel margin; any NaN keeps the block.
+    const float4 sp = a.blk[blockIdx.x];
+    const float dx = sp.x - cam[9], dy = sp.y - cam[10], dz = sp.z - cam[11];
+    const float qx = cam[0] * dx + cam[3] * dy + cam[6] * dz;
+    const float qy = cam[1] * dx + cam[4] * dy + cam[7] * dz;
+    const float qz = cam[2] * dx + cam[5] * dy + cam[8] * dz;
+    const float fe = fabsf(cam[12]), r = sp.w * 1.001f;
+    const float mxl = cam[13] + 2.0f, mxr = (float)a.w - cam[13] + 2.0f;
+    const float myt = cam[14] + 2.0f, myb = (float)a.h - cam[14] + 2.0f;
+    bool out = (qz + r < cam[15]);
+    out = out || (cam[12] * qx + mxl * qz < -r * (fe + fabsf(mxl)));
+    out = out || (-cam[12] * qx + mxr * qz < -r * (fe + fabsf(mxr)));
+    out = out || (cam[12] * qy + myt * qz < -r * (fe + fabsf(myt)));
+    out = out || (-cam[12] * qy + myb * qz < -r * (fe + fabsf(myb)));
+    if (out) return;
+  }
 
   bool keep = false;
   int4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0};
@@ -132,8 +214,8 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
           r0 = make_int4(v0.X, v0.Y, v1.X, v1.Y);
           r1 = make_int4(v2.X, v2.Y, __float_as_int(v0.iz), (int)f);
           r2 = make_int4(__float_as_int(A), __float_as_int(B), jmin | (jmax << 16), imin | (imax << 16));
-          tx0 = jmin >> GR_TILE_LOG2; tx1 = jmax >> GR_TILE_LOG2;
-          ty0 = imin >> GR_TILE_LOG2; ty1 = imax >> GR_TILE_LOG2;
+          tx0 = jmin >> a.twl; tx1 = jmax >> a.twl;
+          ty0 = imin >> a.thl; ty1 = imax >> a.thl;
         }
       }
     }
@@ -148,34 +230,52 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
   uint32_t base = 0;
   if (lane == leader) base = atomicAdd(&ctrl[0], (uint32_t)n);
   base = __shfl(base, leader);
+  // (d) tile counts.  Faces touching at most 2x2 tiles get their list positions here (wave-aggregated atomics);
+  //     larger faces are only counted (cntB) and placed by k_fill_bins.
+  const bool small_fp = keep && (tx1 - tx0 <= 1) && (ty1 - ty0 <= 1);
+  uint32_t *cntS = ctrl + GR_CTRL_HDR;
+  uint32_t *cntB = cntS + a.Tcap;
+  int4 r3 = {0, 0, 0, 0};
+  {
+    const int t00 = small_fp ? ty0 * a.TX + tx0 : -1;
+    const int t01 = (small_fp && tx1 > tx0) ? ty0 * a.TX + tx1 : -1;
+    const int t10 = (small_fp && ty1 > ty0) ? ty1 * a.TX + tx0 : -1;
+    const int t11 = (small_fp && tx1 > tx0 && ty1 > ty0) ? ty1 * a.TX + tx1 : -1;
+    r3.x = (int)wave_count_tile(cntS, t00, lane);
+    if (__ballot(t01 >= 0)) r3.y = (int)wave_count_tile(cntS, t01, lane);
+    if (__ballot(t10 >= 0)) r3.z = (int)wave_count_tile(cntS, t10, lane);
+    if (__ballot(t11 >= 0)) r3.w = (int)wave_count_tile(cntS, t11, lane);
+  }
   if (keep) {
     int4 *rec = a.rec + slot * a.rec_stride;
     const int64_t s = (int64_t)base + prefix;
     rec[s] = r0;
     rec[a.F + s] = r1;
     rec[2 * a.F + s] = r2;
-    uint32_t *cnt = ctrl + GR_CTRL_HDR;
-    for (int ty = ty0; ty <= ty1; ++ty)
-      for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&cnt[ty * a.TX + tx], 1u);
+    rec[3 * a.F + s] = r3;
+    if (!small_fp)
+      for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&cntB[ty * a.TX + tx], 1u);
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K2  exclusive scan of the per-tile counts of one view.  grid (views), 1024 threads
+// K2  exclusive scan of the per-tile counts (cntS + cntB) of one view.  grid (views), 1024 threads
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_scan_tiles(BinArgs a) {
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t carry_s;
   const int slot = blockIdx.x;
   uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
-  const uint32_t *cnt = ctrl + GR_CTRL_HDR;
-  uint32_t *off = ctrl + GR_CTRL_HDR + a.Tcap;
+  const uint32_t *cntS = ctrl + GR_CTRL_HDR;
+  const uint32_t *cntB = cntS + a.Tcap;
+  uint32_t *off = ctrl + GR_CTRL_HDR + 2 * a.Tcap;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid == 0) carry_s = 0;
   __syncthreads();
   for (int base = 0; base < a.T; base += 1024) {
     const int t = base + tid;
-    const uint32_t c = (t < a.T) ? cnt[t] : 0u;
+    const uint32_t c = (t < a.T) ? cntS[t] + cntB[t] : 0u;
     uint32_t incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -205,26 +305,49 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(BinArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K3  scatter record indices into their tiles' lists.  grid (G, views), grid-stride over the surviving records
+// K3  scatter record indices into their tiles' lists.  grid (G, views), grid-stride over the surviving records.
+//     Positions of <= 2x2-tile faces were assigned in K1: plain stores.  Larger faces take a cursor atomic per tile.
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fill_bins(BinArgs a) {
   const int slot = blockIdx.y;
   uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
   const uint32_t n_rec = ctrl[0];
-  const uint32_t *off = ctrl + GR_CTRL_HDR + a.Tcap;
-  uint32_t *cur = ctrl + GR_CTRL_HDR + 2 * a.Tcap;
+  const uint32_t *cntS = ctrl + GR_CTRL_HDR;
+  const uint32_t *off = ctrl + GR_CTRL_HDR + 2 * a.Tcap;
+  uint32_t *cur = ctrl + GR_CTRL_HDR + 3 * a.Tcap;
   const int4 *rec2 = a.rec + slot * a.rec_stride + 2 * a.F;
+  const int4 *rec3 = a.rec + slot * a.rec_stride + 3 * a.F;
   uint32_t *ent = a.entries + slot * a.ent_cap;
   for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n_rec; r += gridDim.x * 256) {
     const int4 q = rec2[r];
-    const int tx0 = (q.z & 0xFFFF) >> GR_TILE_LOG2, tx1 = (int)((uint32_t)q.z >> 16) >> GR_TILE_LOG2;
-    const int ty0 = (q.w & 0xFFFF) >> GR_TILE_LOG2, ty1 = (int)((uint32_t)q.w >> 16) >> GR_TILE_LOG2;
-    for (int ty = ty0; ty <= ty1; ++ty)
-      for (int tx = tx0; tx <= tx1; ++tx) {
-        const int t = ty * a.TX + tx;
-        const int64_t idx = (int64_t)off[t] + atomicAdd(&cur[t], 1u);
+    const int tx0 = (q.z & 0xFFFF) >> a.twl, tx1 = (int)((uint32_t)q.z >> 16) >> a.twl;
+    const int ty0 = (q.w & 0xFFFF) >> a.thl, ty1 = (int)((uint32_t)q.w >> 16) >> a.thl;
+    if ((tx1 - tx0 <= 1) && (ty1 - ty0 <= 1)) {
+      const int4 pos = rec3[r];
+      const int t00 = ty0 * a.TX + tx0;
+      int64_t idx = (int64_t)off[t00] + (uint32_t)pos.x;
+      if (idx < a.ent_cap) ent[idx] = r;
+      if (tx1 > tx0) {
+        idx = (int64_t)off[t00 + 1] + (uint32_t)pos.y;
         if (idx < a.ent_cap) ent[idx] = r;
       }
+      if (ty1 > ty0) {
+        const int t10 = ty1 * a.TX + tx0;
+        idx = (int64_t)off[t10] + (uint32_t)pos.z;
+        if (idx < a.ent_cap) ent[idx] = r;
+        if (tx1 > tx0) {
+          idx = (int64_t)off[t10 + 1] + (uint32_t)pos.w;
+          if (idx < a.ent_cap) ent[idx] = r;
+        }
+      }
+    } else {
+      for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) {
+          const int t = ty * a.TX + tx;
+          const int64_t idx = (int64_t)off[t] + cntS[t] + atomicAdd(&cur[t], 1u);
+          if (idx < a.ent_cap) ent[idx] = r;
+        }
+    }
   }
 }
 
@@ -255,8 +378,8 @@ __global__ __launch_bounds__(GR_RASTER_THREADS) void k_raster_tile(BinArgs a, Ra
   for (int i = tid; i < GR_TILE * GR_TILE; i += GR_RASTER_THREADS) keys[i] = 0ull;
   __syncthreads();
 
-  uint32_t cnt = ctrl[GR_CTRL_HDR + tile];
-  const int64_t beg = ctrl[GR_CTRL_HDR + a.Tcap + tile];
+  uint32_t cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
+  const int64_t beg = ctrl[GR_CTRL_HDR + 2 * a.Tcap + tile];
   if (beg >= a.ent_cap) cnt = 0;
   else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
 
@@ -355,6 +478,217 @@ __global__ __launch_bounds__(GR_RASTER_THREADS) void k_raster_tile(BinArgs a, Ra
       const int gy = py0 + row;
       if (gy >= a.h) break;
       const unsigned long long key = keys[lds_index(row, col)];
+      const int64_t p = plane + (int64_t)gy * a.w + gx;
+      if (out.ids) out.ids[p] = key ? (int32_t)(~(uint32_t)key) : -1;
+      if (out.depth) out.depth[p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K4b  row-item tile rasterizer.  grid (T, views), NT threads, one TW x TH tile per workgroup.
+//      Phase 1: ONE TRIANGLE PER LANE -- edge functions are re-based to the tile origin (E = C + A x + B y with x, y
+//               tile-local pixels) and parked in LDS (64 B per triangle), so the per-triangle setup runs 64-wide
+//               instead of once per wave.
+//      Phase 2: the triangles' row counts are prefix-summed (wave shuffles + LDS) and expanded into a list of
+//               (triangle, row) work items.
+//      Phase 3: ONE SCANLINE OF ONE TRIANGLE PER LANE: the lane walks its row of the bounding box with incremental
+//               32-bit edge adds and resolves visibility with ds_max_u64 on the depth|id key.  Triangles whose edge
+//               values could leave int32 inside this tile take a second, 64-bit loop (same results, exact).
+//      LDS column rotation (col + row) & (TW-1): the rows of one triangle walk the same columns in step, the rotation
+//      spreads them over distinct banks; a row read in the epilogue stays conflict-free.
+// ------------------------------------------------------------------------------------------------------------------
+template <int TWL, int THL>
+__device__ __forceinline__ int lds_rot(int row, int col) {
+  return (row << TWL) + ((col + row) & ((1 << TWL) - 1));
+}
+
+// Integer solution of E + A x >= 0 on one scanline.  A float reciprocal proposes floor(-E/A) (off by at most one in
+// the clamped range [-1, TW]); exact int32 evaluations at the proposal and its neighbours settle the boundary.
+template <int TW>
+__device__ __forceinline__ void span_clip(int E, int A, int &xs, int &xe) {
+  if (A == 0) {
+    if (E < 0) xe = -1;
+    return;
+  }
+  float q = -(float)E * __builtin_amdgcn_rcpf((float)A);
+  q = fminf(fmaxf(q, -1.0f), (float)TW);
+  const int x0 = (int)floorf(q);
+  const int e0 = E + A * x0;
+  if (A > 0) {
+    const int lo = (e0 >= 0) ? ((e0 - A >= 0) ? x0 - 1 : x0) : ((e0 + A >= 0) ? x0 + 1 : x0 + 2);
+    xs = max(xs, lo);
+  } else {
+    const int hi = (e0 >= 0) ? ((e0 + A >= 0) ? x0 + 1 : x0) : ((e0 - A >= 0) ? x0 - 1 : x0 - 2);
+    xe = min(xe, hi);
+  }
+}
+
+template <int TWL, int THL, int NT, int CHUNK>
+__global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
+  constexpr int TW = 1 << TWL, TH = 1 << THL;
+  static_assert(CHUNK <= NT && CHUNK <= 256, "one triangle per lane, u8 item indices");
+  __shared__ unsigned long long keys[TW * TH];
+  __shared__ int4 tris[CHUNK * 4];
+  __shared__ unsigned short row_off[CHUNK + 1];
+  __shared__ unsigned char item_tri[CHUNK * TH];
+  __shared__ int wave_tot[NT / 64];
+
+  const int slot = blockIdx.y;
+  const int tile = blockIdx.x;
+  const int tx = tile % a.TX, ty = tile / a.TX;
+  const int px0 = tx << TWL, py0 = ty << THL;
+  const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+  for (int i = tid; i < TW * TH; i += NT) keys[i] = 0ull;
+
+  uint32_t cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
+  const int64_t beg = ctrl[GR_CTRL_HDR + 2 * a.Tcap + tile];
+  if (beg >= a.ent_cap) cnt = 0;
+  else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
+  const int4 *rec0 = a.rec + slot * a.rec_stride;
+  const int4 *rec1 = rec0 + a.F;
+  const int4 *rec2 = rec1 + a.F;
+  const uint32_t *ent = a.entries + slot * a.ent_cap + beg;
+  const int Pxo = px0 * 256 + 128, Pyo = py0 * 256 + 128;  // centre of the tile's first pixel
+
+  if (a.dbg & 4) cnt = 0;
+  for (uint32_t c0 = 0; c0 < cnt; c0 += CHUNK) {
+    const int n_tri = (int)min((uint32_t)CHUNK, cnt - c0);
+    __syncthreads();  // keys zeroed / previous chunk's items consumed
+    // ---- phase 1: one triangle per lane ---------------------------------------------------------------------------
+    int nrows = 0;
+    if (tid < n_tri) {
+      const uint32_t r = ent[c0 + tid];
+      const int4 p0 = rec0[r], p1 = rec1[r], p2 = rec2[r];
+      const int X0 = p0.x, Y0 = p0.y, X1 = p0.z, Y1 = p0.w, X2 = p1.x, Y2 = p1.y;
+      const int jlo = max((p2.z & 0xFFFF) - px0, 0), jhi = min((int)((uint32_t)p2.z >> 16) - px0, TW - 1);
+      const int ilo = max((p2.w & 0xFFFF) - py0, 0), ihi = min((int)((uint32_t)p2.w >> 16) - py0, TH - 1);
+      nrows = max(ihi - ilo + 1, 0);
+      if (jhi < jlo) nrows = 0;
+      const int dx0 = X1 - X0, dy0 = Y1 - Y0, dx1 = X2 - X1, dy1 = Y2 - Y1, dx2 = X0 - X2, dy2 = Y0 - Y2;
+      const long long b0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;
+      const long long b1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
+      const long long b2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
+      const long long C0 = (long long)dx0 * (Pyo - Y0) - (long long)dy0 * (Pxo - X0) + b0;
+      const long long C1 = (long long)dx1 * (Pyo - Y1) - (long long)dy1 * (Pxo - X1) + b1;
+      const long long C2 = (long long)dx2 * (Pyo - Y2) - (long long)dy2 * (Pxo - X2) + b2;
+      const long long A0 = -(long long)dy0 * 256, A1 = -(long long)dy1 * 256, A2 = -(long long)dy2 * 256;
+      const long long B0 = (long long)dx0 * 256, B1 = (long long)dx1 * 256, B2 = (long long)dx2 * 256;
+      const long long lim = 0x7FFFFFFFll;
+      // int32-safe inside this tile, including the +-2 pixel probes of the span solver
+      const bool small = (llabs(C0) + (TW + 2) * llabs(A0) + TH * llabs(B0) < lim) &&
+                         (llabs(C1) + (TW + 2) * llabs(A1) + TH * llabs(B1) < lim) &&
+                         (llabs(C2) + (TW + 2) * llabs(A2) + TH * llabs(B2) < lim);
+      int4 s0, s1, s2, s3;
+      if (small) {
+        s0 = make_int4((int)C0, (int)C1, (int)C2, (int)A0);
+        s1 = make_int4((int)A1, (int)A2, (int)B0, (int)B1);
+        s2 = make_int4((int)B2, p1.z, p2.x, p2.y);  // B2, iz0, zA, zB
+      } else {
+        s0 = make_int4(X0, Y0, X1, Y1);
+        s1 = make_int4(X2, Y2, 0, 0);
+        s2 = make_int4(0, p1.z, p2.x, p2.y);
+      }
+      // X0rel/Y0rel: (Px - X0) = 256 x + X0rel;  bbox (6 bits each) with bit 31 = needs the 64-bit loop;  ~face
+      s3 = make_int4(Pxo - X0, Pyo - Y0, jlo | (jhi << 8) | (ilo << 16) | (ihi << 24) | (small ? 0 : (int)0x80000000),
+                     (int)~(uint32_t)p1.w);
+      tris[tid * 4 + 0] = s0; tris[tid * 4 + 1] = s1; tris[tid * 4 + 2] = s2; tris[tid * 4 + 3] = s3;
+    }
+    // ---- phase 2: exclusive scan of row counts, expand to (triangle,row) items ------------------------------------------
+    int incl = nrows;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k) {
+      const int t = wave_tot[k];
+      if (k < wv) wbase += t;
+      total += t;
+    }
+    const int excl = wbase + incl - nrows;
+    if (tid < n_tri) {
+      row_off[tid] = (unsigned short)excl;
+      for (int r = 0; r < nrows; ++r) item_tri[excl + r] = (unsigned char)tid;
+    }
+    __syncthreads();
+    // ---- phase 3: one scanline of one triangle per lane -----------------------------------------------------------------
+    if (a.dbg & 1) total = 0;
+    for (int k = tid; k < total; k += NT) {
+      const int t = item_tri[k];
+      const int4 s3 = tris[t * 4 + 3];
+      const int4 s1 = tris[t * 4 + 1];
+      const int4 s0 = tris[t * 4 + 0];
+      const int4 s2 = tris[t * 4 + 2];
+      const int jlo = s3.z & 0xFF, jhi = (s3.z >> 8) & 0xFF, ilo = (s3.z >> 16) & 0xFF;
+      const int y = ilo + (k - (int)row_off[t]);
+      const float iz0 = __int_as_float(s2.y), zA = __int_as_float(s2.z), zB = __int_as_float(s2.w);
+      const float m1 = zB * (float)(y * 256 + s3.y);
+      const uint32_t key_lo = (uint32_t)s3.w;
+      const int rowbase = y << TWL;
+      const bool big = (s3.z < 0);
+      if (!big) {
+        // exact covered span [xs, xe] of this scanline: each edge E(x) = E(0) + A x >= 0 bounds x from one side
+        int xs = jlo, xe = jhi;
+        span_clip<TW>(s0.x + s1.z * y, s0.w, xs, xe);
+        span_clip<TW>(s0.y + s1.w * y, s1.x, xs, xe);
+        span_clip<TW>(s0.z + s2.x * y, s1.y, xs, xe);
+        int fxi = xs * 256 + s3.x;
+        for (int x = xs; x <= xe; ++x, fxi += 256) {
+          const float m0 = zA * (float)fxi;
+          const float s = m0 + m1;
+          const float z = iz0 + s;
+          const int zb = max(__float_as_int(z), 1);
+          const unsigned long long key = ((unsigned long long)(uint32_t)zb << 32) | key_lo;
+          atomicMax(&keys[rowbase + ((x + y) & (TW - 1))], key);
+        }
+      }
+      if (__ballot(big) != 0ull) {
+        if (big) {
+          const int X0 = s0.x, Y0 = s0.y, X1 = s0.z, Y1 = s0.w, X2 = s1.x, Y2 = s1.y;
+          const int dx0 = X1 - X0, dy0 = Y1 - Y0, dx1 = X2 - X1, dy1 = Y2 - Y1, dx2 = X0 - X2, dy2 = Y0 - Y2;
+          const long long b0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;
+          const long long b1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
+          const long long b2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
+          const long long Py = (long long)(py0 + y) * 256 + 128;
+          const long long Px = (long long)(px0 + jlo) * 256 + 128;
+          long long e0 = (long long)dx0 * (Py - Y0) - (long long)dy0 * (Px - X0) + b0;
+          long long e1 = (long long)dx1 * (Py - Y1) - (long long)dy1 * (Px - X1) + b1;
+          long long e2 = (long long)dx2 * (Py - Y2) - (long long)dy2 * (Px - X2) + b2;
+          const long long a0 = -(long long)dy0 * 256, a1 = -(long long)dy1 * 256, a2 = -(long long)dy2 * 256;
+          int fxi = jlo * 256 + s3.x;
+          for (int x = jlo; x <= jhi; ++x, e0 += a0, e1 += a1, e2 += a2, fxi += 256) {
+            if ((e0 | e1 | e2) >= 0) {
+              const float m0 = zA * (float)fxi;
+              const float s = m0 + m1;
+              const float z = iz0 + s;
+              const int zb = max(__float_as_int(z), 1);
+              const unsigned long long key = ((unsigned long long)(uint32_t)zb << 32) | key_lo;
+              atomicMax(&keys[rowbase + ((x + y) & (TW - 1))], key);
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // epilogue: each wave stores whole rows (TW pixels, coalesced); NT/64 waves interleave over the TH rows
+  constexpr int ROWS_PER_PASS = NT / TW;  // rows covered by the workgroup per pass (TW <= NT)
+  const int col = tid & (TW - 1);
+  const int gx = px0 + col;
+  if (gx < a.w && !(a.dbg & 2)) {
+    const int64_t plane = (int64_t)slot * a.h * a.w;
+    for (int row = tid >> TWL; row < TH; row += ROWS_PER_PASS) {
+      const int gy = py0 + row;
+      if (gy >= a.h) break;
+      const unsigned long long key = keys[lds_rot<TWL, THL>(row, col)];
       const int64_t p = plane + (int64_t)gy * a.w + gx;
       if (out.ids) out.ids[p] = key ? (int32_t)(~(uint32_t)key) : -1;
       if (out.depth) out.depth[p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
@@ -539,11 +873,18 @@ struct gr_ctx {
   uint32_t *ctrl = nullptr;
   int4 *rec = nullptr;
   uint32_t *entries = nullptr;
+  float4 *blk = nullptr;
+  int64_t blk_cap = 0;
   unsigned long long *stats = nullptr;
   int *flag = nullptr;
   int64_t ctrl_stride = 0, rec_stride = 0, ent_cap = 0, ent_cap_request = 0;
   int Tcap = 0, slots = 0;
   int64_t rec_F = 0;
+  // tuning knobs (gr_set_option)
+  int opt_kernel = 1;   // 0: 8x8-stamp kernel (64x64 tiles), 1: row-item kernel
+  int opt_thl = 6;      // log2 tile height for the row-item kernel (5 or 6); width is 64
+  int opt_batch = GR_MAX_BATCH;
+  int opt_dbg = 0;
   // winner scratch
   void *winner = nullptr;
   size_t winner_bytes = 0;
@@ -608,15 +949,15 @@ int ensure_bins(gr_ctx *c, int n_slots, int T) {
   const int slots = n_slots > c->slots ? n_slots : c->slots;
   const int Tcap = T > c->Tcap ? T : c->Tcap;
   const int64_t cap = want_cap > c->ent_cap ? want_cap : c->ent_cap;
-  const int64_t ctrl_stride = ((GR_CTRL_HDR + 3 * (int64_t)Tcap) + 63) / 64 * 64;
+  const int64_t ctrl_stride = ((GR_CTRL_HDR + 4 * (int64_t)Tcap) + 63) / 64 * 64;
   if (hipMalloc(&c->ctrl, sizeof(uint32_t) * ctrl_stride * slots) != hipSuccess ||
-      hipMalloc(&c->rec, sizeof(int4) * 3 * (F > 0 ? F : 1) * slots) != hipSuccess ||
+      hipMalloc(&c->rec, sizeof(int4) * 4 * (F > 0 ? F : 1) * slots) != hipSuccess ||
       hipMalloc(&c->entries, sizeof(uint32_t) * cap * slots) != hipSuccess) {
     c->slots = 0; c->Tcap = 0; c->ent_cap = 0;
     return fail(c, GR_ENOMEM, "bin scratch allocation failed (slots=%d F=%lld cap=%lld)", slots, (long long)F,
                 (long long)cap);
   }
-  c->slots = slots; c->Tcap = Tcap; c->ent_cap = cap; c->ctrl_stride = ctrl_stride; c->rec_stride = 3 * F;
+  c->slots = slots; c->Tcap = Tcap; c->ent_cap = cap; c->ctrl_stride = ctrl_stride; c->rec_stride = 4 * F;
   c->rec_F = F;
   return GR_OK;
 }
@@ -634,10 +975,11 @@ int ensure_winner(gr_ctx *c, size_t bytes) {
 
 BinArgs make_args(gr_ctx *c, int h, int w) {
   BinArgs a;
-  a.ctrl = c->ctrl; a.rec = c->rec; a.entries = c->entries; a.stats = c->stats;
+  a.ctrl = c->ctrl; a.rec = c->rec; a.entries = c->entries; a.stats = c->stats; a.blk = c->blk;
   a.ctrl_stride = c->ctrl_stride; a.rec_stride = c->rec_stride; a.ent_cap = c->ent_cap; a.F = c->F;
-  a.TX = (w + GR_TILE - 1) / GR_TILE; a.TY = (h + GR_TILE - 1) / GR_TILE; a.T = a.TX * a.TY; a.Tcap = c->Tcap;
-  a.h = h; a.w = w;
+  a.twl = GR_TILE_LOG2; a.thl = (c->opt_kernel == 0) ? GR_TILE_LOG2 : c->opt_thl;
+  a.TX = (w + (1 << a.twl) - 1) >> a.twl; a.TY = (h + (1 << a.thl) - 1) >> a.thl; a.T = a.TX * a.TY; a.Tcap = c->Tcap;
+  a.h = h; a.w = w; a.dbg = c->opt_dbg;
   return a;
 }
 
@@ -661,7 +1003,20 @@ int raster_batch(gr_ctx *c, const float *cams, int nb, int h, int w, RasterOut o
   }
   {
     Timed t(c, s, ST_RASTER);
-    hipLaunchKernelGGL(k_raster_tile, dim3(a.T, nb), dim3(GR_RASTER_THREADS), 0, s, a, out);
+    if (c->opt_kernel == 0)
+      hipLaunchKernelGGL(k_raster_tile, dim3(a.T, nb), dim3(GR_RASTER_THREADS), 0, s, a, out);
+    else if (c->opt_kernel == 1 && a.thl == 6)
+      hipLaunchKernelGGL((k_raster_rows<6, 6, 256, 128>), dim3(a.T, nb), dim3(256), 0, s, a, out);
+    else if (c->opt_kernel == 1)
+      hipLaunchKernelGGL((k_raster_rows<6, 5, 256, 128>), dim3(a.T, nb), dim3(256), 0, s, a, out);
+    else if (c->opt_kernel == 2 && a.thl == 6)
+      hipLaunchKernelGGL((k_raster_rows<6, 6, 512, 128>), dim3(a.T, nb), dim3(512), 0, s, a, out);
+    else if (c->opt_kernel == 2)
+      hipLaunchKernelGGL((k_raster_rows<6, 5, 512, 128>), dim3(a.T, nb), dim3(512), 0, s, a, out);
+    else if (a.thl == 6)
+      hipLaunchKernelGGL((k_raster_rows<6, 6, 1024, 256>), dim3(a.T, nb), dim3(1024), 0, s, a, out);
+    else
+      hipLaunchKernelGGL((k_raster_rows<6, 5, 1024, 256>), dim3(a.T, nb), dim3(1024), 0, s, a, out);
     c->prof_raster_launches += 1;
   }
   c->prof_views += nb;
@@ -742,6 +1097,7 @@ int gr_ctx_destroy(gr_ctx *c) {
   if (c->rec) (void)hipFree(c->rec);
   if (c->entries) (void)hipFree(c->entries);
   if (c->winner) (void)hipFree(c->winner);
+  if (c->blk) (void)hipFree(c->blk);
   if (c->stats) (void)hipFree(c->stats);
   if (c->flag) (void)hipFree(c->flag);
   delete c;
@@ -757,6 +1113,24 @@ int gr_set_profiling(gr_ctx *c, int enabled) {
   c->spans.clear();
   c->prof_views = 0; c->prof_raster_launches = 0;
   return GR_OK;
+}
+
+int gr_set_option(gr_ctx *c, int key, int value) {
+  if (!c) return GR_EINVAL;
+  switch (key) {
+    case GR_OPT_RASTER_KERNEL:
+      if (value < 0 || value > 3) return fail(c, GR_EINVAL, "raster kernel must be 0..3");
+      c->opt_kernel = value; return GR_OK;
+    case GR_OPT_TILE_H_LOG2:
+      if (value != 5 && value != 6) return fail(c, GR_EINVAL, "tile height log2 must be 5 or 6");
+      c->opt_thl = value; return GR_OK;
+    case GR_OPT_BATCH:
+      if (value < 1 || value > 64) return fail(c, GR_EINVAL, "batch must be in [1, 64]");
+      c->opt_batch = value; return GR_OK;
+    case GR_OPT_DEBUG:
+      c->opt_dbg = value; return GR_OK;
+    default: return fail(c, GR_EINVAL, "unknown option %d", key);
+  }
 }
 
 int gr_get_stage_times(gr_ctx *c, gr_stage_times *o) {
@@ -789,6 +1163,15 @@ int gr_mesh_upload(gr_ctx *c, const float *verts, const int32_t *faces, int64_t 
   GR_HIP(c, hipMemcpyAsync(&bad, c->flag, sizeof(int), hipMemcpyDeviceToHost, s));
   GR_HIP(c, hipStreamSynchronize(s));
   if (bad) return fail(c, GR_EINDEX, "face index outside [0, %lld)", (long long)V);
+  const int64_t nblk = ceil_div(F, 256);
+  if (c->blk_cap < nblk) {
+    if (c->blk) (void)hipFree(c->blk);
+    c->blk = nullptr; c->blk_cap = 0;
+    if (hipMalloc(&c->blk, sizeof(float4) * nblk) != hipSuccess) return fail(c, GR_ENOMEM, "block bounds allocation failed");
+    c->blk_cap = nblk;
+  }
+  hipLaunchKernelGGL(k_block_bounds, dim3((unsigned)nblk), dim3(256), 0, s, verts, faces, F, c->blk);
+  GR_HIP(c, hipGetLastError());
   c->verts = verts; c->faces = faces; c->V = V; c->F = F;
   return GR_OK;
 }
@@ -802,8 +1185,9 @@ int gr_raster_face_ids(gr_ctx *c, const float *cams, int n_views, int h, int w, 
   if (n_views == 0) return GR_OK;
   hipStream_t s = (hipStream_t)stream;
   GR_HIP(c, hipSetDevice(c->device));
-  const int B = n_views < GR_MAX_BATCH ? n_views : GR_MAX_BATCH;
-  const int T = ((w + GR_TILE - 1) / GR_TILE) * ((h + GR_TILE - 1) / GR_TILE);
+  const int B = n_views < c->opt_batch ? n_views : c->opt_batch;
+  const int thl = (c->opt_kernel == 0) ? GR_TILE_LOG2 : c->opt_thl;
+  const int T = ((w + GR_TILE - 1) >> GR_TILE_LOG2) * ((h + (1 << thl) - 1) >> thl);
   rc = ensure_bins(c, B, T);
   if (rc) return rc;
   c->last_stream = s;

@@ -85,6 +85,16 @@ const char *gr_last_error(const gr_ctx *ctx);
 /* Turn per-stage hipEvent timing on (1) or off (0).  When on, events are recorded on `stream` around every
  * kernel group; gr_get_stage_times synchronises on them. */
 int gr_set_profiling(gr_ctx *ctx, int enabled);
+
+/* Tuning knobs (results never depend on them; tests run every setting against the oracle). */
+enum {
+  GR_OPT_RASTER_KERNEL = 1, /* 0: 8x8-stamp tile kernel; row-item tile kernel with 1: 256 (default), 2: 512,
+                               3: 1024 threads per tile                                                  */
+  GR_OPT_TILE_H_LOG2 = 2,   /* row-item kernel tile height: 5 (64x32) or 6 (64x64, default)       */
+  GR_OPT_BATCH = 3,         /* views per launch group, 1..64 (default 16)                         */
+  GR_OPT_DEBUG = 99         /* timing-only ablation mask for tools/ab_raster.py: OUTPUTS BECOME WRONG */
+};
+int gr_set_option(gr_ctx *ctx, int key, int value);
 int gr_get_stage_times(gr_ctx *ctx, gr_stage_times *out_h);
 
 /* mesh -- replaces the per-view mesh + colour upload of meshes.py:1776-1817 (plotter.clear/add_mesh) and the
