@@ -1,7 +1,7 @@
 // geograypher_amd/csrc/geograster.hip -- hand-written CDNA4 (gfx950, wave64) kernels + the C ABI of include/geograster.h.
 //
 // Hot path of geograypher re-designed for MI355X (reference lines in include/geograster.h and DESIGN.md):
-//   pix2face            k_setup_cull -> k_scan_tiles -> k_fill_bins -> k_raster_tile     (meshes.py:1776-1836)
+//   pix2face            k_setup_cull -> k_scan_tiles -> k_fill_compile -> k_raster_rows  (meshes.py:1776-1836)
 //   project/aggregate   k_winner_*   -> k_vote_*                                          (meshes.py:1987-2002, 2057-2067)
 //   render_flat gather  k_gather_texture                                                  (meshes.py:1921-1937)
 // No MFMA anywhere: there is no dense contraction on this path.  The work is integer edge functions, an
@@ -28,9 +28,8 @@
 // ------------------------------------------------------------------------------------------------------------------
 #define GR_TILE 64          // tile edge in pixels (one workgroup rasterizes one 64x64 tile out of LDS)
 #define GR_TILE_LOG2 6
-#define GR_RASTER_THREADS 256
-#define GR_MAX_BATCH 16     // views per launch group (amortises kernel boundaries)
-#define GR_CTRL_HDR 4       // ctrl words before the tile arrays: rec_count, total_entries, overflow, pad
+#define GR_MAX_BATCH 32     // views per launch group (amortises kernel boundaries)
+#define GR_CTRL_HDR 4       // ctrl words before the tile arrays: rec_count, total_entries, overflow, work_count
 #define GR_MAX_DIM 16384    // h, w limit (guard band and 16-bit bbox packing)
 
 namespace {
@@ -42,7 +41,9 @@ struct BinArgs {
   int4 *rec;             // [slot][4][F]  plane0 {X0,Y0,X1,Y1} plane1 {X2,Y2,iz0,face} plane2 {A,B,jmin|jmax<<16,imin|imax<<16}
                          //               plane3 {list position in up to 4 tiles}
   const float4 *blk;     // [ceil(F/256)] bounding sphere (centre, radius) of each block of 256 faces, local frame
-  uint32_t *entries;     // [slot][ent_cap]  record indices grouped by tile
+  uint32_t *work;        // [slot][work_stride] blocks of this view that passed the frustum test (ctrl[3] = count)
+  int64_t work_stride;
+  int4 *comp;            // [slot][ent_cap][4]  compiled (face, tile) entries grouped by tile, 64 B each
   unsigned long long *stats;  // [4] records, entries, max_entries, overflow (accumulated over the call)
   int64_t ctrl_stride;   // words per slot
   int64_t rec_stride;    // int4 per slot (= 3*F)
@@ -137,32 +138,35 @@ __global__ __launch_bounds__(256) void k_block_bounds(const float *__restrict__ 
 //     (d) tile counting is aggregated per wave as well: lanes that hit the same tile share one returning atomicAdd
 //         and receive consecutive list positions, which k_fill_bins later uses without any atomic.
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_count_tile(uint32_t *cnt, int t, int lane) {
-  // every lane with t >= 0 receives a unique position in tile t's list; one atomic per distinct tile in the wave
-  uint32_t pos = 0;
+// Lanes of a wave that hit the same tile form a group: leader lane, rank inside the group, group size -- found with
+// ballots and shuffles only (no memory traffic), so that the leaders' atomics can all be issued back to back.
+__device__ __forceinline__ void wave_group(int t, int lane, int &leader, int &rank, int &size) {
+  leader = lane; rank = 0; size = 0;
   unsigned long long rem = __ballot(t >= 0);
   while (rem) {
-    const int leader = __ffsll((long long)rem) - 1;
-    const int tl = __shfl(t, leader);
+    const int l = __ffsll((long long)rem) - 1;
+    const int tl = __shfl(t, l);
     const unsigned long long m = __ballot(t == tl);
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&cnt[tl], (uint32_t)__popcll(m));
-    base = __shfl(base, leader);
-    if (t == tl) pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (t == tl) {
+      leader = l;
+      rank = __popcll(m & ((1ull << lane) - 1ull));
+      size = __popcll(m);
+    }
     rem &= ~m;
   }
-  return pos;
 }
 
-__global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ verts, const int32_t *__restrict__ faces,
-                                                    const float *__restrict__ cams, BinArgs a) {
+// K0b  per view: sphere-vs-frustum test of every 256-face block (one thread per block); survivors are appended to the
+//      view's work list with one wave-aggregated atomic.  grid (ceil(nblk/256), views)
+__global__ __launch_bounds__(256) void k_cull_blocks(const float *__restrict__ cams, BinArgs a, int nblk) {
   const int slot = blockIdx.y;
-  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.x * 256 + threadIdx.x;
   const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
   uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
-
-  {  // (a) sphere vs frustum, camera space.  Planes carry a 2-pixel margin; any NaN keeps the block.
-    const float4 sp = a.blk[blockIdx.x];
+  bool keep = false;
+  if (b < nblk) {
+    // camera space; planes carry a 2-pixel margin; any NaN keeps the block
+    const float4 sp = a.blk[b];
     const float dx = sp.x - cam[9], dy = sp.y - cam[10], dz = sp.z - cam[11];
     const float qx = cam[0] * dx + cam[3] * dy + cam[6] * dz;
     const float qy = cam[1] * dx + cam[4] * dy + cam[7] * dz;
@@ -175,8 +179,27 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
     out = out || (-cam[12] * qx + mxr * qz < -r * (fe + fabsf(mxr)));
     out = out || (cam[12] * qy + myt * qz < -r * (fe + fabsf(myt)));
     out = out || (-cam[12] * qy + myb * qz < -r * (fe + fabsf(myb)));
-    if (out) return;
+    keep = !out;
   }
+  const unsigned long long m = __ballot(keep);
+  if (m == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)m) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(&ctrl[3], (uint32_t)__popcll(m));
+  base = __shfl(base, leader);
+  if (keep) a.work[(int64_t)slot * a.work_stride + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)b;
+}
+
+__global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ verts, const int32_t *__restrict__ faces,
+                                                    const float *__restrict__ cams, BinArgs a) {
+  const int slot = blockIdx.y;
+  const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
+  uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  const uint32_t n_work = ctrl[3];  // (a) blocks that passed k_cull_blocks for this view
+  const uint32_t *work = a.work + (int64_t)slot * a.work_stride;
+  for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+  const int64_t f = (int64_t)work[wi] * 256 + threadIdx.x;
 
   bool keep = false;
   int4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0};
@@ -222,30 +245,38 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
   }
   // wave-level compaction of survivors
   const unsigned long long m = __ballot(keep);
-  if (m == 0ull) return;
+  if (m == 0ull) continue;
   const int lane = threadIdx.x & 63;
   const int n = __popcll(m);
   const int prefix = __popcll(m & ((1ull << lane) - 1ull));
   const int leader = __ffsll((long long)m) - 1;
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(&ctrl[0], (uint32_t)n);
-  base = __shfl(base, leader);
   // (d) tile counts.  Faces touching at most 2x2 tiles get their list positions here (wave-aggregated atomics);
-  //     larger faces are only counted (cntB) and placed by k_fill_bins.
+  //     larger faces are only counted (cntB) and placed by k_fill_compile.  Groups are found first (registers only),
+  //     then ALL atomics of the wave -- record slot + up to four tile counters -- are issued before any is consumed.
   const bool small_fp = keep && (tx1 - tx0 <= 1) && (ty1 - ty0 <= 1);
   uint32_t *cntS = ctrl + GR_CTRL_HDR;
   uint32_t *cntB = cntS + a.Tcap;
-  int4 r3 = {0, 0, 0, 0};
-  {
-    const int t00 = small_fp ? ty0 * a.TX + tx0 : -1;
-    const int t01 = (small_fp && tx1 > tx0) ? ty0 * a.TX + tx1 : -1;
-    const int t10 = (small_fp && ty1 > ty0) ? ty1 * a.TX + tx0 : -1;
-    const int t11 = (small_fp && tx1 > tx0 && ty1 > ty0) ? ty1 * a.TX + tx1 : -1;
-    r3.x = (int)wave_count_tile(cntS, t00, lane);
-    if (__ballot(t01 >= 0)) r3.y = (int)wave_count_tile(cntS, t01, lane);
-    if (__ballot(t10 >= 0)) r3.z = (int)wave_count_tile(cntS, t10, lane);
-    if (__ballot(t11 >= 0)) r3.w = (int)wave_count_tile(cntS, t11, lane);
-  }
+  const int t00 = small_fp ? ty0 * a.TX + tx0 : -1;
+  const int t01 = (small_fp && tx1 > tx0) ? ty0 * a.TX + tx1 : -1;
+  const int t10 = (small_fp && ty1 > ty0) ? ty1 * a.TX + tx0 : -1;
+  const int t11 = (small_fp && tx1 > tx0 && ty1 > ty0) ? ty1 * a.TX + tx1 : -1;
+  int l0, k0, n0, l1 = lane, k1 = 0, n1 = 0, l2 = lane, k2 = 0, n2 = 0, l3 = lane, k3 = 0, n3 = 0;
+  wave_group(t00, lane, l0, k0, n0);
+  if (__ballot(t01 >= 0)) wave_group(t01, lane, l1, k1, n1);
+  if (__ballot(t10 >= 0)) wave_group(t10, lane, l2, k2, n2);
+  if (__ballot(t11 >= 0)) wave_group(t11, lane, l3, k3, n3);
+  uint32_t base = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+  if (lane == leader) base = atomicAdd(&ctrl[0], (uint32_t)n);
+  if (t00 >= 0 && lane == l0) b0 = atomicAdd(&cntS[t00], (uint32_t)n0);
+  if (t01 >= 0 && lane == l1) b1 = atomicAdd(&cntS[t01], (uint32_t)n1);
+  if (t10 >= 0 && lane == l2) b2 = atomicAdd(&cntS[t10], (uint32_t)n2);
+  if (t11 >= 0 && lane == l3) b3 = atomicAdd(&cntS[t11], (uint32_t)n3);
+  base = __shfl(base, leader);
+  int4 r3;
+  r3.x = (int)(__shfl(b0, l0) + (uint32_t)k0);
+  r3.y = (int)(__shfl(b1, l1) + (uint32_t)k1);
+  r3.z = (int)(__shfl(b2, l2) + (uint32_t)k2);
+  r3.w = (int)(__shfl(b3, l3) + (uint32_t)k3);
   if (keep) {
     int4 *rec = a.rec + slot * a.rec_stride;
     const int64_t s = (int64_t)base + prefix;
@@ -257,6 +288,7 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
       for (int ty = ty0; ty <= ty1; ++ty)
         for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&cntB[ty * a.TX + tx], 1u);
   }
+  }  // work list loop
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -305,200 +337,105 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(BinArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K3  scatter record indices into their tiles' lists.  grid (G, views), grid-stride over the surviving records.
-//     Positions of <= 2x2-tile faces were assigned in K1: plain stores.  Larger faces take a cursor atomic per tile.
+// K3  per (face, tile) entry: re-base the face's edge functions to the tile origin and store the 64-byte "compiled"
+//     entry at its place in the tile's list.  grid (G, views), grid-stride over the surviving records.
+//       E_k(x, y) = C_k + A_k x + B_k y,  x, y = tile-local pixel;  covered <=> all E_k >= 0 (fill rule folded in C_k)
+//     All 64-bit set-up arithmetic happens here, once per entry, at full occupancy; the tile rasterizer then only
+//     streams entries (no index indirection, no 64-bit multiplies).  Entries whose edge values could leave int32
+//     inside the tile keep their vertices instead and are walked with 64-bit adds (flag bit 31 of the bbox word).
+//     List positions of <= 2x2-tile faces come from K1 (plain stores); larger faces take one cursor atomic per tile.
+//       word  0..3   C0 C1 C2 A0        | X0 Y0 X1 Y1      (64-bit form)
+//       word  4..7   A1 A2 B0 B1        | X2 Y2 -  -
+//       word  8..11  B2 iz0 zA zB
+//       word 12..15  X0rel Y0rel bbox ~face      (Px - X0 = 256 x + X0rel;  bbox = jlo | jhi<<8 | ilo<<16 | ihi<<24)
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fill_bins(BinArgs a) {
+__device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, const int4 p0, const int4 p1, const int4 p2,
+                                              int px0, int py0, int TW, int TH) {
+  const int X0 = p0.x, Y0 = p0.y, X1 = p0.z, Y1 = p0.w, X2 = p1.x, Y2 = p1.y;
+  const int Pxo = px0 * 256 + 128, Pyo = py0 * 256 + 128;  // centre of the tile's first pixel
+  const int jlo = max((p2.z & 0xFFFF) - px0, 0), jhi = min((int)((uint32_t)p2.z >> 16) - px0, TW - 1);
+  const int ilo = max((p2.w & 0xFFFF) - py0, 0), ihi = min((int)((uint32_t)p2.w >> 16) - py0, TH - 1);
+  const int dx0 = X1 - X0, dy0 = Y1 - Y0, dx1 = X2 - X1, dy1 = Y2 - Y1, dx2 = X0 - X2, dy2 = Y0 - Y2;
+  const long long b0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;  // R3 top-left rule as a bias
+  const long long b1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
+  const long long b2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
+  const long long C0 = (long long)dx0 * (Pyo - Y0) - (long long)dy0 * (Pxo - X0) + b0;
+  const long long C1 = (long long)dx1 * (Pyo - Y1) - (long long)dy1 * (Pxo - X1) + b1;
+  const long long C2 = (long long)dx2 * (Pyo - Y2) - (long long)dy2 * (Pxo - X2) + b2;
+  const long long A0 = -(long long)dy0 * 256, A1 = -(long long)dy1 * 256, A2 = -(long long)dy2 * 256;
+  const long long B0 = (long long)dx0 * 256, B1 = (long long)dx1 * 256, B2 = (long long)dx2 * 256;
+  const long long lim = 0x7FFFFFFFll;
+  // int32-safe inside this tile, including the +-2 pixel probes of the span solver
+  const bool small = (llabs(C0) + (TW + 2) * llabs(A0) + TH * llabs(B0) < lim) &&
+                     (llabs(C1) + (TW + 2) * llabs(A1) + TH * llabs(B1) < lim) &&
+                     (llabs(C2) + (TW + 2) * llabs(A2) + TH * llabs(B2) < lim);
+  const int bbox = jlo | (jhi << 8) | (ilo << 16) | (ihi << 24) | (small ? 0 : (int)0x80000000);
+  if (small) {
+    dst[0] = make_int4((int)C0, (int)C1, (int)C2, (int)A0);
+    dst[1] = make_int4((int)A1, (int)A2, (int)B0, (int)B1);
+    dst[2] = make_int4((int)B2, p1.z, p2.x, p2.y);
+  } else {
+    dst[0] = make_int4(X0, Y0, X1, Y1);
+    dst[1] = make_int4(X2, Y2, 0, 0);
+    dst[2] = make_int4(0, p1.z, p2.x, p2.y);
+  }
+  dst[3] = make_int4(Pxo - X0, Pyo - Y0, bbox, (int)~(uint32_t)p1.w);
+}
+
+__global__ __launch_bounds__(256) void k_fill_compile(BinArgs a) {
   const int slot = blockIdx.y;
   uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
   const uint32_t n_rec = ctrl[0];
   const uint32_t *cntS = ctrl + GR_CTRL_HDR;
   const uint32_t *off = ctrl + GR_CTRL_HDR + 2 * a.Tcap;
   uint32_t *cur = ctrl + GR_CTRL_HDR + 3 * a.Tcap;
-  const int4 *rec2 = a.rec + slot * a.rec_stride + 2 * a.F;
-  const int4 *rec3 = a.rec + slot * a.rec_stride + 3 * a.F;
-  uint32_t *ent = a.entries + slot * a.ent_cap;
+  const int4 *rec0 = a.rec + slot * a.rec_stride;
+  int4 *comp = a.comp + slot * a.ent_cap * 4;
+  const int TW = 1 << a.twl, TH = 1 << a.thl;
   for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n_rec; r += gridDim.x * 256) {
-    const int4 q = rec2[r];
-    const int tx0 = (q.z & 0xFFFF) >> a.twl, tx1 = (int)((uint32_t)q.z >> 16) >> a.twl;
-    const int ty0 = (q.w & 0xFFFF) >> a.thl, ty1 = (int)((uint32_t)q.w >> 16) >> a.thl;
-    if ((tx1 - tx0 <= 1) && (ty1 - ty0 <= 1)) {
-      const int4 pos = rec3[r];
-      const int t00 = ty0 * a.TX + tx0;
-      int64_t idx = (int64_t)off[t00] + (uint32_t)pos.x;
-      if (idx < a.ent_cap) ent[idx] = r;
-      if (tx1 > tx0) {
-        idx = (int64_t)off[t00 + 1] + (uint32_t)pos.y;
-        if (idx < a.ent_cap) ent[idx] = r;
+    const int4 p0 = rec0[r], p1 = rec0[a.F + r], p2 = rec0[2 * a.F + r];
+    const int tx0 = (p2.z & 0xFFFF) >> a.twl, tx1 = (int)((uint32_t)p2.z >> 16) >> a.twl;
+    const int ty0 = (p2.w & 0xFFFF) >> a.thl, ty1 = (int)((uint32_t)p2.w >> 16) >> a.thl;
+    const bool small_fp = (tx1 - tx0 <= 1) && (ty1 - ty0 <= 1);
+    int4 pos = {0, 0, 0, 0};
+    if (small_fp) pos = rec0[3 * a.F + r];
+#pragma unroll 1
+    for (int ty = ty0; ty <= ty1; ++ty) {
+#pragma unroll 1
+      for (int tx = tx0; tx <= tx1; ++tx) {
+        const int t = ty * a.TX + tx;
+        const int k = ((ty - ty0) << 1) | (tx - tx0);
+        const uint32_t pk = (uint32_t)(k == 0 ? pos.x : k == 1 ? pos.y : k == 2 ? pos.z : pos.w);
+        const int64_t idx = small_fp ? (int64_t)off[t] + pk : (int64_t)off[t] + cntS[t] + atomicAdd(&cur[t], 1u);
+        if (idx < a.ent_cap) compile_entry(comp + idx * 4, p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH);
       }
-      if (ty1 > ty0) {
-        const int t10 = ty1 * a.TX + tx0;
-        idx = (int64_t)off[t10] + (uint32_t)pos.z;
-        if (idx < a.ent_cap) ent[idx] = r;
-        if (tx1 > tx0) {
-          idx = (int64_t)off[t10 + 1] + (uint32_t)pos.w;
-          if (idx < a.ent_cap) ent[idx] = r;
-        }
-      }
-    } else {
-      for (int ty = ty0; ty <= ty1; ++ty)
-        for (int tx = tx0; tx <= tx1; ++tx) {
-          const int t = ty * a.TX + tx;
-          const int64_t idx = (int64_t)off[t] + cntS[t] + atomicAdd(&cur[t], 1u);
-          if (idx < a.ent_cap) ent[idx] = r;
-        }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K4  tile rasterizer (the dominant kernel).  grid (T, views), 256 threads = 4 waves, one 64x64 tile per workgroup.
-//     depth|id keys (u64: 1/z bits << 32 | ~face) live in 32 KiB of LDS; each wave takes every 4th triangle of the
-//     tile's list, walks its bounding box in 8x8 stamps (lane = pixel) and resolves visibility with ds_max_u64, so
-//     the result is independent of list order.  LDS column index is XOR-swizzled by (row & 3) << 3 so the four
-//     rows serviced together by one 32-lane group land on 64 distinct banks.  Epilogue: one coalesced 256-byte row
-//     store per wave-instruction.
+// K4  tile rasterizer (the dominant kernel).  grid (T, views), NT threads = NW waves, one TW x TH tile per workgroup.
+//     depth|id keys (u64: 1/z bits << 32 | ~face) live in LDS; visibility is resolved with ds_max_u64, so the result
+//     does not depend on list order.  Between the two workgroup barriers (keys zeroed / keys complete) every wave
+//     works on its own, without further synchronisation:
+//       phase 1  each lane streams ONE compiled entry of the tile's list (64 B) into 16 registers;
+//       phase 2  the entries' row counts are prefix-summed with wave shuffles: the wave's work is total_rows
+//                (entry, row) items; item q finds its entry by a 6-step search over the lanes' offsets and pulls the
+//                entry's 16 words out of the owning lane's registers (ds_bpermute) -- no LDS staging at all;
+//       phase 3  ONE SCANLINE OF ONE TRIANGLE PER LANE: the exact covered span [xs, xe] comes from the three edge
+//                inequalities (float reciprocal proposal + exact int32 correction), then the lane walks the span
+//                and issues one ds_max_u64 per covered pixel.  Entries flagged 64-bit take a bounding-box walk
+//                with 64-bit edge adds (same results, exact).
+//     LDS column rotation (col + row) & (TW-1): the rows of one triangle walk neighbouring columns in step, the
+//     rotation spreads them over distinct banks; a row read in the epilogue stays conflict-free.
+//     Epilogue: whole rows, one coalesced 256-byte store per wave-instruction.
 // ------------------------------------------------------------------------------------------------------------------
 struct RasterOut {
   int32_t *ids;    // [slot][h][w] or null
   float *depth;    // [slot][h][w] or null
 };
 
-__device__ __forceinline__ int lds_index(int row, int col) { return row * GR_TILE + (col ^ ((row & 3) << 3)); }
-
-__global__ __launch_bounds__(GR_RASTER_THREADS) void k_raster_tile(BinArgs a, RasterOut out) {
-  __shared__ unsigned long long keys[GR_TILE * GR_TILE];
-  const int slot = blockIdx.y;
-  const int tile = blockIdx.x;
-  const int tx = tile % a.TX, ty = tile / a.TX;
-  const int px0 = tx * GR_TILE, py0 = ty * GR_TILE;
-  const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
-  const int tid = threadIdx.x;
-
-  for (int i = tid; i < GR_TILE * GR_TILE; i += GR_RASTER_THREADS) keys[i] = 0ull;
-  __syncthreads();
-
-  uint32_t cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
-  const int64_t beg = ctrl[GR_CTRL_HDR + 2 * a.Tcap + tile];
-  if (beg >= a.ent_cap) cnt = 0;
-  else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
-
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lane = tid & 63, lx = lane & 7, ly = lane >> 3;
-  const int4 *rec0 = a.rec + slot * a.rec_stride;
-  const int4 *rec1 = rec0 + a.F;
-  const int4 *rec2 = rec1 + a.F;
-  const uint32_t *ent = a.entries + slot * a.ent_cap + beg;
-  // lane-constant part of the swizzled LDS index: row ly, column lx, swizzle (ly & 3) << 3
-  const int lds_lane = ly * GR_TILE + lx;
-  const int swz = (ly & 3) << 3;
-
-  for (uint32_t e = wave; e < cnt; e += GR_RASTER_THREADS / 64) {
-    const uint32_t r = __builtin_amdgcn_readfirstlane(ent[e]);
-    const int4 p0 = rec0[r], p1 = rec1[r], p2 = rec2[r];
-    const int X0 = p0.x, Y0 = p0.y, X1 = p0.z, Y1 = p0.w, X2 = p1.x, Y2 = p1.y;
-    const float iz0 = __int_as_float(p1.z);
-    const uint32_t face = (uint32_t)p1.w;
-    const float A = __int_as_float(p2.x), B = __int_as_float(p2.y);
-    // bounding box of pixel centres, intersected with this tile, in tile-local pixels
-    const int jlo = max((p2.z & 0xFFFF) - px0, 0), jhi = min((int)((uint32_t)p2.z >> 16) - px0, GR_TILE - 1);
-    const int ilo = max((p2.w & 0xFFFF) - py0, 0), ihi = min((int)((uint32_t)p2.w >> 16) - py0, GR_TILE - 1);
-    // R3 edges k: (v0->v1), (v1->v2), (v2->v0); covered <=> E_k + bias_k >= 0 with bias = owns ? 0 : -1
-    const int dx0 = X1 - X0, dy0 = Y1 - Y0;
-    const int dx1 = X2 - X1, dy1 = Y2 - Y1;
-    const int dx2 = X0 - X2, dy2 = Y0 - Y2;
-    const int b0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;
-    const int b1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
-    const int b2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
-    const int ext = max(imax3(X0, X1, X2) - imin3(X0, X1, X2), imax3(Y0, Y1, Y2) - imin3(Y0, Y1, Y2));
-    const unsigned long long key_lo = (unsigned long long)(~face);
-
-    if (ext < 16384) {
-      // small triangle (< 64 px): every product fits 32 bits, operands fit 24 bits (full-rate v_mul_i32_i24)
-      const int L0 = __mul24(dx0, ly * 256) - __mul24(dy0, lx * 256);
-      const int L1 = __mul24(dx1, ly * 256) - __mul24(dy1, lx * 256);
-      const int L2 = __mul24(dx2, ly * 256) - __mul24(dy2, lx * 256);
-      for (int sy = ilo & ~7; sy <= ihi; sy += 8) {
-        const int Pys = (py0 + sy) * 256 + 128;  // stamp-origin pixel centre (wave-uniform)
-        for (int sx = jlo & ~7; sx <= jhi; sx += 8) {
-          const int Pxs = (px0 + sx) * 256 + 128;
-          const int E0 = dx0 * (Pys - Y0) - dy0 * (Pxs - X0) + b0;
-          const int E1 = dx1 * (Pys - Y1) - dy1 * (Pxs - X1) + b1;
-          const int E2 = dx2 * (Pys - Y2) - dy2 * (Pxs - X2) + b2;
-          const bool inside = (((E0 + L0) | (E1 + L1) | (E2 + L2)) >= 0);
-          if (__ballot(inside) == 0ull) continue;
-          if (inside) {
-            const float fx = (float)((Pxs - X0) + lx * 256);
-            const float fy = (float)((Pys - Y0) + ly * 256);
-            const float m0 = A * fx;
-            const float m1 = B * fy;
-            const float s = m0 + m1;
-            const float z = iz0 + s;
-            const int zb = max(__float_as_int(z), 1);
-            const unsigned long long key = ((unsigned long long)(uint32_t)zb << 32) | key_lo;
-            atomicMax(&keys[sy * GR_TILE + lds_lane + (sx ^ swz)], key);
-          }
-        }
-      }
-    } else {
-      // large triangle: exact 64-bit edge functions
-      for (int sy = ilo & ~7; sy <= ihi; sy += 8) {
-        for (int sx = jlo & ~7; sx <= jhi; sx += 8) {
-          const long long Px = (long long)(px0 + sx + lx) * 256 + 128;
-          const long long Py = (long long)(py0 + sy + ly) * 256 + 128;
-          const long long E0 = (long long)dx0 * (Py - Y0) - (long long)dy0 * (Px - X0) + b0;
-          const long long E1 = (long long)dx1 * (Py - Y1) - (long long)dy1 * (Px - X1) + b1;
-          const long long E2 = (long long)dx2 * (Py - Y2) - (long long)dy2 * (Px - X2) + b2;
-          const bool inside = ((E0 | E1 | E2) >= 0);
-          if (inside) {
-            const float fx = (float)((int)Px - X0);
-            const float fy = (float)((int)Py - Y0);
-            const float m0 = A * fx;
-            const float m1 = B * fy;
-            const float s = m0 + m1;
-            const float z = iz0 + s;
-            const int zb = max(__float_as_int(z), 1);
-            const unsigned long long key = ((unsigned long long)(uint32_t)zb << 32) | key_lo;
-            atomicMax(&keys[sy * GR_TILE + lds_lane + (sx ^ swz)], key);
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-
-  // epilogue: wave w writes rows w*16 .. w*16+15, one 64-pixel row (256 B) per wave-instruction
-  const int col = lane;
-  const int gx = px0 + col;
-  if (gx < a.w) {
-    const int64_t plane = (int64_t)slot * a.h * a.w;
-#pragma unroll 4
-    for (int k = 0; k < GR_TILE / 4; ++k) {
-      const int row = (tid >> 6) * (GR_TILE / 4) + k;
-      const int gy = py0 + row;
-      if (gy >= a.h) break;
-      const unsigned long long key = keys[lds_index(row, col)];
-      const int64_t p = plane + (int64_t)gy * a.w + gx;
-      if (out.ids) out.ids[p] = key ? (int32_t)(~(uint32_t)key) : -1;
-      if (out.depth) out.depth[p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// K4b  row-item tile rasterizer.  grid (T, views), NT threads, one TW x TH tile per workgroup.
-//      Phase 1: ONE TRIANGLE PER LANE -- edge functions are re-based to the tile origin (E = C + A x + B y with x, y
-//               tile-local pixels) and parked in LDS (64 B per triangle), so the per-triangle setup runs 64-wide
-//               instead of once per wave.
-//      Phase 2: the triangles' row counts are prefix-summed (wave shuffles + LDS) and expanded into a list of
-//               (triangle, row) work items.
-//      Phase 3: ONE SCANLINE OF ONE TRIANGLE PER LANE: the lane walks its row of the bounding box with incremental
-//               32-bit edge adds and resolves visibility with ds_max_u64 on the depth|id key.  Triangles whose edge
-//               values could leave int32 inside this tile take a second, 64-bit loop (same results, exact).
-//      LDS column rotation (col + row) & (TW-1): the rows of one triangle walk the same columns in step, the rotation
-//      spreads them over distinct banks; a row read in the epilogue stays conflict-free.
-// ------------------------------------------------------------------------------------------------------------------
-template <int TWL, int THL>
+template <int TWL>
 __device__ __forceinline__ int lds_rot(int row, int col) {
   return (row << TWL) + ((col + row) & ((1 << TWL) - 1));
 }
@@ -524,122 +461,83 @@ __device__ __forceinline__ void span_clip(int E, int A, int &xs, int &xe) {
   }
 }
 
-template <int TWL, int THL, int NT, int CHUNK>
+template <int TWL, int THL, int NT>
 __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
-  static_assert(CHUNK <= NT && CHUNK <= 256, "one triangle per lane, u8 item indices");
-  __shared__ unsigned long long keys[TW * TH];
-  __shared__ int4 tris[CHUNK * 4];
-  __shared__ unsigned short row_off[CHUNK + 1];
-  __shared__ unsigned char item_tri[CHUNK * TH];
-  __shared__ int wave_tot[NT / 64];
+  __shared__ unsigned long long keys[TW * TH];  // the only LDS of the kernel: 16 KiB (64x32) or 32 KiB (64x64)
 
   const int slot = blockIdx.y;
   const int tile = blockIdx.x;
   const int tx = tile % a.TX, ty = tile / a.TX;
   const int px0 = tx << TWL, py0 = ty << THL;
   const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-
-  for (int i = tid; i < TW * TH; i += NT) keys[i] = 0ull;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   uint32_t cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
   const int64_t beg = ctrl[GR_CTRL_HDR + 2 * a.Tcap + tile];
   if (beg >= a.ent_cap) cnt = 0;
   else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
-  const int4 *rec0 = a.rec + slot * a.rec_stride;
-  const int4 *rec1 = rec0 + a.F;
-  const int4 *rec2 = rec1 + a.F;
-  const uint32_t *ent = a.entries + slot * a.ent_cap + beg;
-  const int Pxo = px0 * 256 + 128, Pyo = py0 * 256 + 128;  // centre of the tile's first pixel
-
   if (a.dbg & 4) cnt = 0;
-  for (uint32_t c0 = 0; c0 < cnt; c0 += CHUNK) {
-    const int n_tri = (int)min((uint32_t)CHUNK, cnt - c0);
-    __syncthreads();  // keys zeroed / previous chunk's items consumed
-    // ---- phase 1: one triangle per lane ---------------------------------------------------------------------------
+  const int4 *comp = a.comp + (slot * a.ent_cap + beg) * 4;
+
+  for (int i = tid; i < TW * TH; i += NT) keys[i] = 0ull;
+  __syncthreads();
+
+  // entries are dealt round-robin to the NW waves (entry e -> wave e % NW) so that a short list still feeds every wave
+  constexpr int NW = NT / 64;
+  for (uint32_t c0 = 0; c0 < cnt; c0 += NT) {
+    // ---- phase 1: one compiled entry per lane, kept in registers ---------------------------------------------------------
+    const uint32_t e = c0 + lane * NW + wv;
+    int4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, s3 = {0, 0, 0, 0};
     int nrows = 0;
-    if (tid < n_tri) {
-      const uint32_t r = ent[c0 + tid];
-      const int4 p0 = rec0[r], p1 = rec1[r], p2 = rec2[r];
-      const int X0 = p0.x, Y0 = p0.y, X1 = p0.z, Y1 = p0.w, X2 = p1.x, Y2 = p1.y;
-      const int jlo = max((p2.z & 0xFFFF) - px0, 0), jhi = min((int)((uint32_t)p2.z >> 16) - px0, TW - 1);
-      const int ilo = max((p2.w & 0xFFFF) - py0, 0), ihi = min((int)((uint32_t)p2.w >> 16) - py0, TH - 1);
-      nrows = max(ihi - ilo + 1, 0);
-      if (jhi < jlo) nrows = 0;
-      const int dx0 = X1 - X0, dy0 = Y1 - Y0, dx1 = X2 - X1, dy1 = Y2 - Y1, dx2 = X0 - X2, dy2 = Y0 - Y2;
-      const long long b0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;
-      const long long b1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
-      const long long b2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
-      const long long C0 = (long long)dx0 * (Pyo - Y0) - (long long)dy0 * (Pxo - X0) + b0;
-      const long long C1 = (long long)dx1 * (Pyo - Y1) - (long long)dy1 * (Pxo - X1) + b1;
-      const long long C2 = (long long)dx2 * (Pyo - Y2) - (long long)dy2 * (Pxo - X2) + b2;
-      const long long A0 = -(long long)dy0 * 256, A1 = -(long long)dy1 * 256, A2 = -(long long)dy2 * 256;
-      const long long B0 = (long long)dx0 * 256, B1 = (long long)dx1 * 256, B2 = (long long)dx2 * 256;
-      const long long lim = 0x7FFFFFFFll;
-      // int32-safe inside this tile, including the +-2 pixel probes of the span solver
-      const bool small = (llabs(C0) + (TW + 2) * llabs(A0) + TH * llabs(B0) < lim) &&
-                         (llabs(C1) + (TW + 2) * llabs(A1) + TH * llabs(B1) < lim) &&
-                         (llabs(C2) + (TW + 2) * llabs(A2) + TH * llabs(B2) < lim);
-      int4 s0, s1, s2, s3;
-      if (small) {
-        s0 = make_int4((int)C0, (int)C1, (int)C2, (int)A0);
-        s1 = make_int4((int)A1, (int)A2, (int)B0, (int)B1);
-        s2 = make_int4((int)B2, p1.z, p2.x, p2.y);  // B2, iz0, zA, zB
-      } else {
-        s0 = make_int4(X0, Y0, X1, Y1);
-        s1 = make_int4(X2, Y2, 0, 0);
-        s2 = make_int4(0, p1.z, p2.x, p2.y);
-      }
-      // X0rel/Y0rel: (Px - X0) = 256 x + X0rel;  bbox (6 bits each) with bit 31 = needs the 64-bit loop;  ~face
-      s3 = make_int4(Pxo - X0, Pyo - Y0, jlo | (jhi << 8) | (ilo << 16) | (ihi << 24) | (small ? 0 : (int)0x80000000),
-                     (int)~(uint32_t)p1.w);
-      tris[tid * 4 + 0] = s0; tris[tid * 4 + 1] = s1; tris[tid * 4 + 2] = s2; tris[tid * 4 + 3] = s3;
+    if (e < cnt) {
+      s0 = comp[e * 4 + 0]; s1 = comp[e * 4 + 1]; s2 = comp[e * 4 + 2]; s3 = comp[e * 4 + 3];
+      const int jlo = s3.z & 0xFF, jhi = (s3.z >> 8) & 0xFF, ilo = (s3.z >> 16) & 0xFF, ihi = (s3.z >> 24) & 0x7F;
+      nrows = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;
     }
-    // ---- phase 2: exclusive scan of row counts, expand to (triangle,row) items ------------------------------------------
+    // ---- phase 2: wave-local scan of the row counts: item q belongs to the entry with excl <= q < excl + nrows ------------
     int incl = nrows;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const int o = __shfl_up(incl, d);
       if (lane >= d) incl += o;
     }
-    if (lane == 63) wave_tot[wv] = incl;
-    __syncthreads();
-    int wbase = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < NT / 64; ++k) {
-      const int t = wave_tot[k];
-      if (k < wv) wbase += t;
-      total += t;
-    }
-    const int excl = wbase + incl - nrows;
-    if (tid < n_tri) {
-      row_off[tid] = (unsigned short)excl;
-      for (int r = 0; r < nrows; ++r) item_tri[excl + r] = (unsigned char)tid;
-    }
-    __syncthreads();
-    // ---- phase 3: one scanline of one triangle per lane -----------------------------------------------------------------
+    int total = __shfl(incl, 63);
+    const int excl = incl - nrows;
     if (a.dbg & 1) total = 0;
-    for (int k = tid; k < total; k += NT) {
-      const int t = item_tri[k];
-      const int4 s3 = tris[t * 4 + 3];
-      const int4 s1 = tris[t * 4 + 1];
-      const int4 s0 = tris[t * 4 + 0];
-      const int4 s2 = tris[t * 4 + 2];
-      const int jlo = s3.z & 0xFF, jhi = (s3.z >> 8) & 0xFF, ilo = (s3.z >> 16) & 0xFF;
-      const int y = ilo + (k - (int)row_off[t]);
-      const float iz0 = __int_as_float(s2.y), zA = __int_as_float(s2.z), zB = __int_as_float(s2.w);
-      const float m1 = zB * (float)(y * 256 + s3.y);
-      const uint32_t key_lo = (uint32_t)s3.w;
+    // ---- phase 3: one scanline of one triangle per lane -------------------------------------------------------------------
+    for (int k0 = 0; k0 < total; k0 += 64) {
+      const int q = k0 + lane;
+      // largest entry lane t with excl[t] <= q (entries beyond the list have excl = total > q)
+      int t = 0, et = 0;
+#pragma unroll
+      for (int step = 32; step > 0; step >>= 1) {
+        const int cand = t + step;
+        const int ec = __shfl(excl, cand);
+        if (ec <= q) { t = cand; et = ec; }
+      }
+      const bool live = q < total;
+      // fetch the entry from lane t's registers (ds_bpermute: no LDS storage)
+      const int C0 = __shfl(s0.x, t), C1 = __shfl(s0.y, t), C2 = __shfl(s0.z, t), A0 = __shfl(s0.w, t);
+      const int A1 = __shfl(s1.x, t), A2 = __shfl(s1.y, t), B0 = __shfl(s1.z, t), B1 = __shfl(s1.w, t);
+      const int B2 = __shfl(s2.x, t);
+      const float iz0 = __int_as_float(__shfl(s2.y, t)), zA = __int_as_float(__shfl(s2.z, t)),
+                  zB = __int_as_float(__shfl(s2.w, t));
+      const int X0rel = __shfl(s3.x, t), Y0rel = __shfl(s3.y, t), bbox = __shfl(s3.z, t);
+      const uint32_t key_lo = (uint32_t)__shfl(s3.w, t);
+      const int jlo = bbox & 0xFF, jhi = (bbox >> 8) & 0xFF, ilo = (bbox >> 16) & 0xFF;
+      const int y = ilo + (q - et);
+      const float m1 = zB * (float)(y * 256 + Y0rel);
       const int rowbase = y << TWL;
-      const bool big = (s3.z < 0);
-      if (!big) {
+      const bool big = live && (bbox < 0);
+      if (live && !big) {
         // exact covered span [xs, xe] of this scanline: each edge E(x) = E(0) + A x >= 0 bounds x from one side
         int xs = jlo, xe = jhi;
-        span_clip<TW>(s0.x + s1.z * y, s0.w, xs, xe);
-        span_clip<TW>(s0.y + s1.w * y, s1.x, xs, xe);
-        span_clip<TW>(s0.z + s2.x * y, s1.y, xs, xe);
-        int fxi = xs * 256 + s3.x;
+        span_clip<TW>(C0 + B0 * y, A0, xs, xe);
+        span_clip<TW>(C1 + B1 * y, A1, xs, xe);
+        span_clip<TW>(C2 + B2 * y, A2, xs, xe);
+        int fxi = xs * 256 + X0rel;
         for (int x = xs; x <= xe; ++x, fxi += 256) {
           const float m0 = zA * (float)fxi;
           const float s = m0 + m1;
@@ -650,8 +548,8 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
         }
       }
       if (__ballot(big) != 0ull) {
-        if (big) {
-          const int X0 = s0.x, Y0 = s0.y, X1 = s0.z, Y1 = s0.w, X2 = s1.x, Y2 = s1.y;
+        if (big) {  // 64-bit form: words 0..5 hold the snapped vertices
+          const int X0 = C0, Y0 = C1, X1 = C2, Y1 = A0, X2 = A1, Y2 = A2;
           const int dx0 = X1 - X0, dy0 = Y1 - Y0, dx1 = X2 - X1, dy1 = Y2 - Y1, dx2 = X0 - X2, dy2 = Y0 - Y2;
           const long long b0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;
           const long long b1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
@@ -662,7 +560,7 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
           long long e1 = (long long)dx1 * (Py - Y1) - (long long)dy1 * (Px - X1) + b1;
           long long e2 = (long long)dx2 * (Py - Y2) - (long long)dy2 * (Px - X2) + b2;
           const long long a0 = -(long long)dy0 * 256, a1 = -(long long)dy1 * 256, a2 = -(long long)dy2 * 256;
-          int fxi = jlo * 256 + s3.x;
+          int fxi = jlo * 256 + X0rel;
           for (int x = jlo; x <= jhi; ++x, e0 += a0, e1 += a1, e2 += a2, fxi += 256) {
             if ((e0 | e1 | e2) >= 0) {
               const float m0 = zA * (float)fxi;
@@ -679,8 +577,8 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
   }
   __syncthreads();
 
-  // epilogue: each wave stores whole rows (TW pixels, coalesced); NT/64 waves interleave over the TH rows
-  constexpr int ROWS_PER_PASS = NT / TW;  // rows covered by the workgroup per pass (TW <= NT)
+  // epilogue: whole rows (TW pixels, coalesced); the NW waves interleave over the TH rows
+  constexpr int ROWS_PER_PASS = NT / TW;
   const int col = tid & (TW - 1);
   const int gx = px0 + col;
   if (gx < a.w && !(a.dbg & 2)) {
@@ -688,7 +586,7 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
     for (int row = tid >> TWL; row < TH; row += ROWS_PER_PASS) {
       const int gy = py0 + row;
       if (gy >= a.h) break;
-      const unsigned long long key = keys[lds_rot<TWL, THL>(row, col)];
+      const unsigned long long key = keys[lds_rot<TWL>(row, col)];
       const int64_t p = plane + (int64_t)gy * a.w + gx;
       if (out.ids) out.ids[p] = key ? (int32_t)(~(uint32_t)key) : -1;
       if (out.depth) out.depth[p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
@@ -872,7 +770,9 @@ struct gr_ctx {
   // bin scratch
   uint32_t *ctrl = nullptr;
   int4 *rec = nullptr;
-  uint32_t *entries = nullptr;
+  int4 *comp = nullptr;
+  uint32_t *work = nullptr;
+  int64_t work_stride = 0;
   float4 *blk = nullptr;
   int64_t blk_cap = 0;
   unsigned long long *stats = nullptr;
@@ -881,8 +781,8 @@ struct gr_ctx {
   int Tcap = 0, slots = 0;
   int64_t rec_F = 0;
   // tuning knobs (gr_set_option)
-  int opt_kernel = 1;   // 0: 8x8-stamp kernel (64x64 tiles), 1: row-item kernel
-  int opt_thl = 6;      // log2 tile height for the row-item kernel (5 or 6); width is 64
+  int opt_kernel = 1;   // threads per tile workgroup: 1 -> 256, 2 -> 512, 3 -> 128
+  int opt_thl = 5;      // log2 tile height (5 or 6); width is 64.  64x32 tiles: 16 KiB of LDS, 8 workgroups per CU
   int opt_batch = GR_MAX_BATCH;
   int opt_dbg = 0;
   // winner scratch
@@ -939,26 +839,28 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 int ensure_bins(gr_ctx *c, int n_slots, int T) {
   const int64_t F = c->F;
-  int64_t want_cap = c->ent_cap_request > 0 ? c->ent_cap_request : (2 * F + 65536);
+  int64_t want_cap = c->ent_cap_request > 0 ? c->ent_cap_request : (F / 2 + 65536);
   if (c->ctrl && c->slots >= n_slots && c->Tcap >= T && c->rec_F == F && c->ent_cap >= want_cap) return GR_OK;
   (void)hipDeviceSynchronize();
   if (c->ctrl) (void)hipFree(c->ctrl);
   if (c->rec) (void)hipFree(c->rec);
-  if (c->entries) (void)hipFree(c->entries);
-  c->ctrl = nullptr; c->rec = nullptr; c->entries = nullptr;
+  if (c->comp) (void)hipFree(c->comp);
+  if (c->work) (void)hipFree(c->work);
+  c->ctrl = nullptr; c->rec = nullptr; c->comp = nullptr; c->work = nullptr;
   const int slots = n_slots > c->slots ? n_slots : c->slots;
   const int Tcap = T > c->Tcap ? T : c->Tcap;
   const int64_t cap = want_cap > c->ent_cap ? want_cap : c->ent_cap;
   const int64_t ctrl_stride = ((GR_CTRL_HDR + 4 * (int64_t)Tcap) + 63) / 64 * 64;
   if (hipMalloc(&c->ctrl, sizeof(uint32_t) * ctrl_stride * slots) != hipSuccess ||
       hipMalloc(&c->rec, sizeof(int4) * 4 * (F > 0 ? F : 1) * slots) != hipSuccess ||
-      hipMalloc(&c->entries, sizeof(uint32_t) * cap * slots) != hipSuccess) {
+      hipMalloc(&c->comp, sizeof(int4) * 4 * cap * slots) != hipSuccess ||
+      hipMalloc(&c->work, sizeof(uint32_t) * ceil_div(F > 0 ? F : 1, 256) * slots) != hipSuccess) {
     c->slots = 0; c->Tcap = 0; c->ent_cap = 0;
     return fail(c, GR_ENOMEM, "bin scratch allocation failed (slots=%d F=%lld cap=%lld)", slots, (long long)F,
                 (long long)cap);
   }
   c->slots = slots; c->Tcap = Tcap; c->ent_cap = cap; c->ctrl_stride = ctrl_stride; c->rec_stride = 4 * F;
-  c->rec_F = F;
+  c->rec_F = F; c->work_stride = ceil_div(F > 0 ? F : 1, 256);
   return GR_OK;
 }
 
@@ -975,9 +877,9 @@ int ensure_winner(gr_ctx *c, size_t bytes) {
 
 BinArgs make_args(gr_ctx *c, int h, int w) {
   BinArgs a;
-  a.ctrl = c->ctrl; a.rec = c->rec; a.entries = c->entries; a.stats = c->stats; a.blk = c->blk;
+  a.ctrl = c->ctrl; a.rec = c->rec; a.comp = c->comp; a.stats = c->stats; a.blk = c->blk; a.work = c->work; a.work_stride = c->work_stride;
   a.ctrl_stride = c->ctrl_stride; a.rec_stride = c->rec_stride; a.ent_cap = c->ent_cap; a.F = c->F;
-  a.twl = GR_TILE_LOG2; a.thl = (c->opt_kernel == 0) ? GR_TILE_LOG2 : c->opt_thl;
+  a.twl = GR_TILE_LOG2; a.thl = c->opt_thl;
   a.TX = (w + (1 << a.twl) - 1) >> a.twl; a.TY = (h + (1 << a.thl) - 1) >> a.thl; a.T = a.TX * a.TY; a.Tcap = c->Tcap;
   a.h = h; a.w = w; a.dbg = c->opt_dbg;
   return a;
@@ -989,8 +891,10 @@ int raster_batch(gr_ctx *c, const float *cams, int nb, int h, int w, RasterOut o
   GR_HIP(c, hipMemsetAsync(c->ctrl, 0, sizeof(uint32_t) * c->ctrl_stride * nb, s));
   {
     Timed t(c, s, ST_SETUP);
-    hipLaunchKernelGGL(k_setup_cull, dim3((unsigned)ceil_div(c->F, 256), nb), dim3(256), 0, s, c->verts, c->faces, cams,
-                       a);
+    const int nblk = (int)ceil_div(c->F, 256);
+    hipLaunchKernelGGL(k_cull_blocks, dim3((unsigned)ceil_div(nblk, 256), nb), dim3(256), 0, s, cams, a, nblk);
+    hipLaunchKernelGGL(k_setup_cull, dim3((unsigned)std::min(nblk, 1024), nb), dim3(256), 0, s, c->verts, c->faces,
+                       cams, a);
   }
   {
     Timed t(c, s, ST_SCAN);
@@ -999,24 +903,22 @@ int raster_batch(gr_ctx *c, const float *cams, int nb, int h, int w, RasterOut o
   {
     Timed t(c, s, ST_FILL);
     const unsigned g = (unsigned)std::min<int64_t>(ceil_div(c->F, 256), 1024);
-    hipLaunchKernelGGL(k_fill_bins, dim3(g, nb), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_fill_compile, dim3(g, nb), dim3(256), 0, s, a);
   }
   {
     Timed t(c, s, ST_RASTER);
-    if (c->opt_kernel == 0)
-      hipLaunchKernelGGL(k_raster_tile, dim3(a.T, nb), dim3(GR_RASTER_THREADS), 0, s, a, out);
-    else if (c->opt_kernel == 1 && a.thl == 6)
-      hipLaunchKernelGGL((k_raster_rows<6, 6, 256, 128>), dim3(a.T, nb), dim3(256), 0, s, a, out);
-    else if (c->opt_kernel == 1)
-      hipLaunchKernelGGL((k_raster_rows<6, 5, 256, 128>), dim3(a.T, nb), dim3(256), 0, s, a, out);
+    if (c->opt_kernel <= 1 && a.thl == 6)
+      hipLaunchKernelGGL((k_raster_rows<6, 6, 256>), dim3(a.T, nb), dim3(256), 0, s, a, out);
+    else if (c->opt_kernel <= 1)
+      hipLaunchKernelGGL((k_raster_rows<6, 5, 256>), dim3(a.T, nb), dim3(256), 0, s, a, out);
     else if (c->opt_kernel == 2 && a.thl == 6)
-      hipLaunchKernelGGL((k_raster_rows<6, 6, 512, 128>), dim3(a.T, nb), dim3(512), 0, s, a, out);
+      hipLaunchKernelGGL((k_raster_rows<6, 6, 512>), dim3(a.T, nb), dim3(512), 0, s, a, out);
     else if (c->opt_kernel == 2)
-      hipLaunchKernelGGL((k_raster_rows<6, 5, 512, 128>), dim3(a.T, nb), dim3(512), 0, s, a, out);
+      hipLaunchKernelGGL((k_raster_rows<6, 5, 512>), dim3(a.T, nb), dim3(512), 0, s, a, out);
     else if (a.thl == 6)
-      hipLaunchKernelGGL((k_raster_rows<6, 6, 1024, 256>), dim3(a.T, nb), dim3(1024), 0, s, a, out);
+      hipLaunchKernelGGL((k_raster_rows<6, 6, 128>), dim3(a.T, nb), dim3(128), 0, s, a, out);
     else
-      hipLaunchKernelGGL((k_raster_rows<6, 5, 1024, 256>), dim3(a.T, nb), dim3(1024), 0, s, a, out);
+      hipLaunchKernelGGL((k_raster_rows<6, 5, 128>), dim3(a.T, nb), dim3(128), 0, s, a, out);
     c->prof_raster_launches += 1;
   }
   c->prof_views += nb;
@@ -1095,7 +997,8 @@ int gr_ctx_destroy(gr_ctx *c) {
   for (auto e : c->pool) (void)hipEventDestroy(e);
   if (c->ctrl) (void)hipFree(c->ctrl);
   if (c->rec) (void)hipFree(c->rec);
-  if (c->entries) (void)hipFree(c->entries);
+  if (c->comp) (void)hipFree(c->comp);
+  if (c->work) (void)hipFree(c->work);
   if (c->winner) (void)hipFree(c->winner);
   if (c->blk) (void)hipFree(c->blk);
   if (c->stats) (void)hipFree(c->stats);
@@ -1119,7 +1022,7 @@ int gr_set_option(gr_ctx *c, int key, int value) {
   if (!c) return GR_EINVAL;
   switch (key) {
     case GR_OPT_RASTER_KERNEL:
-      if (value < 0 || value > 3) return fail(c, GR_EINVAL, "raster kernel must be 0..3");
+      if (value < 1 || value > 3) return fail(c, GR_EINVAL, "raster kernel must be 1..3");
       c->opt_kernel = value; return GR_OK;
     case GR_OPT_TILE_H_LOG2:
       if (value != 5 && value != 6) return fail(c, GR_EINVAL, "tile height log2 must be 5 or 6");
@@ -1186,7 +1089,7 @@ int gr_raster_face_ids(gr_ctx *c, const float *cams, int n_views, int h, int w, 
   hipStream_t s = (hipStream_t)stream;
   GR_HIP(c, hipSetDevice(c->device));
   const int B = n_views < c->opt_batch ? n_views : c->opt_batch;
-  const int thl = (c->opt_kernel == 0) ? GR_TILE_LOG2 : c->opt_thl;
+  const int thl = c->opt_thl;
   const int T = ((w + GR_TILE - 1) >> GR_TILE_LOG2) * ((h + (1 << thl) - 1) >> thl);
   rc = ensure_bins(c, B, T);
   if (rc) return rc;
@@ -1309,7 +1212,7 @@ int gr_project_view_f64(gr_ctx *c, const int32_t *ids, const double *img, int h,
 int gr_raster_project_labels_u8(gr_ctx *c, const float *cams, const uint8_t *labels, int n_views, int h, int w, int C,
                                 uint32_t *votes, uint32_t *counts, int32_t *ids_or_null, int flags, void *stream) {
   // Round-1 form: materialise the ids of one batch in caller- or context-owned memory, then project.  (A later
-  // round folds the winner pass into k_raster_tile's epilogue so the ids never leave LDS.)
+  // round folds the winner pass into k_raster_rows' epilogue so the ids never leave LDS.)
   if (!ids_or_null) return fail(c, GR_EINVAL, "ids buffer required in this version");
   int rc = gr_raster_face_ids(c, cams, n_views, h, w, ids_or_null, nullptr, stream);
   if (rc) return rc;

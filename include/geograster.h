@@ -58,8 +58,8 @@ typedef struct gr_ctx gr_ctx;
 typedef struct gr_stage_times {
   float setup_ms;   /* k_setup_cull : transform + cull + record + tile counts      */
   float scan_ms;    /* k_scan_tiles                                                */
-  float fill_ms;    /* k_fill_bins                                                 */
-  float raster_ms;  /* k_raster_tile (the dominant kernel)                         */
+  float fill_ms;    /* k_fill_compile                                              */
+  float raster_ms;  /* k_raster_rows (the dominant kernel)                         */
   float project_ms; /* k_winner_* : last-writer-wins pixel -> face                 */
   float vote_ms;    /* k_vote_*   : per-face accumulate                            */
   float gather_ms;  /* k_gather_texture                                            */
@@ -88,10 +88,9 @@ int gr_set_profiling(gr_ctx *ctx, int enabled);
 
 /* Tuning knobs (results never depend on them; tests run every setting against the oracle). */
 enum {
-  GR_OPT_RASTER_KERNEL = 1, /* 0: 8x8-stamp tile kernel; row-item tile kernel with 1: 256 (default), 2: 512,
-                               3: 1024 threads per tile                                                  */
-  GR_OPT_TILE_H_LOG2 = 2,   /* row-item kernel tile height: 5 (64x32) or 6 (64x64, default)       */
-  GR_OPT_BATCH = 3,         /* views per launch group, 1..64 (default 16)                         */
+  GR_OPT_RASTER_KERNEL = 1, /* threads per tile workgroup of k_raster_rows: 1: 256 (default), 2: 512, 3: 128 */
+  GR_OPT_TILE_H_LOG2 = 2,   /* tile height: 5 (64x32, default) or 6 (64x64)                                  */
+  GR_OPT_BATCH = 3,         /* views per launch group, 1..64 (default 32)                         */
   GR_OPT_DEBUG = 99         /* timing-only ablation mask for tools/ab_raster.py: OUTPUTS BECOME WRONG */
 };
 int gr_set_option(gr_ctx *ctx, int key, int value);

@@ -26,9 +26,9 @@ def main():
     ids = torch.empty((nv, H, W), dtype=torch.int32, device="cuda")
     ref = None
     variants = [("rows64", 1, 6, 16, 0), ("rows32", 1, 5, 16, 0), ("rows64_512", 2, 6, 16, 0), ("rows32_512", 2, 5, 16, 0),
-                ("rows64_1024", 3, 6, 16, 0), ("rows32_1024", 3, 5, 16, 0), ("rows32_b32", 1, 5, 32, 0),
+                ("rows64_128", 3, 6, 16, 0), ("rows32_128", 3, 5, 16, 0), ("rows32_b32", 1, 5, 32, 0),
                 ("rows32_noscan", 1, 5, 16, 1), ("rows32_nostore", 1, 5, 16, 2), ("rows32_notri", 1, 5, 16, 4),
-                ("rows32_notri_nostore", 1, 5, 16, 6), ("rows64_noscan", 1, 6, 16, 1), ("rows64_notri", 1, 6, 16, 4)]
+                ("rows32_notri_nostore", 1, 5, 16, 6)]
     results = {}
     for rep in range(3):
         for name, k, thl, b, dbg in variants:
