@@ -136,7 +136,7 @@ def main():
     hip.set_profiling(False)
     raster_ms_per_launch = st["raster_ms"] / max(st["raster_launches"], 1)
     views_per_launch = st["views"] / max(st["raster_launches"], 1)
-    # algorithmic bytes of the dominant kernel (k_raster_tile): the int32 id image it writes, 4*P per view.
+    # algorithmic bytes of the dominant kernel (k_raster_rows): the int32 id image it writes, 4*P per view.
     # (k_setup_cull owns the other part of B_r = 12V + 12F + 4P: the mesh read.)  DESIGN.md section "Kernels".
     raster_bytes_per_launch = 4.0 * P * views_per_launch
     achieved = raster_bytes_per_launch / (raster_ms_per_launch * 1e-3) / 1e9
@@ -147,12 +147,12 @@ def main():
     tfile = ROOT / "profiles" / "traffic.json"
     if tfile.is_file():
         try:
-            traffic = json.loads(tfile.read_text()).get("k_raster_tile_bytes_per_launch")
+            traffic = json.loads(tfile.read_text()).get("k_raster_rows", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     roofline = {
         "bound": "hbm",
-        "kernel": "k_raster_tile",
+        "kernel": "k_raster_rows",
         "achieved": round(achieved, 2),
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",

@@ -366,9 +366,12 @@ __device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, const int4
   const long long B0 = (long long)dx0 * 256, B1 = (long long)dx1 * 256, B2 = (long long)dx2 * 256;
   const long long lim = 0x7FFFFFFFll;
   // int32-safe inside this tile, including the +-2 pixel probes of the span solver
+  const long long m24 = (1ll << 23) - 1;  // A, B feed v_mul_i32_i24
   const bool small = (llabs(C0) + (TW + 2) * llabs(A0) + TH * llabs(B0) < lim) &&
                      (llabs(C1) + (TW + 2) * llabs(A1) + TH * llabs(B1) < lim) &&
-                     (llabs(C2) + (TW + 2) * llabs(A2) + TH * llabs(B2) < lim);
+                     (llabs(C2) + (TW + 2) * llabs(A2) + TH * llabs(B2) < lim) &&
+                     llabs(A0) <= m24 && llabs(A1) <= m24 && llabs(A2) <= m24 &&
+                     llabs(B0) <= m24 && llabs(B1) <= m24 && llabs(B2) <= m24;
   const int bbox = jlo | (jhi << 8) | (ilo << 16) | (ihi << 24) | (small ? 0 : (int)0x80000000);
   if (small) {
     dst[0] = make_int4((int)C0, (int)C1, (int)C2, (int)A0);
@@ -435,67 +438,38 @@ struct RasterOut {
   float *depth;    // [slot][h][w] or null
 };
 
+// LDS image of a tile: rows of TW keys padded by ONE key (stride TW+1 = 65 keys = 520 B).  The rows of one triangle
+// walk neighbouring columns in step; the odd stride moves each row by two banks, so they never pile up on one bank,
+// and a pixel's address advances by a plain +8 bytes along the scanline (no wrap arithmetic in the inner loop).
 template <int TWL>
-__device__ __forceinline__ int lds_rot(int row, int col) {
-  return (row << TWL) + ((col + row) & ((1 << TWL) - 1));
+__device__ __forceinline__ int lds_idx(int row, int col) {
+  return row * ((1 << TWL) + 1) + col;
 }
 
-// Integer solution of E + A x >= 0 on one scanline.  A float reciprocal proposes floor(-E/A) (off by at most one in
-// the clamped range [-1, TW]); exact int32 evaluations at the proposal and its neighbours settle the boundary.
+// Integer solution of g(x) = E + A x >= 0 on one scanline, branch-free.  A float reciprocal proposes x0 = floor(-E/A);
+// in the clamped range [-1, TW] the proposal is within one of the true root, so the exact boundary follows from the
+// signs of two exact int32 probes g(x0), g(x0+1):   A > 0: first covered x = x0 - s0 - s1;   A < 0: last covered
+// x = x0 + 1 + s0 + s1   (s = -1 where the probe is negative, 0 otherwise).  |A| < 2^23 (checked when the entry was
+// compiled), so the products are full-rate 24-bit multiplies.
 template <int TW>
 __device__ __forceinline__ void span_clip(int E, int A, int &xs, int &xe) {
-  if (A == 0) {
-    if (E < 0) xe = -1;
-    return;
-  }
   float q = -(float)E * __builtin_amdgcn_rcpf((float)A);
-  q = fminf(fmaxf(q, -1.0f), (float)TW);
+  q = fminf(fmaxf(q, -1.0f), (float)TW);  // NaN (A == 0, E == 0) -> -1
   const int x0 = (int)floorf(q);
-  const int e0 = E + A * x0;
-  if (A > 0) {
-    const int lo = (e0 >= 0) ? ((e0 - A >= 0) ? x0 - 1 : x0) : ((e0 + A >= 0) ? x0 + 1 : x0 + 2);
-    xs = max(xs, lo);
-  } else {
-    const int hi = (e0 >= 0) ? ((e0 + A >= 0) ? x0 + 1 : x0) : ((e0 - A >= 0) ? x0 - 1 : x0 - 2);
-    xe = min(xe, hi);
-  }
+  const int e0 = E + __mul24(A, x0);
+  const int u = (e0 >> 31) + ((e0 + A) >> 31);
+  const int lo = x0 - u, hi = x0 + 1 + u;
+  xs = max(xs, A > 0 ? lo : 0);
+  xe = min(xe, A < 0 ? hi : TW);
+  xe = (A == 0 && E < 0) ? -1 : xe;
 }
 
-template <int TWL, int THL, int NT>
-__global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
-  constexpr int TW = 1 << TWL, TH = 1 << THL;
-  __shared__ unsigned long long keys[TW * TH];  // the only LDS of the kernel: 16 KiB (64x32) or 32 KiB (64x64)
-
-  const int slot = blockIdx.y;
-  const int tile = blockIdx.x;
-  const int tx = tile % a.TX, ty = tile / a.TX;
-  const int px0 = tx << TWL, py0 = ty << THL;
-  const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  uint32_t cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
-  const int64_t beg = ctrl[GR_CTRL_HDR + 2 * a.Tcap + tile];
-  if (beg >= a.ent_cap) cnt = 0;
-  else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
-  if (a.dbg & 4) cnt = 0;
-  const int4 *comp = a.comp + (slot * a.ent_cap + beg) * 4;
-
-  for (int i = tid; i < TW * TH; i += NT) keys[i] = 0ull;
-  __syncthreads();
-
-  // entries are dealt round-robin to the NW waves (entry e -> wave e % NW) so that a short list still feeds every wave
-  constexpr int NW = NT / 64;
-  for (uint32_t c0 = 0; c0 < cnt; c0 += NT) {
-    // ---- phase 1: one compiled entry per lane, kept in registers ---------------------------------------------------------
-    const uint32_t e = c0 + lane * NW + wv;
-    int4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, s3 = {0, 0, 0, 0};
-    int nrows = 0;
-    if (e < cnt) {
-      s0 = comp[e * 4 + 0]; s1 = comp[e * 4 + 1]; s2 = comp[e * 4 + 2]; s3 = comp[e * 4 + 3];
-      const int jlo = s3.z & 0xFF, jhi = (s3.z >> 8) & 0xFF, ilo = (s3.z >> 16) & 0xFF, ihi = (s3.z >> 24) & 0x7F;
-      nrows = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;
-    }
+// Phases 2-3 of the tile rasterizer for the 64 entries a wave holds in registers (s0..s3, nrows per lane).
+template <int TWL>
+__device__ __forceinline__ void raster_wave_entries(unsigned long long *keys, const int4 s0, const int4 s1, const int4 s2,
+                                                    const int4 s3, const int nrows, const int lane, const int px0,
+                                                    const int py0, const int dbg) {
+  constexpr int TW = 1 << TWL;
     // ---- phase 2: wave-local scan of the row counts: item q belongs to the entry with excl <= q < excl + nrows ------------
     int incl = nrows;
 #pragma unroll
@@ -505,7 +479,7 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
     }
     int total = __shfl(incl, 63);
     const int excl = incl - nrows;
-    if (a.dbg & 1) total = 0;
+    if (dbg & 1) total = 0;
     // ---- phase 3: one scanline of one triangle per lane -------------------------------------------------------------------
     for (int k0 = 0; k0 < total; k0 += 64) {
       const int q = k0 + lane;
@@ -525,26 +499,29 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
       const float iz0 = __int_as_float(__shfl(s2.y, t)), zA = __int_as_float(__shfl(s2.z, t)),
                   zB = __int_as_float(__shfl(s2.w, t));
       const int X0rel = __shfl(s3.x, t), Y0rel = __shfl(s3.y, t), bbox = __shfl(s3.z, t);
-      const uint32_t key_lo = (uint32_t)__shfl(s3.w, t);
+      uint32_t key_lo = (uint32_t)__shfl(s3.w, t);
+      // consume the last ds_bpermute result here: otherwise the compiler parks its s_waitcnt lgkmcnt(0) inside the pixel
+      // loop, where it would also wait for the previous iteration's ds_max_u64 and serialise the LDS atomics
+      asm volatile("" : "+v"(key_lo));
       const int jlo = bbox & 0xFF, jhi = (bbox >> 8) & 0xFF, ilo = (bbox >> 16) & 0xFF;
       const int y = ilo + (q - et);
       const float m1 = zB * (float)(y * 256 + Y0rel);
-      const int rowbase = y << TWL;
       const bool big = live && (bbox < 0);
       if (live && !big) {
         // exact covered span [xs, xe] of this scanline: each edge E(x) = E(0) + A x >= 0 bounds x from one side
         int xs = jlo, xe = jhi;
-        span_clip<TW>(C0 + B0 * y, A0, xs, xe);
-        span_clip<TW>(C1 + B1 * y, A1, xs, xe);
-        span_clip<TW>(C2 + B2 * y, A2, xs, xe);
+        span_clip<TW>(C0 + __mul24(B0, y), A0, xs, xe);
+        span_clip<TW>(C1 + __mul24(B1, y), A1, xs, xe);
+        span_clip<TW>(C2 + __mul24(B2, y), A2, xs, xe);
         int fxi = xs * 256 + X0rel;
-        for (int x = xs; x <= xe; ++x, fxi += 256) {
+        const int fxe = xe * 256 + X0rel;
+        unsigned long long *kp = keys + lds_idx<TWL>(y, xs);
+        for (; fxi <= fxe; fxi += 256, ++kp) {
           const float m0 = zA * (float)fxi;
           const float s = m0 + m1;
           const float z = iz0 + s;
           const int zb = max(__float_as_int(z), 1);
-          const unsigned long long key = ((unsigned long long)(uint32_t)zb << 32) | key_lo;
-          atomicMax(&keys[rowbase + ((x + y) & (TW - 1))], key);
+          atomicMax(kp, ((unsigned long long)(uint32_t)zb << 32) | key_lo);
         }
       }
       if (__ballot(big) != 0ull) {
@@ -568,12 +545,50 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
               const float z = iz0 + s;
               const int zb = max(__float_as_int(z), 1);
               const unsigned long long key = ((unsigned long long)(uint32_t)zb << 32) | key_lo;
-              atomicMax(&keys[rowbase + ((x + y) & (TW - 1))], key);
+              atomicMax(&keys[lds_idx<TWL>(y, x)], key);
             }
           }
         }
       }
     }
+}
+
+template <int TWL, int THL, int NT>
+__global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
+  constexpr int TW = 1 << TWL, TH = 1 << THL;
+  __shared__ unsigned long long keys[(TW + 1) * TH];  // the only LDS of the kernel: 16.25 KiB (64x32) or 32.5 KiB
+
+  const int slot = blockIdx.y;
+  const int tile = blockIdx.x;
+  const int tx = tile % a.TX, ty = tile / a.TX;
+  const int px0 = tx << TWL, py0 = ty << THL;
+  const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  uint32_t cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
+  const int64_t beg = ctrl[GR_CTRL_HDR + 2 * a.Tcap + tile];
+  if (beg >= a.ent_cap) cnt = 0;
+  else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
+  if (a.dbg & 4) cnt = 0;
+  const int4 *comp = a.comp + (slot * a.ent_cap + beg) * 4;
+
+  for (int i = tid; i < (TW + 1) * TH; i += NT) keys[i] = 0ull;
+  __syncthreads();
+
+  // entries are dealt round-robin to the NW waves (entry e -> wave e % NW) so that a short list still feeds every wave
+  constexpr int NW = NT / 64;
+  for (uint32_t c0 = 0; c0 < cnt; c0 += NT) {
+    // ---- phase 1: one compiled entry per lane, kept in registers ---------------------------------------------------------
+    const uint32_t e = c0 + lane * NW + wv;
+    int4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, s3 = {0, 0, 0, 0};
+    int nrows = 0;
+    if (e < cnt) {
+      s0 = comp[e * 4 + 0]; s1 = comp[e * 4 + 1]; s2 = comp[e * 4 + 2]; s3 = comp[e * 4 + 3];
+      const int jlo = s3.z & 0xFF, jhi = (s3.z >> 8) & 0xFF, ilo = (s3.z >> 16) & 0xFF, ihi = (s3.z >> 24) & 0x7F;
+      nrows = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;
+    }
+    raster_wave_entries<TWL>(keys, s0, s1, s2, s3, nrows, lane, px0, py0, a.dbg);
   }
   __syncthreads();
 
@@ -586,7 +601,7 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
     for (int row = tid >> TWL; row < TH; row += ROWS_PER_PASS) {
       const int gy = py0 + row;
       if (gy >= a.h) break;
-      const unsigned long long key = keys[lds_rot<TWL>(row, col)];
+      const unsigned long long key = keys[lds_idx<TWL>(row, col)];
       const int64_t p = plane + (int64_t)gy * a.w + gx;
       if (out.ids) out.ids[p] = key ? (int32_t)(~(uint32_t)key) : -1;
       if (out.depth) out.depth[p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
@@ -595,23 +610,126 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K5  last-writer-wins winners.  One thread per pixel.  A pixel can only be its face's LAST pixel in row-major
+// K4p  persistent form of the tile rasterizer.  grid (G) workgroups; workgroup g rasterizes work items g, g+G, ...
+//      (item = tile of a view of the launch group) in a software pipeline that keeps every global-memory latency
+//      off the critical path:
+//        while item i is rasterized   the 64-byte entries of item i+1 are already in flight into a second register set
+//                                     and the (count, offset) words of item i+2 are being fetched;
+//        the id stores of item i      drain while item i+1 is rasterized (the workgroup does not end per tile);
+//        the LDS keys are re-zeroed   by the epilogue itself (read key, write 0): two barriers per tile, no zero pass.
+// ------------------------------------------------------------------------------------------------------------------
+template <int TWL, int THL, int NT, bool PREFETCH>
+__global__ __launch_bounds__(NT) void k_raster_rows_persistent(BinArgs a, RasterOut out, int n_items) {
+  constexpr int TW = 1 << TWL, TH = 1 << THL, NW = NT / 64;
+  __shared__ unsigned long long keys[(TW + 1) * TH];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = gridDim.x;
+
+  for (int i = tid; i < (TW + 1) * TH; i += NT) keys[i] = 0ull;
+
+  // (slot, tile) of an item without a division per step
+  int it0 = blockIdx.x;
+  if (it0 >= n_items) return;
+  int slot0 = it0 / a.T, tile0 = it0 - slot0 * a.T;
+  auto advance = [&](int &slot, int &tile) {
+    tile += G;
+    while (tile >= a.T) { tile -= a.T; ++slot; }
+  };
+  auto load_ctrl = [&](int slot, int tile, uint32_t &cnt, int64_t &beg) {
+    const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+    cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
+    beg = ctrl[GR_CTRL_HDR + 2 * a.Tcap + tile];
+    if (beg >= a.ent_cap) cnt = 0;
+    else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
+    if (a.dbg & 4) cnt = 0;
+  };
+  auto load_entries = [&](int slot, uint32_t cnt, int64_t beg, uint32_t c0, int4 &s0, int4 &s1, int4 &s2, int4 &s3) {
+    const uint32_t e = c0 + lane * NW + wv;
+    s0 = make_int4(0, 0, 0, 0); s1 = s0; s2 = s0; s3 = s0;
+    if (e < cnt) {
+      const int4 *cp = a.comp + ((int64_t)slot * a.ent_cap + beg + e) * 4;
+      s0 = cp[0]; s1 = cp[1]; s2 = cp[2]; s3 = cp[3];
+    }
+  };
+  auto rows_of = [&](const int4 s3, uint32_t e_valid) {
+    const int jlo = s3.z & 0xFF, jhi = (s3.z >> 8) & 0xFF, ilo = (s3.z >> 16) & 0xFF, ihi = (s3.z >> 24) & 0x7F;
+    return (e_valid && jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;
+  };
+
+  // prologue: item 0's control words and first entries, item 1's control words
+  int slot_c = slot0, tile_c = tile0;
+  uint32_t cnt_c; int64_t beg_c;
+  load_ctrl(slot_c, tile_c, cnt_c, beg_c);
+  int4 s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;
+  if (PREFETCH) load_entries(slot_c, cnt_c, beg_c, 0, s0, s1, s2, s3);
+  int it_n = it0 + G, slot_n = slot_c, tile_n = tile_c;
+  uint32_t cnt_n = 0; int64_t beg_n = 0;
+  if (it_n < n_items) { advance(slot_n, tile_n); load_ctrl(slot_n, tile_n, cnt_n, beg_n); }
+
+  for (int it = it0; it < n_items; it += G) {
+    // ---- prefetch: entries of the next item, control words of the one after ----------------------------------------------
+    int4 n0 = {0, 0, 0, 0}, n1 = n0, n2 = n0, n3 = n0;
+    const bool have_next = (it_n < n_items);
+    if (PREFETCH && have_next) load_entries(slot_n, cnt_n, beg_n, 0, n0, n1, n2, n3);
+    int it_nn = it_n + G, slot_nn = slot_n, tile_nn = tile_n;
+    uint32_t cnt_nn = 0; int64_t beg_nn = 0;
+    if (it_nn < n_items) { advance(slot_nn, tile_nn); load_ctrl(slot_nn, tile_nn, cnt_nn, beg_nn); }
+
+    const int tx = tile_c % a.TX, ty = tile_c / a.TX;
+    const int px0 = tx << TWL, py0 = ty << THL;
+    __syncthreads();  // keys are zero and every wave has left the previous epilogue
+    // ---- rasterize the current item --------------------------------------------------------------------------------------
+    if (PREFETCH) {
+      const uint32_t e = lane * NW + wv;
+      raster_wave_entries<TWL>(keys, s0, s1, s2, s3, rows_of(s3, e < cnt_c), lane, px0, py0, a.dbg);
+      for (uint32_t c0 = NT; c0 < cnt_c; c0 += NT) {  // lists longer than one entry per thread (dense views)
+        int4 x0, x1, x2, x3;
+        load_entries(slot_c, cnt_c, beg_c, c0, x0, x1, x2, x3);
+        raster_wave_entries<TWL>(keys, x0, x1, x2, x3, rows_of(x3, c0 + e < cnt_c), lane, px0, py0, a.dbg);
+      }
+    } else {
+      const uint32_t e = lane * NW + wv;
+      for (uint32_t c0 = 0; c0 < cnt_c; c0 += NT) {
+        int4 x0, x1, x2, x3;
+        load_entries(slot_c, cnt_c, beg_c, c0, x0, x1, x2, x3);
+        raster_wave_entries<TWL>(keys, x0, x1, x2, x3, rows_of(x3, c0 + e < cnt_c), lane, px0, py0, a.dbg);
+      }
+    }
+    __syncthreads();
+    // ---- epilogue: whole rows; read the key, leave a zero behind for the next item ------------------------------------------
+    {
+      constexpr int ROWS_PER_PASS = NT / TW;
+      const int col = tid & (TW - 1);
+      const int gx = px0 + col;
+      const int64_t plane = (int64_t)slot_c * a.h * a.w;
+      for (int row = tid >> TWL; row < TH; row += ROWS_PER_PASS) {
+        const int idx = lds_idx<TWL>(row, col);
+        const unsigned long long key = keys[idx];
+        keys[idx] = 0ull;
+        const int gy = py0 + row;
+        if (gx < a.w && gy < a.h && !(a.dbg & 2)) {
+          const int64_t p = plane + (int64_t)gy * a.w + gx;
+          if (out.ids) out.ids[p] = key ? (int32_t)(~(uint32_t)key) : -1;
+          if (out.depth) out.depth[p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
+        }
+      }
+    }
+    // ---- rotate the pipeline -----------------------------------------------------------------------------------------------
+    if (PREFETCH) { s0 = n0; s1 = n1; s2 = n2; s3 = n3; }
+    slot_c = slot_n; tile_c = tile_n; cnt_c = cnt_n; beg_c = beg_n;
+    it_n = it_nn; slot_n = slot_nn; tile_n = tile_nn; cnt_n = cnt_nn; beg_n = beg_nn;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K5  last-writer-wins winners.  Four pixels per thread.  A pixel can only be its face's LAST pixel in row-major
 //     order if neither its right nor its lower neighbour shows the same face, so only those candidates issue the
 //     global atomicMax (~1-3 per visible face instead of ~80).  key = (pixel+1) << LB | label  (LB = 0: pixel+1).
 // ------------------------------------------------------------------------------------------------------------------
 template <typename KeyT>
-__global__ __launch_bounds__(256) void k_winner(const int32_t *__restrict__ ids, const uint8_t *__restrict__ labels,
-                                                KeyT *__restrict__ winner, int64_t F, int h, int w, int C, int LB,
-                                                int compat) {
-  const int slot = blockIdx.y;
-  const int64_t P = (int64_t)h * w;
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= P) return;
-  const int32_t *im = ids + slot * P;
-  const int y = (int)(p / w), x = (int)(p - (int64_t)y * w);
-  int f = im[p];
-  int fr = (x + 1 < w) ? im[p + 1] : -2;
-  int fb = (y + 1 < h) ? im[p + w] : -2;
+__device__ __forceinline__ void winner_pixel(KeyT *__restrict__ winner, int f, int fr, int fb, int64_t p, int label,
+                                              int64_t F, int C, int LB, int compat) {
   if (compat) {  // meshes.py:1998-2001: index -1 aliases the last face
     const int last = (int)F - 1;
     if (f == -1) f = last;
@@ -621,11 +739,53 @@ __global__ __launch_bounds__(256) void k_winner(const int32_t *__restrict__ ids,
   if (f < 0 || f >= F) return;
   if (fr == f || fb == f) return;  // a later pixel of the same face exists
   KeyT key = (KeyT)(p + 1);
-  if (LB) {
-    const int l = labels[slot * P + p];
-    key = (key << LB) | (KeyT)min(l, C);
+  if (LB) key = (key << LB) | (KeyT)min(label, C);
+  atomicMax(&winner[f], key);
+}
+
+// grid (ceil(w/4/256), h, views): one thread per 4 consecutive pixels of a row (16-byte id loads, 4-byte label load)
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_winner(const int32_t *__restrict__ ids, const uint8_t *__restrict__ labels,
+                                                KeyT *__restrict__ winner, int64_t F, int h, int w, int C, int LB,
+                                                int compat) {
+  const int slot = blockIdx.z;
+  const int y = blockIdx.y;
+  const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (x0 >= w) return;
+  const int64_t P = (int64_t)h * w;
+  const int32_t *row = ids + slot * P + (int64_t)y * w;
+  const uint8_t *lrow = LB ? labels + slot * P + (int64_t)y * w : nullptr;
+  KeyT *win = winner + slot * F;
+  const bool has_below = (y + 1 < h);
+  int f[5], b[4], l[4] = {0, 0, 0, 0};
+  if ((w & 3) == 0 && ((reinterpret_cast<uintptr_t>(row + x0) & 15) == 0) &&
+      (!LB || (reinterpret_cast<uintptr_t>(lrow + x0) & 3) == 0)) {  // 16-byte aligned rows
+    const int4 c = *reinterpret_cast<const int4 *>(row + x0);
+    f[0] = c.x; f[1] = c.y; f[2] = c.z; f[3] = c.w;
+    f[4] = (x0 + 4 < w) ? row[x0 + 4] : -2;
+    if (has_below) {
+      const int4 d = *reinterpret_cast<const int4 *>(row + w + x0);
+      b[0] = d.x; b[1] = d.y; b[2] = d.z; b[3] = d.w;
+    } else {
+      b[0] = b[1] = b[2] = b[3] = -2;
+    }
+    if (LB) {
+      const uchar4 q = *reinterpret_cast<const uchar4 *>(lrow + x0);
+      l[0] = q.x; l[1] = q.y; l[2] = q.z; l[3] = q.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) f[k] = (x0 + k < w) ? row[x0 + k] : -2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      b[k] = (has_below && x0 + k < w) ? row[w + x0 + k] : -2;
+      if (LB && x0 + k < w) l[k] = lrow[x0 + k];
+    }
   }
-  atomicMax(&winner[slot * F + f], key);
+  const int64_t p0 = (int64_t)y * w + x0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (x0 + k < w) winner_pixel<KeyT>(win, f[k], f[k + 1], b[k], p0 + k, l[k], F, C, LB, compat);
 }
 
 // K6  per-face vote: one thread per face walks the views of the batch IN ORDER (deterministic, no atomics needed:
@@ -785,6 +945,8 @@ struct gr_ctx {
   int opt_thl = 5;      // log2 tile height (5 or 6); width is 64.  64x32 tiles: 16 KiB of LDS, 8 workgroups per CU
   int opt_batch = GR_MAX_BATCH;
   int opt_dbg = 0;
+  int opt_wg_per_cu = 5;  // persistent raster: resident workgroups per CU
+  int n_cu = 256;
   // winner scratch
   void *winner = nullptr;
   size_t winner_bytes = 0;
@@ -907,7 +1069,21 @@ int raster_batch(gr_ctx *c, const float *cams, int nb, int h, int w, RasterOut o
   }
   {
     Timed t(c, s, ST_RASTER);
-    if (c->opt_kernel <= 1 && a.thl == 6)
+    if (c->opt_kernel == 4) {
+      const int n_items = a.T * nb;
+      const int G = std::min(n_items, c->n_cu * c->opt_wg_per_cu);
+      if (a.thl == 6)
+        hipLaunchKernelGGL((k_raster_rows_persistent<6, 6, 256, true>), dim3(G), dim3(256), 0, s, a, out, n_items);
+      else
+        hipLaunchKernelGGL((k_raster_rows_persistent<6, 5, 256, true>), dim3(G), dim3(256), 0, s, a, out, n_items);
+    } else if (c->opt_kernel == 5) {
+      const int n_items = a.T * nb;
+      const int G = std::min(n_items, c->n_cu * c->opt_wg_per_cu);
+      if (a.thl == 6)
+        hipLaunchKernelGGL((k_raster_rows_persistent<6, 6, 256, false>), dim3(G), dim3(256), 0, s, a, out, n_items);
+      else
+        hipLaunchKernelGGL((k_raster_rows_persistent<6, 5, 256, false>), dim3(G), dim3(256), 0, s, a, out, n_items);
+    } else if (c->opt_kernel <= 1 && a.thl == 6)
       hipLaunchKernelGGL((k_raster_rows<6, 6, 256>), dim3(a.T, nb), dim3(256), 0, s, a, out);
     else if (c->opt_kernel <= 1)
       hipLaunchKernelGGL((k_raster_rows<6, 5, 256>), dim3(a.T, nb), dim3(256), 0, s, a, out);
@@ -951,7 +1127,7 @@ int project_labels_t(gr_ctx *c, const int32_t *ids, const uint8_t *labels, int n
     const int nb = (n_views - v0) < B ? (n_views - v0) : B;
     {
       Timed t(c, s, ST_PROJECT);
-      hipLaunchKernelGGL(k_winner<KeyT>, dim3((unsigned)ceil_div(P, 256), nb), dim3(256), 0, s, ids + v0 * P,
+      hipLaunchKernelGGL(k_winner<KeyT>, dim3((unsigned)ceil_div(ceil_div(w, 4), 256), h, nb), dim3(256), 0, s, ids + v0 * P,
                          labels + v0 * P, win, F, h, w, C, LB, (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0);
     }
     {
@@ -979,6 +1155,11 @@ int gr_ctx_create(int device, gr_ctx **out) {
   gr_ctx *c = new (std::nothrow) gr_ctx();
   if (!c) return GR_ENOMEM;
   c->device = device;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+      c->n_cu = prop.multiProcessorCount;
+  }
   if (hipMalloc(&c->stats, sizeof(unsigned long long) * 4) != hipSuccess ||
       hipMalloc(&c->flag, sizeof(int)) != hipSuccess) {
     delete c;
@@ -1022,7 +1203,7 @@ int gr_set_option(gr_ctx *c, int key, int value) {
   if (!c) return GR_EINVAL;
   switch (key) {
     case GR_OPT_RASTER_KERNEL:
-      if (value < 1 || value > 3) return fail(c, GR_EINVAL, "raster kernel must be 1..3");
+      if (value < 1 || value > 5) return fail(c, GR_EINVAL, "raster kernel must be 1..5");
       c->opt_kernel = value; return GR_OK;
     case GR_OPT_TILE_H_LOG2:
       if (value != 5 && value != 6) return fail(c, GR_EINVAL, "tile height log2 must be 5 or 6");
@@ -1032,6 +1213,9 @@ int gr_set_option(gr_ctx *c, int key, int value) {
       c->opt_batch = value; return GR_OK;
     case GR_OPT_DEBUG:
       c->opt_dbg = value; return GR_OK;
+    case GR_OPT_WG_PER_CU:
+      if (value < 1 || value > 16) return fail(c, GR_EINVAL, "workgroups per CU must be in [1, 16]");
+      c->opt_wg_per_cu = value; return GR_OK;
     default: return fail(c, GR_EINVAL, "unknown option %d", key);
   }
 }
@@ -1170,7 +1354,7 @@ int gr_project_values_f64(gr_ctx *c, const int32_t *ids, const double *img, int 
     const int nb = (n_views - v0) < B ? (n_views - v0) : B;
     {
       Timed t(c, s, ST_PROJECT);
-      hipLaunchKernelGGL(k_winner<uint32_t>, dim3((unsigned)ceil_div(P, 256), nb), dim3(256), 0, s, ids + v0 * P,
+      hipLaunchKernelGGL(k_winner<uint32_t>, dim3((unsigned)ceil_div(ceil_div(w, 4), 256), h, nb), dim3(256), 0, s, ids + v0 * P,
                          (const uint8_t *)nullptr, win, F, h, w, C, 0, (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0);
     }
     {
@@ -1197,7 +1381,7 @@ int gr_project_view_f64(gr_ctx *c, const int32_t *ids, const double *img, int h,
   uint32_t *win = (uint32_t *)c->winner;
   {
     Timed t(c, s, ST_PROJECT);
-    hipLaunchKernelGGL(k_winner<uint32_t>, dim3((unsigned)ceil_div(P, 256), 1), dim3(256), 0, s, ids,
+    hipLaunchKernelGGL(k_winner<uint32_t>, dim3((unsigned)ceil_div(ceil_div(w, 4), 256), h, 1), dim3(256), 0, s, ids,
                        (const uint8_t *)nullptr, win, F, h, w, C, 0, (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0);
   }
   {

@@ -14,7 +14,8 @@ from oracle import oracle_c, oracle_np
 pytestmark = pytest.mark.gpu
 
 # every raster test runs against each tile-kernel variant (include/geograster.h GR_OPT_*): results must not change
-VARIANTS = {"rows64": (1, 6), "rows32": (1, 5), "rows64_512": (2, 6), "rows32_128": (3, 5)}
+VARIANTS = {"rows64": (1, 6), "rows32": (1, 5), "rows64_512": (2, 6), "rows32_128": (3, 5), "persist32": (4, 5),
+            "persist64": (4, 6), "persist32_nopf": (5, 5)}
 
 
 @pytest.fixture(params=list(VARIANTS), autouse=True)
@@ -123,7 +124,7 @@ def test_bin_overflow_is_detected_and_retried(hip, raster_variant):
     hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
     recs = _records(cams)
     ids = hip.raster_face_ids(recs, 3000, 4000).cpu().numpy()
-    tiles = 63 * (47 if "rows32" not in raster_variant else 94)
+    tiles = 63 * (47 if "32" not in raster_variant else 94)
     assert hip.last_stats["overflow"] == 0 and hip.last_stats["entries"] == n * tiles
     assert hip.last_stats["entry_cap"] >= n * tiles
     want = oracle_c.raster(points, faces, recs[0], 3000, 4000)

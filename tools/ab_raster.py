@@ -25,14 +25,14 @@ def main():
     hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
     ids = torch.empty((nv, H, W), dtype=torch.int32, device="cuda")
     ref = None
-    variants = [("rows64", 1, 6, 16, 0), ("rows32", 1, 5, 16, 0), ("rows64_512", 2, 6, 16, 0), ("rows32_512", 2, 5, 16, 0),
-                ("rows64_128", 3, 6, 16, 0), ("rows32_128", 3, 5, 16, 0), ("rows32_b32", 1, 5, 32, 0),
-                ("rows32_noscan", 1, 5, 16, 1), ("rows32_nostore", 1, 5, 16, 2), ("rows32_notri", 1, 5, 16, 4),
-                ("rows32_notri_nostore", 1, 5, 16, 6)]
+    # (name, kernel, tile_h_log2, batch, debug mask, workgroups per CU for the persistent kernel)
+    variants = [("rows32_b32", 1, 5, 32, 0, 5), ("persist32_pf_wg5", 4, 5, 32, 0, 5),
+                ("persist32_nopf_wg6", 5, 5, 32, 0, 6), ("persist32_nopf_wg5", 5, 5, 32, 0, 5), ("persist32_nopf_wg4", 5, 5, 32, 0, 4),
+                ("persist64_nopf_wg4", 5, 6, 32, 0, 4)]
     results = {}
     for rep in range(3):
-        for name, k, thl, b, dbg in variants:
-            hip.set_option(1, k); hip.set_option(2, thl); hip.set_option(3, b); hip.set_option(99, dbg)
+        for name, k, thl, b, dbg, wg in variants:
+            hip.set_option(1, k); hip.set_option(2, thl); hip.set_option(3, b); hip.set_option(99, dbg); hip.set_option(4, wg)
             hip.raster_face_ids(recs, H, W, out=ids, check=True)
             if ref is None:
                 ref = ids.clone()

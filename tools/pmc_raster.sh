@@ -1,0 +1,30 @@
+#!/bin/bash
+# tools/pmc_raster.sh <tag> [kernel] [thl] -- SQ / LDS counter passes over tools/prof_raster.py (GPU box only)
+TAG=${1:-pmc}; K=${2:-1}; THL=${3:-5}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU"
+P2="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU"
+P3="SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_THREAD_CYCLES_VALU SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL"
+i=0
+for P in "$P1" "$P2" "$P3"; do
+  i=$((i+1))
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/p$i -o p$i -- python3 $REPO/tools/prof_raster.py $K $THL 32 2 > $OUT/p$i.log 2>&1
+  echo "pass $i rc=$?" >> $OUT/p$i.log
+done
+cd $REPO && python3 - <<PY
+import csv, glob, collections
+out = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+        out[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open("$OUT/summary.txt", "w") as fo:
+    for k, cs in sorted(out.items()):
+        fo.write(f"{k}\n")
+        for c, v in sorted(cs.items()):
+            fo.write(f"    {c:28s} n={len(v):3d} avg={sum(v)/len(v):16.1f}\n")
+print(open("$OUT/summary.txt").read())
+PY
