@@ -340,21 +340,36 @@ class HipRaster:
         self._check(rc, "gr_project_view_f64")
         return tex
 
-    def raster_project_labels(self, cams, labels, C: int, votes, counts, ids_out=None, neg1_is_last_face: bool = True):
-        """Fused pix2face + label projection for N views (aggregate_projected_images fast path)."""
+    def raster_project_labels(self, cams, labels, C: int, votes, counts, ids_out=None, neg1_is_last_face: bool = True,
+                              check: bool = True):
+        """Fused pix2face + label projection for N views (aggregate_projected_images fast path): the face ids stay in
+        the rasterizer's LDS tiles unless `ids_out` (N,h,w int32) is given.  Accumulates into votes / counts."""
         torch = _torch()
         cams_t = self._dev(cams, torch.float32)
         lab_t = self._dev(labels, torch.uint8)
         n, h, w = (int(x) for x in lab_t.shape)
-        if ids_out is None:
-            ids_out = torch.empty((n, h, w), dtype=torch.int32, device=self.device)
+        if cams_t.shape[0] != n:
+            raise ValueError(f"{cams_t.shape[0]} camera records for {n} label images")
         flags = GR_FLAG_NEG1_IS_LAST_FACE if neg1_is_last_face else 0
-        with torch.cuda.device(self.device):
-            rc = self.lib.gr_raster_project_labels_u8(
-                self._ctx, cams_t.data_ptr(), lab_t.data_ptr(), n, h, w, C, votes.data_ptr(), counts.data_ptr(),
-                ids_out.data_ptr(), flags, self._stream(),
-            )
-        self._check(rc, "gr_raster_project_labels_u8")
+        backup = (votes.clone(), counts.clone()) if check else None
+        for attempt in range(3):
+            with torch.cuda.device(self.device):
+                rc = self.lib.gr_raster_project_labels_u8(
+                    self._ctx, cams_t.data_ptr(), lab_t.data_ptr(), n, h, w, C, votes.data_ptr(), counts.data_ptr(),
+                    ids_out.data_ptr() if ids_out is not None else None, flags, self._stream(),
+                )
+            self._check(rc, "gr_raster_project_labels_u8")
+            if not check:
+                break
+            st = RasterStats()
+            rc = self.lib.gr_raster_status(self._ctx, ctypes.byref(st))
+            if rc == GR_EOVERFLOW and attempt < 2:
+                votes.copy_(backup[0])
+                counts.copy_(backup[1])
+                continue
+            self._check(rc, "gr_raster_status")
+            self.last_stats = st.as_dict()
+            break
         return ids_out
 
     def finalize_votes(self, votes, counts):

@@ -433,9 +433,32 @@ __global__ __launch_bounds__(256) void k_fill_compile(BinArgs a) {
 //     rotation spreads them over distinct banks; a row read in the epilogue stays conflict-free.
 //     Epilogue: whole rows, one coalesced 256-byte store per wave-instruction.
 // ------------------------------------------------------------------------------------------------------------------
+// last-writer-wins candidate (see K5): issue the global atomicMax only when neither the right nor the lower neighbour
+// shows the same face.  key = (pixel+1) << LB | label  (LB = 0: pixel+1)
+template <typename KeyT>
+__device__ __forceinline__ void winner_pixel(KeyT *__restrict__ winner, int f, int fr, int fb, int64_t p, int label,
+                                              int64_t F, int C, int LB, int compat) {
+  if (compat) {  // meshes.py:1998-2001: index -1 aliases the last face
+    const int last = (int)F - 1;
+    if (f == -1) f = last;
+    if (fr == -1) fr = last;
+    if (fb == -1) fb = last;
+  }
+  if (f < 0 || f >= F) return;
+  if (fr == f || fb == f) return;  // a later pixel of the same face exists
+  KeyT key = (KeyT)(p + 1);
+  if (LB) key = (key << LB) | (KeyT)min(label, C);
+  atomicMax(&winner[f], key);
+}
+
 struct RasterOut {
   int32_t *ids;    // [slot][h][w] or null
   float *depth;    // [slot][h][w] or null
+  // fused projection (gr_raster_project_labels_u8): per-face winners straight from the LDS tile
+  const uint8_t *labels;  // [slot][h][w] or null
+  void *winner;           // [slot][F] uint32 / uint64 keys
+  int64_t F;
+  int C, LB, compat, key64;
 };
 
 // LDS image of a tile: rows of TW keys padded by ONE key (stride TW+1 = 65 keys = 520 B).  The rows of one triangle
@@ -553,7 +576,7 @@ __device__ __forceinline__ void raster_wave_entries(unsigned long long *keys, co
     }
 }
 
-template <int TWL, int THL, int NT>
+template <int TWL, int THL, int NT, bool FUSE>
 __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   __shared__ unsigned long long keys[(TW + 1) * TH];  // the only LDS of the kernel: 16.25 KiB (64x32) or 32.5 KiB
@@ -597,14 +620,34 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
   const int col = tid & (TW - 1);
   const int gx = px0 + col;
   if (gx < a.w && !(a.dbg & 2)) {
-    const int64_t plane = (int64_t)slot * a.h * a.w;
+    const int64_t P = (int64_t)a.h * a.w;
+    const int64_t plane = (int64_t)slot * P;
     for (int row = tid >> TWL; row < TH; row += ROWS_PER_PASS) {
       const int gy = py0 + row;
       if (gy >= a.h) break;
       const unsigned long long key = keys[lds_idx<TWL>(row, col)];
-      const int64_t p = plane + (int64_t)gy * a.w + gx;
-      if (out.ids) out.ids[p] = key ? (int32_t)(~(uint32_t)key) : -1;
-      if (out.depth) out.depth[p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
+      const int64_t p = (int64_t)gy * a.w + gx;
+      const int32_t id = key ? (int32_t)(~(uint32_t)key) : -1;
+      if (out.ids) out.ids[plane + p] = id;
+      if (out.depth) out.depth[plane + p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
+      if (FUSE) {
+        // neighbours inside the tile come from LDS; across a tile edge the neighbour is unknown (-3: "differs", one
+        // atomic too many at worst), outside the image it is -2 exactly as in k_winner
+        int fr, fb;
+        if (gx + 1 >= a.w) fr = -2;
+        else if (col + 1 < TW) { const unsigned long long k2 = keys[lds_idx<TWL>(row, col + 1)]; fr = k2 ? (int32_t)(~(uint32_t)k2) : -1; }
+        else fr = -3;
+        if (gy + 1 >= a.h) fb = -2;
+        else if (row + 1 < TH) { const unsigned long long k2 = keys[lds_idx<TWL>(row + 1, col)]; fb = k2 ? (int32_t)(~(uint32_t)k2) : -1; }
+        else fb = -3;
+        const int label = out.labels[plane + p];
+        if (out.key64)
+          winner_pixel<unsigned long long>((unsigned long long *)out.winner + slot * out.F, id, fr, fb, p, label, out.F,
+                                           out.C, out.LB, out.compat);
+        else
+          winner_pixel<uint32_t>((uint32_t *)out.winner + slot * out.F, id, fr, fb, p, label, out.F, out.C, out.LB,
+                                 out.compat);
+      }
     }
   }
 }
@@ -727,65 +770,59 @@ __global__ __launch_bounds__(NT) void k_raster_rows_persistent(BinArgs a, Raster
 //     order if neither its right nor its lower neighbour shows the same face, so only those candidates issue the
 //     global atomicMax (~1-3 per visible face instead of ~80).  key = (pixel+1) << LB | label  (LB = 0: pixel+1).
 // ------------------------------------------------------------------------------------------------------------------
-template <typename KeyT>
-__device__ __forceinline__ void winner_pixel(KeyT *__restrict__ winner, int f, int fr, int fb, int64_t p, int label,
-                                              int64_t F, int C, int LB, int compat) {
-  if (compat) {  // meshes.py:1998-2001: index -1 aliases the last face
-    const int last = (int)F - 1;
-    if (f == -1) f = last;
-    if (fr == -1) fr = last;
-    if (fb == -1) fb = last;
-  }
-  if (f < 0 || f >= F) return;
-  if (fr == f || fb == f) return;  // a later pixel of the same face exists
-  KeyT key = (KeyT)(p + 1);
-  if (LB) key = (key << LB) | (KeyT)min(label, C);
-  atomicMax(&winner[f], key);
-}
-
-// grid (ceil(w/4/256), h, views): one thread per 4 consecutive pixels of a row (16-byte id loads, 4-byte label load)
+// grid (ceil(w/1024), ceil(h/WIN_ROWS), views): a thread owns 4 consecutive columns and walks WIN_ROWS rows downwards;
+// the row below is loaded once and becomes the current row of the next step (16-byte id loads, 4-byte label loads).
+#define WIN_ROWS 16
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_winner(const int32_t *__restrict__ ids, const uint8_t *__restrict__ labels,
                                                 KeyT *__restrict__ winner, int64_t F, int h, int w, int C, int LB,
                                                 int compat) {
   const int slot = blockIdx.z;
-  const int y = blockIdx.y;
+  const int y0 = blockIdx.y * WIN_ROWS;
   const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (x0 >= w) return;
   const int64_t P = (int64_t)h * w;
-  const int32_t *row = ids + slot * P + (int64_t)y * w;
-  const uint8_t *lrow = LB ? labels + slot * P + (int64_t)y * w : nullptr;
+  const int32_t *img = ids + slot * P;
+  const uint8_t *lab = LB ? labels + slot * P : nullptr;
   KeyT *win = winner + slot * F;
-  const bool has_below = (y + 1 < h);
-  int f[5], b[4], l[4] = {0, 0, 0, 0};
-  if ((w & 3) == 0 && ((reinterpret_cast<uintptr_t>(row + x0) & 15) == 0) &&
-      (!LB || (reinterpret_cast<uintptr_t>(lrow + x0) & 3) == 0)) {  // 16-byte aligned rows
-    const int4 c = *reinterpret_cast<const int4 *>(row + x0);
-    f[0] = c.x; f[1] = c.y; f[2] = c.z; f[3] = c.w;
-    f[4] = (x0 + 4 < w) ? row[x0 + 4] : -2;
-    if (has_below) {
-      const int4 d = *reinterpret_cast<const int4 *>(row + w + x0);
-      b[0] = d.x; b[1] = d.y; b[2] = d.z; b[3] = d.w;
+  const bool vec = ((w & 3) == 0) && ((reinterpret_cast<uintptr_t>(img) & 15) == 0) &&
+                   (!LB || (reinterpret_cast<uintptr_t>(lab) & 3) == 0);
+  auto load_row = [&](int y, int (&f)[5]) {
+    const int32_t *row = img + (int64_t)y * w;
+    if (vec) {
+      const int4 c = *reinterpret_cast<const int4 *>(row + x0);
+      f[0] = c.x; f[1] = c.y; f[2] = c.z; f[3] = c.w;
+      f[4] = (x0 + 4 < w) ? row[x0 + 4] : -2;
     } else {
-      b[0] = b[1] = b[2] = b[3] = -2;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) f[k] = (x0 + k < w) ? row[x0 + k] : -2;
     }
+  };
+  int cur[5], nxt[5];
+  load_row(y0, cur);
+  const int y1 = min(y0 + WIN_ROWS, h);
+  for (int y = y0; y < y1; ++y) {
+    const bool has_below = (y + 1 < h);
+    if (has_below) load_row(y + 1, nxt);
+    else { nxt[0] = nxt[1] = nxt[2] = nxt[3] = nxt[4] = -2; }
+    int l[4] = {0, 0, 0, 0};
     if (LB) {
-      const uchar4 q = *reinterpret_cast<const uchar4 *>(lrow + x0);
-      l[0] = q.x; l[1] = q.y; l[2] = q.z; l[3] = q.w;
-    }
-  } else {
+      const uint8_t *lrow = lab + (int64_t)y * w;
+      if (vec) {
+        const uchar4 q = *reinterpret_cast<const uchar4 *>(lrow + x0);
+        l[0] = q.x; l[1] = q.y; l[2] = q.z; l[3] = q.w;
+      } else {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) f[k] = (x0 + k < w) ? row[x0 + k] : -2;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      b[k] = (has_below && x0 + k < w) ? row[w + x0 + k] : -2;
-      if (LB && x0 + k < w) l[k] = lrow[x0 + k];
+        for (int k = 0; k < 4; ++k) if (x0 + k < w) l[k] = lrow[x0 + k];
+      }
     }
+    const int64_t p0 = (int64_t)y * w + x0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (x0 + k < w) winner_pixel<KeyT>(win, cur[k], cur[k + 1], nxt[k], p0 + k, l[k], F, C, LB, compat);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) cur[k] = nxt[k];
   }
-  const int64_t p0 = (int64_t)y * w + x0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (x0 + k < w) winner_pixel<KeyT>(win, f[k], f[k + 1], b[k], p0 + k, l[k], F, C, LB, compat);
 }
 
 // K6  per-face vote: one thread per face walks the views of the batch IN ORDER (deterministic, no atomics needed:
@@ -1069,32 +1106,37 @@ int raster_batch(gr_ctx *c, const float *cams, int nb, int h, int w, RasterOut o
   }
   {
     Timed t(c, s, ST_RASTER);
-    if (c->opt_kernel == 4) {
+    if (c->opt_kernel == 4 && !out.labels) {
       const int n_items = a.T * nb;
       const int G = std::min(n_items, c->n_cu * c->opt_wg_per_cu);
       if (a.thl == 6)
         hipLaunchKernelGGL((k_raster_rows_persistent<6, 6, 256, true>), dim3(G), dim3(256), 0, s, a, out, n_items);
       else
         hipLaunchKernelGGL((k_raster_rows_persistent<6, 5, 256, true>), dim3(G), dim3(256), 0, s, a, out, n_items);
-    } else if (c->opt_kernel == 5) {
+    } else if (c->opt_kernel == 5 && !out.labels) {
       const int n_items = a.T * nb;
       const int G = std::min(n_items, c->n_cu * c->opt_wg_per_cu);
       if (a.thl == 6)
         hipLaunchKernelGGL((k_raster_rows_persistent<6, 6, 256, false>), dim3(G), dim3(256), 0, s, a, out, n_items);
       else
         hipLaunchKernelGGL((k_raster_rows_persistent<6, 5, 256, false>), dim3(G), dim3(256), 0, s, a, out, n_items);
+    } else if (out.labels) {
+      if (a.thl == 6)
+        hipLaunchKernelGGL((k_raster_rows<6, 6, 256, true>), dim3(a.T, nb), dim3(256), 0, s, a, out);
+      else
+        hipLaunchKernelGGL((k_raster_rows<6, 5, 256, true>), dim3(a.T, nb), dim3(256), 0, s, a, out);
     } else if (c->opt_kernel <= 1 && a.thl == 6)
-      hipLaunchKernelGGL((k_raster_rows<6, 6, 256>), dim3(a.T, nb), dim3(256), 0, s, a, out);
+      hipLaunchKernelGGL((k_raster_rows<6, 6, 256, false>), dim3(a.T, nb), dim3(256), 0, s, a, out);
     else if (c->opt_kernel <= 1)
-      hipLaunchKernelGGL((k_raster_rows<6, 5, 256>), dim3(a.T, nb), dim3(256), 0, s, a, out);
+      hipLaunchKernelGGL((k_raster_rows<6, 5, 256, false>), dim3(a.T, nb), dim3(256), 0, s, a, out);
     else if (c->opt_kernel == 2 && a.thl == 6)
-      hipLaunchKernelGGL((k_raster_rows<6, 6, 512>), dim3(a.T, nb), dim3(512), 0, s, a, out);
+      hipLaunchKernelGGL((k_raster_rows<6, 6, 512, false>), dim3(a.T, nb), dim3(512), 0, s, a, out);
     else if (c->opt_kernel == 2)
-      hipLaunchKernelGGL((k_raster_rows<6, 5, 512>), dim3(a.T, nb), dim3(512), 0, s, a, out);
+      hipLaunchKernelGGL((k_raster_rows<6, 5, 512, false>), dim3(a.T, nb), dim3(512), 0, s, a, out);
     else if (a.thl == 6)
-      hipLaunchKernelGGL((k_raster_rows<6, 6, 128>), dim3(a.T, nb), dim3(128), 0, s, a, out);
+      hipLaunchKernelGGL((k_raster_rows<6, 6, 128, false>), dim3(a.T, nb), dim3(128), 0, s, a, out);
     else
-      hipLaunchKernelGGL((k_raster_rows<6, 5, 128>), dim3(a.T, nb), dim3(128), 0, s, a, out);
+      hipLaunchKernelGGL((k_raster_rows<6, 5, 128, false>), dim3(a.T, nb), dim3(128), 0, s, a, out);
     c->prof_raster_launches += 1;
   }
   c->prof_views += nb;
@@ -1127,7 +1169,7 @@ int project_labels_t(gr_ctx *c, const int32_t *ids, const uint8_t *labels, int n
     const int nb = (n_views - v0) < B ? (n_views - v0) : B;
     {
       Timed t(c, s, ST_PROJECT);
-      hipLaunchKernelGGL(k_winner<KeyT>, dim3((unsigned)ceil_div(ceil_div(w, 4), 256), h, nb), dim3(256), 0, s, ids + v0 * P,
+      hipLaunchKernelGGL(k_winner<KeyT>, dim3((unsigned)ceil_div(ceil_div(w, 4), 256), (unsigned)ceil_div(h, WIN_ROWS), nb), dim3(256), 0, s, ids + v0 * P,
                          labels + v0 * P, win, F, h, w, C, LB, (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0);
     }
     {
@@ -1137,6 +1179,55 @@ int project_labels_t(gr_ctx *c, const int32_t *ids, const uint8_t *labels, int n
     }
   }
   GR_HIP(c, hipGetLastError());
+  return GR_OK;
+}
+
+// pix2face for n_views cameras, optionally fused with the label projection (labels != nullptr): per launch group the
+// tile kernel's epilogue feeds the per-face winners straight from LDS and k_vote_labels folds them into votes/counts.
+int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_t *ids, float *depth,
+                 const uint8_t *labels, int C, uint32_t *votes, uint32_t *counts, int flags, hipStream_t s) {
+  int rc = check_common(c, n_views, h, w);
+  if (rc) return rc;
+  if (!c->verts) return fail(c, GR_ENOMESH, "gr_mesh_upload has not been called");
+  if (!cams) return fail(c, GR_EINVAL, "null cams");
+  if (n_views == 0) return GR_OK;
+  GR_HIP(c, hipSetDevice(c->device));
+  const int B = n_views < c->opt_batch ? n_views : c->opt_batch;
+  const int thl = c->opt_thl;
+  const int T = ((w + GR_TILE - 1) >> GR_TILE_LOG2) * ((h + (1 << thl) - 1) >> thl);
+  rc = ensure_bins(c, B, T);
+  if (rc) return rc;
+  const int64_t P = (int64_t)h * w, F = c->F;
+  int LB = 0, key64 = 0;
+  if (labels) {
+    LB = label_bits(C);
+    key64 = (((P + 1) << LB) <= 0xFFFFFFFFll) ? 0 : 1;
+    rc = ensure_winner(c, (key64 ? sizeof(unsigned long long) : sizeof(uint32_t)) * (size_t)F * B);
+    if (rc) return rc;
+  }
+  c->last_stream = s;
+  GR_HIP(c, hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 4, s));
+  for (int v0 = 0; v0 < n_views; v0 += B) {
+    const int nb = (n_views - v0) < B ? (n_views - v0) : B;
+    RasterOut out;
+    out.ids = ids ? ids + v0 * P : nullptr;
+    out.depth = depth ? depth + v0 * P : nullptr;
+    out.labels = labels ? labels + v0 * P : nullptr;
+    out.winner = c->winner; out.F = F; out.C = C; out.LB = LB; out.key64 = key64;
+    out.compat = (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0;
+    rc = raster_batch(c, cams + (int64_t)v0 * GR_CAM_FLOATS, nb, h, w, out, s);
+    if (rc) return rc;
+    if (labels) {
+      Timed t(c, s, ST_VOTE);
+      if (key64)
+        hipLaunchKernelGGL(k_vote_labels<unsigned long long>, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s,
+                           (unsigned long long *)c->winner, nb, F, C, LB, votes, counts);
+      else
+        hipLaunchKernelGGL(k_vote_labels<uint32_t>, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s,
+                           (uint32_t *)c->winner, nb, F, C, LB, votes, counts);
+      GR_HIP(c, hipGetLastError());
+    }
+  }
   return GR_OK;
 }
 
@@ -1265,30 +1356,8 @@ int gr_mesh_upload(gr_ctx *c, const float *verts, const int32_t *faces, int64_t 
 
 int gr_raster_face_ids(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_t *ids, float *depth,
                        void *stream) {
-  int rc = check_common(c, n_views, h, w);
-  if (rc) return rc;
-  if (!c->verts) return fail(c, GR_ENOMESH, "gr_mesh_upload has not been called");
-  if (!cams || (!ids && !depth)) return fail(c, GR_EINVAL, "null cams / outputs");
-  if (n_views == 0) return GR_OK;
-  hipStream_t s = (hipStream_t)stream;
-  GR_HIP(c, hipSetDevice(c->device));
-  const int B = n_views < c->opt_batch ? n_views : c->opt_batch;
-  const int thl = c->opt_thl;
-  const int T = ((w + GR_TILE - 1) >> GR_TILE_LOG2) * ((h + (1 << thl) - 1) >> thl);
-  rc = ensure_bins(c, B, T);
-  if (rc) return rc;
-  c->last_stream = s;
-  GR_HIP(c, hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 4, s));
-  const int64_t P = (int64_t)h * w;
-  for (int v0 = 0; v0 < n_views; v0 += B) {
-    const int nb = (n_views - v0) < B ? (n_views - v0) : B;
-    RasterOut out;
-    out.ids = ids ? ids + v0 * P : nullptr;
-    out.depth = depth ? depth + v0 * P : nullptr;
-    rc = raster_batch(c, cams + (int64_t)v0 * GR_CAM_FLOATS, nb, h, w, out, s);
-    if (rc) return rc;
-  }
-  return GR_OK;
+  if (c && !ids && !depth) return fail(c, GR_EINVAL, "null outputs");
+  return raster_views(c, cams, n_views, h, w, ids, depth, nullptr, 0, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 
 int gr_raster_status(gr_ctx *c, gr_raster_stats *o) {
@@ -1354,7 +1423,7 @@ int gr_project_values_f64(gr_ctx *c, const int32_t *ids, const double *img, int 
     const int nb = (n_views - v0) < B ? (n_views - v0) : B;
     {
       Timed t(c, s, ST_PROJECT);
-      hipLaunchKernelGGL(k_winner<uint32_t>, dim3((unsigned)ceil_div(ceil_div(w, 4), 256), h, nb), dim3(256), 0, s, ids + v0 * P,
+      hipLaunchKernelGGL(k_winner<uint32_t>, dim3((unsigned)ceil_div(ceil_div(w, 4), 256), (unsigned)ceil_div(h, WIN_ROWS), nb), dim3(256), 0, s, ids + v0 * P,
                          (const uint8_t *)nullptr, win, F, h, w, C, 0, (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0);
     }
     {
@@ -1381,7 +1450,7 @@ int gr_project_view_f64(gr_ctx *c, const int32_t *ids, const double *img, int h,
   uint32_t *win = (uint32_t *)c->winner;
   {
     Timed t(c, s, ST_PROJECT);
-    hipLaunchKernelGGL(k_winner<uint32_t>, dim3((unsigned)ceil_div(ceil_div(w, 4), 256), h, 1), dim3(256), 0, s, ids,
+    hipLaunchKernelGGL(k_winner<uint32_t>, dim3((unsigned)ceil_div(ceil_div(w, 4), 256), (unsigned)ceil_div(h, WIN_ROWS), 1), dim3(256), 0, s, ids,
                        (const uint8_t *)nullptr, win, F, h, w, C, 0, (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0);
   }
   {
@@ -1395,12 +1464,9 @@ int gr_project_view_f64(gr_ctx *c, const int32_t *ids, const double *img, int h,
 
 int gr_raster_project_labels_u8(gr_ctx *c, const float *cams, const uint8_t *labels, int n_views, int h, int w, int C,
                                 uint32_t *votes, uint32_t *counts, int32_t *ids_or_null, int flags, void *stream) {
-  // Round-1 form: materialise the ids of one batch in caller- or context-owned memory, then project.  (A later
-  // round folds the winner pass into k_raster_rows' epilogue so the ids never leave LDS.)
-  if (!ids_or_null) return fail(c, GR_EINVAL, "ids buffer required in this version");
-  int rc = gr_raster_face_ids(c, cams, n_views, h, w, ids_or_null, nullptr, stream);
-  if (rc) return rc;
-  return gr_project_labels_u8(c, ids_or_null, labels, n_views, h, w, C, votes, counts, flags, stream);
+  if (!c) return GR_EINVAL;
+  if (!labels || !votes || !counts || C <= 0 || C > 255) return fail(c, GR_EINVAL, "bad fused project args C=%d", C);
+  return raster_views(c, cams, n_views, h, w, ids_or_null, nullptr, labels, C, votes, counts, flags, (hipStream_t)stream);
 }
 
 int gr_finalize_votes(gr_ctx *c, const uint32_t *votes, const uint32_t *counts, int64_t F, int C, double *average,

@@ -280,8 +280,8 @@ class TexturedPhotogrammetryMesh:
             self._uploaded_key = key
 
     # -- pix2face ------------------------------------------------------------------------------------------------
-    def _pix2face_device(self, cameras, mesh, render_img_scale, near=None, principal_point="center"):
-        """(N,h,w) int32 device tensor of face ids for a camera or camera set."""
+    def _raster_records(self, cameras, mesh, render_img_scale, near=None, principal_point="center"):
+        """Upload the local mesh if needed and pack the (N,16) camera records; returns (records, (h, w))."""
         if isinstance(cameras, PhotogrammetryCamera):
             cameras = PhotogrammetryCameraSet([cameras], local_to_epsg_4978_transform=cameras._local_to_epsg_4978_transform)
         if mesh is None:
@@ -294,7 +294,11 @@ class TexturedPhotogrammetryMesh:
             bounds = mesh.bounds()
             near = [vtk_like_near_plane(np.asarray(c.cam_to_world_transform, dtype=np.float64), bounds) for c in cameras.cameras]
         records = cameras.get_raster_records(render_img_scale, near=near, principal_point=principal_point)
-        h, w = cameras.cameras[0].get_image_size(render_img_scale)
+        return records, cameras.cameras[0].get_image_size(render_img_scale)
+
+    def _pix2face_device(self, cameras, mesh, render_img_scale, near=None, principal_point="center"):
+        """(N,h,w) int32 device tensor of face ids for a camera or camera set."""
+        records, (h, w) = self._raster_records(cameras, mesh, render_img_scale, near=near, principal_point=principal_point)
         return self.backend.raster_face_ids(records, h, w)
 
     def pix2face(
@@ -473,18 +477,21 @@ class TexturedPhotogrammetryMesh:
             C = int(cameras.n_image_channels())
             self._ensure_uploaded(mesh)
             votes, counts = self.backend.new_vote_buffers(C)
-            chunk = max(int(batch_size), 8)
+            chunk = max(int(batch_size), 32)
             for c0 in tqdm(range(0, len(my_inds), chunk), total=(len(my_inds) + chunk - 1) // chunk,
                            desc="Aggregating projected viewpoints"):
                 inds = my_inds[c0 : c0 + chunk]
                 sub = cameras.get_subset_cameras(inds)
-                ids = self._pix2face_device(sub, mesh, aggregate_img_scale, **_raster_kwargs(kwargs))
                 labels = [first_label if i == view_inds[0] else label_fn(i, aggregate_img_scale) for i in inds]
                 if isinstance(labels[0], torch.Tensor):
                     lab = torch.stack([l.to(self.backend.device, torch.uint8) for l in labels], dim=0)
                 else:
                     lab = np.stack([np.asarray(l).astype(np.uint8) for l in labels], axis=0)
-                self.backend.project_labels(ids, lab, C, votes, counts, neg1_is_last_face=self.neg1_is_last_face)
+                # fused: face ids stay in the rasterizer's LDS tiles, only per-face winners reach HBM
+                records, _ = self._raster_records(sub, mesh, aggregate_img_scale, **_raster_kwargs(kwargs))
+                self.backend.raster_project_labels(
+                    records, lab, C, votes, counts, neg1_is_last_face=self.neg1_is_last_face
+                )
             if distributed and world > 1:
                 dist_utils.all_reduce_votes(votes, counts)
             avg, summed, cnt = self.backend.finalize_votes(votes, counts)

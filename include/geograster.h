@@ -134,7 +134,9 @@ int gr_project_view_f64(gr_ctx *ctx, const int32_t *ids, const double *img, int 
                         int flags, void *stream);
 
 /* fused pix2face + project_labels (ids never leave the chip unless ids_or_null != NULL): the
- * aggregate_projected_images fast path, meshes.py:2004-2084 over n_views cameras. */
+ * aggregate_projected_images fast path, meshes.py:2004-2084 over n_views cameras.  The tile rasterizer's epilogue feeds
+ * the per-face winners straight from its LDS tile.  If gr_raster_status afterwards reports GR_EOVERFLOW the votes of
+ * this call are incomplete: restore votes/counts to their state before the call and call again. */
 int gr_raster_project_labels_u8(gr_ctx *ctx, const float *cams, const uint8_t *labels, int n_views, int h, int w,
                                 int C, uint32_t *votes, uint32_t *counts, int32_t *ids_or_null, int flags,
                                 void *stream);

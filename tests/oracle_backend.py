@@ -55,6 +55,12 @@ class OracleBackend:
         for k in range(ids.shape[0]):
             oracle_c.project_labels(ids[k], labels[k], self.n_faces, C, v, c, neg1_is_last_face)
 
+    def raster_project_labels(self, cams, labels, C, votes, counts, ids_out=None, neg1_is_last_face=True, check=True):
+        labels = np.asarray(labels)
+        ids = self.raster_face_ids(cams, labels.shape[1], labels.shape[2])
+        self.project_labels(ids, labels, C, votes, counts, neg1_is_last_face=neg1_is_last_face)
+        return ids
+
     def project_view(self, ids, img, neg1_is_last_face=True):
         tex = oracle_np.project_image(np.asarray(ids).astype(np.int64), np.asarray(img), self.n_faces,
                                       neg1_is_last_face=neg1_is_last_face)

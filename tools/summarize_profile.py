@@ -82,6 +82,16 @@ def main():
         f.write("\n".join(lines) + "\n")
     with open(os.path.join(raw, f"summary_{tag}.json"), "w") as f:
         json.dump(summary, f, indent=1)
+    # traffic.json: HBM bytes per launch of each kernel = 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE
+    traffic = {}
+    for k, v in summary.items():
+        name = k.replace("void ", "").split("<")[0].strip()
+        fm, wm = v["fetch_x2_MB_per_launch"], v["write_MB_per_launch"]
+        if fm == fm and wm == wm:
+            traffic[name] = {"hbm_bytes_per_launch": (fm + wm) * 1e6, "fetch_x2_MB": fm, "write_MB": wm,
+                             "launches": v["launches"], "source": f"profiles/summary_{tag}.txt"}
+    with open(os.path.join(raw, "traffic.json"), "w") as f:
+        json.dump(traffic, f, indent=1)
     print("\n".join(lines))
 
 
