@@ -81,7 +81,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = "WORLD_SIZE" in os.environ and "RANK" in os.environ  # launched by torch.distributed.run
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

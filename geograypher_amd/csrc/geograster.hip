@@ -487,6 +487,8 @@ __device__ __forceinline__ void span_clip(int E, int A, int &xs, int &xe) {
   xe = (A == 0 && E < 0) ? -1 : xe;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // Phases 2-3 of the tile rasterizer for the 64 entries a wave holds in registers (s0..s3, nrows per lane).
 template <int TWL>
 __device__ __forceinline__ void raster_wave_entries(unsigned long long *keys, const int4 s0, const int4 s1, const int4 s2,
@@ -536,15 +538,22 @@ __device__ __forceinline__ void raster_wave_entries(unsigned long long *keys, co
         span_clip<TW>(C0 + __mul24(B0, y), A0, xs, xe);
         span_clip<TW>(C1 + __mul24(B1, y), A1, xs, xe);
         span_clip<TW>(C2 + __mul24(B2, y), A2, xs, xe);
-        int fxi = xs * 256 + X0rel;
-        const int fxe = xe * 256 + X0rel;
-        unsigned long long *kp = keys + lds_idx<TWL>(y, xs);
-        for (; fxi <= fxe; fxi += 256, ++kp) {
-          const float m0 = zA * (float)fxi;
-          const float s = m0 + m1;
-          const float z = iz0 + s;
-          const int zb = max(__float_as_int(z), 1);
-          atomicMax(kp, ((unsigned long long)(uint32_t)zb << 32) | key_lo);
+        // two pixels per step with packed fp32 math (v_pk_mul_f32 / v_pk_add_f32: same IEEE results as the scalar
+        // forms, R4 op for op).  float(P_x - X0) advances by exact float adds (integers below 2^24).  An odd span's
+        // spare slot is steered to the row's padding key (column TW), which nobody reads.
+        if (xs <= xe) {
+          const f32x2 zA2 = {zA, zA}, m12 = {m1, m1}, iz2 = {iz0, iz0}, step = {512.0f, 512.0f};
+          const float fx0 = (float)(xs * 256 + X0rel);
+          f32x2 fx = {fx0, fx0 + 256.0f};
+          unsigned long long *kp = keys + lds_idx<TWL>(y, xs);
+          unsigned long long *const pad = keys + lds_idx<TWL>(y, TW);
+          unsigned long long *const kend = keys + lds_idx<TWL>(y, xe);
+          for (; kp <= kend; kp += 2, fx += step) {
+            const f32x2 z = iz2 + (zA2 * fx + m12);
+            const int zb0 = max(__float_as_int(z.x), 1), zb1 = max(__float_as_int(z.y), 1);
+            atomicMax(kp, ((unsigned long long)(uint32_t)zb0 << 32) | key_lo);
+            atomicMax(kp < kend ? kp + 1 : pad, ((unsigned long long)(uint32_t)zb1 << 32) | key_lo);
+          }
         }
       }
       if (__ballot(big) != 0ull) {
@@ -983,7 +992,11 @@ struct gr_ctx {
   int opt_batch = GR_MAX_BATCH;
   int opt_dbg = 0;
   int opt_wg_per_cu = 5;  // persistent raster: resident workgroups per CU
+  int opt_overlap = 0;    // 1: bin the next launch group on a side stream while the current one is rasterized.
+                          // Measured neutral on MI355X (41.1 vs 40.9 us/view): the stages share the same VALU/LDS pipes.
   int n_cu = 256;
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_bins[2] = {nullptr, nullptr}, ev_tiles[2] = {nullptr, nullptr};
   // winner scratch
   void *winner = nullptr;
   size_t winner_bytes = 0;
@@ -1074,20 +1087,23 @@ int ensure_winner(gr_ctx *c, size_t bytes) {
   return GR_OK;
 }
 
-BinArgs make_args(gr_ctx *c, int h, int w) {
+BinArgs make_args(gr_ctx *c, int h, int w, int slot0) {
   BinArgs a;
-  a.ctrl = c->ctrl; a.rec = c->rec; a.comp = c->comp; a.stats = c->stats; a.blk = c->blk; a.work = c->work; a.work_stride = c->work_stride;
   a.ctrl_stride = c->ctrl_stride; a.rec_stride = c->rec_stride; a.ent_cap = c->ent_cap; a.F = c->F;
+  a.work_stride = c->work_stride;
+  a.ctrl = c->ctrl + slot0 * a.ctrl_stride; a.rec = c->rec + slot0 * a.rec_stride;
+  a.comp = c->comp + slot0 * a.ent_cap * 4; a.work = c->work + slot0 * a.work_stride;
+  a.stats = c->stats; a.blk = c->blk;
   a.twl = GR_TILE_LOG2; a.thl = c->opt_thl;
   a.TX = (w + (1 << a.twl) - 1) >> a.twl; a.TY = (h + (1 << a.thl) - 1) >> a.thl; a.T = a.TX * a.TY; a.Tcap = c->Tcap;
   a.h = h; a.w = w; a.dbg = c->opt_dbg;
   return a;
 }
 
-// bin + rasterize `nb` views starting at camera `cams`, results into out (already offset to the first view)
-int raster_batch(gr_ctx *c, const float *cams, int nb, int h, int w, RasterOut out, hipStream_t s) {
-  BinArgs a = make_args(c, h, w);
-  GR_HIP(c, hipMemsetAsync(c->ctrl, 0, sizeof(uint32_t) * c->ctrl_stride * nb, s));
+// stage 1 of a launch group: cull, set up and bin `nb` views (camera records `cams`) into scratch slots slot0..
+int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, hipStream_t s) {
+  BinArgs a = make_args(c, h, w, slot0);
+  GR_HIP(c, hipMemsetAsync(a.ctrl, 0, sizeof(uint32_t) * c->ctrl_stride * nb, s));
   {
     Timed t(c, s, ST_SETUP);
     const int nblk = (int)ceil_div(c->F, 256);
@@ -1104,6 +1120,13 @@ int raster_batch(gr_ctx *c, const float *cams, int nb, int h, int w, RasterOut o
     const unsigned g = (unsigned)std::min<int64_t>(ceil_div(c->F, 256), 1024);
     hipLaunchKernelGGL(k_fill_compile, dim3(g, nb), dim3(256), 0, s, a);
   }
+  GR_HIP(c, hipGetLastError());
+  return GR_OK;
+}
+
+// stage 2: rasterize the binned views of scratch slots slot0.. into out (already offset to the group's first view)
+int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStream_t s) {
+  BinArgs a = make_args(c, h, w, slot0);
   {
     Timed t(c, s, ST_RASTER);
     if (c->opt_kernel == 4 && !out.labels) {
@@ -1195,7 +1218,11 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   const int B = n_views < c->opt_batch ? n_views : c->opt_batch;
   const int thl = c->opt_thl;
   const int T = ((w + GR_TILE - 1) >> GR_TILE_LOG2) * ((h + (1 << thl) - 1) >> thl);
-  rc = ensure_bins(c, B, T);
+  // Two scratch sets when there is more than one launch group: group g+1 is culled / set up / binned on the context's
+  // side stream while group g is rasterized on the caller's stream.  The binning kernels are latency-bound and the tile
+  // kernel is VALU-bound, so the two overlap instead of queueing behind each other.
+  const bool overlap = c->opt_overlap && n_views > B && c->side_stream != nullptr;
+  rc = ensure_bins(c, overlap ? 2 * B : B, T);
   if (rc) return rc;
   const int64_t P = (int64_t)h * w, F = c->F;
   int LB = 0, key64 = 0;
@@ -1207,16 +1234,31 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   }
   c->last_stream = s;
   GR_HIP(c, hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 4, s));
-  for (int v0 = 0; v0 < n_views; v0 += B) {
+  hipStream_t s2 = overlap ? c->side_stream : s;
+  if (overlap) {  // the side stream starts after everything already queued on the caller's stream
+    GR_HIP(c, hipEventRecord(c->ev_fork, s));
+    GR_HIP(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
+  }
+  int g = 0;
+  for (int v0 = 0; v0 < n_views; v0 += B, ++g) {
     const int nb = (n_views - v0) < B ? (n_views - v0) : B;
+    const int set = overlap ? (g & 1) : 0;
+    if (overlap && g >= 2) GR_HIP(c, hipStreamWaitEvent(s2, c->ev_tiles[set], 0));  // set free again
+    rc = bin_batch(c, cams + (int64_t)v0 * GR_CAM_FLOATS, nb, h, w, set * B, s2);
+    if (rc) return rc;
+    if (overlap) {
+      GR_HIP(c, hipEventRecord(c->ev_bins[set], s2));
+      GR_HIP(c, hipStreamWaitEvent(s, c->ev_bins[set], 0));
+    }
     RasterOut out;
     out.ids = ids ? ids + v0 * P : nullptr;
     out.depth = depth ? depth + v0 * P : nullptr;
     out.labels = labels ? labels + v0 * P : nullptr;
     out.winner = c->winner; out.F = F; out.C = C; out.LB = LB; out.key64 = key64;
     out.compat = (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0;
-    rc = raster_batch(c, cams + (int64_t)v0 * GR_CAM_FLOATS, nb, h, w, out, s);
+    rc = tile_batch(c, nb, h, w, set * B, out, s);
     if (rc) return rc;
+    if (overlap) GR_HIP(c, hipEventRecord(c->ev_tiles[set], s));
     if (labels) {
       Timed t(c, s, ST_VOTE);
       if (key64)
@@ -1257,6 +1299,13 @@ int gr_ctx_create(int device, gr_ctx **out) {
     return GR_ENOMEM;
   }
   (void)hipMemset(c->stats, 0, sizeof(unsigned long long) * 4);
+  if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) c->side_stream = nullptr;
+  bool ev_ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; i < 2; ++i) {
+    ev_ok = ev_ok && hipEventCreateWithFlags(&c->ev_bins[i], hipEventDisableTiming) == hipSuccess;
+    ev_ok = ev_ok && hipEventCreateWithFlags(&c->ev_tiles[i], hipEventDisableTiming) == hipSuccess;
+  }
+  if (!ev_ok && c->side_stream) { (void)hipStreamDestroy(c->side_stream); c->side_stream = nullptr; }
   *out = c;
   return GR_OK;
 }
@@ -1267,6 +1316,12 @@ int gr_ctx_destroy(gr_ctx *c) {
   (void)hipDeviceSynchronize();
   for (auto &sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   for (auto e : c->pool) (void)hipEventDestroy(e);
+  if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  for (int i = 0; i < 2; ++i) {
+    if (c->ev_bins[i]) (void)hipEventDestroy(c->ev_bins[i]);
+    if (c->ev_tiles[i]) (void)hipEventDestroy(c->ev_tiles[i]);
+  }
   if (c->ctrl) (void)hipFree(c->ctrl);
   if (c->rec) (void)hipFree(c->rec);
   if (c->comp) (void)hipFree(c->comp);
@@ -1304,6 +1359,8 @@ int gr_set_option(gr_ctx *c, int key, int value) {
       c->opt_batch = value; return GR_OK;
     case GR_OPT_DEBUG:
       c->opt_dbg = value; return GR_OK;
+    case GR_OPT_OVERLAP:
+      c->opt_overlap = value ? 1 : 0; return GR_OK;
     case GR_OPT_WG_PER_CU:
       if (value < 1 || value > 16) return fail(c, GR_EINVAL, "workgroups per CU must be in [1, 16]");
       c->opt_wg_per_cu = value; return GR_OK;

@@ -105,12 +105,29 @@ def test_empty_view_and_single_face(hip):
     assert np.all(ids[0] == -1) and set(np.unique(ids[1])) == {-1, 0}
 
 
-def test_many_views_in_one_call_cross_batch_boundary(hip):
-    """More views than the library batches per launch group (32): results must not depend on the batching."""
+@pytest.mark.parametrize("batch,overlap", [(32, 1), (5, 1), (5, 0), (1, 1)])
+def test_many_views_in_one_call_cross_batch_boundary(hip, batch, overlap):
+    """More views than one launch group: results must not depend on the batching nor on the two-stream overlap of the
+    binning and tile stages (scratch double buffering)."""
+    hip.set_option(3, batch)
+    hip.set_option(5, overlap)
     (points, faces), cams = synthetic.config1_scene()
     poses = [synthetic.nadir_pose(3.0 * k - 30, 2.0 * k - 20, 35.0 + k, yaw_deg=11.0 * k) for k in range(37)]
     cams = synthetic.camera_set_from_poses(poses, f=260.0, width=320, height=200)
-    _check_views(hip, points, faces, _records(cams), 200, 320)
+    try:
+        _check_views(hip, points, faces, _records(cams), 200, 320)
+        # the fused aggregation path runs through the same pipelining
+        recs = _records(cams)
+        ids = hip.raster_face_ids(recs, 200, 320)
+        labels = np.stack([synthetic.synthetic_labels(ids[v].cpu().numpy(), v, 3) for v in range(len(cams))])
+        v1, c1 = hip.new_vote_buffers(3)
+        hip.project_labels(ids, labels, 3, v1, c1)
+        v2, c2 = hip.new_vote_buffers(3)
+        hip.raster_project_labels(recs, labels, 3, v2, c2)
+        assert torch.equal(v1, v2) and torch.equal(c1, c2)
+    finally:
+        hip.set_option(3, 32)
+        hip.set_option(5, 0)
 
 
 def test_bin_overflow_is_detected_and_retried(hip, raster_variant):

@@ -25,14 +25,13 @@ def main():
     hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
     ids = torch.empty((nv, H, W), dtype=torch.int32, device="cuda")
     ref = None
-    # (name, kernel, tile_h_log2, batch, debug mask, workgroups per CU for the persistent kernel)
-    variants = [("rows32_b32", 1, 5, 32, 0, 5), ("persist32_pf_wg5", 4, 5, 32, 0, 5),
-                ("persist32_nopf_wg6", 5, 5, 32, 0, 6), ("persist32_nopf_wg5", 5, 5, 32, 0, 5), ("persist32_nopf_wg4", 5, 5, 32, 0, 4),
-                ("persist64_nopf_wg4", 5, 6, 32, 0, 4)]
+    # (name, kernel, tile_h_log2, batch, debug mask, overlap)
+    variants = [("b32_serial", 1, 5, 32, 0, 0), ("b32_overlap", 1, 5, 32, 0, 1), ("b64x64_32_serial", 1, 6, 32, 0, 0),
+                ("noscan", 1, 5, 32, 1, 0), ("notri", 1, 5, 32, 4, 0)]
     results = {}
     for rep in range(3):
-        for name, k, thl, b, dbg, wg in variants:
-            hip.set_option(1, k); hip.set_option(2, thl); hip.set_option(3, b); hip.set_option(99, dbg); hip.set_option(4, wg)
+        for name, k, thl, b, dbg, ov in variants:
+            hip.set_option(1, k); hip.set_option(2, thl); hip.set_option(3, b); hip.set_option(99, dbg); hip.set_option(5, ov)
             hip.raster_face_ids(recs, H, W, out=ids, check=True)
             if ref is None:
                 ref = ids.clone()
@@ -40,10 +39,10 @@ def main():
                 assert torch.equal(ref, ids), name
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(3):
+            for _ in range(6):
                 hip.raster_face_ids(recs, H, W, out=ids, check=False)
             torch.cuda.synchronize()
-            wall = (time.perf_counter() - t0) / 3 / nv * 1e3
+            wall = (time.perf_counter() - t0) / 6 / nv * 1e3
             hip.set_profiling(True)
             for _ in range(3):
                 hip.raster_face_ids(recs, H, W, out=ids, check=False)
