@@ -39,6 +39,8 @@ EXPORTED_SYMBOLS = (
     "gr_project_values_f64",
     "gr_project_view_f64",
     "gr_raster_project_labels_u8",
+    "gr_warp_nearest_i32",
+    "gr_warp_f64",
     "gr_finalize_votes",
     "gr_finalize_sums_f64",
     "gr_argmax_nonzero_f64",
@@ -122,6 +124,11 @@ def load_library() -> ctypes.CDLL:
     lib.gr_project_view_f64.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, vp]
     lib.gr_raster_project_labels_u8.restype = i32
     lib.gr_raster_project_labels_u8.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp]
+    f64 = ctypes.c_double
+    lib.gr_warp_nearest_i32.restype = i32
+    lib.gr_warp_nearest_i32.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, ctypes.c_int32, i32, f64, f64, vp, vp]
+    lib.gr_warp_f64.restype = i32
+    lib.gr_warp_f64.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32, f64, vp, vp]
     lib.gr_finalize_votes.restype = i32
     lib.gr_finalize_votes.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp]
     lib.gr_finalize_sums_f64.restype = i32
@@ -136,6 +143,31 @@ def _torch():
     import torch
 
     return torch
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_default_backends = {}
+
+
+def default_backend(device: Optional[int] = None):
+    """One shared `HipRaster` per device for callers that are not handed a backend (camera-set warps)."""
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "geograypher_amd: no ROCm GPU visible (torch.cuda.is_available() is False). "
+            "The projection path runs on MI355X only; there is no CPU fallback."
+        )
+    key = torch.cuda.current_device() if device is None else int(device)
+    if key not in _default_backends:
+        _default_backends[key] = HipRaster(key)
+    return _default_backends[key]
 
 
 class HipRaster:
@@ -371,6 +403,79 @@ class HipRaster:
             self.last_stats = st.as_dict()
             break
         return ids_out
+
+    # -- distortion warp (row f1) --------------------------------------------------------------------------------
+    def upload_map(self, inverse_map):
+        """(2, H, W) float64 sampling map (rows, cols) -> device tensor."""
+        torch = _torch()
+        m = self._dev(inverse_map, torch.float64)
+        if m.ndim != 3 or m.shape[0] != 2:
+            raise ValueError(f"sampling map must be (2, H, W), got {tuple(m.shape)}")
+        return m
+
+    def warp_image(self, input_image, map_t, order: int = 1, fill_value: float = 0.0,
+                   reference_float_roundtrip: bool = False):
+        """Resample `input_image` ((I,J) or (I,J,C)) through the (2,H,W) device map: utils/image.py:72-126 on device.
+
+        Integer images with order 0 are gathered as integers (gr_warp_nearest_i32); everything else goes through the
+        float64 kernel and is cast back to the input dtype by truncation like the reference's `.astype(initial_dtype)`.
+        numpy in -> numpy out, tensor in -> tensor out."""
+        torch = _torch()
+        is_tensor = isinstance(input_image, torch.Tensor)
+        img = input_image if is_tensor else np.asarray(input_image)
+        if img.ndim not in (2, 3):
+            raise ValueError(f"image must be (I,J) or (I,J,C), got shape {tuple(img.shape)}")
+        np_dtype = None if is_tensor else img.dtype
+        h_out, w_out = int(map_t.shape[1]), int(map_t.shape[2])
+        h_in, w_in = int(img.shape[0]), int(img.shape[1])
+        is_int = (not torch.is_floating_point(img)) if is_tensor else np.issubdtype(img.dtype, np.integer) or img.dtype == bool
+        # utils/image.py:86-96: an image without variation (fill included) is returned as a constant of the INPUT shape
+        if is_tensor:
+            vmin, vmax = float(img.min()), float(img.max())
+        else:
+            vmin, vmax = float(np.min(img)), float(np.max(img))
+        lo, hi = min(vmin, float(fill_value)), max(vmax, float(fill_value))
+        if hi - lo == 0:
+            if is_tensor:
+                return torch.full_like(img.squeeze(), fill_value)
+            return np.full_like(np.squeeze(img), fill_value=fill_value)
+        small_int = is_int and -2**31 <= lo and hi < 2**31 and float(fill_value) == int(fill_value)
+        with torch.cuda.device(self.device) if self.device.type == "cuda" else _nullcontext():
+            if small_int and order == 0:
+                src = self._dev(img, torch.int32)
+                squeeze = src.ndim == 2
+                if squeeze:
+                    src = src[..., None]
+                outs = []
+                for ch in range(src.shape[2]):
+                    plane = src[..., ch].contiguous()
+                    out = torch.empty((h_out, w_out), dtype=torch.int32, device=self.device)
+                    rc = self.lib.gr_warp_nearest_i32(
+                        self._ctx, plane.data_ptr(), h_in, w_in, map_t[0].data_ptr(), map_t[1].data_ptr(), h_out, w_out,
+                        int(fill_value), 1 if reference_float_roundtrip else 0, lo, hi - lo, out.data_ptr(),
+                        self._stream(),
+                    )
+                    self._check(rc, "gr_warp_nearest_i32")
+                    outs.append(out)
+                res = outs[0] if squeeze else torch.stack(outs, dim=-1)
+            else:
+                src = self._dev(img, torch.float64)
+                squeeze = src.ndim == 2
+                if squeeze:
+                    src = src[..., None]
+                src = src.contiguous()
+                C = int(src.shape[2])
+                res = torch.empty((h_out, w_out, C), dtype=torch.float64, device=self.device)
+                rc = self.lib.gr_warp_f64(
+                    self._ctx, src.data_ptr(), h_in, w_in, C, map_t[0].data_ptr(), map_t[1].data_ptr(), h_out, w_out,
+                    int(order), float(fill_value), res.data_ptr(), self._stream(),
+                )
+                self._check(rc, "gr_warp_f64")
+                if squeeze:
+                    res = res[..., 0]
+        if is_tensor:
+            return res.to(img.dtype)
+        return np.squeeze(res.cpu().numpy().astype(np_dtype))
 
     def finalize_votes(self, votes, counts):
         """(votes, counts) -> average (F,C), summed (F,C), counts (F,) float64 tensors (meshes.py:2069-2082)."""

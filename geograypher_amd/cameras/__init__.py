@@ -1,9 +1,11 @@
 from geograypher_amd.cameras.cameras import PhotogrammetryCamera, PhotogrammetryCameraSet, vtk_like_near_plane
 from geograypher_amd.cameras.segmentor import SegmentorPhotogrammetryCameraSet
+from geograypher_amd.cameras.derived_cameras import MetashapeCameraSet
 
 __all__ = [
     "PhotogrammetryCamera",
     "PhotogrammetryCameraSet",
     "SegmentorPhotogrammetryCameraSet",
+    "MetashapeCameraSet",
     "vtk_like_near_plane",
 ]

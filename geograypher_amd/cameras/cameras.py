@@ -292,6 +292,15 @@ class PhotogrammetryCameraSet:
             )
 
     # -- container -----------------------------------------------------------------------------------------------
+    def __deepcopy__(self, memo):
+        """`get_subset_cameras` deep-copies the set (cameras.py:861-864); device-resident sampling maps and the GPU
+        context they belong to are shared, never duplicated."""
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = v if k == "_maps_device" else deepcopy(v, memo)
+        return new
+
     def __len__(self):
         return self.n_cameras()
 
@@ -358,6 +367,39 @@ class PhotogrammetryCameraSet:
         strings = [f"{key}:{parameters[key]:.8f}" for key in keys] + [f"image_scale:{image_scale:.8f}"]
         return "|".join(strings)
 
+    def make_distortion_map(self, camera: PhotogrammetryCamera, inversion_downsample: int, image_scale: float = 1.0) -> None:
+        """Build and cache the two sampling maps of a distortion key (reference: cameras.py:995-1062).
+
+        `_maps_ideal_to_warped[key]` (2, H, W): for every pixel of the IDEAL image, where it lands in the warped image
+        (`ideal_to_warped` evaluated on the pixel grid; for a down-scaled image the model is evaluated at the original
+        pixel positions of the scaled pixel centres and the result is scaled).  `_maps_warped_to_ideal[key]`: its
+        inverse by scattered-data interpolation on every `inversion_downsample`-th pixel.  One-time host work per key;
+        the per-view warp that uses the maps runs on the GPU.
+        """
+        from geograypher_amd.utils.indexing import inverse_map_interpolation
+
+        im_h, im_w = camera.image_size
+        if np.isclose(image_scale, 1.0):
+            h_range = np.arange(im_h)
+            w_range = np.arange(im_w)
+        else:
+            start, step = 1 / (2 * image_scale), 1 / image_scale
+            h_range = np.arange(start, im_h, step)[: int(im_h * image_scale)]
+            w_range = np.arange(start, im_w, step)[: int(im_w * image_scale)]
+        rows, cols = np.meshgrid(h_range, w_range, indexing="ij")
+        warp_cols, warp_rows = self.ideal_to_warped(camera, cols, rows)
+        if not np.isclose(image_scale, 1.0):
+            warp_cols = warp_cols * image_scale
+            warp_rows = warp_rows * image_scale
+        dkey = self.distortion_key(camera.distortion_params, image_scale)
+        self._maps_ideal_to_warped[dkey] = np.stack([warp_rows, warp_cols], axis=0)
+        self._maps_warped_to_ideal[dkey] = inverse_map_interpolation(
+            self._maps_ideal_to_warped[dkey], downsample=inversion_downsample
+        )
+        self._maps_device = getattr(self, "_maps_device", {})
+        self._maps_device.pop((dkey, True), None)
+        self._maps_device.pop((dkey, False), None)
+
     def ideal_to_warped(self, camera: PhotogrammetryCamera, xpix: np.ndarray, ypix: np.ndarray):
         """reference: cameras.py:1064-1090 -- only derived sets know a distortion model."""
         raise NotImplementedError(f"ideal_to_warped not implemented for {self.__class__}.")
@@ -365,14 +407,52 @@ class PhotogrammetryCameraSet:
     def warp_dewarp_image(
         self,
         camera: PhotogrammetryCamera,
-        input_image: np.ndarray,
+        input_image,
         fill_value: float = 0.0,
         inversion_downsample: int = 8,
         interpolation_order: int = 1,
         warped_to_ideal: bool = True,
         image_scale: float = 1.0,
-    ) -> np.ndarray:
-        """reference: cameras.py:1092-1156.  The base set has no distortion model, so -- exactly like the reference
-        (pinned by tests/test_derived_cameras.py:318-337) -- asking for a warp raises NotImplementedError."""
-        self.ideal_to_warped(camera, np.zeros(1), np.zeros(1))
-        raise NotImplementedError("distortion warp is not part of the round-1 scope (SURVEY.md section 8, row f1)")
+        backend=None,
+        reference_float_roundtrip: bool = False,
+    ):
+        """Apply (ideal->warped) or undo (warped->ideal) a camera's lens distortion on an image
+        (reference: cameras.py:1092-1156 + utils/image.py:72-126).
+
+        The cached (2, H, W) map gives, for every output pixel, the position to sample in the input; the resampling
+        itself (nearest neighbour for `interpolation_order=0`, bilinear for 1; `fill_value` outside the input) is a
+        HIP gather kernel (`gr_warp_nearest_i32` / `gr_warp_f64`).  Input may be a numpy array (numpy is returned,
+        same dtype) or a device tensor (a tensor is returned).
+
+        reference_float_roundtrip: the reference pushes every image -- integer face-id images included -- through a
+            float rescale to [0,1] and back before truncating to the input dtype (utils/image.py:102, 123), which
+            returns ids that are off by one for a few percent of the pixels.  False (default) gathers integers exactly;
+            True reproduces the reference's arithmetic bit for bit (order 0).
+        """
+        dkey = self.distortion_key(camera.distortion_params, image_scale)
+        if dkey not in self._maps_ideal_to_warped:
+            self.make_distortion_map(camera, inversion_downsample, image_scale)
+        inverse_map = self._maps_ideal_to_warped[dkey] if warped_to_ideal else self._maps_warped_to_ideal[dkey]
+        if backend is None:
+            from geograypher_amd._hip import default_backend
+
+            backend = default_backend()
+        self._maps_device = getattr(self, "_maps_device", {})
+        mkey = (dkey, bool(warped_to_ideal))
+        if mkey not in self._maps_device or self._maps_device[mkey][0] is not backend:
+            self._maps_device[mkey] = (backend, backend.upload_map(inverse_map))
+        return backend.warp_image(
+            input_image, self._maps_device[mkey][1], order=interpolation_order, fill_value=fill_value,
+            reference_float_roundtrip=reference_float_roundtrip,
+        )
+
+    def warp_dewarp_pixels(self, camera: PhotogrammetryCamera, pixels: np.ndarray, inversion_downsample: int = 8,
+                           warped_to_ideal: bool = True):
+        """(N,2) integer (i,j) pixels -> their float positions in the other image (reference: cameras.py:1158-1205)."""
+        dkey = self.distortion_key(camera.distortion_params)
+        if dkey not in self._maps_ideal_to_warped:
+            self.make_distortion_map(camera, inversion_downsample)
+        rowmap, colmap = self._maps_warped_to_ideal[dkey] if warped_to_ideal else self._maps_ideal_to_warped[dkey]
+        rows = rowmap[pixels[:, 0], pixels[:, 1]]
+        cols = colmap[pixels[:, 0], pixels[:, 1]]
+        return np.stack([rows, cols], axis=0).T

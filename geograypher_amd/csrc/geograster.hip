@@ -903,6 +903,58 @@ __global__ __launch_bounds__(256) void k_gather_texture(const int32_t *__restric
   out[i] = (f >= 0 && f < F) ? tex[(int64_t)f * C + ch] : __longlong_as_double(0x7FF8000000000000ll);
 }
 
+// K8  distortion warp (row f1): out[i][j] = in[nearest(map_r[i][j]), nearest(map_c[i][j])] or fill.
+//     Replaces skimage.transform.warp(order=0, mode="constant") driven by utils/image.py:72-126 on the face-id image
+//     (meshes.py:1842-1854).  Nearest = floor(x + 0.5) (scipy.ndimage.map_coordinates, order 0); a sample outside the
+//     input reads `fill`.  roundtrip != 0 reproduces the reference's float rescale + truncation (image.py:102, 123)
+//     bit for bit: v -> trunc(((v - lo) / range) * range + lo) in double precision.
+__global__ __launch_bounds__(256) void k_warp_nearest_i32(const int32_t *__restrict__ in, int h_in, int w_in,
+                                                          const double *__restrict__ map_r,
+                                                          const double *__restrict__ map_c, int64_t n_out, int32_t fill,
+                                                          int roundtrip, double lo, double range,
+                                                          int32_t *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_out) return;
+  const double r = floor(map_r[i] + 0.5), c = floor(map_c[i] + 0.5);
+  int32_t v = fill;
+  if (r >= 0.0 && r < (double)h_in && c >= 0.0 && c < (double)w_in) v = in[(int64_t)r * w_in + (int64_t)c];
+  if (roundtrip) {
+    const double t = ((double)v - lo) / range;
+    const double o = t * range + lo;
+    v = (int32_t)o;  // C truncation, as numpy's astype
+  }
+  out[i] = v;
+}
+
+// float64 images, C channels: order 0 (nearest) or 1 (bilinear, samples outside the input read `fill`: scipy's
+// "grid-constant" boundary as used by the skimage version the reference pins).
+__global__ __launch_bounds__(256) void k_warp_f64(const double *__restrict__ in, int h_in, int w_in, int C,
+                                                  const double *__restrict__ map_r, const double *__restrict__ map_c,
+                                                  int64_t n_out, int order, double fill, double *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_out * C) return;
+  const int64_t p = i / C;
+  const int ch = (int)(i - p * C);
+  const double mr = map_r[p], mc = map_c[p];
+  auto at = [&](double rr, double cc) -> double {
+    if (rr >= 0.0 && rr < (double)h_in && cc >= 0.0 && cc < (double)w_in)
+      return in[((int64_t)rr * w_in + (int64_t)cc) * C + ch];
+    return fill;
+  };
+  double v;
+  if (order == 0) {
+    v = at(floor(mr + 0.5), floor(mc + 0.5));
+  } else {
+    const double r0 = floor(mr), c0 = floor(mc);
+    const double tr = mr - r0, tc = mc - c0;
+    const double top = at(r0, c0) * (1.0 - tc) + at(r0, c0 + 1.0) * tc;
+    const double bot = at(r0 + 1.0, c0) * (1.0 - tc) + at(r0 + 1.0, c0 + 1.0) * tc;
+    v = top * (1.0 - tr) + bot * tr;
+    if (!(mr == mr) || !(mc == mc)) v = fill;  // NaN coordinates
+  }
+  out[i] = v;
+}
+
 __global__ __launch_bounds__(256) void k_finalize_votes(const uint32_t *__restrict__ votes,
                                                         const uint32_t *__restrict__ counts, int64_t F, int C,
                                                         double *__restrict__ average, double *__restrict__ summed,
@@ -1524,6 +1576,37 @@ int gr_raster_project_labels_u8(gr_ctx *c, const float *cams, const uint8_t *lab
   if (!c) return GR_EINVAL;
   if (!labels || !votes || !counts || C <= 0 || C > 255) return fail(c, GR_EINVAL, "bad fused project args C=%d", C);
   return raster_views(c, cams, n_views, h, w, ids_or_null, nullptr, labels, C, votes, counts, flags, (hipStream_t)stream);
+}
+
+int gr_warp_nearest_i32(gr_ctx *c, const int32_t *in, int h_in, int w_in, const double *map_rows, const double *map_cols,
+                        int h_out, int w_out, int32_t fill, int reference_float_roundtrip, double value_min,
+                        double value_range, int32_t *out, void *stream) {
+  if (!c) return GR_EINVAL;
+  if (!in || !map_rows || !map_cols || !out || h_in <= 0 || w_in <= 0 || h_out <= 0 || w_out <= 0)
+    return fail(c, GR_EINVAL, "bad warp args");
+  if (reference_float_roundtrip && !(value_range > 0.0)) return fail(c, GR_EINVAL, "value_range must be positive");
+  hipStream_t s = (hipStream_t)stream;
+  GR_HIP(c, hipSetDevice(c->device));
+  const int64_t n = (int64_t)h_out * w_out;
+  hipLaunchKernelGGL(k_warp_nearest_i32, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, in, h_in, w_in, map_rows,
+                     map_cols, n, fill, reference_float_roundtrip, value_min, value_range, out);
+  GR_HIP(c, hipGetLastError());
+  return GR_OK;
+}
+
+int gr_warp_f64(gr_ctx *c, const double *in, int h_in, int w_in, int C, const double *map_rows, const double *map_cols,
+                int h_out, int w_out, int order, double fill, double *out, void *stream) {
+  if (!c) return GR_EINVAL;
+  if (!in || !map_rows || !map_cols || !out || h_in <= 0 || w_in <= 0 || h_out <= 0 || w_out <= 0 || C <= 0)
+    return fail(c, GR_EINVAL, "bad warp args");
+  if (order != 0 && order != 1) return fail(c, GR_EINVAL, "interpolation order %d not supported (0 or 1)", order);
+  hipStream_t s = (hipStream_t)stream;
+  GR_HIP(c, hipSetDevice(c->device));
+  const int64_t n = (int64_t)h_out * w_out;
+  hipLaunchKernelGGL(k_warp_f64, dim3((unsigned)ceil_div(n * C, 256)), dim3(256), 0, s, in, h_in, w_in, C, map_rows,
+                     map_cols, n, order, fill, out);
+  GR_HIP(c, hipGetLastError());
+  return GR_OK;
 }
 
 int gr_finalize_votes(gr_ctx *c, const uint32_t *votes, const uint32_t *counts, int64_t F, int C, double *average,

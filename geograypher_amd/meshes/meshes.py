@@ -332,18 +332,23 @@ class TexturedPhotogrammetryMesh:
         if apply_distortion:
             # reference: meshes.py:1842-1854.  A base camera set raises NotImplementedError here, as the reference does
             cams = [cameras] if single else cameras.cameras
-            warped = [
-                distortion_set.warp_dewarp_image(
+            torch = _torch()
+            warped = []
+            for i, cam in enumerate(cams):
+                # the id image stays on the device: tensor in, tensor out (gr_warp_nearest_i32)
+                out_i = distortion_set.warp_dewarp_image(
                     camera=cam,
-                    input_image=ids[i].cpu().numpy().astype(np.int64),
+                    input_image=ids[i],
                     warped_to_ideal=False,
                     fill_value=-1,
                     interpolation_order=0,
                     image_scale=render_img_scale,
                 )
-                for i, cam in enumerate(cams)
-            ]
-            out = np.stack(warped, axis=0)
+                warped.append(out_i if isinstance(out_i, torch.Tensor) else torch.as_tensor(np.asarray(out_i)))
+            out = torch.stack([w.to(torch.int32) for w in warped], dim=0)
+            if return_tensor:
+                return out[0] if single else out
+            out = out.cpu().numpy().astype(np.int64)
             return out[0] if single else out
         if return_tensor:
             return ids[0] if single else ids

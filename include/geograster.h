@@ -143,6 +143,19 @@ int gr_raster_project_labels_u8(gr_ctx *ctx, const float *cams, const uint8_t *l
                                 int C, uint32_t *votes, uint32_t *counts, int32_t *ids_or_null, int flags,
                                 void *stream);
 
+/* distortion warp of an image through a cached sampling map (row f1) -- replaces utils/image.py:72-126
+ * (flexible_inputs_warp -> skimage.transform.warp, mode "constant") as called by cameras.py:1092-1156 for the face-id
+ * image of pix2face (meshes.py:1842-1854).  map_rows/map_cols: h_out x w_out f64, the position to sample in `in` for
+ * every output pixel (cameras.py:995-1062).  Nearest neighbour = floor(x + 0.5); samples outside `in` read `fill`.
+ * reference_float_roundtrip != 0 reproduces the reference's rescale-to-[0,1]-and-back truncation bit for bit
+ * (value_min = min(in.min(), fill), value_range = max(in.max(), fill) - value_min as the reference computes them). */
+int gr_warp_nearest_i32(gr_ctx *ctx, const int32_t *in, int h_in, int w_in, const double *map_rows,
+                        const double *map_cols, int h_out, int w_out, int32_t fill, int reference_float_roundtrip,
+                        double value_min, double value_range, int32_t *out, void *stream);
+/* same for float64 images with C interleaved channels; order 0 (nearest) or 1 (bilinear). */
+int gr_warp_f64(gr_ctx *ctx, const double *in, int h_in, int w_in, int C, const double *map_rows, const double *map_cols,
+                int h_out, int w_out, int order, double fill, double *out, void *stream);
+
 /* finalise -- meshes.py:2069-2082: summed[counts==0] = NaN; average = summed / counts.
  * votes_u32 (F x C) is converted to f64 `summed`; average and summed are F x C f64, counts_f64 is F f64. */
 int gr_finalize_votes(gr_ctx *ctx, const uint32_t *votes, const uint32_t *counts, int64_t F, int C, double *average,

@@ -32,6 +32,14 @@ def golden_cameras():
 
 
 @pytest.fixture(scope="session")
+def golden_warp():
+    import numpy as np
+
+    with np.load(GOLDEN / "reference_warp.npz", allow_pickle=False) as d:
+        return {k: d[k] for k in d.files}
+
+
+@pytest.fixture(scope="session")
 def oracle_backend_cls():
     from tests.oracle_backend import OracleBackend
 

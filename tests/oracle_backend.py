@@ -6,7 +6,7 @@ geograypher_amd.meshes) without a GPU.  Test-only: nothing under geograypher_amd
 import numpy as np
 import torch
 
-from oracle import oracle_c, oracle_np
+from oracle import oracle_c, oracle_np, oracle_warp
 
 
 class OracleBackend:
@@ -93,6 +93,13 @@ class OracleBackend:
         with np.errstate(divide="ignore", invalid="ignore"):
             avg = s / c[:, None]
         return torch.from_numpy(avg), torch.from_numpy(s), torch.from_numpy(c)
+
+    def upload_map(self, inverse_map):
+        return torch.from_numpy(np.ascontiguousarray(inverse_map, dtype=np.float64))
+
+    def warp_image(self, input_image, map_t, order=1, fill_value=0.0, reference_float_roundtrip=False):
+        fn = oracle_warp.flexible_inputs_warp_reference if reference_float_roundtrip else oracle_warp.warp_exact
+        return fn(np.asarray(input_image), map_t.numpy(), order, fill_value)
 
     def argmax_nonzero(self, array):
         return torch.from_numpy(oracle_np.find_argmax_nonzero_value(np.asarray(array)))
