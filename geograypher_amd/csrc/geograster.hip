@@ -461,12 +461,14 @@ struct RasterOut {
   int C, LB, compat, key64;
 };
 
-// LDS image of a tile: rows of TW keys padded by ONE key (stride TW+1 = 65 keys = 520 B).  The rows of one triangle
-// walk neighbouring columns in step; the odd stride moves each row by two banks, so they never pile up on one bank,
-// and a pixel's address advances by a plain +8 bytes along the scanline (no wrap arithmetic in the inner loop).
+// LDS image of a tile: rows of TW keys padded by GR_LDS_PAD keys (stride 69 keys = 552 B).  The rows of one triangle
+// walk their spans in step; with a row offset of 5 key-banks a pile-up on one bank needs a left edge that recedes
+// 5 px per row (a pad of 1 piled up every 45-degree edge: 530 of 1820 LDS cycles per tile were bank conflicts), and a
+// pixel's address advances by a plain +8 bytes along the scanline (no wrap arithmetic in the inner loop).
+#define GR_LDS_PAD 5
 template <int TWL>
 __device__ __forceinline__ int lds_idx(int row, int col) {
-  return row * ((1 << TWL) + 1) + col;
+  return row * ((1 << TWL) + GR_LDS_PAD) + col;
 }
 
 // Integer solution of g(x) = E + A x >= 0 on one scanline, branch-free.  A float reciprocal proposes x0 = floor(-E/A);
@@ -588,7 +590,7 @@ __device__ __forceinline__ void raster_wave_entries(unsigned long long *keys, co
 template <int TWL, int THL, int NT, bool FUSE>
 __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
-  __shared__ unsigned long long keys[(TW + 1) * TH];  // the only LDS of the kernel: 16.25 KiB (64x32) or 32.5 KiB
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[(TW + GR_LDS_PAD) * TH];  // the kernel's only LDS: 16.25 KiB (64x32)
 
   const int slot = blockIdx.y;
   const int tile = blockIdx.x;
@@ -605,7 +607,11 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
   if (a.dbg & 4) cnt = 0;
   const int4 *comp = a.comp + (slot * a.ent_cap + beg) * 4;
 
-  for (int i = tid; i < (TW + 1) * TH; i += NT) keys[i] = 0ull;
+  {  // zero the tile: 16-byte LDS stores
+    static_assert(((TW + GR_LDS_PAD) * TH) % 2 == 0, "key pairs");
+    ulonglong2 *k2 = reinterpret_cast<ulonglong2 *>(keys);
+    for (int i = tid; i < (TW + GR_LDS_PAD) * TH / 2; i += NT) k2[i] = make_ulonglong2(0ull, 0ull);
+  }
   __syncthreads();
 
   // entries are dealt round-robin to the NW waves (entry e -> wave e % NW) so that a short list still feeds every wave
@@ -631,24 +637,40 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
   if (gx < a.w && !(a.dbg & 2)) {
     const int64_t P = (int64_t)a.h * a.w;
     const int64_t plane = (int64_t)slot * P;
+    if (!FUSE && out.ids && !out.depth) {
+      // ids only (the common case): the key's low dword is ~face, and 0 for an empty pixel, so id = ~low for both;
+      // one 4-byte LDS read, one NOT, one store per pixel, the output pointer advances by a constant stride
+      const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
+      const int rows_here = min(TH, a.h - py0);
+      int32_t *dst = out.ids + plane + (int64_t)(py0 + (tid >> TWL)) * a.w + gx;
+      const int64_t dstep = (int64_t)ROWS_PER_PASS * a.w;
+      for (int row = tid >> TWL; row < rows_here; row += ROWS_PER_PASS, dst += dstep)
+        *dst = (int32_t)~klo[2 * lds_idx<TWL>(row, col)];
+      return;
+    }
     for (int row = tid >> TWL; row < TH; row += ROWS_PER_PASS) {
       const int gy = py0 + row;
       if (gy >= a.h) break;
       const unsigned long long key = keys[lds_idx<TWL>(row, col)];
       const int64_t p = (int64_t)gy * a.w + gx;
-      const int32_t id = key ? (int32_t)(~(uint32_t)key) : -1;
+      const int32_t id = (int32_t)~(uint32_t)key;  // low dword = ~face, 0 when empty: ~0 = -1
       if (out.ids) out.ids[plane + p] = id;
       if (out.depth) out.depth[plane + p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
       if (FUSE) {
         // neighbours inside the tile come from LDS; across a tile edge the neighbour is unknown (-3: "differs", one
         // atomic too many at worst), outside the image it is -2 exactly as in k_winner
+        const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
         int fr, fb;
         if (gx + 1 >= a.w) fr = -2;
-        else if (col + 1 < TW) { const unsigned long long k2 = keys[lds_idx<TWL>(row, col + 1)]; fr = k2 ? (int32_t)(~(uint32_t)k2) : -1; }
+        else if (col + 1 < TW) fr = (int32_t)~klo[2 * lds_idx<TWL>(row, col + 1)];
         else fr = -3;
         if (gy + 1 >= a.h) fb = -2;
-        else if (row + 1 < TH) { const unsigned long long k2 = keys[lds_idx<TWL>(row + 1, col)]; fb = k2 ? (int32_t)(~(uint32_t)k2) : -1; }
+        else if (row + 1 < TH) fb = (int32_t)~klo[2 * lds_idx<TWL>(row + 1, col)];
         else fb = -3;
+        // only candidates (neither neighbour shows the same face) need their label
+        int f = id, r2 = fr, b2 = fb;
+        if (out.compat) { const int last = (int)out.F - 1; f = f == -1 ? last : f; r2 = r2 == -1 ? last : r2; b2 = b2 == -1 ? last : b2; }
+        if (f < 0 || r2 == f || b2 == f) continue;
         const int label = out.labels[plane + p];
         if (out.key64)
           winner_pixel<unsigned long long>((unsigned long long *)out.winner + slot * out.F, id, fr, fb, p, label, out.F,
@@ -673,12 +695,12 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
 template <int TWL, int THL, int NT, bool PREFETCH>
 __global__ __launch_bounds__(NT) void k_raster_rows_persistent(BinArgs a, RasterOut out, int n_items) {
   constexpr int TW = 1 << TWL, TH = 1 << THL, NW = NT / 64;
-  __shared__ unsigned long long keys[(TW + 1) * TH];
+  __shared__ unsigned long long keys[(TW + GR_LDS_PAD) * TH];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = gridDim.x;
 
-  for (int i = tid; i < (TW + 1) * TH; i += NT) keys[i] = 0ull;
+  for (int i = tid; i < (TW + GR_LDS_PAD) * TH; i += NT) keys[i] = 0ull;
 
   // (slot, tile) of an item without a division per step
   int it0 = blockIdx.x;
