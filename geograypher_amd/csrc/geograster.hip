@@ -52,6 +52,7 @@ struct BinArgs {
   int T, TX, TY, Tcap;
   int h, w;
   int twl, thl;          // log2 of the tile width / height in pixels
+  int cap_tile;          // > 0: single-pass binning, every tile owns cap_tile entry slots (list base = tile * cap_tile)
   int dbg;               // timing-only ablation mask (GR_OPT_DEBUG): 1 skip scanline loop, 2 skip id stores, 4 skip triangles
 };
 
@@ -191,6 +192,14 @@ __global__ __launch_bounds__(256) void k_cull_blocks(const float *__restrict__ c
   if (keep) a.work[(int64_t)slot * a.work_stride + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)b;
 }
 
+__device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, const int4 p0, const int4 p1, const int4 p2,
+                                              int px0, int py0, int TW, int TH);
+
+// DIRECT = true: single-pass binning.  Every tile owns a fixed segment of a.cap_tile entries; the list position
+// returned by the (wave-aggregated) tile counter is final, so the compiled entry is written straight from here and
+// the record planes, k_scan_tiles and k_fill_compile are skipped.  A tile that receives more than cap_tile entries
+// raises the view's overflow word; the caller then repeats the call with the exact two-pass path (DIRECT = false).
+template <bool DIRECT>
 __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ verts, const int32_t *__restrict__ faces,
                                                     const float *__restrict__ cams, BinArgs a) {
   const int slot = blockIdx.y;
@@ -277,7 +286,25 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
   r3.y = (int)(__shfl(b1, l1) + (uint32_t)k1);
   r3.z = (int)(__shfl(b2, l2) + (uint32_t)k2);
   r3.w = (int)(__shfl(b3, l3) + (uint32_t)k3);
-  if (keep) {
+  if (keep && DIRECT) {
+    int4 *comp = a.comp + slot * a.ent_cap * 4;
+    const int TW = 1 << a.twl, TH = 1 << a.thl;
+#pragma unroll 1
+    for (int ty = ty0; ty <= ty1; ++ty) {
+#pragma unroll 1
+      for (int tx = tx0; tx <= tx1; ++tx) {
+        const int t = ty * a.TX + tx;
+        const int k = ((ty - ty0) << 1) | (tx - tx0);
+        uint32_t pos;
+        if (small_fp) pos = (uint32_t)(k == 0 ? r3.x : k == 1 ? r3.y : k == 2 ? r3.z : r3.w);
+        else pos = atomicAdd(&cntS[t], 1u);  // faces over more than 2x2 tiles: one plain atomic per tile
+        if (pos < (uint32_t)a.cap_tile) compile_entry(comp + ((int64_t)t * a.cap_tile + pos) * 4, r0, r1, r2, tx << a.twl,
+                                                      ty << a.thl, TW, TH);
+        else ctrl[2] = 1u;
+      }
+    }
+  }
+  if (keep && !DIRECT) {
     int4 *rec = a.rec + slot * a.rec_stride;
     const int64_t s = (int64_t)base + prefix;
     rec[s] = r0;
@@ -289,6 +316,31 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
         for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&cntB[ty * a.TX + tx], 1u);
   }
   }  // work list loop
+}
+
+// K2d  (single-pass binning) per view: totals of the per-tile counters for gr_raster_status.  grid (views), 1024 threads
+__global__ __launch_bounds__(1024) void k_bin_stats(BinArgs a) {
+  __shared__ unsigned long long part[16];
+  __shared__ uint32_t pmax[16];
+  const int slot = blockIdx.x;
+  uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  const uint32_t *cnt = ctrl + GR_CTRL_HDR;
+  unsigned long long sum = 0;
+  uint32_t mx = 0;
+  for (int t = threadIdx.x; t < a.T; t += 1024) { const uint32_t c = cnt[t]; sum += c; mx = max(mx, c); }
+  for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); }
+  if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = sum; pmax[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long total = 0; uint32_t m = 0;
+    for (int k = 0; k < 16; ++k) { total += part[k]; m = max(m, pmax[k]); }
+    ctrl[1] = (uint32_t)total;
+    const bool ovf = m > (uint32_t)a.cap_tile || ctrl[2] != 0;
+    atomicAdd(&a.stats[0], (unsigned long long)ctrl[0]);
+    atomicAdd(&a.stats[1], total);
+    atomicMax(&a.stats[2], (unsigned long long)m);  // direct mode: the largest per-tile count
+    if (ovf) atomicMax(&a.stats[3], 1ull);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -600,10 +652,17 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  uint32_t cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
-  const int64_t beg = ctrl[GR_CTRL_HDR + 2 * a.Tcap + tile];
-  if (beg >= a.ent_cap) cnt = 0;
-  else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
+  uint32_t cnt;
+  int64_t beg;
+  if (a.cap_tile > 0) {  // single-pass binning: fixed segment per tile
+    cnt = min(ctrl[GR_CTRL_HDR + tile], (uint32_t)a.cap_tile);
+    beg = (int64_t)tile * a.cap_tile;
+  } else {
+    cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
+    beg = ctrl[GR_CTRL_HDR + 2 * a.Tcap + tile];
+    if (beg >= a.ent_cap) cnt = 0;
+    else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
+  }
   if (a.dbg & 4) cnt = 0;
   const int4 *comp = a.comp + (slot * a.ent_cap + beg) * 4;
 
@@ -712,10 +771,15 @@ __global__ __launch_bounds__(NT) void k_raster_rows_persistent(BinArgs a, Raster
   };
   auto load_ctrl = [&](int slot, int tile, uint32_t &cnt, int64_t &beg) {
     const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
-    cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
-    beg = ctrl[GR_CTRL_HDR + 2 * a.Tcap + tile];
-    if (beg >= a.ent_cap) cnt = 0;
-    else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
+    if (a.cap_tile > 0) {
+      cnt = min(ctrl[GR_CTRL_HDR + tile], (uint32_t)a.cap_tile);
+      beg = (int64_t)tile * a.cap_tile;
+    } else {
+      cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
+      beg = ctrl[GR_CTRL_HDR + 2 * a.Tcap + tile];
+      if (beg >= a.ent_cap) cnt = 0;
+      else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
+    }
     if (a.dbg & 4) cnt = 0;
   };
   auto load_entries = [&](int slot, uint32_t cnt, int64_t beg, uint32_t c0, int4 &s0, int4 &s1, int4 &s2, int4 &s3) {
@@ -1066,6 +1130,9 @@ struct gr_ctx {
   int opt_batch = GR_MAX_BATCH;
   int opt_dbg = 0;
   int opt_wg_per_cu = 5;  // persistent raster: resident workgroups per CU
+  int opt_direct_cap = 512;  // single-pass binning: entry slots per tile (0 = always use the exact two-pass path)
+  bool direct_ok = true;     // cleared when a tile overflowed its slots: later calls take the exact path
+  bool last_direct = false;
   int opt_overlap = 0;    // 1: bin the next launch group on a side stream while the current one is rasterized.
                           // Measured neutral on MI355X (41.1 vs 40.9 us/view): the stages share the same VALU/LDS pipes.
   int n_cu = 256;
@@ -1126,6 +1193,7 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 int ensure_bins(gr_ctx *c, int n_slots, int T) {
   const int64_t F = c->F;
   int64_t want_cap = c->ent_cap_request > 0 ? c->ent_cap_request : (F / 2 + 65536);
+  if (c->opt_direct_cap > 0 && c->direct_ok) want_cap = std::max<int64_t>(want_cap, (int64_t)T * c->opt_direct_cap);
   if (c->ctrl && c->slots >= n_slots && c->Tcap >= T && c->rec_F == F && c->ent_cap >= want_cap) return GR_OK;
   (void)hipDeviceSynchronize();
   if (c->ctrl) (void)hipFree(c->ctrl);
@@ -1171,6 +1239,7 @@ BinArgs make_args(gr_ctx *c, int h, int w, int slot0) {
   a.twl = GR_TILE_LOG2; a.thl = c->opt_thl;
   a.TX = (w + (1 << a.twl) - 1) >> a.twl; a.TY = (h + (1 << a.thl) - 1) >> a.thl; a.T = a.TX * a.TY; a.Tcap = c->Tcap;
   a.h = h; a.w = w; a.dbg = c->opt_dbg;
+  a.cap_tile = (c->opt_direct_cap > 0 && c->direct_ok) ? c->opt_direct_cap : 0;
   return a;
 }
 
@@ -1182,17 +1251,27 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, hip
     Timed t(c, s, ST_SETUP);
     const int nblk = (int)ceil_div(c->F, 256);
     hipLaunchKernelGGL(k_cull_blocks, dim3((unsigned)ceil_div(nblk, 256), nb), dim3(256), 0, s, cams, a, nblk);
-    hipLaunchKernelGGL(k_setup_cull, dim3((unsigned)std::min(nblk, 1024), nb), dim3(256), 0, s, c->verts, c->faces,
-                       cams, a);
+    if (a.cap_tile > 0)
+      hipLaunchKernelGGL(k_setup_cull<true>, dim3((unsigned)std::min(nblk, 1024), nb), dim3(256), 0, s, c->verts,
+                         c->faces, cams, a);
+    else
+      hipLaunchKernelGGL(k_setup_cull<false>, dim3((unsigned)std::min(nblk, 1024), nb), dim3(256), 0, s, c->verts,
+                         c->faces, cams, a);
   }
-  {
+  c->last_direct = a.cap_tile > 0;
+  if (a.cap_tile > 0) {
     Timed t(c, s, ST_SCAN);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(nb), dim3(1024), 0, s, a);
-  }
-  {
-    Timed t(c, s, ST_FILL);
-    const unsigned g = (unsigned)std::min<int64_t>(ceil_div(c->F, 256), 1024);
-    hipLaunchKernelGGL(k_fill_compile, dim3(g, nb), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_bin_stats, dim3(nb), dim3(1024), 0, s, a);
+  } else {
+    {
+      Timed t(c, s, ST_SCAN);
+      hipLaunchKernelGGL(k_scan_tiles, dim3(nb), dim3(1024), 0, s, a);
+    }
+    {
+      Timed t(c, s, ST_FILL);
+      const unsigned g = (unsigned)std::min<int64_t>(ceil_div(c->F, 256), 1024);
+      hipLaunchKernelGGL(k_fill_compile, dim3(g, nb), dim3(256), 0, s, a);
+    }
   }
   GR_HIP(c, hipGetLastError());
   return GR_OK;
@@ -1433,6 +1512,9 @@ int gr_set_option(gr_ctx *c, int key, int value) {
       c->opt_batch = value; return GR_OK;
     case GR_OPT_DEBUG:
       c->opt_dbg = value; return GR_OK;
+    case GR_OPT_DIRECT_CAP:
+      if (value < 0 || value > 65536) return fail(c, GR_EINVAL, "slots per tile must be in [0, 65536]");
+      c->opt_direct_cap = value; c->direct_ok = true; return GR_OK;
     case GR_OPT_OVERLAP:
       c->opt_overlap = value ? 1 : 0; return GR_OK;
     case GR_OPT_WG_PER_CU:
@@ -1498,6 +1580,11 @@ int gr_raster_status(gr_ctx *c, gr_raster_stats *o) {
   GR_HIP(c, hipStreamSynchronize(c->last_stream));
   o->records = (int64_t)st[0]; o->entries = (int64_t)st[1]; o->max_entries = (int64_t)st[2];
   o->entry_cap = c->ent_cap; o->overflow = (int32_t)st[3];
+  if (st[3] && c->last_direct) {
+    c->direct_ok = false;  // a tile outgrew its fixed segment: the retry bins exactly (count, scan, fill)
+    return fail(c, GR_EOVERFLOW, "single-pass binning overflow: a tile received %llu entries (slots per tile %d); "
+                "retry the call", st[2], c->opt_direct_cap);
+  }
   if (st[3]) {
     // grow on the next call: exact need is known
     c->ent_cap_request = (int64_t)st[2] + (int64_t)st[2] / 8 + 65536;

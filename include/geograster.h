@@ -94,6 +94,9 @@ enum {
   GR_OPT_TILE_H_LOG2 = 2,   /* tile height: 5 (64x32, default) or 6 (64x64)                                  */
   GR_OPT_BATCH = 3,         /* views per launch group, 1..64 (default 32)                         */
   GR_OPT_WG_PER_CU = 4,     /* persistent kernel: resident workgroups per CU, 1..16 (default 5)    */
+  GR_OPT_DIRECT_CAP = 6,    /* single-pass binning: entry slots per tile (default 512); 0 = always bin exactly
+                               (count, scan, fill).  A tile that outgrows its slots is reported by
+                               gr_raster_status (GR_EOVERFLOW); the context then bins exactly from the retry on */
   GR_OPT_OVERLAP = 5,       /* 1: bin launch group g+1 on a side stream while g is rasterized (default 0) */
   GR_OPT_DEBUG = 99         /* timing-only ablation mask for tools/ab_raster.py: OUTPUTS BECOME WRONG */
 };

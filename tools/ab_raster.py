@@ -25,13 +25,13 @@ def main():
     hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
     ids = torch.empty((nv, H, W), dtype=torch.int32, device="cuda")
     ref = None
-    # (name, kernel, tile_h_log2, batch, debug mask, overlap)
-    variants = [("b32_serial", 1, 5, 32, 0, 0), ("b32_overlap", 1, 5, 32, 0, 1), ("b64x64_32_serial", 1, 6, 32, 0, 0),
-                ("noscan", 1, 5, 32, 1, 0), ("notri", 1, 5, 32, 4, 0)]
+    # (name, kernel, tile_h_log2, batch, debug mask, single-pass slots per tile)
+    variants = [("exact", 1, 5, 32, 0, 0), ("direct512", 1, 5, 32, 0, 512), ("direct1024", 1, 5, 32, 0, 1024),
+                ("direct512_64x64", 1, 6, 32, 0, 512), ("direct512_b16", 1, 5, 16, 0, 512)]
     results = {}
     for rep in range(3):
-        for name, k, thl, b, dbg, ov in variants:
-            hip.set_option(1, k); hip.set_option(2, thl); hip.set_option(3, b); hip.set_option(99, dbg); hip.set_option(5, ov)
+        for name, k, thl, b, dbg, cap in variants:
+            hip.set_option(1, k); hip.set_option(2, thl); hip.set_option(3, b); hip.set_option(99, dbg); hip.set_option(6, cap)
             hip.raster_face_ids(recs, H, W, out=ids, check=True)
             if ref is None:
                 ref = ids.clone()
@@ -50,7 +50,9 @@ def main():
             hip.set_profiling(False)
             per = {k2: round(st[k2] / st["views"] * 1e3, 2) for k2 in ("setup_ms", "scan_ms", "fill_ms", "raster_ms")}
             per["wall_us_per_view"] = round(wall * 1e3, 2)
-            per["entries_per_view"] = hip.raster_status()["entries"] / nv
+            stt = hip.raster_status()
+            per["entries_per_view"] = stt["entries"] / nv
+            per["max_entries"] = stt["max_entries"]
             results.setdefault(name, []).append(per)
     for name, runs in results.items():
         print(name, json.dumps(runs[-1]))
