@@ -707,6 +707,43 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
         *dst = (int32_t)~klo[2 * lds_idx<TWL>(row, col)];
       return;
     }
+    if (FUSE && !out.depth && TW == 64) {
+      // Fused projection epilogue.  Each wave owns TH/NW CONSECUTIVE rows: the row below is read from LDS once and
+      // becomes the current row of the next step; the right neighbour comes from the next lane (DPP wave shift), so a
+      // pixel costs one 4-byte LDS read.  Across a tile edge the neighbour is unknown (-3: "differs", one atomic too
+      // many at worst); outside the image it is -2 exactly as in k_winner.
+      constexpr int RW = TH / (NT / 64);
+      const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
+      const int r0 = (tid >> 6) * RW;
+      const int last = (int)out.F - 1;
+      int cur = (int32_t)~klo[2 * lds_idx<TWL>(r0, col)];
+      const int rows_here = min(RW, a.h - (py0 + r0));          // rows of this wave inside the image (wave-uniform)
+      const bool right_out = (gx + 1 >= a.w);
+      const int bg = out.compat ? last : -1;                     // what a background pixel counts as (meshes.py:1998-2001)
+      int64_t p = (int64_t)(py0 + r0) * a.w + gx;                // linear pixel index, advanced by w per row
+      int32_t *idp = out.ids ? out.ids + plane + p : nullptr;
+      const uint8_t *lp = out.labels + plane + p;
+      uint32_t *win32 = (uint32_t *)out.winner + slot * out.F;
+      unsigned long long *win64 = (unsigned long long *)out.winner + slot * out.F;
+      for (int k = 0; k < rows_here; ++k, p += a.w, lp += a.w) {
+        const int row = r0 + k;
+        const int nxt = (row + 1 < TH) ? (int32_t)~klo[2 * lds_idx<TWL>(min(row + 1, TH - 1), col)] : -3;
+        int fr = __builtin_amdgcn_update_dpp(-3, cur, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+        fr = right_out ? -2 : fr;
+        int fb = (py0 + row + 1 >= a.h) ? -2 : nxt;
+        if (idp) { *idp = cur; idp += a.w; }
+        const int f = cur == -1 ? bg : cur;
+        fr = fr == -1 ? bg : fr;
+        fb = fb == -1 ? bg : fb;
+        if (f >= 0 && fr != f && fb != f) {  // candidate: only now is the label needed
+          const int label = min((int)*lp, out.C);
+          if (out.key64) atomicMax(win64 + f, ((unsigned long long)(p + 1) << out.LB) | (unsigned long long)label);
+          else atomicMax(win32 + f, ((uint32_t)(p + 1) << out.LB) | (uint32_t)label);
+        }
+        cur = nxt;
+      }
+      return;
+    }
     for (int row = tid >> TWL; row < TH; row += ROWS_PER_PASS) {
       const int gy = py0 + row;
       if (gy >= a.h) break;
@@ -715,29 +752,6 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
       const int32_t id = (int32_t)~(uint32_t)key;  // low dword = ~face, 0 when empty: ~0 = -1
       if (out.ids) out.ids[plane + p] = id;
       if (out.depth) out.depth[plane + p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
-      if (FUSE) {
-        // neighbours inside the tile come from LDS; across a tile edge the neighbour is unknown (-3: "differs", one
-        // atomic too many at worst), outside the image it is -2 exactly as in k_winner
-        const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
-        int fr, fb;
-        if (gx + 1 >= a.w) fr = -2;
-        else if (col + 1 < TW) fr = (int32_t)~klo[2 * lds_idx<TWL>(row, col + 1)];
-        else fr = -3;
-        if (gy + 1 >= a.h) fb = -2;
-        else if (row + 1 < TH) fb = (int32_t)~klo[2 * lds_idx<TWL>(row + 1, col)];
-        else fb = -3;
-        // only candidates (neither neighbour shows the same face) need their label
-        int f = id, r2 = fr, b2 = fb;
-        if (out.compat) { const int last = (int)out.F - 1; f = f == -1 ? last : f; r2 = r2 == -1 ? last : r2; b2 = b2 == -1 ? last : b2; }
-        if (f < 0 || r2 == f || b2 == f) continue;
-        const int label = out.labels[plane + p];
-        if (out.key64)
-          winner_pixel<unsigned long long>((unsigned long long *)out.winner + slot * out.F, id, fr, fb, p, label, out.F,
-                                           out.C, out.LB, out.compat);
-        else
-          winner_pixel<uint32_t>((uint32_t *)out.winner + slot * out.F, id, fr, fb, p, label, out.F, out.C, out.LB,
-                                 out.compat);
-      }
     }
   }
 }
