@@ -39,6 +39,9 @@ EXPORTED_SYMBOLS = (
     "gr_project_values_f64",
     "gr_project_view_f64",
     "gr_raster_project_labels_u8",
+    "gr_gather_texture_u8",
+    "gr_project_index_pairs",
+    "gr_count_pairs",
     "gr_warp_nearest_i32",
     "gr_warp_f64",
     "gr_finalize_votes",
@@ -125,6 +128,12 @@ def load_library() -> ctypes.CDLL:
     lib.gr_raster_project_labels_u8.restype = i32
     lib.gr_raster_project_labels_u8.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp]
     f64 = ctypes.c_double
+    lib.gr_gather_texture_u8.restype = i32
+    lib.gr_gather_texture_u8.argtypes = [vp, vp, i64, vp, i64, i32, i32, vp, vp]
+    lib.gr_project_index_pairs.restype = i32
+    lib.gr_project_index_pairs.argtypes = [vp, vp, vp, i32, i32, i32, i64, vp, vp, i64, vp, i32, vp]
+    lib.gr_count_pairs.restype = i32
+    lib.gr_count_pairs.argtypes = [vp, vp, i64, vp, vp, ctypes.POINTER(ctypes.c_int64), vp]
     lib.gr_warp_nearest_i32.restype = i32
     lib.gr_warp_nearest_i32.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, ctypes.c_int32, i32, f64, f64, vp, vp]
     lib.gr_warp_f64.restype = i32
@@ -309,6 +318,58 @@ class HipRaster:
             )
         self._check(rc, "gr_gather_texture_f64")
         return out
+
+    def gather_texture_u8(self, ids, face_texture, null_value: int = 0):
+        """save_renders epilogue: ids (...,) int32, face_texture (F,C) -> (..., C) uint8 tensor (meshes.py:2325-2337)."""
+        torch = _torch()
+        ids_t = self._dev(ids, torch.int32)
+        tex = self._dev(face_texture, torch.float64)
+        F, C = int(tex.shape[0]), int(tex.shape[1])
+        out = torch.empty(tuple(ids_t.shape) + (C,), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gr_gather_texture_u8(
+                self._ctx, ids_t.data_ptr(), ids_t.numel(), tex.data_ptr(), F, C, int(null_value), out.data_ptr(),
+                self._stream(),
+            )
+        self._check(rc, "gr_gather_texture_u8")
+        return out
+
+    def project_index_pairs(self, ids, img, n_classes: int, counts, neg1_is_last_face: bool = True):
+        """Sparse index aggregation step (derived_meshes.py:470-520) for N views: ids (N,h,w) int32, img (N,h,w) float64
+        with NaN = no prediction.  Accumulates counts (F,) and returns (pair_keys, multiplicities) int64 numpy arrays
+        with pair key = face * n_classes + class."""
+        torch = _torch()
+        ids_t = self._dev(ids, torch.int32)
+        img_t = self._dev(img, torch.float64)
+        if ids_t.ndim == 2:
+            ids_t, img_t = ids_t[None], img_t[None]
+        if img_t.ndim == 4 and img_t.shape[-1] == 1:
+            img_t = img_t[..., 0]
+        if ids_t.shape != img_t.shape:
+            raise ValueError(f"ids {tuple(ids_t.shape)} and index image {tuple(img_t.shape)} differ in shape")
+        n, h, w = (int(x) for x in ids_t.shape)
+        cap = n * self.n_faces
+        keys = torch.empty((max(cap, 1),), dtype=torch.int64, device=self.device)
+        key_count = torch.zeros((1,), dtype=torch.int64, device=self.device)
+        flags = GR_FLAG_NEG1_IS_LAST_FACE if neg1_is_last_face else 0
+        with torch.cuda.device(self.device):
+            rc = self.lib.gr_project_index_pairs(
+                self._ctx, ids_t.data_ptr(), img_t.contiguous().data_ptr(), n, h, w, int(n_classes), counts.data_ptr(),
+                keys.data_ptr(), cap, key_count.data_ptr(), flags, self._stream(),
+            )
+        self._check(rc, "gr_project_index_pairs")
+        m = int(key_count.item())
+        if m == 0:
+            return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+        uniq = torch.empty((m,), dtype=torch.int64, device=self.device)
+        mult = torch.empty((m,), dtype=torch.int32, device=self.device)
+        n_unique = ctypes.c_int64(0)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gr_count_pairs(self._ctx, keys.data_ptr(), m, uniq.data_ptr(), mult.data_ptr(),
+                                         ctypes.byref(n_unique), self._stream())
+        self._check(rc, "gr_count_pairs")
+        k = int(n_unique.value)
+        return uniq[:k].cpu().numpy(), mult[:k].cpu().numpy().astype(np.int64)
 
     # -- projection / aggregation --------------------------------------------------------------------------------
     def new_vote_buffers(self, C: int):

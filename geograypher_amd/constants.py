@@ -27,3 +27,6 @@ EXAMPLE_INTRINSICS = {
 # Name of the CRS the reference meshes live in (EPSG:4978); kept as a plain string because pyproj is not a
 # dependency of the projection path (the CRS hand-over itself is out of scope).
 EARTH_CENTERED_EARTH_FIXED_CRS = "EPSG:4978"
+
+# geograypher/constants.py:16 (default output root of save_renders)
+VIS_FOLDER = Path(Path(__file__).parent, "..", "vis").resolve()

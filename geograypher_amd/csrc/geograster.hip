@@ -12,6 +12,7 @@
 // Compile with -ffp-contract=off: every floating-point operation below is individually rounded on purpose.
 
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <cmath>
 #include <cstdarg>
@@ -1069,6 +1070,67 @@ __global__ __launch_bounds__(256) void k_warp_f64(const double *__restrict__ in,
   out[i] = v;
 }
 
+// K9  save_renders epilogue (row f2): gather the face texture and cast it the way meshes.py:2325-2337 does --
+//     values < 0, > 255 or non-finite (and pixels without a face) become `null_value`, the rest is truncated to uint8.
+__global__ __launch_bounds__(256) void k_gather_texture_u8(const int32_t *__restrict__ ids, int64_t n_pix,
+                                                           const double *__restrict__ tex, int64_t F, int C,
+                                                           uint8_t null_value, uint8_t *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_pix * C) return;
+  const int64_t p = i / C;
+  const int ch = (int)(i - p * C);
+  const int f = ids[p];
+  uint8_t v = null_value;
+  if (f >= 0 && f < F) {
+    const double x = tex[(int64_t)f * C + ch];
+    if (x >= 0.0 && x <= 255.0) v = (uint8_t)x;  // false for NaN; truncation like numpy's astype(uint8)
+  }
+  out[i] = v;
+}
+
+// K10 sparse index aggregation (row f3, derived_meshes.py:470-520): one thread per face walks the views of the batch;
+//     a finite winner value v is one observation of class int(v): counts[f] += 1 and the pair key f * n_classes + class
+//     is appended to `keys` (wave ballot + one atomic per wave).  The pairs are counted later by sort + run-length.
+__global__ __launch_bounds__(256) void k_emit_index_pairs(uint32_t *__restrict__ winner, const double *__restrict__ img,
+                                                          int n_views, int64_t F, int64_t P, long long n_classes,
+                                                          uint32_t *__restrict__ counts,
+                                                          unsigned long long *__restrict__ keys, long long key_cap,
+                                                          unsigned long long *__restrict__ key_count,
+                                                          int *__restrict__ bad) {
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  uint32_t c = 0;
+  for (int v = 0; v < n_views; ++v) {
+    bool emit = false;
+    unsigned long long key = 0;
+    if (f < F) {
+      const uint32_t w = winner[v * F + f];
+      if (w != 0) {
+        winner[v * F + f] = 0;
+        const double x = img[(int64_t)v * P + (w - 1)];
+        if (isfinite(x)) {
+          ++c;
+          const long long cls = (long long)x;  // astype(int): truncation
+          if (cls < 0 || cls >= n_classes) atomicOr(bad, 1);
+          else { emit = true; key = (unsigned long long)f * (unsigned long long)n_classes + (unsigned long long)cls; }
+        }
+      }
+    }
+    const unsigned long long m = __ballot(emit);
+    if (m) {
+      const int leader = __ffsll((long long)m) - 1;
+      unsigned long long base = 0;
+      if (lane == leader) base = atomicAdd(key_count, (unsigned long long)__popcll(m));
+      base = __shfl(base, leader);
+      if (emit) {
+        const unsigned long long idx = base + __popcll(m & ((1ull << lane) - 1ull));
+        if ((long long)idx < key_cap) keys[idx] = key;
+      }
+    }
+  }
+  if (f < F && c) counts[f] += c;
+}
+
 __global__ __launch_bounds__(256) void k_finalize_votes(const uint32_t *__restrict__ votes,
                                                         const uint32_t *__restrict__ counts, int64_t F, int C,
                                                         double *__restrict__ average, double *__restrict__ summed,
@@ -1171,6 +1233,8 @@ struct gr_ctx {
   // winner scratch
   void *winner = nullptr;
   size_t winner_bytes = 0;
+  void *sort_tmp = nullptr;
+  size_t sort_bytes = 0;
   hipStream_t last_stream = nullptr;
   // profiling
   bool profiling = false;
@@ -1510,6 +1574,7 @@ int gr_ctx_destroy(gr_ctx *c) {
   if (c->comp) (void)hipFree(c->comp);
   if (c->work) (void)hipFree(c->work);
   if (c->winner) (void)hipFree(c->winner);
+  if (c->sort_tmp) (void)hipFree(c->sort_tmp);
   if (c->blk) (void)hipFree(c->blk);
   if (c->soup) (void)hipFree(c->soup);
   if (c->stats) (void)hipFree(c->stats);
@@ -1753,6 +1818,99 @@ int gr_warp_f64(gr_ctx *c, const double *in, int h_in, int w_in, int C, const do
   hipLaunchKernelGGL(k_warp_f64, dim3((unsigned)ceil_div(n * C, 256)), dim3(256), 0, s, in, h_in, w_in, C, map_rows,
                      map_cols, n, order, fill, out);
   GR_HIP(c, hipGetLastError());
+  return GR_OK;
+}
+
+int gr_gather_texture_u8(gr_ctx *c, const int32_t *ids, int64_t n_pix, const double *face_tex, int64_t F, int C,
+                         int null_value, uint8_t *out, void *stream) {
+  if (!c) return GR_EINVAL;
+  if (!ids || !face_tex || !out || n_pix < 0 || F <= 0 || C <= 0 || null_value < 0 || null_value > 255)
+    return fail(c, GR_EINVAL, "bad gather args");
+  if (n_pix == 0) return GR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  GR_HIP(c, hipSetDevice(c->device));
+  Timed t(c, s, ST_GATHER);
+  hipLaunchKernelGGL(k_gather_texture_u8, dim3((unsigned)ceil_div(n_pix * C, 256)), dim3(256), 0, s, ids, n_pix, face_tex,
+                     F, C, (uint8_t)null_value, out);
+  GR_HIP(c, hipGetLastError());
+  return GR_OK;
+}
+
+int gr_project_index_pairs(gr_ctx *c, const int32_t *ids, const double *img, int n_views, int h, int w, int64_t n_classes,
+                           uint32_t *counts, uint64_t *keys, int64_t key_cap, uint64_t *key_count, int flags,
+                           void *stream) {
+  int rc = check_common(c, n_views, h, w);
+  if (rc) return rc;
+  if (c->F <= 0) return fail(c, GR_ENOMESH, "gr_mesh_upload has not been called");
+  if (!ids || !img || !counts || !keys || !key_count || n_classes <= 0 || key_cap < 0)
+    return fail(c, GR_EINVAL, "bad sparse projection args");
+  if (n_views == 0) return GR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  GR_HIP(c, hipSetDevice(c->device));
+  const int64_t P = (int64_t)h * w, F = c->F;
+  const int B = n_views < GR_MAX_BATCH ? n_views : GR_MAX_BATCH;
+  rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F * B);
+  if (rc) return rc;
+  uint32_t *win = (uint32_t *)c->winner;
+  GR_HIP(c, hipMemsetAsync(c->flag, 0, sizeof(int), s));
+  for (int v0 = 0; v0 < n_views; v0 += B) {
+    const int nb = (n_views - v0) < B ? (n_views - v0) : B;
+    {
+      Timed t(c, s, ST_PROJECT);
+      hipLaunchKernelGGL(k_winner<uint32_t>, dim3((unsigned)ceil_div(ceil_div(w, 4), 256), (unsigned)ceil_div(h, WIN_ROWS), nb),
+                         dim3(256), 0, s, ids + v0 * P, (const uint8_t *)nullptr, win, F, h, w, 1, 0,
+                         (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0);
+    }
+    {
+      Timed t(c, s, ST_VOTE);
+      hipLaunchKernelGGL(k_emit_index_pairs, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s, win, img + v0 * P, nb, F, P,
+                         (long long)n_classes, counts, (unsigned long long *)keys, (long long)key_cap,
+                         (unsigned long long *)key_count, c->flag);
+    }
+  }
+  GR_HIP(c, hipGetLastError());
+  int bad = 0;
+  GR_HIP(c, hipMemcpyAsync(&bad, c->flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  GR_HIP(c, hipStreamSynchronize(s));
+  if (bad) return fail(c, GR_EINDEX, "an image value is not a class index in [0, %lld)", (long long)n_classes);
+  return GR_OK;
+}
+
+int gr_count_pairs(gr_ctx *c, uint64_t *keys, int64_t n, uint64_t *unique_keys, uint32_t *pair_counts, int64_t *n_unique_h,
+                   void *stream) {
+  if (!c) return GR_EINVAL;
+  if (!keys || !unique_keys || !pair_counts || !n_unique_h || n < 0 || n > 0x7FFFFFFFll)
+    return fail(c, GR_EINVAL, "bad pair-count args");
+  *n_unique_h = 0;
+  if (n == 0) return GR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  GR_HIP(c, hipSetDevice(c->device));
+  // radix sort (keys -> sorted copy in context scratch) + run-length encode, both rocPRIM through hipcub
+  size_t sort_bytes = 0, rle_bytes = 0;
+  unsigned long long *kin = (unsigned long long *)keys, *uo = (unsigned long long *)unique_keys;
+  GR_HIP(c, hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, kin, kin, (int)n, 0, 64, s));
+  int *d_runs = nullptr;
+  GR_HIP(c, hipcub::DeviceRunLengthEncode::Encode(nullptr, rle_bytes, kin, uo, pair_counts, d_runs, (int)n, s));
+  const size_t tmp_bytes = (sort_bytes > rle_bytes ? sort_bytes : rle_bytes) + 256;
+  const size_t need = tmp_bytes + sizeof(unsigned long long) * (size_t)n + 256;
+  if (c->sort_bytes < need) {
+    (void)hipDeviceSynchronize();
+    if (c->sort_tmp) (void)hipFree(c->sort_tmp);
+    c->sort_tmp = nullptr; c->sort_bytes = 0;
+    if (hipMalloc(&c->sort_tmp, need) != hipSuccess) return fail(c, GR_ENOMEM, "sort scratch allocation failed");
+    c->sort_bytes = need;
+  }
+  char *base = (char *)c->sort_tmp;
+  unsigned long long *sorted = (unsigned long long *)base;
+  void *tmp = base + ((sizeof(unsigned long long) * (size_t)n + 255) / 256) * 256;
+  size_t tb = sort_bytes;
+  GR_HIP(c, hipcub::DeviceRadixSort::SortKeys(tmp, tb, kin, sorted, (int)n, 0, 64, s));
+  tb = rle_bytes;
+  GR_HIP(c, hipcub::DeviceRunLengthEncode::Encode(tmp, tb, sorted, uo, pair_counts, (int *)c->flag, (int)n, s));
+  int runs = 0;
+  GR_HIP(c, hipMemcpyAsync(&runs, c->flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  GR_HIP(c, hipStreamSynchronize(s));
+  *n_unique_h = runs;
   return GR_OK;
 }
 

@@ -23,7 +23,13 @@ from pathlib import Path
 import numpy as np
 
 from geograypher_amd.cameras.cameras import PhotogrammetryCamera, PhotogrammetryCameraSet, vtk_like_near_plane
-from geograypher_amd.constants import CACHE_FOLDER, EARTH_CENTERED_EARTH_FIXED_CRS, PATH_TYPE
+from geograypher_amd.constants import (
+    CACHE_FOLDER,
+    EARTH_CENTERED_EARTH_FIXED_CRS,
+    NULL_TEXTURE_INT_VALUE,
+    PATH_TYPE,
+    VIS_FOLDER,
+)
 
 try:  # tqdm is optional: the reference wraps its view loops in it (meshes.py:2049-2053)
     from tqdm import tqdm
@@ -541,6 +547,129 @@ class TexturedPhotogrammetryMesh:
 
     # the north star's name for the same method
     aggregate_viewpoints = aggregate_projected_images
+
+    # -- save_renders ----------------------------------------------------------------
+    def save_IDs_to_labels(self, savepath: PATH_TYPE):
+        """reference: meshes.py:1081-1108"""
+        import json
+
+        Path(savepath).parent.mkdir(parents=True, exist_ok=True)
+        if self.is_discrete_texture():
+            self.logger.info(f"Saving IDs_to_labels to {str(savepath)}")
+            try:
+                with open(savepath, "w") as outfile_h:
+                    json.dump(self.get_IDs_to_labels(), outfile_h, ensure_ascii=False, indent=4, default=str)
+            except Exception:
+                self.logger.warning("Could not serialize IDs_to_labels due to JSON error")
+        else:
+            self.logger.warning("non-discrete texture, not saving classes")
+
+    @staticmethod
+    def _resize_map(src_hw, dst_hw):
+        """(2, H, W) sampling map of skimage.transform.resize: destination pixel centres mapped into the source grid,
+        mirrored at the borders (skimage's default mode "reflect")."""
+        (h, w), (H, W) = src_hw, dst_hw
+        r = (np.arange(H) + 0.5) * (h / H) - 0.5
+        c = (np.arange(W) + 0.5) * (w / W) - 0.5
+        r = np.where(r < 0, -r, np.where(r > h - 1, 2 * (h - 1) - r, r))
+        c = np.where(c < 0, -c, np.where(c > w - 1, 2 * (w - 1) - c, c))
+        rr, cc = np.meshgrid(r, c, indexing="ij")
+        return np.stack([rr, cc], axis=0)
+
+    def save_renders(
+        self,
+        camera_set: PhotogrammetryCameraSet,
+        render_image_scale=1.0,
+        output_folder: PATH_TYPE = Path(VIS_FOLDER, "renders"),
+        make_composites: bool = False,
+        save_native_resolution: bool = False,
+        cast_to_uint8: bool = True,
+        save_as_npy: bool = False,
+        uint8_value_for_null_texture: np.uint8 = NULL_TEXTURE_INT_VALUE,
+        **render_kwargs,
+    ):
+        """Render the face texture from every camera and save one file per image (reference: meshes.py:2248-2397).
+
+        Same arguments, same on-disk layout (`<output_folder>/<image path relative to camera_set.image_folder>` as
+        deflate-compressed .tif, or .npy with `save_as_npy`; `IDs_to_labels.json` for discrete textures).  The
+        post-processing of meshes.py:2312-2349 runs on the device: with `cast_to_uint8` the texture gather, the
+        null/out-of-range masking and the uint8 cast are ONE kernel (`gr_gather_texture_u8`), so a 4000x3000 view
+        leaves the GPU as 12 MB instead of the reference's 96 MB float64 image; the optional native-resolution
+        upsampling (nearest for discrete textures, bilinear otherwise) is the warp kernel with a resize map.
+        Like the reference this renders with `distortion_set=camera_set` (a camera set without a distortion model
+        needs `apply_distortion=False`).  `make_composites` (matplotlib visualisation) is outside the projection path.
+        """
+        from PIL import Image
+
+        if make_composites:
+            raise NotImplementedError("composite visualisations are outside the projection path (utils/visualization.py)")
+        torch = _torch()
+        output_folder = Path(output_folder)
+        output_folder.mkdir(parents=True, exist_ok=True)
+        self.logger.info(f"Saving renders to {output_folder}")
+        self.save_IDs_to_labels(Path(output_folder, "IDs_to_labels.json"))
+
+        face_texture = np.asarray(
+            self.get_texture(request_vertex_texture=False, try_verts_faces_conversion=True), dtype=np.float64
+        )
+        tex_dev = self.backend._dev(face_texture, torch.float64)
+        mesh = self.get_mesh_in_cameras_coords(camera_set)
+        discrete = self.is_discrete_texture()
+        resize_maps = {}
+        render_kwargs = dict(render_kwargs)
+        render_kwargs.setdefault("distortion_set", camera_set)
+
+        for i in tqdm(range(len(camera_set)), total=len(camera_set), desc="Computing and saving renders"):
+            camera = camera_set[i]
+            ids = self.pix2face(cameras=camera, mesh=mesh, render_img_scale=render_image_scale, return_tensor=True,
+                                **render_kwargs)
+            if isinstance(ids, np.ndarray):
+                ids = self.backend._dev(ids.astype(np.int32), torch.int32)
+            native = save_native_resolution and render_image_scale != 1
+            if native:
+                key = (tuple(ids.shape), tuple(camera.get_image_size()))
+                if key not in resize_maps:
+                    resize_maps[key] = self.backend.upload_map(self._resize_map(*key))
+            if cast_to_uint8 and (not native or discrete):
+                if native:  # nearest-neighbour upsampling commutes with the per-pixel gather: resize the ids
+                    ids = self.backend.warp_image(ids, resize_maps[key], order=0, fill_value=-1)
+                rendered = self.backend.gather_texture_u8(ids, tex_dev, int(uint8_value_for_null_texture)).cpu().numpy()
+                rendered = np.squeeze(rendered)
+            else:
+                rendered = self.backend.gather_texture(ids, tex_dev)  # (h, w, C) float64, NaN without a face
+                if native:
+                    rendered = self.backend.warp_image(rendered, resize_maps[key], order=0 if discrete else 1,
+                                                       fill_value=float("nan"))
+                rendered = rendered.cpu().numpy()
+                if cast_to_uint8:
+                    mask = np.logical_or.reduce([rendered < 0, rendered > 255, np.logical_not(np.isfinite(rendered))])
+                    rendered[mask] = uint8_value_for_null_texture
+                    rendered = np.squeeze(rendered.astype(np.uint8))
+            if rendered.ndim == 3:
+                rendered = rendered[..., :3]
+            try:
+                camera_filename = Path(camera.get_image_filename()).relative_to(camera_set.image_folder)
+            except (ValueError, TypeError):
+                raise ValueError(
+                    "Tried to find the relative path of the camera path"
+                    f" ({camera.get_image_filename()}) inside of the camera set image"
+                    f" folder ({camera_set.image_folder}), but failed. The tool being called"
+                    " may have an 'original_image_folder' argument, which could be used to"
+                    " delete the initial, mismatched portion of the camera path."
+                )
+            output_filename = Path(output_folder, camera_filename)
+            output_filename.parent.mkdir(parents=True, exist_ok=True)
+            if save_as_npy is True:
+                np.save(str(output_filename.with_suffix(".npy")), rendered)
+            else:
+                rendered = np.squeeze(rendered)
+                if cast_to_uint8 is False:
+                    with np.errstate(invalid="ignore"):
+                        if np.nanmax(rendered) <= np.iinfo(np.uint16).max:
+                            rendered = rendered.astype(np.uint16)
+                        else:
+                            rendered = rendered.astype(np.uint32)
+                Image.fromarray(rendered).save(str(output_filename.with_suffix(".tif")), compression="tiff_deflate")
 
 
 def _raster_kwargs(kwargs: dict) -> dict:

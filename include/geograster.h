@@ -146,6 +146,25 @@ int gr_raster_project_labels_u8(gr_ctx *ctx, const float *cams, const uint8_t *l
                                 int C, uint32_t *votes, uint32_t *counts, int32_t *ids_or_null, int flags,
                                 void *stream);
 
+/* save_renders epilogue (row f2) -- replaces meshes.py:1921-1937 + 2325-2337 in one pass: out[p,c] = uint8(tex[ids[p],c]),
+ * with `null_value` where the pixel has no face or the value is < 0, > 255 or not finite.  out: n_pix x C uint8. */
+int gr_gather_texture_u8(gr_ctx *ctx, const int32_t *ids, int64_t n_pix, const double *face_tex, int64_t F, int C,
+                         int null_value, uint8_t *out, void *stream);
+
+/* sparse index aggregation (row f3) -- replaces the loop body of TexturedPhotogrammetryMeshIndexPredictions
+ * .aggregate_projected_images (derived_meshes.py:470-520) for single-channel images whose finite values are class
+ * indices: per view the last pixel of each face wins (as project_images); a finite value v adds one observation:
+ * counts[f] += 1 and the pair key f * n_classes + int(v) is appended to keys[*key_count ...] (device counter, capacity
+ * key_cap; pairs beyond it are dropped but still counted in *key_count).  Synchronises `stream`; GR_EINDEX when a
+ * value is outside [0, n_classes). */
+int gr_project_index_pairs(gr_ctx *ctx, const int32_t *ids, const double *img, int n_views, int h, int w,
+                           int64_t n_classes, uint32_t *counts, uint64_t *keys, int64_t key_cap, uint64_t *key_count,
+                           int flags, void *stream);
+/* multiplicity of every distinct pair key: radix sort + run-length encode (rocPRIM via hipcub) in context scratch.
+ * unique_keys / pair_counts: capacity n.  *n_unique_h (host) receives the number of distinct keys.  Synchronises. */
+int gr_count_pairs(gr_ctx *ctx, uint64_t *keys, int64_t n, uint64_t *unique_keys, uint32_t *pair_counts,
+                   int64_t *n_unique_h, void *stream);
+
 /* distortion warp of an image through a cached sampling map (row f1) -- replaces utils/image.py:72-126
  * (flexible_inputs_warp -> skimage.transform.warp, mode "constant") as called by cameras.py:1092-1156 for the face-id
  * image of pix2face (meshes.py:1842-1854).  map_rows/map_cols: h_out x w_out f64, the position to sample in `in` for

@@ -98,3 +98,29 @@ def find_argmax_nonzero_value(array, keepdims=False, axis=1):
     infinite_mask = np.any(~np.isfinite(array), axis=axis)
     argmax[np.logical_or(zero_sum_mask, infinite_mask)] = np.nan
     return argmax
+
+
+def render_postprocess_uint8(rendered, null_value=0):
+    """meshes.py:2325-2337 -- values that cannot be represented as uint8 become the null value, then cast + squeeze."""
+    rendered = np.array(rendered, dtype=float, copy=True)
+    with np.errstate(invalid="ignore"):
+        mask = np.logical_or.reduce([rendered < 0, rendered > 255, np.logical_not(np.isfinite(rendered))])
+    rendered[mask] = null_value
+    return np.squeeze(rendered.astype(np.uint8))
+
+
+def aggregate_index_sparse(projections, n_faces, n_classes):
+    """derived_meshes.py:470-550 over an iterable of per-view (F,1) projections (NaN = no prediction), dense output:
+    (average (F, n_classes), counts (F, 1), summed (F, n_classes))."""
+    counts = np.zeros((n_faces, 1), dtype=int)
+    summed = np.zeros((n_faces, n_classes), dtype=int)
+    for proj in projections:
+        inds = np.nonzero(np.isfinite(np.squeeze(proj)))[0]
+        if len(inds) == 0:
+            continue
+        counts[inds, 0] += 1
+        classes = proj[inds, 0].astype(int)
+        summed[inds, classes] += 1
+    with np.errstate(divide="ignore", invalid="ignore"):
+        recip = np.where(counts > 0, 1.0 / np.where(counts > 0, counts, 1), 0.0)
+    return summed * recip, counts, summed

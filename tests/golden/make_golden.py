@@ -9,6 +9,7 @@ unmodified.  Nothing of the reference travels: only the .npz data files written 
     PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 
 Captured (function -> reference lines executed):
+    TexturedPhotogrammetryMeshIndexPredictions.aggregate_projected_images   derived_meshes.py:414-550 (sparse)
     TexturedPhotogrammetryMesh.project_images              meshes.py:1970-2002
     TexturedPhotogrammetryMesh.aggregate_projected_images  meshes.py:2033-2084
     TexturedPhotogrammetryMesh.render_flat                 meshes.py:1891-1942
@@ -165,6 +166,21 @@ def main():
     out["hash_plain"] = np.array(cam.get_camera_hash())
     out["hash_with_image"] = np.array(cam.get_camera_hash(include_image_hash=True))
     out["distortion_key"] = np.array(PhotogrammetryCameraSet([cam]).distortion_key({"k1": -0.0919367147, "b1": 0.5262}, 0.5))
+
+    # ---- sparse index aggregation (derived_meshes.py:414-550), real reference, scipy from this interpreter ---------------
+    from geograypher.meshes.derived_meshes import TexturedPhotogrammetryMeshIndexPredictions as TPMI
+
+    n_classes = 37
+    index_imgs = rng.integers(0, n_classes, size=(N, h, w)).astype(float)
+    index_imgs[rng.random((N, h, w)) < 0.4] = np.nan
+    index_imgs[2] = np.nan  # a null image (skipped by check_null_image)
+    cs = FakeSet(cams, index_imgs)
+    avg_sp, info_sp = TPMI.aggregate_projected_images(fs, cs, n_classes=n_classes)
+    out["index_imgs"] = index_imgs
+    out["index_n_classes"] = n_classes
+    out["index_average"] = np.asarray(avg_sp.todense())
+    out["index_counts"] = np.asarray(info_sp["projection_counts"].todense())
+    out["index_summed"] = np.asarray(info_sp["summed_projections"].todense())
 
     np.savez_compressed(Path(__file__).with_name("reference_numpy_stages.npz"), **out)
     print("wrote reference_numpy_stages.npz with", len(out), "arrays")

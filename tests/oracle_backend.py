@@ -42,6 +42,32 @@ class OracleBackend:
         flat = oracle_np.render_flat_gather(ids.reshape(-1, 1).astype(np.int64), tex)
         return torch.from_numpy(flat.reshape(ids.shape + (tex.shape[1],)))
 
+    def gather_texture_u8(self, ids, face_texture, null_value=0):
+        f64 = self.gather_texture(ids, face_texture).numpy()
+        with np.errstate(invalid="ignore"):
+            bad = (f64 < 0) | (f64 > 255) | ~np.isfinite(f64)
+        f64[bad] = null_value
+        return torch.from_numpy(f64.astype(np.uint8))
+
+    def project_index_pairs(self, ids, img, n_classes, counts, neg1_is_last_face=True):
+        ids = np.asarray(ids)
+        img = np.asarray(img)
+        if ids.ndim == 2:
+            ids, img = ids[None], img[None]
+        keys = []
+        for k in range(ids.shape[0]):
+            proj = oracle_np.project_image(ids[k].astype(np.int64), img[k], self.n_faces,
+                                           neg1_is_last_face=neg1_is_last_face)
+            inds = np.nonzero(np.isfinite(proj[:, 0]))[0]
+            counts += torch.from_numpy(np.bincount(inds, minlength=self.n_faces).astype(np.int32))
+            cls = proj[inds, 0].astype(np.int64)
+            if cls.size and (cls.min() < 0 or cls.max() >= n_classes):
+                raise IndexError("class index out of range")
+            keys.append(inds.astype(np.int64) * n_classes + cls)
+        keys = np.concatenate(keys) if keys else np.zeros(0, dtype=np.int64)
+        uniq, mult = np.unique(keys, return_counts=True)
+        return uniq, mult.astype(np.int64)
+
     def new_vote_buffers(self, C):
         return torch.zeros((self.n_faces, C), dtype=torch.int32), torch.zeros((self.n_faces,), dtype=torch.int32)
 
