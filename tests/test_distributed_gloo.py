@@ -73,3 +73,47 @@ def test_two_rank_gloo_all_reduce_equals_single_process(tmp_path):
     for r in range(world):
         np.testing.assert_array_equal(np.load(tmp_path / f"votes_{r}.npy").view(np.uint32), want_votes)
         np.testing.assert_array_equal(np.load(tmp_path / f"counts_{r}.npy").view(np.uint32), want_counts)
+
+
+def _mesh_worker(rank, world, port, out_dir):
+    """aggregate_projected_images(distributed=True) through the product's mesh class (oracle backend on CPU)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from geograypher_amd.cameras import SegmentorPhotogrammetryCameraSet
+        from geograypher_amd.meshes import TexturedPhotogrammetryMesh
+        from geograypher_amd.predictors import ArrayLabelSegmentor
+        from geograypher_amd.utils import synthetic
+        from tests.oracle_backend import OracleBackend
+
+        (points, faces), cams = synthetic.config1_scene()
+        for c in cams.cameras:  # small images keep the CPU oracle fast
+            c.image_width, c.image_height, c.image_size, c.f = 160, 120, (120, 160), 125.0
+        mesh = TexturedPhotogrammetryMesh((points, faces), log_level="ERROR", backend=OracleBackend())
+        ids = mesh.pix2face(cams, apply_distortion=False)
+        labels = [synthetic.synthetic_labels(ids[v], v, 4) for v in range(len(cams))]
+        seg = ArrayLabelSegmentor(labels, 4, filenames=[c.image_filename for c in cams.cameras])
+        seg_set = SegmentorPhotogrammetryCameraSet(cams, seg)
+        avg, info = mesh.aggregate_projected_images(seg_set, distributed=True)
+        np.save(os.path.join(out_dir, f"avg_{rank}.npy"), avg)
+        np.save(os.path.join(out_dir, f"cnt_{rank}.npy"), info["projection_counts"])
+        if rank == 0:
+            avg1, info1 = mesh.aggregate_projected_images(seg_set, distributed=False)
+            np.save(os.path.join(out_dir, "avg_single.npy"), avg1)
+            np.save(os.path.join(out_dir, "cnt_single.npy"), info1["projection_counts"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_mesh_class_distributed_aggregation_equals_single_process(tmp_path):
+    world = 2
+    mp.spawn(_mesh_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want_avg, want_cnt = np.load(tmp_path / "avg_single.npy"), np.load(tmp_path / "cnt_single.npy")
+    assert np.nansum(want_cnt) > 1000
+    for r in range(world):
+        got = np.load(tmp_path / f"avg_{r}.npy")
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(want_avg))
+        np.testing.assert_array_equal(np.nan_to_num(got), np.nan_to_num(want_avg))
+        np.testing.assert_array_equal(np.load(tmp_path / f"cnt_{r}.npy"), want_cnt)
