@@ -67,6 +67,19 @@ def vtk_like_near_plane(cam_to_world: np.ndarray, bounds: np.ndarray, tolerance:
     return float(near)
 
 
+def vtk_like_near_planes(cam_to_worlds: np.ndarray, bounds: np.ndarray, tolerance: float = 0.001) -> np.ndarray:
+    """`vtk_like_near_plane` for N cameras at once: cam_to_worlds (N,4,4) -> (N,) near distances."""
+    T = np.asarray(cam_to_worlds, dtype=np.float64)
+    corners = np.array([[x, y, z] for x in bounds[0:2] for y in bounds[2:4] for z in bounds[4:6]], dtype=np.float64)
+    d = np.einsum("nk,nck->nc", T[:, :3, 2], corners[None, :, :] - T[:, None, :3, 3])
+    near = np.maximum(d.min(axis=1), 0.0)
+    far = np.maximum(d.max(axis=1), 1e-18)
+    near = 0.99 * near - (far - near) * 0.5
+    far = 1.01 * far + (far - near) * 0.5
+    near = np.where(near >= far, 0.01 * far, near)
+    return np.where(near < tolerance * far, tolerance * far, near)
+
+
 class PhotogrammetryCamera:
     def __init__(
         self,

@@ -22,7 +22,12 @@ from pathlib import Path
 
 import numpy as np
 
-from geograypher_amd.cameras.cameras import PhotogrammetryCamera, PhotogrammetryCameraSet, vtk_like_near_plane
+from geograypher_amd.cameras.cameras import (
+    PhotogrammetryCamera,
+    PhotogrammetryCameraSet,
+    vtk_like_near_plane,
+    vtk_like_near_planes,
+)
 from geograypher_amd.constants import (
     CACHE_FOLDER,
     EARTH_CENTERED_EARTH_FIXED_CRS,
@@ -53,8 +58,10 @@ class LocalMesh:
         return int(self.faces.shape[0])
 
     def bounds(self) -> np.ndarray:
-        lo, hi = self.points.min(axis=0), self.points.max(axis=0)
-        return np.array([lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]], dtype=np.float64)
+        if getattr(self, "_bounds", None) is None:
+            lo, hi = self.points.min(axis=0), self.points.max(axis=0)
+            self._bounds = np.array([lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]], dtype=np.float64)
+        return self._bounds
 
 
 def _parse_mesh(mesh) -> typing.Tuple[np.ndarray, np.ndarray]:
@@ -269,10 +276,17 @@ class TexturedPhotogrammetryMesh:
         float64, with T = cameras.get_local_to_epsg_4978_transform()."""
         T = cameras.get_local_to_epsg_4978_transform()
         T = np.eye(4) if T is None else np.asarray(T, dtype=np.float64)
+        key = hashlib.sha1(T.tobytes()).hexdigest()
+        cache = self.__dict__.setdefault("_local_mesh_cache", {})
+        if not inplace and key in cache and cache[key][0] is self.points:
+            return cache[key][1]  # the reference transforms the whole mesh again for every call (meshes.py:1659-1666)
         epsg_4978_to_camera = np.linalg.inv(T)
         pts = np.asarray(self.points, dtype=np.float64)
         local = pts @ epsg_4978_to_camera[:3, :3].T + epsg_4978_to_camera[:3, 3]
-        mesh = LocalMesh(local, self.faces, key=hashlib.sha1(T.tobytes()).hexdigest())
+        mesh = LocalMesh(local, self.faces, key=key)
+        if not inplace:
+            cache.clear()
+            cache[key] = (self.points, mesh)
         if inplace:
             self.points = local
             self.CRS = None
@@ -297,8 +311,9 @@ class TexturedPhotogrammetryMesh:
             mesh = LocalMesh(np.asarray(pts, dtype=np.float64), fcs)
         self._ensure_uploaded(mesh)
         if near is None:
-            bounds = mesh.bounds()
-            near = [vtk_like_near_plane(np.asarray(c.cam_to_world_transform, dtype=np.float64), bounds) for c in cameras.cameras]
+            near = vtk_like_near_planes(
+                np.stack([np.asarray(c.cam_to_world_transform, dtype=np.float64) for c in cameras.cameras]), mesh.bounds()
+            )
         records = cameras.get_raster_records(render_img_scale, near=near, principal_point=principal_point)
         return records, cameras.cameras[0].get_image_size(render_img_scale)
 
@@ -354,11 +369,12 @@ class TexturedPhotogrammetryMesh:
             out = torch.stack([w.to(torch.int32) for w in warped], dim=0)
             if return_tensor:
                 return out[0] if single else out
-            out = out.cpu().numpy().astype(np.int64)
+            out = out.to(torch.int64).cpu().numpy()
             return out[0] if single else out
         if return_tensor:
             return ids[0] if single else ids
-        out = ids.cpu().numpy().astype(np.int64)
+        # int64 like the reference (meshes.py:1804): widened on the device, one copy to the host
+        out = ids.to(_torch().int64).cpu().numpy()
         return out[0] if single else out
 
     # -- render_flat ---------------------------------------------------------------------------------------------
