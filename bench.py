@@ -223,7 +223,7 @@ def main():
         assert np.array_equal(one[0], ids[0].cpu().numpy()), "GPU ids differ from the CPU oracle on view 0"
         # bounded sample: passes over the rank's views on all host cores until ~cpu_seconds of CPU work are done
         n_done, tc, used = 0, 0.0, 1
-        per_pass = int(min(max(cores, nv), 64))  # one view per thread, output buffer capped at 64 x 48 MB
+        per_pass = int(min(max(cores, nv), 64))  # one view per thread (more threads only contend for host memory bandwidth)
         recs_pass = np.concatenate([recs_np] * (per_pass // nv + 1), axis=0)[:per_pass]
         while tc < args.cpu_seconds and n_done < 4000:
             t0 = time.perf_counter()
@@ -253,7 +253,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32 ids / fp32 transform + 32-bit fixed-point edges",
+            "dtype": "int32 (fixed-point edge functions) / fp32 (vertex transform, depth)",
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE config 2: {F}-face heightfield (V={V}), {nv} pinhole views/GPU @ {W}x{H}, "

@@ -29,7 +29,7 @@
 // ------------------------------------------------------------------------------------------------------------------
 #define GR_TILE 64          // tile edge in pixels (one workgroup rasterizes one 64x64 tile out of LDS)
 #define GR_TILE_LOG2 6
-#define GR_MAX_BATCH 32     // views per launch group (amortises kernel boundaries)
+#define GR_MAX_BATCH 64     // views per launch group (amortises kernel boundaries and per-launch tails)
 #define GR_CTRL_HDR 4       // ctrl words before the tile arrays: rec_count, total_entries, overflow, work_count
 #define GR_MAX_DIM 16384    // h, w limit (guard band and 16-bit bbox packing)
 
@@ -1288,7 +1288,10 @@ int ensure_bins(gr_ctx *c, int n_slots, int T) {
   const int64_t F = c->F;
   int64_t want_cap = c->ent_cap_request > 0 ? c->ent_cap_request : (F / 2 + 65536);
   if (c->opt_direct_cap > 0 && c->direct_ok) want_cap = std::max<int64_t>(want_cap, (int64_t)T * c->opt_direct_cap);
-  if (c->ctrl && c->slots >= n_slots && c->Tcap >= T && c->rec_F == F && c->ent_cap >= want_cap) return GR_OK;
+  const bool need_rec = !(c->opt_direct_cap > 0 && c->direct_ok);  // record planes only feed the exact two-pass path
+  if (c->ctrl && c->slots >= n_slots && c->Tcap >= T && c->rec_F == F && c->ent_cap >= want_cap &&
+      (!need_rec || c->rec != nullptr))
+    return GR_OK;
   (void)hipDeviceSynchronize();
   if (c->ctrl) (void)hipFree(c->ctrl);
   if (c->rec) (void)hipFree(c->rec);
@@ -1300,7 +1303,7 @@ int ensure_bins(gr_ctx *c, int n_slots, int T) {
   const int64_t cap = want_cap > c->ent_cap ? want_cap : c->ent_cap;
   const int64_t ctrl_stride = ((GR_CTRL_HDR + 4 * (int64_t)Tcap) + 63) / 64 * 64;
   if (hipMalloc(&c->ctrl, sizeof(uint32_t) * ctrl_stride * slots) != hipSuccess ||
-      hipMalloc(&c->rec, sizeof(int4) * 4 * (F > 0 ? F : 1) * slots) != hipSuccess ||
+      (need_rec && hipMalloc(&c->rec, sizeof(int4) * 4 * (F > 0 ? F : 1) * slots) != hipSuccess) ||
       hipMalloc(&c->comp, sizeof(int4) * 4 * cap * slots) != hipSuccess ||
       hipMalloc(&c->work, sizeof(uint32_t) * ceil_div(F > 0 ? F : 1, 256) * slots) != hipSuccess) {
     c->slots = 0; c->Tcap = 0; c->ent_cap = 0;

@@ -92,7 +92,7 @@ enum {
   GR_OPT_RASTER_KERNEL = 1, /* k_raster_rows with 1: 256 (default), 2: 512, 3: 128 threads per tile;
                                4: k_raster_rows_persistent (software-pipelined, 256 threads)           */
   GR_OPT_TILE_H_LOG2 = 2,   /* tile height: 5 (64x32, default) or 6 (64x64)                                  */
-  GR_OPT_BATCH = 3,         /* views per launch group, 1..64 (default 32)                         */
+  GR_OPT_BATCH = 3,         /* views per launch group, 1..64 (default 64)                         */
   GR_OPT_WG_PER_CU = 4,     /* persistent kernel: resident workgroups per CU, 1..16 (default 5)    */
   GR_OPT_DIRECT_CAP = 6,    /* single-pass binning: entry slots per tile (default 512); 0 = always bin exactly
                                (count, scan, fill).  A tile that outgrows its slots is reported by

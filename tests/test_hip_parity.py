@@ -108,14 +108,14 @@ def test_empty_view_and_single_face(hip):
     assert np.all(ids[0] == -1) and set(np.unique(ids[1])) == {-1, 0}
 
 
-@pytest.mark.parametrize("batch,overlap", [(32, 1), (5, 1), (5, 0), (1, 1)])
+@pytest.mark.parametrize("batch,overlap", [(64, 1), (32, 0), (5, 1), (5, 0), (1, 1)])
 def test_many_views_in_one_call_cross_batch_boundary(hip, batch, overlap):
     """More views than one launch group: results must not depend on the batching nor on the two-stream overlap of the
     binning and tile stages (scratch double buffering)."""
     hip.set_option(3, batch)
     hip.set_option(5, overlap)
     (points, faces), cams = synthetic.config1_scene()
-    poses = [synthetic.nadir_pose(3.0 * k - 30, 2.0 * k - 20, 35.0 + k, yaw_deg=11.0 * k) for k in range(37)]
+    poses = [synthetic.nadir_pose(3.0 * k - 30, 2.0 * k - 20, 35.0 + k, yaw_deg=11.0 * k) for k in range(70)]
     cams = synthetic.camera_set_from_poses(poses, f=260.0, width=320, height=200)
     try:
         _check_views(hip, points, faces, _records(cams), 200, 320)
@@ -129,7 +129,7 @@ def test_many_views_in_one_call_cross_batch_boundary(hip, batch, overlap):
         hip.raster_project_labels(recs, labels, 3, v2, c2)
         assert torch.equal(v1, v2) and torch.equal(c1, c2)
     finally:
-        hip.set_option(3, 32)
+        hip.set_option(3, 64)
         hip.set_option(5, 0)
 
 

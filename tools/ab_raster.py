@@ -26,8 +26,8 @@ def main():
     ids = torch.empty((nv, H, W), dtype=torch.int32, device="cuda")
     ref = None
     # (name, kernel, tile_h_log2, batch, debug mask, single-pass slots per tile)
-    variants = [("exact", 1, 5, 32, 0, 0), ("direct512", 1, 5, 32, 0, 512), ("direct1024", 1, 5, 32, 0, 1024),
-                ("direct512_64x64", 1, 6, 32, 0, 512), ("direct512_b16", 1, 5, 16, 0, 512)]
+    variants = [("direct512_b32", 1, 5, 32, 0, 512), ("direct512_b25", 1, 5, 25, 0, 512), ("direct512_b50", 1, 5, 50, 0, 512),
+                ("direct512_b64", 1, 5, 64, 0, 512), ("direct384_b50", 1, 5, 50, 0, 384)]
     results = {}
     for rep in range(3):
         for name, k, thl, b, dbg, cap in variants:
