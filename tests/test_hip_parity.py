@@ -98,6 +98,35 @@ def test_triangle_soup_occlusion_degenerates_behind_camera(hip, seed):
     assert len(np.unique(ids)) > 20
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_stress(hip, seed):
+    """Randomised scenes across the corner cases of the pipeline: image sizes from 1 pixel to non-multiples of the tile,
+    hundreds to thousands of entries per tile (entry chunks beyond one per thread, single-pass segments overflowing into
+    the exact path), edges parallel to the axes (A == 0 / B == 0), faces far larger than the image, cameras inside
+    the scene's bounding box, principal points off-centre."""
+    rng = np.random.default_rng(1000 + seed)
+    h, w = [(1, 1), (3, 70), (65, 33), (64, 64), (97, 131), (200, 257)][seed % 6]
+    n = [50, 400, 3000, 9000][seed % 4]
+    if seed % 3 == 0:  # axis-aligned lattice of small quads plus noise-free coordinates -> exact ties and A/B == 0
+        g = int(np.sqrt(n / 2)) + 1
+        xs, ys = np.meshgrid(np.linspace(-3, 3, g + 1), np.linspace(-3, 3, g + 1))
+        points = np.stack([xs.ravel(), ys.ravel(), np.zeros(xs.size)], axis=1)
+        faces = synthetic.grid_faces(g + 1, g + 1)
+    else:
+        centers = rng.uniform(-4, 4, (n, 1, 3)) * np.array([1, 1, 0.2])
+        size = np.exp(rng.uniform(np.log(0.01), np.log(30.0 if seed % 2 else 0.3), (n, 1, 1)))
+        points = (centers + rng.normal(0, 1, (n, 3, 3)) * size).reshape(-1, 3)
+        faces = np.arange(3 * n).reshape(n, 3)
+    z_cam = [6.0, 1.0, 0.05][seed % 3]  # the last one sits inside the scene's bounding box
+    poses = [synthetic.nadir_pose(rng.uniform(-1, 1), rng.uniform(-1, 1), z_cam, yaw_deg=rng.uniform(0, 360),
+                                  tilt_x_deg=rng.uniform(-20, 20), tilt_y_deg=rng.uniform(-20, 20)) for _ in range(3)]
+    cams = synthetic.camera_set_from_poses(poses, f=float(max(h, w)) * rng.uniform(0.3, 2.0), width=w, height=h)
+    for c in cams.cameras:
+        c.cx, c.cy = rng.uniform(-5, 5), rng.uniform(-5, 5)
+    recs = cams.get_raster_records(1.0, near=0.02, principal_point="intrinsics" if seed % 2 else "center")
+    _check_views(hip, points, faces, recs, h, w, depth=True)
+
+
 def test_empty_view_and_single_face(hip):
     points = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float64)
     faces = np.array([[0, 1, 2]])
