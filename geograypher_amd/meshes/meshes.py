@@ -505,20 +505,36 @@ class TexturedPhotogrammetryMesh:
             self._ensure_uploaded(mesh)
             votes, counts = self.backend.new_vote_buffers(C)
             chunk = max(int(batch_size), 32)
-            for c0 in tqdm(range(0, len(my_inds), chunk), total=(len(my_inds) + chunk - 1) // chunk,
-                           desc="Aggregating projected viewpoints"):
-                inds = my_inds[c0 : c0 + chunk]
-                sub = cameras.get_subset_cameras(inds)
+            chunks = [my_inds[c0 : c0 + chunk] for c0 in range(0, len(my_inds), chunk)]
+
+            def load_chunk(inds):
+                """Label images of one chunk as a pinned (n,h,w) uint8 host tensor (or a device tensor when the
+                segmentor already produces tensors).  Runs on a worker thread: PNG decode and the NN resize of the next
+                chunk overlap the GPU work on the current one (row f4, input pipeline)."""
                 labels = [first_label if i == view_inds[0] else label_fn(i, aggregate_img_scale) for i in inds]
                 if isinstance(labels[0], torch.Tensor):
-                    lab = torch.stack([l.to(self.backend.device, torch.uint8) for l in labels], dim=0)
-                else:
-                    lab = np.stack([np.asarray(l).astype(np.uint8) for l in labels], axis=0)
-                # fused: face ids stay in the rasterizer's LDS tiles, only per-face winners reach HBM
-                records, _ = self._raster_records(sub, mesh, aggregate_img_scale, **_raster_kwargs(kwargs))
-                self.backend.raster_project_labels(
-                    records, lab, C, votes, counts, neg1_is_last_face=self.neg1_is_last_face
-                )
+                    return torch.stack([l.to(self.backend.device, torch.uint8) for l in labels], dim=0)
+                arr = np.stack([np.asarray(l).astype(np.uint8, copy=False) for l in labels], axis=0)
+                t = torch.from_numpy(arr)
+                if self.backend.device.type == "cuda":
+                    t = t.pin_memory()
+                return t
+
+            from concurrent.futures import ThreadPoolExecutor
+
+            with ThreadPoolExecutor(max_workers=1) as pool:
+                pending = pool.submit(load_chunk, chunks[0]) if chunks else None
+                for ci in tqdm(range(len(chunks)), total=len(chunks), desc="Aggregating projected viewpoints"):
+                    lab = pending.result()
+                    pending = pool.submit(load_chunk, chunks[ci + 1]) if ci + 1 < len(chunks) else None
+                    sub = cameras.get_subset_cameras(chunks[ci])
+                    if lab.device.type != self.backend.device.type:
+                        lab = lab.to(self.backend.device, non_blocking=True)
+                    # fused: face ids stay in the rasterizer's LDS tiles, only per-face winners reach HBM
+                    records, _ = self._raster_records(sub, mesh, aggregate_img_scale, **_raster_kwargs(kwargs))
+                    self.backend.raster_project_labels(
+                        records, lab, C, votes, counts, neg1_is_last_face=self.neg1_is_last_face
+                    )
             if distributed and world > 1:
                 dist_utils.all_reduce_votes(votes, counts)
             avg, summed, cnt = self.backend.finalize_votes(votes, counts)
