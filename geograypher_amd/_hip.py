@@ -246,7 +246,8 @@ class HipRaster:
         self._check(self.lib.gr_set_profiling(self._ctx, 1 if enabled else 0), "gr_set_profiling")
 
     def set_option(self, key: int, value: int):
-        """Tuning knobs of include/geograster.h (GR_OPT_*): 1 raster kernel, 2 tile height log2, 3 batch."""
+        """Tuning knobs of include/geograster.h (GR_OPT_*): 2 tile height log2, 3 views per launch group, 6 single-pass
+        slots per tile (0 = exact binning)."""
         self._check(self.lib.gr_set_option(self._ctx, int(key), int(value)), "gr_set_option")
 
     def stage_times(self) -> dict:

@@ -772,124 +772,6 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K4p  persistent form of the tile rasterizer.  grid (G) workgroups; workgroup g rasterizes work items g, g+G, ...
-//      (item = tile of a view of the launch group) in a software pipeline that keeps every global-memory latency
-//      off the critical path:
-//        while item i is rasterized   the 64-byte entries of item i+1 are already in flight into a second register set
-//                                     and the (count, offset) words of item i+2 are being fetched;
-//        the id stores of item i      drain while item i+1 is rasterized (the workgroup does not end per tile);
-//        the LDS keys are re-zeroed   by the epilogue itself (read key, write 0): two barriers per tile, no zero pass.
-// ------------------------------------------------------------------------------------------------------------------
-template <int TWL, int THL, int NT, bool PREFETCH>
-__global__ __launch_bounds__(NT) void k_raster_rows_persistent(BinArgs a, RasterOut out, int n_items) {
-  constexpr int TW = 1 << TWL, TH = 1 << THL, NW = NT / 64;
-  __shared__ unsigned long long keys[(TW + GR_LDS_PAD) * TH];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int G = gridDim.x;
-
-  for (int i = tid; i < (TW + GR_LDS_PAD) * TH; i += NT) keys[i] = 0ull;
-
-  // (slot, tile) of an item without a division per step
-  int it0 = blockIdx.x;
-  if (it0 >= n_items) return;
-  int slot0 = it0 / a.T, tile0 = it0 - slot0 * a.T;
-  auto advance = [&](int &slot, int &tile) {
-    tile += G;
-    while (tile >= a.T) { tile -= a.T; ++slot; }
-  };
-  auto load_ctrl = [&](int slot, int tile, uint32_t &cnt, int64_t &beg) {
-    const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
-    if (a.cap_tile > 0) {
-      cnt = min(ctrl[GR_CTRL_HDR + tile], (uint32_t)a.cap_tile);
-      beg = (int64_t)tile * a.cap_tile;
-    } else {
-      cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
-      beg = ctrl[GR_CTRL_HDR + 2 * a.Tcap + tile];
-      if (beg >= a.ent_cap) cnt = 0;
-      else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
-    }
-    if (a.dbg & 4) cnt = 0;
-  };
-  auto load_entries = [&](int slot, uint32_t cnt, int64_t beg, uint32_t c0, int4 &s0, int4 &s1, int4 &s2, int4 &s3) {
-    const uint32_t e = c0 + lane * NW + wv;
-    s0 = make_int4(0, 0, 0, 0); s1 = s0; s2 = s0; s3 = s0;
-    if (e < cnt) {
-      const int4 *cp = a.comp + ((int64_t)slot * a.ent_cap + beg + e) * 4;
-      s0 = cp[0]; s1 = cp[1]; s2 = cp[2]; s3 = cp[3];
-    }
-  };
-  auto rows_of = [&](const int4 s3, uint32_t e_valid) {
-    const int jlo = s3.z & 0xFF, jhi = (s3.z >> 8) & 0xFF, ilo = (s3.z >> 16) & 0xFF, ihi = (s3.z >> 24) & 0x7F;
-    return (e_valid && jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;
-  };
-
-  // prologue: item 0's control words and first entries, item 1's control words
-  int slot_c = slot0, tile_c = tile0;
-  uint32_t cnt_c; int64_t beg_c;
-  load_ctrl(slot_c, tile_c, cnt_c, beg_c);
-  int4 s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;
-  if (PREFETCH) load_entries(slot_c, cnt_c, beg_c, 0, s0, s1, s2, s3);
-  int it_n = it0 + G, slot_n = slot_c, tile_n = tile_c;
-  uint32_t cnt_n = 0; int64_t beg_n = 0;
-  if (it_n < n_items) { advance(slot_n, tile_n); load_ctrl(slot_n, tile_n, cnt_n, beg_n); }
-
-  for (int it = it0; it < n_items; it += G) {
-    // ---- prefetch: entries of the next item, control words of the one after ----------------------------------------------
-    int4 n0 = {0, 0, 0, 0}, n1 = n0, n2 = n0, n3 = n0;
-    const bool have_next = (it_n < n_items);
-    if (PREFETCH && have_next) load_entries(slot_n, cnt_n, beg_n, 0, n0, n1, n2, n3);
-    int it_nn = it_n + G, slot_nn = slot_n, tile_nn = tile_n;
-    uint32_t cnt_nn = 0; int64_t beg_nn = 0;
-    if (it_nn < n_items) { advance(slot_nn, tile_nn); load_ctrl(slot_nn, tile_nn, cnt_nn, beg_nn); }
-
-    const int tx = tile_c % a.TX, ty = tile_c / a.TX;
-    const int px0 = tx << TWL, py0 = ty << THL;
-    __syncthreads();  // keys are zero and every wave has left the previous epilogue
-    // ---- rasterize the current item --------------------------------------------------------------------------------------
-    if (PREFETCH) {
-      const uint32_t e = lane * NW + wv;
-      raster_wave_entries<TWL>(keys, s0, s1, s2, s3, rows_of(s3, e < cnt_c), lane, px0, py0, a.dbg);
-      for (uint32_t c0 = NT; c0 < cnt_c; c0 += NT) {  // lists longer than one entry per thread (dense views)
-        int4 x0, x1, x2, x3;
-        load_entries(slot_c, cnt_c, beg_c, c0, x0, x1, x2, x3);
-        raster_wave_entries<TWL>(keys, x0, x1, x2, x3, rows_of(x3, c0 + e < cnt_c), lane, px0, py0, a.dbg);
-      }
-    } else {
-      const uint32_t e = lane * NW + wv;
-      for (uint32_t c0 = 0; c0 < cnt_c; c0 += NT) {
-        int4 x0, x1, x2, x3;
-        load_entries(slot_c, cnt_c, beg_c, c0, x0, x1, x2, x3);
-        raster_wave_entries<TWL>(keys, x0, x1, x2, x3, rows_of(x3, c0 + e < cnt_c), lane, px0, py0, a.dbg);
-      }
-    }
-    __syncthreads();
-    // ---- epilogue: whole rows; read the key, leave a zero behind for the next item ------------------------------------------
-    {
-      constexpr int ROWS_PER_PASS = NT / TW;
-      const int col = tid & (TW - 1);
-      const int gx = px0 + col;
-      const int64_t plane = (int64_t)slot_c * a.h * a.w;
-      for (int row = tid >> TWL; row < TH; row += ROWS_PER_PASS) {
-        const int idx = lds_idx<TWL>(row, col);
-        const unsigned long long key = keys[idx];
-        keys[idx] = 0ull;
-        const int gy = py0 + row;
-        if (gx < a.w && gy < a.h && !(a.dbg & 2)) {
-          const int64_t p = plane + (int64_t)gy * a.w + gx;
-          if (out.ids) out.ids[p] = key ? (int32_t)(~(uint32_t)key) : -1;
-          if (out.depth) out.depth[p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
-        }
-      }
-    }
-    // ---- rotate the pipeline -----------------------------------------------------------------------------------------------
-    if (PREFETCH) { s0 = n0; s1 = n1; s2 = n2; s3 = n3; }
-    slot_c = slot_n; tile_c = tile_n; cnt_c = cnt_n; beg_c = beg_n;
-    it_n = it_nn; slot_n = slot_nn; tile_n = tile_nn; cnt_n = cnt_nn; beg_n = beg_nn;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // K5  last-writer-wins winners.  Four pixels per thread.  A pixel can only be its face's LAST pixel in row-major
 //     order if neither its right nor its lower neighbour shows the same face, so only those candidates issue the
 //     global atomicMax (~1-3 per visible face instead of ~80).  key = (pixel+1) << LB | label  (LB = 0: pixel+1).
@@ -1214,22 +1096,16 @@ struct gr_ctx {
   unsigned long long *stats = nullptr;
   int *flag = nullptr;
   int64_t ctrl_stride = 0, rec_stride = 0, ent_cap = 0, ent_cap_request = 0;
+  int64_t ctrl_have = 0, comp_have = 0, work_have = 0, rec_have = 0;  // allocated element counts
   int Tcap = 0, slots = 0;
   int64_t rec_F = 0;
   // tuning knobs (gr_set_option)
-  int opt_kernel = 1;   // threads per tile workgroup: 1 -> 256, 2 -> 512, 3 -> 128
   int opt_thl = 5;      // log2 tile height (5 or 6); width is 64.  64x32 tiles: 16 KiB of LDS, 8 workgroups per CU
   int opt_batch = GR_MAX_BATCH;
   int opt_dbg = 0;
-  int opt_wg_per_cu = 5;  // persistent raster: resident workgroups per CU
   int opt_direct_cap = 512;  // single-pass binning: entry slots per tile (0 = always use the exact two-pass path)
   bool direct_ok = true;     // cleared when a tile overflowed its slots: later calls take the exact path
   bool last_direct = false;
-  int opt_overlap = 0;    // 1: bin the next launch group on a side stream while the current one is rasterized.
-                          // Measured neutral on MI355X (41.1 vs 40.9 us/view): the stages share the same VALU/LDS pipes.
-  int n_cu = 256;
-  hipStream_t side_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_bins[2] = {nullptr, nullptr}, ev_tiles[2] = {nullptr, nullptr};
   // winner scratch
   void *winner = nullptr;
   size_t winner_bytes = 0;
@@ -1284,34 +1160,39 @@ struct Timed {  // RAII span around a kernel group when profiling is on
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-int ensure_bins(gr_ctx *c, int n_slots, int T) {
-  const int64_t F = c->F;
-  int64_t want_cap = c->ent_cap_request > 0 ? c->ent_cap_request : (F / 2 + 65536);
-  if (c->opt_direct_cap > 0 && c->direct_ok) want_cap = std::max<int64_t>(want_cap, (int64_t)T * c->opt_direct_cap);
-  const bool need_rec = !(c->opt_direct_cap > 0 && c->direct_ok);  // record planes only feed the exact two-pass path
-  if (c->ctrl && c->slots >= n_slots && c->Tcap >= T && c->rec_F == F && c->ent_cap >= want_cap &&
-      (!need_rec || c->rec != nullptr))
-    return GR_OK;
+// Grow-only scratch: every buffer keeps its own capacity and is re-allocated only when it is too small (a new mesh or
+// image size does not touch buffers that are already large enough).
+template <typename T>
+int grow(gr_ctx *c, T *&ptr, int64_t &have, int64_t want, const char *what) {
+  if (ptr && have >= want) return GR_OK;
   (void)hipDeviceSynchronize();
-  if (c->ctrl) (void)hipFree(c->ctrl);
-  if (c->rec) (void)hipFree(c->rec);
-  if (c->comp) (void)hipFree(c->comp);
-  if (c->work) (void)hipFree(c->work);
-  c->ctrl = nullptr; c->rec = nullptr; c->comp = nullptr; c->work = nullptr;
-  const int slots = n_slots > c->slots ? n_slots : c->slots;
-  const int Tcap = T > c->Tcap ? T : c->Tcap;
-  const int64_t cap = want_cap > c->ent_cap ? want_cap : c->ent_cap;
+  if (ptr) (void)hipFree(ptr);
+  ptr = nullptr; have = 0;
+  if (hipMalloc(&ptr, sizeof(T) * (size_t)want) != hipSuccess)
+    return fail(c, GR_ENOMEM, "%s scratch allocation failed (%lld bytes)", what, (long long)(sizeof(T) * (size_t)want));
+  have = want;
+  return GR_OK;
+}
+
+int ensure_bins(gr_ctx *c, int n_slots, int T) {
+  const int64_t F = c->F > 0 ? c->F : 1;
+  const bool direct = c->opt_direct_cap > 0 && c->direct_ok;
+  int64_t want_cap = c->ent_cap_request > 0 ? c->ent_cap_request : (F / 2 + 65536);
+  if (direct) want_cap = std::max<int64_t>(want_cap, (int64_t)T * c->opt_direct_cap);
+  // strides only ever grow, so a layout change re-allocates (rare: a larger image, mesh or launch group)
+  const int slots = std::max(n_slots, c->slots);
+  const int Tcap = std::max(T, c->Tcap);
+  const int64_t cap = std::max(want_cap, c->ent_cap);
   const int64_t ctrl_stride = ((GR_CTRL_HDR + 4 * (int64_t)Tcap) + 63) / 64 * 64;
-  if (hipMalloc(&c->ctrl, sizeof(uint32_t) * ctrl_stride * slots) != hipSuccess ||
-      (need_rec && hipMalloc(&c->rec, sizeof(int4) * 4 * (F > 0 ? F : 1) * slots) != hipSuccess) ||
-      hipMalloc(&c->comp, sizeof(int4) * 4 * cap * slots) != hipSuccess ||
-      hipMalloc(&c->work, sizeof(uint32_t) * ceil_div(F > 0 ? F : 1, 256) * slots) != hipSuccess) {
-    c->slots = 0; c->Tcap = 0; c->ent_cap = 0;
-    return fail(c, GR_ENOMEM, "bin scratch allocation failed (slots=%d F=%lld cap=%lld)", slots, (long long)F,
-                (long long)cap);
-  }
-  c->slots = slots; c->Tcap = Tcap; c->ent_cap = cap; c->ctrl_stride = ctrl_stride; c->rec_stride = 4 * F;
-  c->rec_F = F; c->work_stride = ceil_div(F > 0 ? F : 1, 256);
+  const int64_t work_stride = std::max<int64_t>(ceil_div(F, 256), c->work_stride);
+  const int64_t rec_F = std::max<int64_t>(F, c->rec_F);
+  int rc = grow(c, c->ctrl, c->ctrl_have, ctrl_stride * slots, "bin control");
+  if (!rc) rc = grow(c, c->comp, c->comp_have, 4 * cap * slots, "entry list");
+  if (!rc) rc = grow(c, c->work, c->work_have, work_stride * slots, "work list");
+  if (!rc && !direct) rc = grow(c, c->rec, c->rec_have, 4 * rec_F * slots, "record planes");  // exact path only
+  if (rc) return rc;
+  c->slots = slots; c->Tcap = Tcap; c->ent_cap = cap; c->ctrl_stride = ctrl_stride; c->work_stride = work_stride;
+  if (!direct) { c->rec_F = rec_F; c->rec_stride = 4 * rec_F; }
   return GR_OK;
 }
 
@@ -1379,37 +1260,15 @@ int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStr
   BinArgs a = make_args(c, h, w, slot0);
   {
     Timed t(c, s, ST_RASTER);
-    if (c->opt_kernel == 4 && !out.labels) {
-      const int n_items = a.T * nb;
-      const int G = std::min(n_items, c->n_cu * c->opt_wg_per_cu);
-      if (a.thl == 6)
-        hipLaunchKernelGGL((k_raster_rows_persistent<6, 6, 256, true>), dim3(G), dim3(256), 0, s, a, out, n_items);
-      else
-        hipLaunchKernelGGL((k_raster_rows_persistent<6, 5, 256, true>), dim3(G), dim3(256), 0, s, a, out, n_items);
-    } else if (c->opt_kernel == 5 && !out.labels) {
-      const int n_items = a.T * nb;
-      const int G = std::min(n_items, c->n_cu * c->opt_wg_per_cu);
-      if (a.thl == 6)
-        hipLaunchKernelGGL((k_raster_rows_persistent<6, 6, 256, false>), dim3(G), dim3(256), 0, s, a, out, n_items);
-      else
-        hipLaunchKernelGGL((k_raster_rows_persistent<6, 5, 256, false>), dim3(G), dim3(256), 0, s, a, out, n_items);
-    } else if (out.labels) {
+    if (out.labels) {
       if (a.thl == 6)
         hipLaunchKernelGGL((k_raster_rows<6, 6, 256, true>), dim3(a.T, nb), dim3(256), 0, s, a, out);
       else
         hipLaunchKernelGGL((k_raster_rows<6, 5, 256, true>), dim3(a.T, nb), dim3(256), 0, s, a, out);
-    } else if (c->opt_kernel <= 1 && a.thl == 6)
+    } else if (a.thl == 6)
       hipLaunchKernelGGL((k_raster_rows<6, 6, 256, false>), dim3(a.T, nb), dim3(256), 0, s, a, out);
-    else if (c->opt_kernel <= 1)
-      hipLaunchKernelGGL((k_raster_rows<6, 5, 256, false>), dim3(a.T, nb), dim3(256), 0, s, a, out);
-    else if (c->opt_kernel == 2 && a.thl == 6)
-      hipLaunchKernelGGL((k_raster_rows<6, 6, 512, false>), dim3(a.T, nb), dim3(512), 0, s, a, out);
-    else if (c->opt_kernel == 2)
-      hipLaunchKernelGGL((k_raster_rows<6, 5, 512, false>), dim3(a.T, nb), dim3(512), 0, s, a, out);
-    else if (a.thl == 6)
-      hipLaunchKernelGGL((k_raster_rows<6, 6, 128, false>), dim3(a.T, nb), dim3(128), 0, s, a, out);
     else
-      hipLaunchKernelGGL((k_raster_rows<6, 5, 128, false>), dim3(a.T, nb), dim3(128), 0, s, a, out);
+      hipLaunchKernelGGL((k_raster_rows<6, 5, 256, false>), dim3(a.T, nb), dim3(256), 0, s, a, out);
     c->prof_raster_launches += 1;
   }
   c->prof_views += nb;
@@ -1468,11 +1327,7 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   const int B = n_views < c->opt_batch ? n_views : c->opt_batch;
   const int thl = c->opt_thl;
   const int T = ((w + GR_TILE - 1) >> GR_TILE_LOG2) * ((h + (1 << thl) - 1) >> thl);
-  // Two scratch sets when there is more than one launch group: group g+1 is culled / set up / binned on the context's
-  // side stream while group g is rasterized on the caller's stream.  The binning kernels are latency-bound and the tile
-  // kernel is VALU-bound, so the two overlap instead of queueing behind each other.
-  const bool overlap = c->opt_overlap && n_views > B && c->side_stream != nullptr;
-  rc = ensure_bins(c, overlap ? 2 * B : B, T);
+  rc = ensure_bins(c, B, T);
   if (rc) return rc;
   const int64_t P = (int64_t)h * w, F = c->F;
   int LB = 0, key64 = 0;
@@ -1484,31 +1339,18 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   }
   c->last_stream = s;
   GR_HIP(c, hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 4, s));
-  hipStream_t s2 = overlap ? c->side_stream : s;
-  if (overlap) {  // the side stream starts after everything already queued on the caller's stream
-    GR_HIP(c, hipEventRecord(c->ev_fork, s));
-    GR_HIP(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
-  }
-  int g = 0;
-  for (int v0 = 0; v0 < n_views; v0 += B, ++g) {
+  for (int v0 = 0; v0 < n_views; v0 += B) {
     const int nb = (n_views - v0) < B ? (n_views - v0) : B;
-    const int set = overlap ? (g & 1) : 0;
-    if (overlap && g >= 2) GR_HIP(c, hipStreamWaitEvent(s2, c->ev_tiles[set], 0));  // set free again
-    rc = bin_batch(c, cams + (int64_t)v0 * GR_CAM_FLOATS, nb, h, w, set * B, s2);
+    rc = bin_batch(c, cams + (int64_t)v0 * GR_CAM_FLOATS, nb, h, w, 0, s);
     if (rc) return rc;
-    if (overlap) {
-      GR_HIP(c, hipEventRecord(c->ev_bins[set], s2));
-      GR_HIP(c, hipStreamWaitEvent(s, c->ev_bins[set], 0));
-    }
     RasterOut out;
     out.ids = ids ? ids + v0 * P : nullptr;
     out.depth = depth ? depth + v0 * P : nullptr;
     out.labels = labels ? labels + v0 * P : nullptr;
     out.winner = c->winner; out.F = F; out.C = C; out.LB = LB; out.key64 = key64;
     out.compat = (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0;
-    rc = tile_batch(c, nb, h, w, set * B, out, s);
+    rc = tile_batch(c, nb, h, w, 0, out, s);
     if (rc) return rc;
-    if (overlap) GR_HIP(c, hipEventRecord(c->ev_tiles[set], s));
     if (labels) {
       Timed t(c, s, ST_VOTE);
       if (key64)
@@ -1538,24 +1380,12 @@ int gr_ctx_create(int device, gr_ctx **out) {
   gr_ctx *c = new (std::nothrow) gr_ctx();
   if (!c) return GR_ENOMEM;
   c->device = device;
-  {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-      c->n_cu = prop.multiProcessorCount;
-  }
   if (hipMalloc(&c->stats, sizeof(unsigned long long) * 4) != hipSuccess ||
       hipMalloc(&c->flag, sizeof(int)) != hipSuccess) {
     delete c;
     return GR_ENOMEM;
   }
   (void)hipMemset(c->stats, 0, sizeof(unsigned long long) * 4);
-  if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) c->side_stream = nullptr;
-  bool ev_ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
-  for (int i = 0; i < 2; ++i) {
-    ev_ok = ev_ok && hipEventCreateWithFlags(&c->ev_bins[i], hipEventDisableTiming) == hipSuccess;
-    ev_ok = ev_ok && hipEventCreateWithFlags(&c->ev_tiles[i], hipEventDisableTiming) == hipSuccess;
-  }
-  if (!ev_ok && c->side_stream) { (void)hipStreamDestroy(c->side_stream); c->side_stream = nullptr; }
   *out = c;
   return GR_OK;
 }
@@ -1566,12 +1396,6 @@ int gr_ctx_destroy(gr_ctx *c) {
   (void)hipDeviceSynchronize();
   for (auto &sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   for (auto e : c->pool) (void)hipEventDestroy(e);
-  if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
-  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-  for (int i = 0; i < 2; ++i) {
-    if (c->ev_bins[i]) (void)hipEventDestroy(c->ev_bins[i]);
-    if (c->ev_tiles[i]) (void)hipEventDestroy(c->ev_tiles[i]);
-  }
   if (c->ctrl) (void)hipFree(c->ctrl);
   if (c->rec) (void)hipFree(c->rec);
   if (c->comp) (void)hipFree(c->comp);
@@ -1600,9 +1424,6 @@ int gr_set_profiling(gr_ctx *c, int enabled) {
 int gr_set_option(gr_ctx *c, int key, int value) {
   if (!c) return GR_EINVAL;
   switch (key) {
-    case GR_OPT_RASTER_KERNEL:
-      if (value < 1 || value > 5) return fail(c, GR_EINVAL, "raster kernel must be 1..5");
-      c->opt_kernel = value; return GR_OK;
     case GR_OPT_TILE_H_LOG2:
       if (value != 5 && value != 6) return fail(c, GR_EINVAL, "tile height log2 must be 5 or 6");
       c->opt_thl = value; return GR_OK;
@@ -1614,11 +1435,6 @@ int gr_set_option(gr_ctx *c, int key, int value) {
     case GR_OPT_DIRECT_CAP:
       if (value < 0 || value > 65536) return fail(c, GR_EINVAL, "slots per tile must be in [0, 65536]");
       c->opt_direct_cap = value; c->direct_ok = true; return GR_OK;
-    case GR_OPT_OVERLAP:
-      c->opt_overlap = value ? 1 : 0; return GR_OK;
-    case GR_OPT_WG_PER_CU:
-      if (value < 1 || value > 16) return fail(c, GR_EINVAL, "workgroups per CU must be in [1, 16]");
-      c->opt_wg_per_cu = value; return GR_OK;
     default: return fail(c, GR_EINVAL, "unknown option %d", key);
   }
 }

@@ -12,8 +12,7 @@
  *  - The caller allocates and owns all inputs and outputs.  The library allocates only per-context scratch
  *    (bin lists, per-face winners), grown lazily, freed by gr_ctx_destroy.
  *  - All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream) and is
- *    asynchronous.  (Calls that span several launch groups fork part of their work to a context-owned side stream and
- *    join it back with events before returning control of `stream`: the caller only ever orders against `stream`.)  No hidden synchronisation except: gr_ctx_destroy, gr_mesh_upload (index validation) and
+ *    asynchronous.  No hidden synchronisation except: gr_ctx_destroy, gr_mesh_upload (index validation) and
  *    scratch growth (hipMalloc/hipFree when a larger batch, image or mesh is first seen).
  *  - Return value: 0 (GR_OK) or a negative GR_E* code; text via gr_last_error().  No C++ exception crosses the ABI.
  *  - A context belongs to one (device, host thread); distinct contexts are independent.
@@ -89,16 +88,12 @@ int gr_set_profiling(gr_ctx *ctx, int enabled);
 
 /* Tuning knobs (results never depend on them; tests run every setting against the oracle). */
 enum {
-  GR_OPT_RASTER_KERNEL = 1, /* k_raster_rows with 1: 256 (default), 2: 512, 3: 128 threads per tile;
-                               4: k_raster_rows_persistent (software-pipelined, 256 threads)           */
   GR_OPT_TILE_H_LOG2 = 2,   /* tile height: 5 (64x32, default) or 6 (64x64)                                  */
-  GR_OPT_BATCH = 3,         /* views per launch group, 1..64 (default 64)                         */
-  GR_OPT_WG_PER_CU = 4,     /* persistent kernel: resident workgroups per CU, 1..16 (default 5)    */
+  GR_OPT_BATCH = 3,         /* views per launch group, 1..64 (default 64)                                    */
   GR_OPT_DIRECT_CAP = 6,    /* single-pass binning: entry slots per tile (default 512); 0 = always bin exactly
                                (count, scan, fill).  A tile that outgrows its slots is reported by
                                gr_raster_status (GR_EOVERFLOW); the context then bins exactly from the retry on */
-  GR_OPT_OVERLAP = 5,       /* 1: bin launch group g+1 on a side stream while g is rasterized (default 0) */
-  GR_OPT_DEBUG = 99         /* timing-only ablation mask for tools/ab_raster.py: OUTPUTS BECOME WRONG */
+  GR_OPT_DEBUG = 99         /* timing-only ablation mask for tools/ab_raster.py: OUTPUTS BECOME WRONG         */
 };
 int gr_set_option(gr_ctx *ctx, int key, int value);
 int gr_get_stage_times(gr_ctx *ctx, gr_stage_times *out_h);

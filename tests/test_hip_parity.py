@@ -14,19 +14,16 @@ from oracle import oracle_c, oracle_np
 pytestmark = pytest.mark.gpu
 
 # every raster test runs against each tile-kernel variant (include/geograster.h GR_OPT_*): results must not change
-# (tile kernel, tile height log2, single-pass slots per tile: 0 = exact two-pass binning)
-VARIANTS = {"rows64": (1, 6, 512), "rows32": (1, 5, 512), "rows32_exact": (1, 5, 0), "rows64_512_exact": (2, 6, 0),
-            "rows32_128": (3, 5, 512), "persist32": (4, 5, 512), "persist64_exact": (4, 6, 0), "persist32_nopf": (5, 5, 512)}
+# (tile height log2, single-pass slots per tile: 0 = exact two-pass binning): results must not depend on the knobs
+VARIANTS = {"tile32_direct": (5, 512), "tile64_direct": (6, 512), "tile32_exact": (5, 0), "tile64_exact": (6, 0)}
 
 
 @pytest.fixture(params=list(VARIANTS), autouse=True)
 def raster_variant(request, hip):
-    kernel, thl, cap = VARIANTS[request.param]
-    hip.set_option(1, kernel)
+    thl, cap = VARIANTS[request.param]
     hip.set_option(2, thl)
     hip.set_option(6, cap)
     yield request.param
-    hip.set_option(1, 1)
     hip.set_option(2, 5)
     hip.set_option(6, 512)
 
@@ -137,12 +134,10 @@ def test_empty_view_and_single_face(hip):
     assert np.all(ids[0] == -1) and set(np.unique(ids[1])) == {-1, 0}
 
 
-@pytest.mark.parametrize("batch,overlap", [(64, 1), (32, 0), (5, 1), (5, 0), (1, 1)])
-def test_many_views_in_one_call_cross_batch_boundary(hip, batch, overlap):
-    """More views than one launch group: results must not depend on the batching nor on the two-stream overlap of the
-    binning and tile stages (scratch double buffering)."""
+@pytest.mark.parametrize("batch", [64, 32, 5, 1])
+def test_many_views_in_one_call_cross_batch_boundary(hip, batch):
+    """More views than one launch group: results must not depend on the batching."""
     hip.set_option(3, batch)
-    hip.set_option(5, overlap)
     (points, faces), cams = synthetic.config1_scene()
     poses = [synthetic.nadir_pose(3.0 * k - 30, 2.0 * k - 20, 35.0 + k, yaw_deg=11.0 * k) for k in range(70)]
     cams = synthetic.camera_set_from_poses(poses, f=260.0, width=320, height=200)
@@ -159,7 +154,6 @@ def test_many_views_in_one_call_cross_batch_boundary(hip, batch, overlap):
         assert torch.equal(v1, v2) and torch.equal(c1, c2)
     finally:
         hip.set_option(3, 64)
-        hip.set_option(5, 0)
 
 
 def test_single_pass_binning_overflow_falls_back_to_exact(hip):
@@ -183,7 +177,7 @@ def test_bin_overflow_is_detected_and_retried(hip, raster_variant):
     hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
     recs = _records(cams)
     ids = hip.raster_face_ids(recs, 3000, 4000).cpu().numpy()
-    tiles = 63 * (47 if "32" not in raster_variant else 94)
+    tiles = 63 * (47 if "tile64" in raster_variant else 94)
     assert hip.last_stats["overflow"] == 0 and hip.last_stats["entries"] == n * tiles
     if "exact" in raster_variant:
         assert hip.last_stats["entry_cap"] >= n * tiles

@@ -25,13 +25,14 @@ def main():
     hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
     ids = torch.empty((nv, H, W), dtype=torch.int32, device="cuda")
     ref = None
-    # (name, kernel, tile_h_log2, batch, debug mask, single-pass slots per tile)
-    variants = [("direct512_b32", 1, 5, 32, 0, 512), ("direct512_b25", 1, 5, 25, 0, 512), ("direct512_b50", 1, 5, 50, 0, 512),
-                ("direct512_b64", 1, 5, 64, 0, 512), ("direct384_b50", 1, 5, 50, 0, 384)]
+    # (name, tile_h_log2, batch, debug mask, single-pass slots per tile)
+    variants = [("direct512_b64", 5, 64, 0, 512), ("exact_b64", 5, 64, 0, 0), ("direct512_b32", 5, 32, 0, 512),
+                ("tile64_direct1024", 6, 64, 0, 1024), ("noscan", 5, 64, 1, 512), ("nostore", 5, 64, 2, 512),
+                ("notri", 5, 64, 4, 512)]
     results = {}
     for rep in range(3):
-        for name, k, thl, b, dbg, cap in variants:
-            hip.set_option(1, k); hip.set_option(2, thl); hip.set_option(3, b); hip.set_option(99, dbg); hip.set_option(6, cap)
+        for name, thl, b, dbg, cap in variants:
+            hip.set_option(2, thl); hip.set_option(3, b); hip.set_option(99, dbg); hip.set_option(6, cap)
             hip.raster_face_ids(recs, H, W, out=ids, check=True)
             if ref is None:
                 ref = ids.clone()
