@@ -150,22 +150,21 @@ __global__ __launch_bounds__(256) void k_build_soup(const float *__restrict__ ve
 //     (d) tile counting is aggregated per wave as well: lanes that hit the same tile share one returning atomicAdd
 //         and receive consecutive list positions, which k_fill_bins later uses without any atomic.
 // ------------------------------------------------------------------------------------------------------------------
-// Lanes of a wave that hit the same tile form a group: leader lane, rank inside the group, group size -- found with
-// ballots and shuffles only (no memory traffic), so that the leaders' atomics can all be issued back to back.
+// Neighbouring lanes of a wave that hit the same tile form a run (photogrammetry meshes keep neighbouring faces close
+// in index order, so runs are long): leader lane, rank inside the run, run length -- found with two ballots and bit
+// arithmetic in constant time (no loop over distinct tiles, no memory traffic), so that the leaders' atomics can all be
+// issued back to back.  Equal tiles that are not adjacent in lane order simply form separate runs (one atomic each).
 __device__ __forceinline__ void wave_group(int t, int lane, int &leader, int &rank, int &size) {
-  leader = lane; rank = 0; size = 0;
-  unsigned long long rem = __ballot(t >= 0);
-  while (rem) {
-    const int l = __ffsll((long long)rem) - 1;
-    const int tl = __shfl(t, l);
-    const unsigned long long m = __ballot(t == tl);
-    if (t == tl) {
-      leader = l;
-      rank = __popcll(m & ((1ull << lane) - 1ull));
-      size = __popcll(m);
-    }
-    rem &= ~m;
-  }
+  const int tprev = __builtin_amdgcn_update_dpp(-2, t, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);  // lane 0 keeps -2
+  const unsigned long long valid = __ballot(t >= 0);
+  const unsigned long long heads = __ballot(t >= 0 && tprev != t);
+  const unsigned long long upto = (2ull << lane) - 1ull;                 // bits 0..lane
+  const unsigned long long mine = heads & upto;                          // run heads at or below this lane
+  leader = mine ? 63 - __clzll((long long)mine) : lane;
+  rank = lane - leader;
+  const unsigned long long stop = (heads | ~valid) & ~upto;              // next run head or inactive lane above
+  size = (stop ? __ffsll((long long)stop) - 1 : 64) - leader;
+  if (t < 0) { leader = lane; rank = 0; size = 0; }
 }
 
 // K0b  per view: sphere-vs-frustum test of every 256-face block (one thread per block); survivors are appended to the
@@ -213,6 +212,8 @@ __device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, const int4
 template <bool DIRECT>
 __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ verts, const int32_t *__restrict__ faces,
                                                     const float *__restrict__ cams, BinArgs a) {
+  // single-pass binning: per-wave staging rows for the transposed entry stores (5 x 16 B per lane: 64 B + bank padding)
+  __shared__ int4 stage[DIRECT ? 4 : 1][DIRECT ? 64 : 1][5];
   const int slot = blockIdx.y;
   const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
   uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
@@ -301,21 +302,46 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
   r3.y = (int)(__shfl(b1, l1) + (uint32_t)k1);
   r3.z = (int)(__shfl(b2, l2) + (uint32_t)k2);
   r3.w = (int)(__shfl(b3, l3) + (uint32_t)k3);
-  if (keep && DIRECT) {
+  if (DIRECT) {
     int4 *comp = a.comp + slot * a.ent_cap * 4;
     const int TW = 1 << a.twl, TH = 1 << a.thl;
+    const int wv = threadIdx.x >> 6;
+    // Faces over at most 2x2 tiles: tile k of the footprint is compiled by the face's lane into the wave's LDS staging
+    // rows, then FOUR lanes store one entry (16 bytes each): every store instruction writes whole 64-byte entries
+    // instead of a 16-byte piece of 64 different ones (the scattered partial writes cost 2 us per C2 view).
 #pragma unroll 1
-    for (int ty = ty0; ty <= ty1; ++ty) {
+    for (int k = 0; k < 4; ++k) {
+      const int tx = tx0 + (k & 1), ty = ty0 + (k >> 1);
+      const bool need = small_fp && tx <= tx1 && ty <= ty1;
+      if (__ballot(need) == 0ull) continue;
+      uint32_t idx = 0xFFFFFFFFu;
+      if (need) {
+        const uint32_t pos = (uint32_t)(k == 0 ? r3.x : k == 1 ? r3.y : k == 2 ? r3.z : r3.w);
+        if (pos < (uint32_t)a.cap_tile) {
+          compile_entry(&stage[wv][lane][0], r0, r1, r2, tx << a.twl, ty << a.thl, TW, TH);
+          idx = (uint32_t)(ty * a.TX + tx) * (uint32_t)a.cap_tile + pos;
+        } else {
+          ctrl[2] = 1u;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = 16 * j + (lane >> 2), q = lane & 3;
+        const uint32_t di = (uint32_t)__shfl((int)idx, e);
+        if (di != 0xFFFFFFFFu) comp[(int64_t)di * 4 + q] = stage[wv][e][q];
+      }
+    }
+    if (keep && !small_fp) {  // faces over more than 2x2 tiles (rare): one plain atomic and a direct store per tile
 #pragma unroll 1
-      for (int tx = tx0; tx <= tx1; ++tx) {
-        const int t = ty * a.TX + tx;
-        const int k = ((ty - ty0) << 1) | (tx - tx0);
-        uint32_t pos;
-        if (small_fp) pos = (uint32_t)(k == 0 ? r3.x : k == 1 ? r3.y : k == 2 ? r3.z : r3.w);
-        else pos = atomicAdd(&cntS[t], 1u);  // faces over more than 2x2 tiles: one plain atomic per tile
-        if (pos < (uint32_t)a.cap_tile) compile_entry(comp + ((int64_t)t * a.cap_tile + pos) * 4, r0, r1, r2, tx << a.twl,
-                                                      ty << a.thl, TW, TH);
-        else ctrl[2] = 1u;
+      for (int ty = ty0; ty <= ty1; ++ty) {
+#pragma unroll 1
+        for (int tx = tx0; tx <= tx1; ++tx) {
+          const int t = ty * a.TX + tx;
+          const uint32_t pos = atomicAdd(&cntS[t], 1u);
+          if (pos < (uint32_t)a.cap_tile) compile_entry(comp + ((int64_t)t * a.cap_tile + pos) * 4, r0, r1, r2, tx << a.twl,
+                                                        ty << a.thl, TW, TH);
+          else ctrl[2] = 1u;
+        }
       }
     }
   }
@@ -416,6 +442,13 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(BinArgs a) {
 //       word  8..11  B2 iz0 zA zB
 //       word 12..15  X0rel Y0rel bbox ~face      (Px - X0 = 256 x + X0rel;  bbox = jlo | jhi<<8 | ilo<<16 | ihi<<24)
 // ------------------------------------------------------------------------------------------------------------------
+// Faces whose snapped bounding box is smaller than GR_FAST_EXT sub-pixels (93 px) take a short form of the set-up: the
+// face overlaps the tile, so every pixel the tile rasterizer can probe (x in [-2, TW+2], y in [0, TH]) lies within
+// reach = (64 + 3) * 256 + ext < 41152 sub-pixels of every vertex, |dx|, |dy| <= ext, hence
+//   |E| <= (|dx| + |dy|) * reach + 1 < 48000 * 41152 < 2^31   and   |A|, |B| = 256 * |d| < 2^23:
+// every product has 24-bit factors and every value fits int32 -- no 64-bit arithmetic, no per-tile range test.
+// Larger faces take the general form below (identical coverage: both forms are exact).
+#define GR_FAST_EXT 24000
 __device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, const int4 p0, const int4 p1, const int4 p2,
                                               int px0, int py0, int TW, int TH) {
   const int X0 = p0.x, Y0 = p0.y, X1 = p0.z, Y1 = p0.w, X2 = p1.x, Y2 = p1.y;
@@ -423,9 +456,22 @@ __device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, const int4
   const int jlo = max((p2.z & 0xFFFF) - px0, 0), jhi = min((int)((uint32_t)p2.z >> 16) - px0, TW - 1);
   const int ilo = max((p2.w & 0xFFFF) - py0, 0), ihi = min((int)((uint32_t)p2.w >> 16) - py0, TH - 1);
   const int dx0 = X1 - X0, dy0 = Y1 - Y0, dx1 = X2 - X1, dy1 = Y2 - Y1, dx2 = X0 - X2, dy2 = Y0 - Y2;
-  const long long b0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;  // R3 top-left rule as a bias
-  const long long b1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
-  const long long b2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
+  const int t0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;  // R3 top-left rule as a bias
+  const int t1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
+  const int t2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
+  const int ext = max(imax3(X0, X1, X2) - imin3(X0, X1, X2), imax3(Y0, Y1, Y2) - imin3(Y0, Y1, Y2));
+  const int box = jlo | (jhi << 8) | (ilo << 16) | (ihi << 24);
+  if (ext < GR_FAST_EXT) {
+    const int c0 = __mul24(dx0, Pyo - Y0) - __mul24(dy0, Pxo - X0) + t0;
+    const int c1 = __mul24(dx1, Pyo - Y1) - __mul24(dy1, Pxo - X1) + t1;
+    const int c2 = __mul24(dx2, Pyo - Y2) - __mul24(dy2, Pxo - X2) + t2;
+    dst[0] = make_int4(c0, c1, c2, -dy0 * 256);
+    dst[1] = make_int4(-dy1 * 256, -dy2 * 256, dx0 * 256, dx1 * 256);
+    dst[2] = make_int4(dx2 * 256, p1.z, p2.x, p2.y);
+    dst[3] = make_int4(Pxo - X0, Pyo - Y0, box, (int)~(uint32_t)p1.w);
+    return;
+  }
+  const long long b0 = t0, b1 = t1, b2 = t2;
   const long long C0 = (long long)dx0 * (Pyo - Y0) - (long long)dy0 * (Pxo - X0) + b0;
   const long long C1 = (long long)dx1 * (Pyo - Y1) - (long long)dy1 * (Pxo - X1) + b1;
   const long long C2 = (long long)dx2 * (Pyo - Y2) - (long long)dy2 * (Pxo - X2) + b2;
@@ -439,7 +485,7 @@ __device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, const int4
                      (llabs(C2) + (TW + 2) * llabs(A2) + TH * llabs(B2) < lim) &&
                      llabs(A0) <= m24 && llabs(A1) <= m24 && llabs(A2) <= m24 &&
                      llabs(B0) <= m24 && llabs(B1) <= m24 && llabs(B2) <= m24;
-  const int bbox = jlo | (jhi << 8) | (ilo << 16) | (ihi << 24) | (small ? 0 : (int)0x80000000);
+  const int bbox = box | (small ? 0 : (int)0x80000000);
   if (small) {
     dst[0] = make_int4((int)C0, (int)C1, (int)C2, (int)A0);
     dst[1] = make_int4((int)A1, (int)A2, (int)B0, (int)B1);
@@ -654,120 +700,175 @@ __device__ __forceinline__ void raster_wave_entries(unsigned long long *keys, co
     }
 }
 
+// GR_TILES_PER_WG consecutive tiles of one view can be rasterized by the same workgroup, one after the other, with the
+// NEXT tile's first entries requested before the current tile's ids are stored (vector memory completes in issue
+// order, so those loads do not wait for the younger stores, and the stores drain while the next tile is rasterized).
+// Measured on MI355X (C2): 4 tiles per workgroup 23.5 us/view against 21.7 for 1 -- the tile loop costs 14 VGPRs
+// (6 instead of 8 waves per SIMD), and occupancy is worth more to this kernel than the overlap.  Kept at 1.
+#define GR_TILES_PER_WG 1
 template <int TWL, int THL, int NT, bool FUSE>
 __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
+  constexpr int KT = GR_TILES_PER_WG;
   __shared__ __attribute__((aligned(16))) unsigned long long keys[(TW + GR_LDS_PAD) * TH];  // the kernel's only LDS: 16.25 KiB (64x32)
 
   const int slot = blockIdx.y;
-  const int tile = blockIdx.x;
-  const int tx = tile % a.TX, ty = tile / a.TX;
-  const int px0 = tx << TWL, py0 = ty << THL;
+  const int tile0 = blockIdx.x * KT;
   const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  uint32_t cnt;
-  int64_t beg;
-  if (a.cap_tile > 0) {  // single-pass binning: fixed segment per tile
-    cnt = min(ctrl[GR_CTRL_HDR + tile], (uint32_t)a.cap_tile);
-    beg = (int64_t)tile * a.cap_tile;
-  } else {
-    cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
-    beg = ctrl[GR_CTRL_HDR + 2 * a.Tcap + tile];
-    if (beg >= a.ent_cap) cnt = 0;
-    else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
-  }
-  if (a.dbg & 4) cnt = 0;
-  const int4 *comp = a.comp + (slot * a.ent_cap + beg) * 4;
-
-  {  // zero the tile: 16-byte LDS stores
-    static_assert(((TW + GR_LDS_PAD) * TH) % 2 == 0, "key pairs");
-    ulonglong2 *k2 = reinterpret_cast<ulonglong2 *>(keys);
-    for (int i = tid; i < (TW + GR_LDS_PAD) * TH / 2; i += NT) k2[i] = make_ulonglong2(0ull, 0ull);
-  }
-  __syncthreads();
-
-  // entries are dealt round-robin to the NW waves (entry e -> wave e % NW) so that a short list still feeds every wave
   constexpr int NW = NT / 64;
-  for (uint32_t c0 = 0; c0 < cnt; c0 += NT) {
-    // ---- phase 1: one compiled entry per lane, kept in registers ---------------------------------------------------------
-    const uint32_t e = c0 + lane * NW + wv;
-    int4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, s3 = {0, 0, 0, 0};
-    int nrows = 0;
-    if (e < cnt) {
-      s0 = comp[e * 4 + 0]; s1 = comp[e * 4 + 1]; s2 = comp[e * 4 + 2]; s3 = comp[e * 4 + 3];
-      const int jlo = s3.z & 0xFF, jhi = (s3.z >> 8) & 0xFF, ilo = (s3.z >> 16) & 0xFF, ihi = (s3.z >> 24) & 0x7F;
-      nrows = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;
-    }
-    raster_wave_entries<TWL>(keys, s0, s1, s2, s3, nrows, lane, px0, py0, a.dbg);
-  }
-  __syncthreads();
-
-  // epilogue: whole rows (TW pixels, coalesced); the NW waves interleave over the TH rows
   constexpr int ROWS_PER_PASS = NT / TW;
-  const int col = tid & (TW - 1);
-  const int gx = px0 + col;
-  if (gx < a.w && !(a.dbg & 2)) {
-    const int64_t P = (int64_t)a.h * a.w;
-    const int64_t plane = (int64_t)slot * P;
-    if (!FUSE && out.ids && !out.depth) {
-      // ids only (the common case): the key's low dword is ~face, and 0 for an empty pixel, so id = ~low for both;
-      // one 4-byte LDS read, one NOT, one store per pixel, the output pointer advances by a constant stride
-      const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
-      const int rows_here = min(TH, a.h - py0);
-      int32_t *dst = out.ids + plane + (int64_t)(py0 + (tid >> TWL)) * a.w + gx;
-      const int64_t dstep = (int64_t)ROWS_PER_PASS * a.w;
-      for (int row = tid >> TWL; row < rows_here; row += ROWS_PER_PASS, dst += dstep)
-        *dst = (int32_t)~klo[2 * lds_idx<TWL>(row, col)];
-      return;
+  constexpr int RW = TH / (NT / 64);
+  const int64_t P = (int64_t)a.h * a.w;
+  const int64_t plane = (int64_t)slot * P;
+
+  // Single-pass binning: a tile's segment starts at a known address, so its first GR_SPEC entries are requested before
+  // its count is known (count read and entry read are ONE memory round trip instead of two dependent ones; most tiles
+  // hold fewer entries than that).  Slots beyond the count hold stale data and are dropped.
+  constexpr uint32_t GR_SPEC = 64;
+  const uint32_t e_first = (uint32_t)(lane * NW + wv);
+  const bool direct = a.cap_tile > 0;
+  const bool spec = a.cap_tile >= (int)GR_SPEC && e_first < GR_SPEC;
+  int4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, s3 = {0, 0, 0, 0};  // this lane's entry
+  auto prefetch = [&](int tile) {
+    if (spec && tile < a.T) {
+      const int4 *cs = a.comp + (slot * a.ent_cap + (int64_t)tile * a.cap_tile + e_first) * 4;
+      s0 = cs[0]; s1 = cs[1]; s2 = cs[2]; s3 = cs[3];
     }
-    if (FUSE && !out.depth && TW == 64) {
-      // Fused projection epilogue.  Each wave owns TH/NW CONSECUTIVE rows: the row below is read from LDS once and
-      // becomes the current row of the next step; the right neighbour comes from the next lane (DPP wave shift), so a
-      // pixel costs one 4-byte LDS read.  Across a tile edge the neighbour is unknown (-3: "differs", one atomic too
-      // many at worst); outside the image it is -2 exactly as in k_winner.
-      constexpr int RW = TH / (NT / 64);
-      const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
-      const int r0 = (tid >> 6) * RW;
-      const int last = (int)out.F - 1;
-      int cur = (int32_t)~klo[2 * lds_idx<TWL>(r0, col)];
-      const int rows_here = min(RW, a.h - (py0 + r0));          // rows of this wave inside the image (wave-uniform)
-      const bool right_out = (gx + 1 >= a.w);
-      const int bg = out.compat ? last : -1;                     // what a background pixel counts as (meshes.py:1998-2001)
-      int64_t p = (int64_t)(py0 + r0) * a.w + gx;                // linear pixel index, advanced by w per row
-      int32_t *idp = out.ids ? out.ids + plane + p : nullptr;
-      const uint8_t *lp = out.labels + plane + p;
-      uint32_t *win32 = (uint32_t *)out.winner + slot * out.F;
-      unsigned long long *win64 = (unsigned long long *)out.winner + slot * out.F;
-      for (int k = 0; k < rows_here; ++k, p += a.w, lp += a.w) {
-        const int row = r0 + k;
-        const int nxt = (row + 1 < TH) ? (int32_t)~klo[2 * lds_idx<TWL>(min(row + 1, TH - 1), col)] : -3;
-        int fr = __builtin_amdgcn_update_dpp(-3, cur, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-        fr = right_out ? -2 : fr;
-        int fb = (py0 + row + 1 >= a.h) ? -2 : nxt;
-        if (idp) { *idp = cur; idp += a.w; }
-        const int f = cur == -1 ? bg : cur;
-        fr = fr == -1 ? bg : fr;
-        fb = fb == -1 ? bg : fb;
-        if (f >= 0 && fr != f && fb != f) {  // candidate: only now is the label needed
-          const int label = min((int)*lp, out.C);
-          if (out.key64) atomicMax(win64 + f, ((unsigned long long)(p + 1) << out.LB) | (unsigned long long)label);
-          else atomicMax(win32 + f, ((uint32_t)(p + 1) << out.LB) | (uint32_t)label);
-        }
-        cur = nxt;
+  };
+  prefetch(tile0);
+  // the counts of all KT tiles (single-pass binning); words past the view's last tile are valid memory and unused
+  uint32_t cn0 = 0, cn1 = 0, cn2 = 0, cn3 = 0;
+  if (direct) {
+    const uint32_t *cp = ctrl + GR_CTRL_HDR + tile0;
+    cn0 = cp[0];
+    if (KT > 1) cn1 = cp[1];
+    if (KT > 2) cn2 = cp[2];
+    if (KT > 3) cn3 = cp[3];
+  }
+  static_assert(KT >= 1 && KT <= 4, "tile counts are held in four scalars");
+
+#pragma unroll 1
+  for (int it = 0; it < KT; ++it) {
+    const int tile = tile0 + it;
+    if (tile >= a.T) break;
+    const int tx = tile % a.TX, ty = tile / a.TX;
+    const int px0 = tx << TWL, py0 = ty << THL;
+    uint32_t cnt;
+    int64_t beg;
+    if (direct) {
+      cnt = min(it == 0 ? cn0 : it == 1 ? cn1 : it == 2 ? cn2 : cn3, (uint32_t)a.cap_tile);
+      beg = (int64_t)tile * a.cap_tile;
+    } else {
+      cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
+      beg = ctrl[GR_CTRL_HDR + 2 * a.Tcap + tile];
+      if (beg >= a.ent_cap) cnt = 0;
+      else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
+    }
+    if (a.dbg & 4) cnt = 0;
+    const int4 *comp = a.comp + (slot * a.ent_cap + beg) * 4;
+
+    {  // zero the tile: 16-byte LDS stores
+      static_assert(((TW + GR_LDS_PAD) * TH) % 2 == 0, "key pairs");
+      ulonglong2 *k2 = reinterpret_cast<ulonglong2 *>(keys);
+      int tz = tid;
+      asm volatile("" : "+v"(tz));  // per-thread addresses are re-derived here, not kept in registers across the tile loop
+      for (int i = tz; i < (TW + GR_LDS_PAD) * TH / 2; i += NT) k2[i] = make_ulonglong2(0ull, 0ull);
+    }
+    __syncthreads();
+
+    // entries are dealt round-robin to the NW waves (entry e -> wave e % NW) so that a short list still feeds every wave
+    for (uint32_t c0 = 0; c0 < cnt; c0 += NT) {
+      // ---- phase 1: one compiled entry per lane, kept in registers -------------------------------------------------------
+      const uint32_t e = c0 + e_first;
+      int nrows = 0;
+      if (e < cnt) {
+        if (!(c0 == 0 && spec)) { s0 = comp[e * 4 + 0]; s1 = comp[e * 4 + 1]; s2 = comp[e * 4 + 2]; s3 = comp[e * 4 + 3]; }
+        const int jlo = s3.z & 0xFF, jhi = (s3.z >> 8) & 0xFF, ilo = (s3.z >> 16) & 0xFF, ihi = (s3.z >> 24) & 0x7F;
+        nrows = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;
       }
-      return;
+      raster_wave_entries<TWL>(keys, s0, s1, s2, s3, nrows, lane, px0, py0, a.dbg);
     }
-    for (int row = tid >> TWL; row < TH; row += ROWS_PER_PASS) {
-      const int gy = py0 + row;
-      if (gy >= a.h) break;
-      const unsigned long long key = keys[lds_idx<TWL>(row, col)];
-      const int64_t p = (int64_t)gy * a.w + gx;
-      const int32_t id = (int32_t)~(uint32_t)key;  // low dword = ~face, 0 when empty: ~0 = -1
-      if (out.ids) out.ids[plane + p] = id;
-      if (out.depth) out.depth[plane + p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
+    // fused projection: the label bytes of this wave's rows are requested BEFORE the barrier (coalesced 64-byte row
+    // segments, all RW loads in flight at once), so the candidates' atomics in the epilogue never wait on a dependent load
+    int te = tid;
+    asm volatile("" : "+v"(te));  // as above: everything the epilogue needs is derived from here
+    const int col = te & (TW - 1);
+    const int gx = px0 + col;
+    uint32_t lab[RW];
+    if (FUSE && out.labels && gx < a.w) {
+      const int r0 = (te >> 6) * RW;
+      const int rows_here = min(RW, a.h - (py0 + r0));
+      const uint8_t *lp = out.labels + plane + (int64_t)(py0 + r0) * a.w + gx;
+#pragma unroll
+      for (int k = 0; k < RW; ++k) lab[k] = (k < rows_here) ? (uint32_t)lp[(int64_t)k * a.w] : 0u;
     }
+    __syncthreads();
+
+    // the next tile's entries are requested now, ahead of this tile's stores
+    if (it + 1 < KT) prefetch(tile + 1);
+
+    // epilogue: whole rows (TW pixels, coalesced); the NW waves interleave over the TH rows
+    if (gx < a.w && !(a.dbg & 2)) {
+      if (!FUSE && out.ids && !out.depth) {
+        // ids only (the common case): the key's low dword is ~face, and 0 for an empty pixel, so id = ~low for both;
+        // one 4-byte LDS read, one NOT, one store per pixel, the output pointer advances by a constant stride
+        const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
+        const int rows_here = min(TH, a.h - py0);
+        int32_t *dst = out.ids + plane + (int64_t)(py0 + (te >> TWL)) * a.w + gx;
+        const int64_t dstep = (int64_t)ROWS_PER_PASS * a.w;
+        for (int row = te >> TWL; row < rows_here; row += ROWS_PER_PASS, dst += dstep)
+          *dst = (int32_t)~klo[2 * lds_idx<TWL>(row, col)];
+      } else if (FUSE && !out.depth && TW == 64) {
+        // Fused projection epilogue.  Each wave owns TH/NW CONSECUTIVE rows: the row below is read from LDS once and
+        // becomes the current row of the next step; the right neighbour comes from the next lane (DPP wave shift), so a
+        // pixel costs one 4-byte LDS read.  Across a tile edge the neighbour is unknown (-3: "differs", one atomic too
+        // many at worst); outside the image it is -2 exactly as in k_winner.
+        const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
+        const int r0 = (te >> 6) * RW;
+        const int last = (int)out.F - 1;
+        int cur = (int32_t)~klo[2 * lds_idx<TWL>(r0, col)];
+        const int rows_here = min(RW, a.h - (py0 + r0));          // rows of this wave inside the image (wave-uniform)
+        const bool right_out = (gx + 1 >= a.w);
+        const int bg = out.compat ? last : -1;                     // what a background pixel counts as (meshes.py:1998-2001)
+        int64_t p = (int64_t)(py0 + r0) * a.w + gx;                // linear pixel index, advanced by w per row
+        int32_t *idp = out.ids ? out.ids + plane + p : nullptr;
+        uint32_t *win32 = (uint32_t *)out.winner + slot * out.F;
+        unsigned long long *win64 = (unsigned long long *)out.winner + slot * out.F;
+#pragma unroll
+        for (int k = 0; k < RW; ++k) {
+          if (k >= rows_here) break;
+          const int row = r0 + k;
+          const int nxt = (row + 1 < TH) ? (int32_t)~klo[2 * lds_idx<TWL>(min(row + 1, TH - 1), col)] : -3;
+          int fr = __builtin_amdgcn_update_dpp(-3, cur, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+          fr = right_out ? -2 : fr;
+          int fb = (py0 + row + 1 >= a.h) ? -2 : nxt;
+          if (idp) { *idp = cur; idp += a.w; }
+          const int f = cur == -1 ? bg : cur;
+          fr = fr == -1 ? bg : fr;
+          fb = fb == -1 ? bg : fb;
+          if (f >= 0 && fr != f && fb != f) {
+            const int label = min((int)lab[k], out.C);
+            if (out.key64) atomicMax(win64 + f, ((unsigned long long)(p + 1) << out.LB) | (unsigned long long)label);
+            else atomicMax(win32 + f, ((uint32_t)(p + 1) << out.LB) | (uint32_t)label);
+          }
+          p += a.w;
+          cur = nxt;
+        }
+      } else {
+        for (int row = te >> TWL; row < TH; row += ROWS_PER_PASS) {
+          const int gy = py0 + row;
+          if (gy >= a.h) break;
+          const unsigned long long key = keys[lds_idx<TWL>(row, col)];
+          const int64_t p = (int64_t)gy * a.w + gx;
+          const int32_t id = (int32_t)~(uint32_t)key;  // low dword = ~face, 0 when empty: ~0 = -1
+          if (out.ids) out.ids[plane + p] = id;
+          if (out.depth) out.depth[plane + p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
+        }
+      }
+    }
+    if (it + 1 < KT) __syncthreads();  // the rows have been read: the next tile may zero them
   }
 }
 
@@ -1262,13 +1363,13 @@ int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStr
     Timed t(c, s, ST_RASTER);
     if (out.labels) {
       if (a.thl == 6)
-        hipLaunchKernelGGL((k_raster_rows<6, 6, 256, true>), dim3(a.T, nb), dim3(256), 0, s, a, out);
+        hipLaunchKernelGGL((k_raster_rows<6, 6, 256, true>), dim3((a.T + GR_TILES_PER_WG - 1) / GR_TILES_PER_WG, nb), dim3(256), 0, s, a, out);
       else
-        hipLaunchKernelGGL((k_raster_rows<6, 5, 256, true>), dim3(a.T, nb), dim3(256), 0, s, a, out);
+        hipLaunchKernelGGL((k_raster_rows<6, 5, 256, true>), dim3((a.T + GR_TILES_PER_WG - 1) / GR_TILES_PER_WG, nb), dim3(256), 0, s, a, out);
     } else if (a.thl == 6)
-      hipLaunchKernelGGL((k_raster_rows<6, 6, 256, false>), dim3(a.T, nb), dim3(256), 0, s, a, out);
+      hipLaunchKernelGGL((k_raster_rows<6, 6, 256, false>), dim3((a.T + GR_TILES_PER_WG - 1) / GR_TILES_PER_WG, nb), dim3(256), 0, s, a, out);
     else
-      hipLaunchKernelGGL((k_raster_rows<6, 5, 256, false>), dim3(a.T, nb), dim3(256), 0, s, a, out);
+      hipLaunchKernelGGL((k_raster_rows<6, 5, 256, false>), dim3((a.T + GR_TILES_PER_WG - 1) / GR_TILES_PER_WG, nb), dim3(256), 0, s, a, out);
     c->prof_raster_launches += 1;
   }
   c->prof_views += nb;
