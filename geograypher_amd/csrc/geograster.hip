@@ -55,7 +55,8 @@ struct BinArgs {
   int h, w;
   int twl, thl;          // log2 of the tile width / height in pixels
   int cap_tile;          // > 0: single-pass binning, every tile owns cap_tile entry slots (list base = tile * cap_tile)
-  int dbg;               // timing-only ablation mask (GR_OPT_DEBUG): 1 skip scanline loop, 2 skip id stores, 4 skip triangles
+  int dbg;               // timing-only ablation mask (GR_OPT_DEBUG): 1 skip scanline loop, 2 skip id stores, 4 skip triangles,
+                         // fused epilogue: 8 skip winner atomics, 16 skip label loads
 };
 
 __device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b, c)); }
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(256) void k_fill_compile(BinArgs a) {
 //     Epilogue: whole rows, one coalesced 256-byte store per wave-instruction.
 // ------------------------------------------------------------------------------------------------------------------
 // last-writer-wins candidate (see K5): issue the global atomicMax only when neither the right nor the lower neighbour
-// shows the same face.  key = (pixel+1) << LB | label  (LB = 0: pixel+1)
+// shows the same face (the fused tile epilogue also looks at the two diagonal neighbours below).  key = (pixel+1) << LB | label  (LB = 0: pixel+1)
 template <typename KeyT>
 __device__ __forceinline__ void winner_pixel(KeyT *__restrict__ winner, int f, int fr, int fb, int64_t p, int label,
                                               int64_t F, int C, int LB, int compat) {
@@ -797,7 +798,7 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
     const int col = te & (TW - 1);
     const int gx = px0 + col;
     uint32_t lab[RW];
-    if (FUSE && out.labels && gx < a.w) {
+    if (FUSE && out.labels && gx < a.w && !(a.dbg & 16)) {
       const int r0 = (te >> 6) * RW;
       const int rows_here = min(RW, a.h - (py0 + r0));
       const uint8_t *lp = out.labels + plane + (int64_t)(py0 + r0) * a.w + gx;
@@ -805,6 +806,9 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
       for (int k = 0; k < RW; ++k) lab[k] = (k < rows_here) ? (uint32_t)lp[(int64_t)k * a.w] : 0u;
     }
     __syncthreads();
+    // the label bytes are waited for HERE, once (vmcnt(0), other counters untouched): left to the compiler, the wait lands
+    // inside the row loop, where it would also wait for the previous row's winner atomics and serialise them
+    if (FUSE) __builtin_amdgcn_s_waitcnt(0x0F70);
 
     // the next tile's entries are requested now, ahead of this tile's stores
     if (it + 1 < KT) prefetch(tile + 1);
@@ -822,39 +826,44 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
           *dst = (int32_t)~klo[2 * lds_idx<TWL>(row, col)];
       } else if (FUSE && !out.depth && TW == 64) {
         // Fused projection epilogue.  Each wave owns TH/NW CONSECUTIVE rows: the row below is read from LDS once and
-        // becomes the current row of the next step; the right neighbour comes from the next lane (DPP wave shift), so a
-        // pixel costs one 4-byte LDS read.  Across a tile edge the neighbour is unknown (-3: "differs", one atomic too
-        // many at worst); outside the image it is -2 exactly as in k_winner.
+        // becomes the current row of the next step; the right and the two diagonal neighbours come from the adjacent
+        // lanes (DPP wave shifts), so a pixel costs one 4-byte LDS read.  A pixel is a candidate for its face's last
+        // pixel only if none of right / below-left / below / below-right shows the same face (a face's consecutive
+        // scanlines touch at least diagonally unless it is a steep sliver; extra candidates are harmless).  Unknown
+        // neighbours count as "differs": -3 across a tile edge or next to a lane outside the image (a DPP read from
+        // a disabled lane keeps the old value), -2 below the last image row.  Background is mapped to the face it
+        // aliases (meshes.py:1998-2001) once, when the row is read.
         const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
         const int r0 = (te >> 6) * RW;
-        const int last = (int)out.F - 1;
-        int cur = (int32_t)~klo[2 * lds_idx<TWL>(r0, col)];
+        const int bg = out.compat ? (int)out.F - 1 : -1;
         const int rows_here = min(RW, a.h - (py0 + r0));          // rows of this wave inside the image (wave-uniform)
-        const bool right_out = (gx + 1 >= a.w);
-        const int bg = out.compat ? last : -1;                     // what a background pixel counts as (meshes.py:1998-2001)
-        int64_t p = (int64_t)(py0 + r0) * a.w + gx;                // linear pixel index, advanced by w per row
-        int32_t *idp = out.ids ? out.ids + plane + p : nullptr;
+        int raw = (int32_t)~klo[2 * lds_idx<TWL>(r0, col)];
+        int cur = raw == -1 ? bg : raw;
+        int p1 = (py0 + r0) * a.w + gx + 1;                        // linear pixel index + 1 (h, w <= 16384)
+        int32_t *idp = out.ids ? out.ids + plane + (p1 - 1) : nullptr;
         uint32_t *win32 = (uint32_t *)out.winner + slot * out.F;
         unsigned long long *win64 = (unsigned long long *)out.winner + slot * out.F;
 #pragma unroll
         for (int k = 0; k < RW; ++k) {
           if (k >= rows_here) break;
           const int row = r0 + k;
-          const int nxt = (row + 1 < TH) ? (int32_t)~klo[2 * lds_idx<TWL>(min(row + 1, TH - 1), col)] : -3;
-          int fr = __builtin_amdgcn_update_dpp(-3, cur, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-          fr = right_out ? -2 : fr;
-          int fb = (py0 + row + 1 >= a.h) ? -2 : nxt;
-          if (idp) { *idp = cur; idp += a.w; }
-          const int f = cur == -1 ? bg : cur;
-          fr = fr == -1 ? bg : fr;
-          fb = fb == -1 ? bg : fb;
-          if (f >= 0 && fr != f && fb != f) {
-            const int label = min((int)lab[k], out.C);
-            if (out.key64) atomicMax(win64 + f, ((unsigned long long)(p + 1) << out.LB) | (unsigned long long)label);
-            else atomicMax(win32 + f, ((uint32_t)(p + 1) << out.LB) | (uint32_t)label);
+          int nraw = -3, nxt = -3;
+          if (row + 1 < TH) {
+            nraw = (int32_t)~klo[2 * lds_idx<TWL>(row + 1, col)];
+            nxt = (py0 + row + 1 >= a.h) ? -2 : (nraw == -1 ? bg : nraw);
           }
-          p += a.w;
+          const int fr = __builtin_amdgcn_update_dpp(-3, cur, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+          const int fbr = __builtin_amdgcn_update_dpp(-3, nxt, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+          const int fbl = __builtin_amdgcn_update_dpp(-3, nxt, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+          if (idp) { *idp = raw; idp += a.w; }
+          if (cur >= 0 && fr != cur && nxt != cur && fbr != cur && fbl != cur && !(a.dbg & 8)) {
+            const int label = min((int)lab[k], out.C);
+            if (out.key64) atomicMax(win64 + cur, ((unsigned long long)(uint32_t)p1 << out.LB) | (unsigned long long)label);
+            else atomicMax(win32 + cur, ((uint32_t)p1 << out.LB) | (uint32_t)label);
+          }
+          p1 += a.w;
           cur = nxt;
+          raw = nraw;
         }
       } else {
         for (int row = te >> TWL; row < TH; row += ROWS_PER_PASS) {
