@@ -42,7 +42,7 @@ struct BinArgs {
   int4 *rec;             // [slot][4][F]  plane0 {X0,Y0,X1,Y1} plane1 {X2,Y2,iz0,face} plane2 {A,B,jmin|jmax<<16,imin|imax<<16}
                          //               plane3 {list position in up to 4 tiles}
   const float *soup;     // [F][9] the three vertex positions of every face (built once per upload: k_build_soup)
-  const float4 *blk;     // [ceil(F/256)] bounding sphere (centre, radius) of each block of 256 faces, local frame
+  const float4 *blk;     // [ceil(F/64)] bounding sphere (centre, radius) of each block of GR_BLOCK faces, local frame
   uint32_t *work;        // [slot][work_stride] blocks of this view that passed the frustum test (ctrl[3] = count)
   int64_t work_stride;
   int4 *comp;            // [slot][ent_cap][4]  compiled (face, tile) entries grouped by tile, 64 B each
@@ -95,12 +95,13 @@ __device__ __forceinline__ Vtx project_vertex(const float *__restrict__ p, const
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K0  (once per mesh upload) bounding sphere of every block of 256 consecutive faces.  Photogrammetry meshes keep
-//     neighbouring faces close in index order, so a view's frustum rejects most blocks with one sphere test.
+// K0  (once per mesh upload) bounding sphere of every block of GR_BLOCK = 64 consecutive faces (one wave per block).
+//     Photogrammetry meshes keep neighbouring faces close in index order, so a view's frustum rejects most blocks with
+//     one sphere test.
 // ------------------------------------------------------------------------------------------------------------------
+#define GR_BLOCK 64
 __global__ __launch_bounds__(256) void k_block_bounds(const float *__restrict__ verts, const int32_t *__restrict__ faces,
                                                       int64_t F, float4 *__restrict__ blk) {
-  __shared__ float red[6][4];
   const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   if (f < F) {
@@ -109,26 +110,22 @@ __global__ __launch_bounds__(256) void k_block_bounds(const float *__restrict__ 
       for (int d = 0; d < 3; ++d) { lo[d] = fminf(lo[d], p[d]); hi[d] = fmaxf(hi[d], p[d]); }
     }
   }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int d = 0; d < 3; ++d) {
     for (int o = 32; o > 0; o >>= 1) {
       lo[d] = fminf(lo[d], __shfl_xor(lo[d], o));
       hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o));
     }
-    if (lane == 0) { red[d][wv] = lo[d]; red[3 + d][wv] = hi[d]; }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
+  const int64_t b = f >> 6;  // wave-uniform
+  if ((threadIdx.x & 63) == 0 && b * GR_BLOCK < F) {
     float c[3], r2 = 0.f;
     for (int d = 0; d < 3; ++d) {
-      const float l = fminf(fminf(red[d][0], red[d][1]), fminf(red[d][2], red[d][3]));
-      const float h = fmaxf(fmaxf(red[3 + d][0], red[3 + d][1]), fmaxf(red[3 + d][2], red[3 + d][3]));
-      c[d] = 0.5f * (l + h);
-      const float e = 0.5f * (h - l);
+      c[d] = 0.5f * (lo[d] + hi[d]);
+      const float e = 0.5f * (hi[d] - lo[d]);
       r2 += e * e;
     }
     // NaN / inf vertices give a NaN radius: the cull test below is written so that NaN never culls
-    blk[blockIdx.x] = make_float4(c[0], c[1], c[2], sqrtf(r2) * 1.0001f + 1e-6f);
+    blk[b] = make_float4(c[0], c[1], c[2], sqrtf(r2) * 1.0001f + 1e-6f);
   }
 }
 
@@ -143,7 +140,7 @@ __global__ __launch_bounds__(256) void k_build_soup(const float *__restrict__ ve
 
 // ------------------------------------------------------------------------------------------------------------------
 // K1  transform + cull + compact record + per-tile counts.   grid (ceil(F/256), views)
-//     (a) block cull: the 256-face block's bounding sphere against the view frustum (2-pixel margin) -- wave-uniform,
+//     (a) block cull: the 64-face block's bounding sphere against the view frustum (2-pixel margin) -- wave-uniform,
 //         rejects ~85 % of a survey mesh per view before a single face is read;
 //     (b) faces (F,3) int32 read coalesced; vertices gathered (12 B each, L2-resident for mesh-local face order);
 //     (c) survivors compacted with wave ballot + popcount, ONE atomicAdd per wave; record planes written as
@@ -168,7 +165,7 @@ __device__ __forceinline__ void wave_group(int t, int lane, int &leader, int &ra
   if (t < 0) { leader = lane; rank = 0; size = 0; }
 }
 
-// K0b  per view: sphere-vs-frustum test of every 256-face block (one thread per block); survivors are appended to the
+// K0b  per view: sphere-vs-frustum test of every 64-face block (one thread per block); survivors are appended to the
 //      view's work list with one wave-aggregated atomic.  grid (ceil(nblk/256), views)
 __global__ __launch_bounds__(256) void k_cull_blocks(const float *__restrict__ cams, BinArgs a, int nblk) {
   const int slot = blockIdx.y;
@@ -219,11 +216,14 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
   const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
   uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
   const uint32_t *work = a.work + (int64_t)slot * a.work_stride;
-  uint32_t blk_next = work[blockIdx.x];  // read alongside the count (any slot of the list is valid memory)
+  // every wave takes its own 64-face block from the view's work list (wave-uniform control flow, no workgroup barrier)
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), wstep = gridDim.x * 4;
+  uint32_t blk_next = work[wave0];       // read alongside the count (any slot of the list is valid memory)
   const uint32_t n_work = ctrl[3];       // (a) blocks that passed k_cull_blocks for this view
-  for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
-  const int64_t f = (int64_t)blk_next * 256 + threadIdx.x;
-  if (wi + gridDim.x < n_work) blk_next = work[wi + gridDim.x];
+  for (uint32_t wi = wave0; wi < n_work; wi += wstep) {
+  const int64_t f = (int64_t)blk_next * GR_BLOCK + lane;
+  if (wi + wstep < n_work) blk_next = work[wi + wstep];
 
   bool keep = false;
   int4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0};
@@ -272,7 +272,6 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
   // wave-level compaction of survivors
   const unsigned long long m = __ballot(keep);
   if (m == 0ull) continue;
-  const int lane = threadIdx.x & 63;
   const int n = __popcll(m);
   const int prefix = __popcll(m & ((1ull << lane) - 1ull));
   const int leader = __ffsll((long long)m) - 1;
@@ -1294,7 +1293,7 @@ int ensure_bins(gr_ctx *c, int n_slots, int T) {
   const int Tcap = std::max(T, c->Tcap);
   const int64_t cap = std::max(want_cap, c->ent_cap);
   const int64_t ctrl_stride = ((GR_CTRL_HDR + 4 * (int64_t)Tcap) + 63) / 64 * 64;
-  const int64_t work_stride = std::max<int64_t>(ceil_div(F, 256), c->work_stride);
+  const int64_t work_stride = std::max<int64_t>(ceil_div(F, GR_BLOCK) + 4, c->work_stride);
   const int64_t rec_F = std::max<int64_t>(F, c->rec_F);
   int rc = grow(c, c->ctrl, c->ctrl_have, ctrl_stride * slots, "bin control");
   if (!rc) rc = grow(c, c->comp, c->comp_have, 4 * cap * slots, "entry list");
@@ -1337,13 +1336,13 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, hip
   GR_HIP(c, hipMemsetAsync(a.ctrl, 0, sizeof(uint32_t) * c->ctrl_stride * nb, s));
   {
     Timed t(c, s, ST_SETUP);
-    const int nblk = (int)ceil_div(c->F, 256);
+    const int nblk = (int)ceil_div(c->F, GR_BLOCK);
     hipLaunchKernelGGL(k_cull_blocks, dim3((unsigned)ceil_div(nblk, 256), nb), dim3(256), 0, s, cams, a, nblk);
     if (a.cap_tile > 0)
-      hipLaunchKernelGGL(k_setup_cull<true>, dim3((unsigned)std::min(nblk, 1024), nb), dim3(256), 0, s, c->verts,
+      hipLaunchKernelGGL(k_setup_cull<true>, dim3((unsigned)std::min((nblk + 3) / 4, 1024), nb), dim3(256), 0, s, c->verts,
                          c->faces, cams, a);
     else
-      hipLaunchKernelGGL(k_setup_cull<false>, dim3((unsigned)std::min(nblk, 1024), nb), dim3(256), 0, s, c->verts,
+      hipLaunchKernelGGL(k_setup_cull<false>, dim3((unsigned)std::min((nblk + 3) / 4, 1024), nb), dim3(256), 0, s, c->verts,
                          c->faces, cams, a);
   }
   c->last_direct = a.cap_tile > 0;
@@ -1579,7 +1578,7 @@ int gr_mesh_upload(gr_ctx *c, const float *verts, const int32_t *faces, int64_t 
   GR_HIP(c, hipMemcpyAsync(&bad, c->flag, sizeof(int), hipMemcpyDeviceToHost, s));
   GR_HIP(c, hipStreamSynchronize(s));
   if (bad) return fail(c, GR_EINDEX, "face index outside [0, %lld)", (long long)V);
-  const int64_t nblk = ceil_div(F, 256);
+  const int64_t nblk = ceil_div(F, GR_BLOCK);
   if (c->blk_cap < nblk) {
     if (c->blk) (void)hipFree(c->blk);
     c->blk = nullptr; c->blk_cap = 0;
@@ -1593,7 +1592,7 @@ int gr_mesh_upload(gr_ctx *c, const float *verts, const int32_t *faces, int64_t 
     c->soup_cap = F;
   }
   hipLaunchKernelGGL(k_build_soup, dim3((unsigned)ceil_div(3 * F, 256)), dim3(256), 0, s, verts, faces, F, c->soup);
-  hipLaunchKernelGGL(k_block_bounds, dim3((unsigned)nblk), dim3(256), 0, s, verts, faces, F, c->blk);
+  hipLaunchKernelGGL(k_block_bounds, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s, verts, faces, F, c->blk);
   GR_HIP(c, hipGetLastError());
   c->verts = verts; c->faces = faces; c->V = V; c->F = F;
   return GR_OK;
