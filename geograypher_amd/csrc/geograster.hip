@@ -435,12 +435,14 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(BinArgs a) {
 //       E_k(x, y) = C_k + A_k x + B_k y,  x, y = tile-local pixel;  covered <=> all E_k >= 0 (fill rule folded in C_k)
 //     All 64-bit set-up arithmetic happens here, once per entry, at full occupancy; the tile rasterizer then only
 //     streams entries (no index indirection, no 64-bit multiplies).  Entries whose edge values could leave int32
-//     inside the tile keep their vertices instead and are walked with 64-bit adds (flag bit 31 of the bbox word).
+//     inside the tile keep their vertices instead and are walked with 64-bit adds (flag bit 31 of the Yw word).
 //     List positions of <= 2x2-tile faces come from K1 (plain stores); larger faces take one cursor atomic per tile.
-//       word  0..3   C0 C1 C2 A0        | X0 Y0 X1 Y1      (64-bit form)
-//       word  4..7   A1 A2 B0 B1        | X2 Y2 -  -
-//       word  8..11  B2 iz0 zA zB
-//       word 12..15  X0rel Y0rel bbox ~face      (Px - X0 = 256 x + X0rel;  bbox = jlo | jhi<<8 | ilo<<16 | ihi<<24)
+//     Only 12 words of an entry travel to the lanes that walk its scanlines (each is one ds_bpermute per 64 items, and
+//     the LDS pipe is the tile kernel's bottleneck), so A_k / 256 and B_k / 256 (|.| < 2^15) are packed in pairs:
+//       word  0..3   C0 C1 C2 a0|a1<<16          | X0 Y0 X1 Y1      (64-bit form)
+//       word  4..7   a2|b0<<16 b1|b2<<16 iz0 zA  | X2 Y2 iz0 zA
+//       word  8..11  zB X0rel Yw ~face           (Px - X0 = 256 x + X0rel;  Yw = Y0rel (24 bit) | ilo<<24 | 64-bit flag<<31)
+//       word 12      bbox = jlo | jhi<<8 | ilo<<16 | ihi<<24   (row count; the 64-bit form also walks jlo..jhi)
 // ------------------------------------------------------------------------------------------------------------------
 // Faces whose snapped bounding box is smaller than GR_FAST_EXT sub-pixels (93 px) take a short form of the set-up: the
 // face overlaps the tile, so every pixel the tile rasterizer can probe (x in [-2, TW+2], y in [0, TH]) lies within
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(BinArgs a) {
 // every product has 24-bit factors and every value fits int32 -- no 64-bit arithmetic, no per-tile range test.
 // Larger faces take the general form below (identical coverage: both forms are exact).
 #define GR_FAST_EXT 24000
+__device__ __forceinline__ int pack16(int lo, int hi) { return (lo & 0xFFFF) | (hi << 16); }
 __device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, const int4 p0, const int4 p1, const int4 p2,
                                               int px0, int py0, int TW, int TH) {
   const int X0 = p0.x, Y0 = p0.y, X1 = p0.z, Y1 = p0.w, X2 = p1.x, Y2 = p1.y;
@@ -461,14 +464,15 @@ __device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, const int4
   const int t2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
   const int ext = max(imax3(X0, X1, X2) - imin3(X0, X1, X2), imax3(Y0, Y1, Y2) - imin3(Y0, Y1, Y2));
   const int box = jlo | (jhi << 8) | (ilo << 16) | (ihi << 24);
+  const int yw = ((Pyo - Y0) & 0xFFFFFF) | (ilo << 24);  // |Pyo - Y0| < 2^23 inside the guard band
   if (ext < GR_FAST_EXT) {
     const int c0 = __mul24(dx0, Pyo - Y0) - __mul24(dy0, Pxo - X0) + t0;
     const int c1 = __mul24(dx1, Pyo - Y1) - __mul24(dy1, Pxo - X1) + t1;
     const int c2 = __mul24(dx2, Pyo - Y2) - __mul24(dy2, Pxo - X2) + t2;
-    dst[0] = make_int4(c0, c1, c2, -dy0 * 256);
-    dst[1] = make_int4(-dy1 * 256, -dy2 * 256, dx0 * 256, dx1 * 256);
-    dst[2] = make_int4(dx2 * 256, p1.z, p2.x, p2.y);
-    dst[3] = make_int4(Pxo - X0, Pyo - Y0, box, (int)~(uint32_t)p1.w);
+    dst[0] = make_int4(c0, c1, c2, pack16(-dy0, -dy1));
+    dst[1] = make_int4(pack16(-dy2, dx0), pack16(dx1, dx2), p1.z, p2.x);
+    dst[2] = make_int4(p2.y, Pxo - X0, yw, (int)~(uint32_t)p1.w);
+    dst[3] = make_int4(box, 0, 0, 0);
     return;
   }
   const long long b0 = t0, b1 = t1, b2 = t2;
@@ -485,17 +489,15 @@ __device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, const int4
                      (llabs(C2) + (TW + 2) * llabs(A2) + TH * llabs(B2) < lim) &&
                      llabs(A0) <= m24 && llabs(A1) <= m24 && llabs(A2) <= m24 &&
                      llabs(B0) <= m24 && llabs(B1) <= m24 && llabs(B2) <= m24;
-  const int bbox = box | (small ? 0 : (int)0x80000000);
-  if (small) {
-    dst[0] = make_int4((int)C0, (int)C1, (int)C2, (int)A0);
-    dst[1] = make_int4((int)A1, (int)A2, (int)B0, (int)B1);
-    dst[2] = make_int4((int)B2, p1.z, p2.x, p2.y);
+  if (small) {  // |A|, |B| <= m24 and multiples of 256: the quotients fit 16 bits
+    dst[0] = make_int4((int)C0, (int)C1, (int)C2, pack16(-dy0, -dy1));
+    dst[1] = make_int4(pack16(-dy2, dx0), pack16(dx1, dx2), p1.z, p2.x);
   } else {
     dst[0] = make_int4(X0, Y0, X1, Y1);
-    dst[1] = make_int4(X2, Y2, 0, 0);
-    dst[2] = make_int4(0, p1.z, p2.x, p2.y);
+    dst[1] = make_int4(X2, Y2, p1.z, p2.x);
   }
-  dst[3] = make_int4(Pxo - X0, Pyo - Y0, bbox, (int)~(uint32_t)p1.w);
+  dst[2] = make_int4(p2.y, Pxo - X0, yw | (small ? 0 : (int)0x80000000), (int)~(uint32_t)p1.w);
+  dst[3] = make_int4(box, 0, 0, 0);
 }
 
 __global__ __launch_bounds__(256) void k_fill_compile(BinArgs a) {
@@ -604,6 +606,19 @@ __device__ __forceinline__ void span_clip(int E, int A, int &xs, int &xe) {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Inclusive prefix sum over the 64 lanes with DPP moves only: the LDS pipe (ds_bpermute shuffles included) is the tile
+// kernel's scarcest resource, VALU issue is not (one extra ds_bpermute per 64-item batch costs 0.34 us per C2 view, 48
+// extra VALU instructions 0.9).  Sources outside a row / masked rows contribute the `old` operand, 0.
+__device__ __forceinline__ int wave_incl_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118 /* row_shr:8 */, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);  // rows 1, 3 += total of rows 0, 2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);  // rows 2, 3 += total of rows 0-1
+  return x;
+}
+
 // Phases 2-3 of the tile rasterizer for the 64 entries a wave holds in registers (s0..s3, nrows per lane).
 template <int TWL>
 __device__ __forceinline__ void raster_wave_entries(unsigned long long *keys, const int4 s0, const int4 s1, const int4 s2,
@@ -611,13 +626,8 @@ __device__ __forceinline__ void raster_wave_entries(unsigned long long *keys, co
                                                     const int py0, const int dbg) {
   constexpr int TW = 1 << TWL;
     // ---- phase 2: wave-local scan of the row counts: item q belongs to the entry with excl <= q < excl + nrows ------------
-    int incl = nrows;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(incl, d);
-      if (lane >= d) incl += o;
-    }
-    int total = __shfl(incl, 63);
+    const int incl = wave_incl_scan(nrows);
+    int total = __builtin_amdgcn_readlane(incl, 63);
     const int excl = incl - nrows;
     if (dbg & 1) total = 0;
     // ---- phase 3: one scanline of one triangle per lane -------------------------------------------------------------------
@@ -632,24 +642,26 @@ __device__ __forceinline__ void raster_wave_entries(unsigned long long *keys, co
         if (ec <= q) { t = cand; et = ec; }
       }
       const bool live = q < total;
-      // fetch the entry from lane t's registers (ds_bpermute: no LDS storage)
-      const int C0 = __shfl(s0.x, t), C1 = __shfl(s0.y, t), C2 = __shfl(s0.z, t), A0 = __shfl(s0.w, t);
-      const int A1 = __shfl(s1.x, t), A2 = __shfl(s1.y, t), B0 = __shfl(s1.z, t), B1 = __shfl(s1.w, t);
-      const int B2 = __shfl(s2.x, t);
-      const float iz0 = __int_as_float(__shfl(s2.y, t)), zA = __int_as_float(__shfl(s2.z, t)),
-                  zB = __int_as_float(__shfl(s2.w, t));
-      const int X0rel = __shfl(s3.x, t), Y0rel = __shfl(s3.y, t), bbox = __shfl(s3.z, t);
-      uint32_t key_lo = (uint32_t)__shfl(s3.w, t);
+      // fetch the entry from lane t's registers (ds_bpermute: no LDS storage) -- 12 words
+      const int C0 = __shfl(s0.x, t), C1 = __shfl(s0.y, t), C2 = __shfl(s0.z, t);
+      const int w3 = __shfl(s0.w, t), w4 = __shfl(s1.x, t), w5 = __shfl(s1.y, t);
+      const float iz0 = __int_as_float(__shfl(s1.z, t)), zA = __int_as_float(__shfl(s1.w, t)),
+                  zB = __int_as_float(__shfl(s2.x, t));
+      const int X0rel = __shfl(s2.y, t), yw = __shfl(s2.z, t);
+      uint32_t key_lo = (uint32_t)__shfl(s2.w, t);
       // consume the last ds_bpermute result here: otherwise the compiler parks its s_waitcnt lgkmcnt(0) inside the pixel
       // loop, where it would also wait for the previous iteration's ds_max_u64 and serialise the LDS atomics
       asm volatile("" : "+v"(key_lo));
-      const int jlo = bbox & 0xFF, jhi = (bbox >> 8) & 0xFF, ilo = (bbox >> 16) & 0xFF;
+      const int Y0rel = (yw << 8) >> 8, ilo = (yw >> 24) & 0x3F;
       const int y = ilo + (q - et);
       const float m1 = zB * (float)(y * 256 + Y0rel);
-      const bool big = live && (bbox < 0);
+      const bool big = live && (yw < 0);
       if (live && !big) {
         // exact covered span [xs, xe] of this scanline: each edge E(x) = E(0) + A x >= 0 bounds x from one side
-        int xs = jlo, xe = jhi;
+        // (the three edges bound the span completely: the face's bounding box is not needed here)
+        const int A0 = (w3 << 16) >> 8, A1 = (w3 >> 16) << 8, A2 = (w4 << 16) >> 8;   // 256 * signed 16-bit halves
+        const int B0 = (w4 >> 16) << 8, B1 = (w5 << 16) >> 8, B2 = (w5 >> 16) << 8;
+        int xs = 0, xe = TW - 1;
         span_clip<TW>(C0 + __mul24(B0, y), A0, xs, xe);
         span_clip<TW>(C1 + __mul24(B1, y), A1, xs, xe);
         span_clip<TW>(C2 + __mul24(B2, y), A2, xs, xe);
@@ -672,8 +684,10 @@ __device__ __forceinline__ void raster_wave_entries(unsigned long long *keys, co
         }
       }
       if (__ballot(big) != 0ull) {
+        const int bbox = __shfl(s3.x, t);  // rare path: one more word for the column range
         if (big) {  // 64-bit form: words 0..5 hold the snapped vertices
-          const int X0 = C0, Y0 = C1, X1 = C2, Y1 = A0, X2 = A1, Y2 = A2;
+          const int X0 = C0, Y0 = C1, X1 = C2, Y1 = w3, X2 = w4, Y2 = w5;
+          const int jlo = bbox & 0xFF, jhi = (bbox >> 8) & 0xFF;
           const int dx0 = X1 - X0, dy0 = Y1 - Y0, dx1 = X2 - X1, dy1 = Y2 - Y1, dx2 = X0 - X2, dy2 = Y0 - Y2;
           const long long b0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;
           const long long b1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
@@ -734,7 +748,7 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
   auto prefetch = [&](int tile) {
     if (spec && tile < a.T) {
       const int4 *cs = a.comp + (slot * a.ent_cap + (int64_t)tile * a.cap_tile + e_first) * 4;
-      s0 = cs[0]; s1 = cs[1]; s2 = cs[2]; s3 = cs[3];
+      s0 = cs[0]; s1 = cs[1]; s2 = cs[2]; s3.x = cs[3].x;
     }
   };
   prefetch(tile0);
@@ -784,8 +798,8 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
       const uint32_t e = c0 + e_first;
       int nrows = 0;
       if (e < cnt) {
-        if (!(c0 == 0 && spec)) { s0 = comp[e * 4 + 0]; s1 = comp[e * 4 + 1]; s2 = comp[e * 4 + 2]; s3 = comp[e * 4 + 3]; }
-        const int jlo = s3.z & 0xFF, jhi = (s3.z >> 8) & 0xFF, ilo = (s3.z >> 16) & 0xFF, ihi = (s3.z >> 24) & 0x7F;
+        if (!(c0 == 0 && spec)) { s0 = comp[e * 4 + 0]; s1 = comp[e * 4 + 1]; s2 = comp[e * 4 + 2]; s3.x = comp[e * 4 + 3].x; }
+        const int jlo = s3.x & 0xFF, jhi = (s3.x >> 8) & 0xFF, ilo = (s3.x >> 16) & 0xFF, ihi = (s3.x >> 24) & 0x7F;
         nrows = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;
       }
       raster_wave_entries<TWL>(keys, s0, s1, s2, s3, nrows, lane, px0, py0, a.dbg);
