@@ -619,11 +619,23 @@ __device__ __forceinline__ int wave_incl_scan(int x) {
   return x;
 }
 
+// Inclusive prefix maximum of non-negative values, same DPP pattern.
+__device__ __forceinline__ int wave_incl_max(int x) {
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112 /* row_shr:2 */, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114 /* row_shr:4 */, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118 /* row_shr:8 */, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
+  return x;
+}
+
 // Phases 2-3 of the tile rasterizer for the 64 entries a wave holds in registers (s0..s3, nrows per lane).
+// tab: the wave's 64 mailbox words in LDS (zeroed with the tile), gen: the wave's batch counter (mailbox generation).
 template <int TWL>
-__device__ __forceinline__ void raster_wave_entries(unsigned long long *keys, const int4 s0, const int4 s1, const int4 s2,
-                                                    const int4 s3, const int nrows, const int lane, const int px0,
-                                                    const int py0, const int dbg) {
+__device__ __forceinline__ void raster_wave_entries(unsigned long long *keys, uint32_t *tab, uint32_t &gen, const int4 s0,
+                                                    const int4 s1, const int4 s2, const int4 s3, const int nrows,
+                                                    const int lane, const int px0, const int py0, const int dbg) {
   constexpr int TW = 1 << TWL;
     // ---- phase 2: wave-local scan of the row counts: item q belongs to the entry with excl <= q < excl + nrows ------------
     const int incl = wave_incl_scan(nrows);
@@ -633,14 +645,20 @@ __device__ __forceinline__ void raster_wave_entries(unsigned long long *keys, co
     // ---- phase 3: one scanline of one triangle per lane -------------------------------------------------------------------
     for (int k0 = 0; k0 < total; k0 += 64) {
       const int q = k0 + lane;
-      // largest entry lane t with excl[t] <= q (entries beyond the list have excl = total > q)
-      int t = 0, et = 0;
-#pragma unroll
-      for (int step = 32; step > 0; step >>= 1) {
-        const int cand = t + step;
-        const int ec = __shfl(excl, cand);
-        if (ec <= q) { t = cand; et = ec; }
-      }
+      // Item -> entry.  Every entry that STARTS inside this batch posts (its lane, its start slot) into the start slot's
+      // mailbox (one masked LDS write), every item lane reads its own mailbox (one LDS read), and a DPP prefix maximum
+      // carries the latest start forward: two LDS operations instead of a six-step ds_bpermute search.  Mailboxes are
+      // never cleared: a word counts only if it carries this batch's generation.  Items before the first start of the
+      // batch belong to the entry that holds item k0 (wave-uniform: the entries ending at or before k0 are counted).
+      ++gen;
+      const int slot = excl - k0;
+      if (nrows > 0 && slot >= 0 && slot < 64) tab[slot] = (gen << 13) | (uint32_t)((lane + 1) << 6) | (uint32_t)slot;
+      const int carry_t = __popcll(__ballot(incl <= k0));
+      const int carry_e = __builtin_amdgcn_readlane(excl, carry_t & 63);
+      const uint32_t mail = tab[lane];
+      const int m = wave_incl_max((mail >> 13) == gen ? (int)(mail & 0x1FFFu) : 0);
+      const int t = m ? (m >> 6) - 1 : carry_t;
+      const int et = m ? k0 + (m & 63) : carry_e;
       const bool live = q < total;
       // fetch the entry from lane t's registers (ds_bpermute: no LDS storage) -- 12 words
       const int C0 = __shfl(s0.x, t), C1 = __shfl(s0.y, t), C2 = __shfl(s0.z, t);
@@ -724,7 +742,9 @@ template <int TWL, int THL, int NT, bool FUSE>
 __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   constexpr int KT = GR_TILES_PER_WG;
-  __shared__ __attribute__((aligned(16))) unsigned long long keys[(TW + GR_LDS_PAD) * TH];  // the kernel's only LDS: 16.25 KiB (64x32)
+  // the kernel's only LDS: the tile's keys (17.25 KiB for 64x32) + 64 mailbox words per wave (1 KiB) -> 8 workgroups/CU
+  constexpr int NKEYS = (TW + GR_LDS_PAD) * TH;
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[NKEYS + (NT / 64) * 32];
 
   const int slot = blockIdx.y;
   const int tile0 = blockIdx.x * KT;
@@ -784,15 +804,17 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
     const int4 *comp = a.comp + (slot * a.ent_cap + beg) * 4;
 
     {  // zero the tile: 16-byte LDS stores
-      static_assert(((TW + GR_LDS_PAD) * TH) % 2 == 0, "key pairs");
+      static_assert(NKEYS % 2 == 0, "key pairs");
       ulonglong2 *k2 = reinterpret_cast<ulonglong2 *>(keys);
       int tz = tid;
       asm volatile("" : "+v"(tz));  // per-thread addresses are re-derived here, not kept in registers across the tile loop
-      for (int i = tz; i < (TW + GR_LDS_PAD) * TH / 2; i += NT) k2[i] = make_ulonglong2(0ull, 0ull);
+      for (int i = tz; i < (NKEYS + (NT / 64) * 32) / 2; i += NT) k2[i] = make_ulonglong2(0ull, 0ull);  // keys + mailboxes
     }
     __syncthreads();
 
     // entries are dealt round-robin to the NW waves (entry e -> wave e % NW) so that a short list still feeds every wave
+    uint32_t *tab = reinterpret_cast<uint32_t *>(keys + NKEYS) + wv * 64;
+    uint32_t gen = 0;
     for (uint32_t c0 = 0; c0 < cnt; c0 += NT) {
       // ---- phase 1: one compiled entry per lane, kept in registers -------------------------------------------------------
       const uint32_t e = c0 + e_first;
@@ -802,7 +824,7 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
         const int jlo = s3.x & 0xFF, jhi = (s3.x >> 8) & 0xFF, ilo = (s3.x >> 16) & 0xFF, ihi = (s3.x >> 24) & 0x7F;
         nrows = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;
       }
-      raster_wave_entries<TWL>(keys, s0, s1, s2, s3, nrows, lane, px0, py0, a.dbg);
+      raster_wave_entries<TWL>(keys, tab, gen, s0, s1, s2, s3, nrows, lane, px0, py0, a.dbg);
     }
     // fused projection: the label bytes of this wave's rows are requested BEFORE the barrier (coalesced 64-byte row
     // segments, all RW loads in flight at once), so the candidates' atomics in the epilogue never wait on a dependent load
