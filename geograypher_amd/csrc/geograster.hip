@@ -583,14 +583,16 @@ struct RasterOut {
 #define GR_LDS_PAD 5
 template <int TWL>
 __device__ __forceinline__ int lds_idx(int row, int col) {
-  return row * ((1 << TWL) + GR_LDS_PAD) + col;
+  return __mul24(row, (1 << TWL) + GR_LDS_PAD) + col;
 }
 
 // Integer solution of g(x) = E + A x >= 0 on one scanline, branch-free.  A float reciprocal proposes x0 = floor(-E/A);
 // in the clamped range [-1, TW] the proposal is within one of the true root, so the exact boundary follows from the
-// signs of two exact int32 probes g(x0), g(x0+1):   A > 0: first covered x = x0 - s0 - s1;   A < 0: last covered
+// signs of two exact int32 probes g(x0), g(x0+1):   A >= 0: first covered x = x0 - s0 - s1;   A < 0: last covered
 // x = x0 + 1 + s0 + s1   (s = -1 where the probe is negative, 0 otherwise).  |A| < 2^23 (checked when the entry was
-// compiled), so the products are full-rate 24-bit multiplies.
+// compiled), so the products are full-rate 24-bit multiplies.  A == 0 needs no case of its own: the quotient is -inf
+// or NaN for E >= 0 (clamped to x0 = -1: both probes pass, first covered x = -1, no constraint) and +inf for E < 0
+// (x0 = TW, both probes fail, first covered x = TW + 2: the span is empty).
 template <int TW>
 __device__ __forceinline__ void span_clip(int E, int A, int &xs, int &xe) {
   float q = -(float)E * __builtin_amdgcn_rcpf((float)A);
@@ -598,10 +600,9 @@ __device__ __forceinline__ void span_clip(int E, int A, int &xs, int &xe) {
   const int x0 = (int)floorf(q);
   const int e0 = E + __mul24(A, x0);
   const int u = (e0 >> 31) + ((e0 + A) >> 31);
-  const int lo = x0 - u, hi = x0 + 1 + u;
-  xs = max(xs, A > 0 ? lo : 0);
-  xe = min(xe, A < 0 ? hi : TW);
-  xe = (A == 0 && E < 0) ? -1 : xe;
+  const int lo = max(xs, x0 - u), hi = min(xe, x0 + 1 + u);
+  xs = A < 0 ? xs : lo;
+  xe = A < 0 ? hi : xe;
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
