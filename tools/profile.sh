@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+BENCH="python3 $REPO/bench.py --steps 20 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.log 2>&1
 echo "trace rc=$?" >> $OUT/trace_bench.log
 SHORT="python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-aggregate"

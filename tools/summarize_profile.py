@@ -55,7 +55,7 @@ def main():
     out_txt = os.path.join(raw, f"summary_{tag}.txt")
     lines = []
     path, rows = kernel_stats(raw)
-    lines.append(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline   [{tag}]")
+    lines.append(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline   [{tag}]")
     lines.append(f"# source: {path}")
     lines.append(f"{'kernel':58s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
     for r in rows[:25]:
