@@ -536,16 +536,17 @@ __global__ __launch_bounds__(256) void k_fill_compile(BinArgs a) {
 //     depth|id keys (u64: 1/z bits << 32 | ~face) live in LDS; visibility is resolved with ds_max_u64, so the result
 //     does not depend on list order.  Between the two workgroup barriers (keys zeroed / keys complete) every wave
 //     works on its own, without further synchronisation:
-//       phase 1  each lane streams ONE compiled entry of the tile's list (64 B) into 16 registers;
-//       phase 2  the entries' row counts are prefix-summed with wave shuffles: the wave's work is total_rows
-//                (entry, row) items; item q finds its entry by a 6-step search over the lanes' offsets and pulls the
-//                entry's 16 words out of the owning lane's registers (ds_bpermute) -- no LDS staging at all;
+//       phase 1  each lane streams ONE compiled entry of the tile's list (13 words) into registers; in single-pass
+//                mode the first 64 slots of the tile's segment are requested before the tile's count is known;
+//       phase 2  the entries' row counts are prefix-summed with DPP moves: the wave's work is total_rows
+//                (entry, row) items, taken 64 at a time; an item finds its entry through the wave's LDS mailboxes
+//                (starts post, items read, a DPP prefix maximum carries the latest start forward) and pulls the
+//                entry's 12 words out of the owning lane's registers (ds_bpermute) -- no LDS staging at all;
 //       phase 3  ONE SCANLINE OF ONE TRIANGLE PER LANE: the exact covered span [xs, xe] comes from the three edge
 //                inequalities (float reciprocal proposal + exact int32 correction), then the lane walks the span
 //                and issues one ds_max_u64 per covered pixel.  Entries flagged 64-bit take a bounding-box walk
 //                with 64-bit edge adds (same results, exact).
-//     LDS column rotation (col + row) & (TW-1): the rows of one triangle walk neighbouring columns in step, the
-//     rotation spreads them over distinct banks; a row read in the epilogue stays conflict-free.
+//     The LDS pipe (atomics AND shuffles) is the kernel's scarcest resource, VALU issue the second.
 //     Epilogue: whole rows, one coalesced 256-byte store per wave-instruction.
 // ------------------------------------------------------------------------------------------------------------------
 // last-writer-wins candidate (see K5): issue the global atomicMax only when neither the right nor the lower neighbour
@@ -733,22 +734,15 @@ __device__ __forceinline__ void raster_wave_entries(unsigned long long *keys, ui
     }
 }
 
-// GR_TILES_PER_WG consecutive tiles of one view can be rasterized by the same workgroup, one after the other, with the
-// NEXT tile's first entries requested before the current tile's ids are stored (vector memory completes in issue
-// order, so those loads do not wait for the younger stores, and the stores drain while the next tile is rasterized).
-// Measured on MI355X (C2): 4 tiles per workgroup 23.5 us/view against 21.7 for 1 -- the tile loop costs 14 VGPRs
-// (6 instead of 8 waves per SIMD), and occupancy is worth more to this kernel than the overlap.  Kept at 1.
-#define GR_TILES_PER_WG 1
 template <int TWL, int THL, int NT, bool FUSE>
 __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
-  constexpr int KT = GR_TILES_PER_WG;
   // the kernel's only LDS: the tile's keys (17.25 KiB for 64x32) + 64 mailbox words per wave (1 KiB) -> 8 workgroups/CU
   constexpr int NKEYS = (TW + GR_LDS_PAD) * TH;
   __shared__ __attribute__((aligned(16))) unsigned long long keys[NKEYS + (NT / 64) * 32];
 
   const int slot = blockIdx.y;
-  const int tile0 = blockIdx.x * KT;
+  const int tile = blockIdx.x;
   const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -758,42 +752,27 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
   const int64_t P = (int64_t)a.h * a.w;
   const int64_t plane = (int64_t)slot * P;
 
-  // Single-pass binning: a tile's segment starts at a known address, so its first GR_SPEC entries are requested before
+  // Single-pass binning: the tile's segment starts at a known address, so its first GR_SPEC entries are requested before
   // its count is known (count read and entry read are ONE memory round trip instead of two dependent ones; most tiles
   // hold fewer entries than that).  Slots beyond the count hold stale data and are dropped.
   constexpr uint32_t GR_SPEC = 64;
   const uint32_t e_first = (uint32_t)(lane * NW + wv);
   const bool direct = a.cap_tile > 0;
   const bool spec = a.cap_tile >= (int)GR_SPEC && e_first < GR_SPEC;
-  int4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, s3 = {0, 0, 0, 0};  // this lane's entry
-  auto prefetch = [&](int tile) {
-    if (spec && tile < a.T) {
-      const int4 *cs = a.comp + (slot * a.ent_cap + (int64_t)tile * a.cap_tile + e_first) * 4;
-      s0 = cs[0]; s1 = cs[1]; s2 = cs[2]; s3.x = cs[3].x;
-    }
-  };
-  prefetch(tile0);
-  // the counts of all KT tiles (single-pass binning); words past the view's last tile are valid memory and unused
-  uint32_t cn0 = 0, cn1 = 0, cn2 = 0, cn3 = 0;
-  if (direct) {
-    const uint32_t *cp = ctrl + GR_CTRL_HDR + tile0;
-    cn0 = cp[0];
-    if (KT > 1) cn1 = cp[1];
-    if (KT > 2) cn2 = cp[2];
-    if (KT > 3) cn3 = cp[3];
+  // this lane's entry; deliberately left undefined where no entry is loaded (such lanes have no rows and are never a
+  // shuffle source): a zero initialiser would cost a register copy -- and a wait -- right behind the early loads
+  int4 s0, s1, s2, s3;
+  if (spec) {
+    const int4 *cs = a.comp + (slot * a.ent_cap + (int64_t)tile * a.cap_tile + e_first) * 4;
+    s0 = cs[0]; s1 = cs[1]; s2 = cs[2]; s3.x = cs[3].x;
   }
-  static_assert(KT >= 1 && KT <= 4, "tile counts are held in four scalars");
-
-#pragma unroll 1
-  for (int it = 0; it < KT; ++it) {
-    const int tile = tile0 + it;
-    if (tile >= a.T) break;
+  {
     const int tx = tile % a.TX, ty = tile / a.TX;
     const int px0 = tx << TWL, py0 = ty << THL;
     uint32_t cnt;
     int64_t beg;
     if (direct) {
-      cnt = min(it == 0 ? cn0 : it == 1 ? cn1 : it == 2 ? cn2 : cn3, (uint32_t)a.cap_tile);
+      cnt = min(ctrl[GR_CTRL_HDR + tile], (uint32_t)a.cap_tile);
       beg = (int64_t)tile * a.cap_tile;
     } else {
       cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
@@ -807,47 +786,56 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
     {  // zero the tile: 16-byte LDS stores
       static_assert(NKEYS % 2 == 0, "key pairs");
       ulonglong2 *k2 = reinterpret_cast<ulonglong2 *>(keys);
-      int tz = tid;
-      asm volatile("" : "+v"(tz));  // per-thread addresses are re-derived here, not kept in registers across the tile loop
-      for (int i = tz; i < (NKEYS + (NT / 64) * 32) / 2; i += NT) k2[i] = make_ulonglong2(0ull, 0ull);  // keys + mailboxes
+      for (int i = tid; i < (NKEYS + (NT / 64) * 32) / 2; i += NT) k2[i] = make_ulonglong2(0ull, 0ull);  // keys + mailboxes
     }
     __syncthreads();
 
     // entries are dealt round-robin to the NW waves (entry e -> wave e % NW) so that a short list still feeds every wave
     uint32_t *tab = reinterpret_cast<uint32_t *>(keys + NKEYS) + wv * 64;
     uint32_t gen = 0;
-    for (uint32_t c0 = 0; c0 < cnt; c0 += NT) {
-      // ---- phase 1: one compiled entry per lane, kept in registers -------------------------------------------------------
-      const uint32_t e = c0 + e_first;
+    // ---- phase 1: one compiled entry per lane, kept in registers.  The first NT entries (nearly always all of them) are
+    //      handled outside the loop so that the early-requested registers are used where they landed.
+    {
       int nrows = 0;
-      if (e < cnt) {
-        if (!(c0 == 0 && spec)) { s0 = comp[e * 4 + 0]; s1 = comp[e * 4 + 1]; s2 = comp[e * 4 + 2]; s3.x = comp[e * 4 + 3].x; }
+      if (e_first < cnt) {
+        if (!spec) { s0 = comp[e_first * 4 + 0]; s1 = comp[e_first * 4 + 1]; s2 = comp[e_first * 4 + 2]; s3.x = comp[e_first * 4 + 3].x; }
         const int jlo = s3.x & 0xFF, jhi = (s3.x >> 8) & 0xFF, ilo = (s3.x >> 16) & 0xFF, ihi = (s3.x >> 24) & 0x7F;
         nrows = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;
       }
       raster_wave_entries<TWL>(keys, tab, gen, s0, s1, s2, s3, nrows, lane, px0, py0, a.dbg);
     }
+#pragma unroll 1
+    for (uint32_t c0 = NT; c0 < cnt; c0 += NT) {
+      const uint32_t e = c0 + e_first;
+      int4 t0, t1, t2, t3;
+      int nrows = 0;
+      if (e < cnt) {
+        t0 = comp[e * 4 + 0]; t1 = comp[e * 4 + 1]; t2 = comp[e * 4 + 2]; t3.x = comp[e * 4 + 3].x;
+        const int jlo = t3.x & 0xFF, jhi = (t3.x >> 8) & 0xFF, ilo = (t3.x >> 16) & 0xFF, ihi = (t3.x >> 24) & 0x7F;
+        nrows = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;
+      }
+      raster_wave_entries<TWL>(keys, tab, gen, t0, t1, t2, t3, nrows, lane, px0, py0, a.dbg);
+    }
     // fused projection: the label bytes of this wave's rows are requested BEFORE the barrier (coalesced 64-byte row
     // segments, all RW loads in flight at once), so the candidates' atomics in the epilogue never wait on a dependent load
     int te = tid;
-    asm volatile("" : "+v"(te));  // as above: everything the epilogue needs is derived from here
+    asm volatile("" : "+v"(te));  // the epilogue's addresses are derived here, not hoisted above the scanline phase
     const int col = te & (TW - 1);
     const int gx = px0 + col;
     uint32_t lab[RW];
     if (FUSE && out.labels && gx < a.w && !(a.dbg & 16)) {
       const int r0 = (te >> 6) * RW;
       const int rows_here = min(RW, a.h - (py0 + r0));
-      const uint8_t *lp = out.labels + plane + (int64_t)(py0 + r0) * a.w + gx;
+      if (rows_here > 0) {  // straight-line loads (rows below the image re-read the last valid row: never used)
+        const uint8_t *lp = out.labels + plane + (int64_t)(py0 + r0) * a.w + gx;
 #pragma unroll
-      for (int k = 0; k < RW; ++k) lab[k] = (k < rows_here) ? (uint32_t)lp[(int64_t)k * a.w] : 0u;
+        for (int k = 0; k < RW; ++k) lab[k] = (uint32_t)lp[(int64_t)min(k, rows_here - 1) * a.w];
+      }
     }
     __syncthreads();
     // the label bytes are waited for HERE, once (vmcnt(0), other counters untouched): left to the compiler, the wait lands
     // inside the row loop, where it would also wait for the previous row's winner atomics and serialise them
     if (FUSE) __builtin_amdgcn_s_waitcnt(0x0F70);
-
-    // the next tile's entries are requested now, ahead of this tile's stores
-    if (it + 1 < KT) prefetch(tile + 1);
 
     // epilogue: whole rows (TW pixels, coalesced); the NW waves interleave over the TH rows
     if (gx < a.w && !(a.dbg & 2)) {
@@ -913,7 +901,6 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
         }
       }
     }
-    if (it + 1 < KT) __syncthreads();  // the rows have been read: the next tile may zero them
   }
 }
 
@@ -1408,13 +1395,13 @@ int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStr
     Timed t(c, s, ST_RASTER);
     if (out.labels) {
       if (a.thl == 6)
-        hipLaunchKernelGGL((k_raster_rows<6, 6, 256, true>), dim3((a.T + GR_TILES_PER_WG - 1) / GR_TILES_PER_WG, nb), dim3(256), 0, s, a, out);
+        hipLaunchKernelGGL((k_raster_rows<6, 6, 256, true>), dim3(a.T, nb), dim3(256), 0, s, a, out);
       else
-        hipLaunchKernelGGL((k_raster_rows<6, 5, 256, true>), dim3((a.T + GR_TILES_PER_WG - 1) / GR_TILES_PER_WG, nb), dim3(256), 0, s, a, out);
+        hipLaunchKernelGGL((k_raster_rows<6, 5, 256, true>), dim3(a.T, nb), dim3(256), 0, s, a, out);
     } else if (a.thl == 6)
-      hipLaunchKernelGGL((k_raster_rows<6, 6, 256, false>), dim3((a.T + GR_TILES_PER_WG - 1) / GR_TILES_PER_WG, nb), dim3(256), 0, s, a, out);
+      hipLaunchKernelGGL((k_raster_rows<6, 6, 256, false>), dim3(a.T, nb), dim3(256), 0, s, a, out);
     else
-      hipLaunchKernelGGL((k_raster_rows<6, 5, 256, false>), dim3((a.T + GR_TILES_PER_WG - 1) / GR_TILES_PER_WG, nb), dim3(256), 0, s, a, out);
+      hipLaunchKernelGGL((k_raster_rows<6, 5, 256, false>), dim3(a.T, nb), dim3(256), 0, s, a, out);
     c->prof_raster_launches += 1;
   }
   c->prof_views += nb;
