@@ -369,12 +369,12 @@ class TexturedPhotogrammetryMesh:
             out = torch.stack([w.to(torch.int32) for w in warped], dim=0)
             if return_tensor:
                 return out[0] if single else out
-            out = out.to(torch.int64).cpu().numpy()
+            out = _to_host(out.to(torch.int64))
             return out[0] if single else out
         if return_tensor:
             return ids[0] if single else ids
         # int64 like the reference (meshes.py:1804): widened on the device, one copy to the host
-        out = ids.to(_torch().int64).cpu().numpy()
+        out = _to_host(ids.to(_torch().int64))
         return out[0] if single else out
 
     # -- render_flat ---------------------------------------------------------------------------------------------
@@ -408,7 +408,7 @@ class TexturedPhotogrammetryMesh:
                 batch_pix2face = self.backend._dev(batch_pix2face.astype(np.int32), _torch().int32)
             if tex_dev is None:
                 tex_dev = self.backend._dev(face_texture, _torch().float64)
-            rendered = self.backend.gather_texture(batch_pix2face, tex_dev).cpu().numpy()
+            rendered = _to_host(self.backend.gather_texture(batch_pix2face, tex_dev))
             for i in range(rendered.shape[0]):
                 if return_camera:
                     yield (rendered[i], batch_cameras[i])
@@ -459,7 +459,7 @@ class TexturedPhotogrammetryMesh:
             if img is None:
                 yield np.full((n_faces, n_channels), fill_value=np.nan)
             else:
-                yield self.backend.project_view(ids, img, neg1_is_last_face=self.neg1_is_last_face).cpu().numpy()
+                yield _to_host(self.backend.project_view(ids, img, neg1_is_last_face=self.neg1_is_last_face))
 
     # -- aggregate_projected_images ------------------------------------------------------------------------------
     def aggregate_projected_images(
@@ -538,9 +538,9 @@ class TexturedPhotogrammetryMesh:
             if distributed and world > 1:
                 dist_utils.all_reduce_votes(votes, counts)
             avg, summed, cnt = self.backend.finalize_votes(votes, counts)
-            return avg.cpu().numpy(), {
-                "projection_counts": cnt.cpu().numpy(),
-                "summed_projections": summed.cpu().numpy(),
+            return _to_host(avg), {
+                "projection_counts": _to_host(cnt),
+                "summed_projections": _to_host(summed),
             }
 
         # ---- general path: float images; nansum + finite-row counts accumulate on device (meshes.py:2057-2067) ----------
@@ -558,14 +558,14 @@ class TexturedPhotogrammetryMesh:
                 if img is None:
                     proj = np.full((n_faces, n_channels), fill_value=np.nan)
                 else:
-                    proj = self.backend.project_view(ids, img, neg1_is_last_face=self.neg1_is_last_face).cpu().numpy()
+                    proj = _to_host(self.backend.project_view(ids, img, neg1_is_last_face=self.neg1_is_last_face))
                 if return_all:
                     all_projections.append(proj)
                 first = proj if first is None else first
             if img is not None:
                 self.backend.project_values(ids, img, sums, counts, neg1_is_last_face=self.neg1_is_last_face)
         avg, summed, cnt = self.backend.finalize_sums(sums, counts)
-        avg, summed, cnt = avg.cpu().numpy(), summed.cpu().numpy(), cnt.cpu().numpy()
+        avg, summed, cnt = _to_host(avg), _to_host(summed), _to_host(cnt)
         if single_view:
             # the reference keeps the first projection as is (meshes.py:2057-2058): a NaN channel of a seen face survives
             summed = first.astype(float)
@@ -665,14 +665,14 @@ class TexturedPhotogrammetryMesh:
             if cast_to_uint8 and (not native or discrete):
                 if native:  # nearest-neighbour upsampling commutes with the per-pixel gather: resize the ids
                     ids = self.backend.warp_image(ids, resize_maps[key], order=0, fill_value=-1)
-                rendered = self.backend.gather_texture_u8(ids, tex_dev, int(uint8_value_for_null_texture)).cpu().numpy()
+                rendered = _to_host(self.backend.gather_texture_u8(ids, tex_dev, int(uint8_value_for_null_texture)))
                 rendered = np.squeeze(rendered)
             else:
                 rendered = self.backend.gather_texture(ids, tex_dev)  # (h, w, C) float64, NaN without a face
                 if native:
                     rendered = self.backend.warp_image(rendered, resize_maps[key], order=0 if discrete else 1,
                                                        fill_value=float("nan"))
-                rendered = rendered.cpu().numpy()
+                rendered = _to_host(rendered)
                 if cast_to_uint8:
                     mask = np.logical_or.reduce([rendered < 0, rendered > 255, np.logical_not(np.isfinite(rendered))])
                     rendered[mask] = uint8_value_for_null_texture
@@ -706,6 +706,29 @@ class TexturedPhotogrammetryMesh:
 
 def _raster_kwargs(kwargs: dict) -> dict:
     return {k: kwargs[k] for k in ("near", "principal_point") if k in kwargs}
+
+
+# device -> host through pinned memory.  A pageable destination moves at ~10 GB/s on the MI355X host link, a pinned one
+# at the link rate; torch's caching host allocator hands the same pinned blocks back once earlier results are dropped.
+_PINNED_LIMIT_BYTES = 8 << 30
+
+
+def _to_host(t) -> np.ndarray:
+    """numpy copy of a tensor.  Device tensors are copied into a pinned staging tensor and returned as a numpy view of
+    it (kept alive through the array's base); tensors that are already on the host are returned as they are."""
+    torch = _torch()
+    if not t.is_cuda:
+        return t.numpy()
+    nbytes = t.numel() * t.element_size()
+    if nbytes == 0 or nbytes > _PINNED_LIMIT_BYTES:
+        return t.cpu().numpy()
+    try:
+        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    except RuntimeError:  # pinned memory exhausted: pageable copy
+        return t.cpu().numpy()
+    host.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return host.numpy()
 
 
 def _torch():
