@@ -38,14 +38,14 @@ namespace {
 struct BinArgs {
   uint32_t *ctrl;        // [slot][GR_CTRL_HDR + 4*Tcap]  rec_count,total,overflow,pad | cntS[T] | cntB[T] | offset[T] | curB[T]
                          //   cntS: entries whose list position was handed out in k_setup_cull (faces touching <= 2x2 tiles)
-                         //   cntB: entries of larger faces, placed by k_fill_bins behind the cntS block of their tile
+                         //   cntB: entries of larger faces, placed by k_fill_compile behind the cntS block of their tile (exact path)
   int4 *rec;             // [slot][4][F]  plane0 {X0,Y0,X1,Y1} plane1 {X2,Y2,iz0,face} plane2 {A,B,jmin|jmax<<16,imin|imax<<16}
                          //               plane3 {list position in up to 4 tiles}
   const float *soup;     // [F][9] the three vertex positions of every face (built once per upload: k_build_soup)
   const float4 *blk;     // [ceil(F/64)] bounding sphere (centre, radius) of each block of GR_BLOCK faces, local frame
   uint32_t *work;        // [slot][work_stride] blocks of this view that passed the frustum test (ctrl[3] = count)
   int64_t work_stride;
-  int4 *comp;            // [slot][ent_cap][4]  compiled (face, tile) entries grouped by tile, 64 B each
+  int4 *comp;            // [slot][ent_cap][4]  compiled (face, tile) entries grouped by tile, 64-byte slots (13 words used)
   unsigned long long *stats;  // [4] records, entries, max_entries, overflow (accumulated over the call)
   int64_t ctrl_stride;   // words per slot
   int64_t rec_stride;    // int4 per slot (= 3*F)
@@ -139,14 +139,15 @@ __global__ __launch_bounds__(256) void k_build_soup(const float *__restrict__ ve
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K1  transform + cull + compact record + per-tile counts.   grid (ceil(F/256), views)
-//     (a) block cull: the 64-face block's bounding sphere against the view frustum (2-pixel margin) -- wave-uniform,
-//         rejects ~85 % of a survey mesh per view before a single face is read;
-//     (b) faces (F,3) int32 read coalesced; vertices gathered (12 B each, L2-resident for mesh-local face order);
-//     (c) survivors compacted with wave ballot + popcount, ONE atomicAdd per wave; record planes written as
-//         consecutive 16-byte slots (full-rate coalesced stores);
-//     (d) tile counting is aggregated per wave as well: lanes that hit the same tile share one returning atomicAdd
-//         and receive consecutive list positions, which k_fill_bins later uses without any atomic.
+// K1  transform + cull + per-tile counts (+ compiled entries in single-pass mode).   grid (<= 1024, views)
+//     (a) work list: the 64-face blocks whose bounding sphere passed k_cull_blocks (~87 % of a survey mesh is rejected
+//         per view before a single face is read); every wave takes its own blocks;
+//     (b) the face's three vertices are read from the de-indexed soup (36 coalesced bytes per lane);
+//     (c) exact path: survivors compacted with wave ballot + popcount, ONE atomicAdd per wave; record planes written
+//         as consecutive 16-byte slots (full-rate coalesced stores);
+//     (d) tile counting is aggregated per wave as well: neighbouring lanes that hit the same tile share one returning
+//         atomicAdd and receive consecutive list positions; single-pass mode compiles and stores the entries at once,
+//         the exact path leaves that to k_fill_compile (no atomics there for faces over at most 2x2 tiles).
 // ------------------------------------------------------------------------------------------------------------------
 // Neighbouring lanes of a wave that hit the same tile form a run (photogrammetry meshes keep neighbouring faces close
 // in index order, so runs are long): leader lane, rank inside the run, run length -- found with two ballots and bit
