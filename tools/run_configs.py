@@ -43,6 +43,10 @@ def run(name, points, faces, cams, H, W, C, hip, check_views=(0,)):
                 assert np.array_equal(ids[v - c0].cpu().numpy(), want), f"{name}: view {v} differs from the oracle"
         labels = torch.stack([device_labels(ids[k], c0 + k, C) for k in range(n)])
         del ids
+        if c0 == 0:  # untimed first call: scratch allocation (winner keys) for this mesh / image size
+            v0, k0 = hip.new_vote_buffers(C)
+            hip.raster_project_labels(r, labels, C, v0, k0, check=False)
+            del v0, k0
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         hip.raster_project_labels(r, labels, C, votes, counts, check=False)
