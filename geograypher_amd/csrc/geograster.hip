@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -41,7 +43,8 @@ struct BinArgs {
                          //   cntB: entries of larger faces, placed by k_fill_compile behind the cntS block of their tile (exact path)
   int4 *rec;             // [slot][4][F]  plane0 {X0,Y0,X1,Y1} plane1 {X2,Y2,iz0,face} plane2 {A,B,jmin|jmax<<16,imin|imax<<16}
                          //               plane3 {list position in up to 4 tiles}
-  const float *soup;     // [F][9] the three vertex positions of every face (built once per upload: k_build_soup)
+  const float *soup;     // [F][9] the three vertex positions of every face, in Morton order (built once per upload)
+  const int32_t *orig;   // [F] soup position -> face id of the caller's mesh
   const float4 *blk;     // [ceil(F/64)] bounding sphere (centre, radius) of each block of GR_BLOCK faces, local frame
   uint32_t *work;        // [slot][work_stride] blocks of this view that passed the frustum test (ctrl[3] = count)
   int64_t work_stride;
@@ -95,18 +98,85 @@ __device__ __forceinline__ Vtx project_vertex(const float *__restrict__ p, const
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K0  (once per mesh upload) bounding sphere of every block of GR_BLOCK = 64 consecutive faces (one wave per block).
-//     Photogrammetry meshes keep neighbouring faces close in index order, so a view's frustum rejects most blocks with
-//     one sphere test.
+// K0  (once per mesh upload) the mesh is re-ordered along a Morton curve of the face centroids and de-indexed:
+//     soup[n] = the 9 vertex coordinates of face orig[n].  A block of GR_BLOCK = 64 consecutive soup faces is then a
+//     compact patch whatever the caller's face order: one bounding sphere per block rejects most of a survey mesh with
+//     one test per view, and the 64 faces of a wave fall into one to four tiles (few, long runs for the tile counters).
+//     Rasterization does not depend on the order in which faces are processed (ds_max_u64 resolve), ids are the caller's.
 // ------------------------------------------------------------------------------------------------------------------
 #define GR_BLOCK 64
-__global__ __launch_bounds__(256) void k_block_bounds(const float *__restrict__ verts, const int32_t *__restrict__ faces,
-                                                      int64_t F, float4 *__restrict__ blk) {
+// order-preserving float -> uint32 (for atomicMin / atomicMax on floats)
+__device__ __forceinline__ uint32_t float_ordered(float f) {
+  const uint32_t b = (uint32_t)__float_as_int(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float ordered_float(uint32_t u) {
+  const uint32_t b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+  union { uint32_t i; float f; } c; c.i = b; return c.f;
+}
+
+// bounds[0..2] = min, bounds[3..5] = max of the finite vertex coordinates (ordered-uint encoding)
+__global__ __launch_bounds__(256) void k_mesh_bounds(const float *__restrict__ verts, int64_t V, uint32_t *__restrict__ bounds) {
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (int64_t)gridDim.x * 256)
+    for (int d = 0; d < 3; ++d) {
+      const float x = verts[3 * v + d];
+      if (isfinite(x)) { lo[d] = fminf(lo[d], x); hi[d] = fmaxf(hi[d], x); }
+    }
+  for (int d = 0; d < 3; ++d) {
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[d] = fminf(lo[d], __shfl_xor(lo[d], o));
+      hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&bounds[d], float_ordered(lo[d]));
+      atomicMax(&bounds[3 + d], float_ordered(hi[d]));
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t spread16(uint32_t x) {  // abcd -> 0a0b0c0d
+  x &= 0xFFFFu;
+  x = (x | (x << 8)) & 0x00FF00FFu;
+  x = (x | (x << 4)) & 0x0F0F0F0Fu;
+  x = (x | (x << 2)) & 0x33333333u;
+  x = (x | (x << 1)) & 0x55555555u;
+  return x;
+}
+
+// 32-bit Morton code of the face centroid on the two axes of largest extent (16 bits each); code[f], idx[f] = f
+__global__ __launch_bounds__(256) void k_face_codes(const float *__restrict__ verts, const int32_t *__restrict__ faces, int64_t F,
+                                                    int ax0, int ax1, float lo0, float inv0, float lo1, float inv1,
+                                                    uint32_t *__restrict__ code, int32_t *__restrict__ idx) {
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  const float *p0 = verts + 3 * (int64_t)faces[3 * f], *p1 = verts + 3 * (int64_t)faces[3 * f + 1],
+              *p2 = verts + 3 * (int64_t)faces[3 * f + 2];
+  const float c0 = (p0[ax0] + p1[ax0] + p2[ax0]) * (1.0f / 3.0f), c1 = (p0[ax1] + p1[ax1] + p2[ax1]) * (1.0f / 3.0f);
+  const float q0 = (c0 - lo0) * inv0, q1 = (c1 - lo1) * inv1;  // NaN -> 0 below
+  const uint32_t u0 = (uint32_t)fminf(fmaxf(q0, 0.0f), 65535.0f), u1 = (uint32_t)fminf(fmaxf(q1, 0.0f), 65535.0f);
+  code[f] = spread16(u0) | (spread16(u1) << 1);
+  idx[f] = (int32_t)f;
+}
+
+// soup[n] = the 9 vertex coordinates of face orig[n]   (one thread per (face, corner))
+__global__ __launch_bounds__(256) void k_build_soup(const float *__restrict__ verts, const int32_t *__restrict__ faces,
+                                                    const int32_t *__restrict__ orig, int64_t F, float *__restrict__ soup) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= 3 * F) return;
+  const int64_t n = i / 3;
+  const int k = (int)(i - 3 * n);
+  const float *p = verts + 3 * (int64_t)faces[3 * (int64_t)orig[n] + k];
+  soup[3 * i + 0] = p[0]; soup[3 * i + 1] = p[1]; soup[3 * i + 2] = p[2];
+}
+
+// bounding sphere of every block of 64 consecutive soup faces (one wave per block)
+__global__ __launch_bounds__(256) void k_block_bounds(const float *__restrict__ soup, int64_t F, float4 *__restrict__ blk) {
   const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   if (f < F) {
     for (int k = 0; k < 3; ++k) {
-      const float *p = verts + 3 * (int64_t)faces[3 * f + k];
+      const float *p = soup + 9 * f + 3 * k;
       for (int d = 0; d < 3; ++d) { lo[d] = fminf(lo[d], p[d]); hi[d] = fmaxf(hi[d], p[d]); }
     }
   }
@@ -129,15 +199,6 @@ __global__ __launch_bounds__(256) void k_block_bounds(const float *__restrict__ 
   }
 }
 
-// K0a (once per mesh upload) de-index the mesh: soup[f] = the 9 vertex coordinates of face f.
-__global__ __launch_bounds__(256) void k_build_soup(const float *__restrict__ verts, const int32_t *__restrict__ faces,
-                                                    int64_t F, float *__restrict__ soup) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per (face, corner)
-  if (i >= 3 * F) return;
-  const float *p = verts + 3 * (int64_t)faces[i];
-  soup[3 * i + 0] = p[0]; soup[3 * i + 1] = p[1]; soup[3 * i + 2] = p[2];
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // K1  transform + cull + per-tile counts (+ compiled entries in single-pass mode).   grid (<= 1024, views)
 //     (a) work list: the 64-face blocks whose bounding sphere passed k_cull_blocks (~87 % of a survey mesh is rejected
@@ -149,21 +210,23 @@ __global__ __launch_bounds__(256) void k_build_soup(const float *__restrict__ ve
 //         atomicAdd and receive consecutive list positions; single-pass mode compiles and stores the entries at once,
 //         the exact path leaves that to k_fill_compile (no atomics there for faces over at most 2x2 tiles).
 // ------------------------------------------------------------------------------------------------------------------
-// Neighbouring lanes of a wave that hit the same tile form a run (photogrammetry meshes keep neighbouring faces close
-// in index order, so runs are long): leader lane, rank inside the run, run length -- found with two ballots and bit
-// arithmetic in constant time (no loop over distinct tiles, no memory traffic), so that the leaders' atomics can all be
-// issued back to back.  Equal tiles that are not adjacent in lane order simply form separate runs (one atomic each).
+// Lanes of a wave that hit the same tile form a group: leader lane, rank inside the group, group size -- found with
+// ballots and shuffles only (no memory traffic), so that the leaders' atomics can all be issued back to back.  The 64
+// faces of a wave are a compact patch of the mesh (Morton order): a handful of distinct tiles, hence few iterations.
 __device__ __forceinline__ void wave_group(int t, int lane, int &leader, int &rank, int &size) {
-  const int tprev = __builtin_amdgcn_update_dpp(-2, t, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);  // lane 0 keeps -2
-  const unsigned long long valid = __ballot(t >= 0);
-  const unsigned long long heads = __ballot(t >= 0 && tprev != t);
-  const unsigned long long upto = (2ull << lane) - 1ull;                 // bits 0..lane
-  const unsigned long long mine = heads & upto;                          // run heads at or below this lane
-  leader = mine ? 63 - __clzll((long long)mine) : lane;
-  rank = lane - leader;
-  const unsigned long long stop = (heads | ~valid) & ~upto;              // next run head or inactive lane above
-  size = (stop ? __ffsll((long long)stop) - 1 : 64) - leader;
-  if (t < 0) { leader = lane; rank = 0; size = 0; }
+  leader = lane; rank = 0; size = 0;
+  unsigned long long rem = __ballot(t >= 0);
+  while (rem) {
+    const int l = __ffsll((long long)rem) - 1;
+    const int tl = __builtin_amdgcn_readlane(t, l);
+    const unsigned long long m = __ballot(t == tl);
+    if (t == tl) {
+      leader = l;
+      rank = __popcll(m & ((1ull << lane) - 1ull));
+      size = __popcll(m);
+    }
+    rem &= ~m;
+  }
 }
 
 // K0b  per view: sphere-vs-frustum test of every 64-face block (one thread per block); survivors are appended to the
@@ -262,7 +325,7 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
           n1 = d2 * (double)(v1.X - v0.X); n2 = d1 * (double)(v2.X - v0.X);
           const float B = (float)((n1 - n2) / a2);
           r0 = make_int4(v0.X, v0.Y, v1.X, v1.Y);
-          r1 = make_int4(v2.X, v2.Y, __float_as_int(v0.iz), (int)f);
+          r1 = make_int4(v2.X, v2.Y, __float_as_int(v0.iz), a.orig[f]);
           r2 = make_int4(__float_as_int(A), __float_as_int(B), jmin | (jmax << 16), imin | (imax << 16));
           tx0 = jmin >> a.twl; tx1 = jmax >> a.twl;
           ty0 = imin >> a.thl; ty1 = imax >> a.thl;
@@ -1226,6 +1289,7 @@ struct gr_ctx {
   float4 *blk = nullptr;
   int64_t blk_cap = 0;
   float *soup = nullptr;
+  int32_t *orig = nullptr;   // soup position -> caller's face id (Morton order)
   int64_t soup_cap = 0;
   unsigned long long *stats = nullptr;
   int *flag = nullptr;
@@ -1347,7 +1411,7 @@ BinArgs make_args(gr_ctx *c, int h, int w, int slot0) {
   a.work_stride = c->work_stride;
   a.ctrl = c->ctrl + slot0 * a.ctrl_stride; a.rec = c->rec + slot0 * a.rec_stride;
   a.comp = c->comp + slot0 * a.ent_cap * 4; a.work = c->work + slot0 * a.work_stride;
-  a.stats = c->stats; a.blk = c->blk; a.soup = c->soup;
+  a.stats = c->stats; a.blk = c->blk; a.soup = c->soup; a.orig = c->orig;
   a.twl = GR_TILE_LOG2; a.thl = c->opt_thl;
   a.TX = (w + (1 << a.twl) - 1) >> a.twl; a.TY = (h + (1 << a.thl) - 1) >> a.thl; a.T = a.TX * a.TY; a.Tcap = c->Tcap;
   a.h = h; a.w = w; a.dbg = c->opt_dbg;
@@ -1515,7 +1579,7 @@ int gr_ctx_create(int device, gr_ctx **out) {
   if (!c) return GR_ENOMEM;
   c->device = device;
   if (hipMalloc(&c->stats, sizeof(unsigned long long) * 4) != hipSuccess ||
-      hipMalloc(&c->flag, sizeof(int)) != hipSuccess) {
+      hipMalloc(&c->flag, sizeof(int) * 8) != hipSuccess) {  // flag word + upload scratch (vertex bounds)
     delete c;
     return GR_ENOMEM;
   }
@@ -1538,6 +1602,7 @@ int gr_ctx_destroy(gr_ctx *c) {
   if (c->sort_tmp) (void)hipFree(c->sort_tmp);
   if (c->blk) (void)hipFree(c->blk);
   if (c->soup) (void)hipFree(c->soup);
+  if (c->orig) (void)hipFree(c->orig);
   if (c->stats) (void)hipFree(c->stats);
   if (c->flag) (void)hipFree(c->flag);
   delete c;
@@ -1597,12 +1662,30 @@ int gr_mesh_upload(gr_ctx *c, const float *verts, const int32_t *faces, int64_t 
     return fail(c, GR_EINVAL, "bad mesh V=%lld F=%lld", (long long)V, (long long)F);
   hipStream_t s = (hipStream_t)stream;
   GR_HIP(c, hipSetDevice(c->device));
-  GR_HIP(c, hipMemsetAsync(c->flag, 0, sizeof(int), s));
+  // scratch of the upload: [0] bad-index flag, [1..6] vertex bounds (ordered-uint min x3, max x3)
+  uint32_t init[8] = {0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0};
+  uint32_t *up = reinterpret_cast<uint32_t *>(c->flag);
+  GR_HIP(c, hipMemcpyAsync(up, init, sizeof(init), hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_validate_faces, dim3((unsigned)ceil_div(3 * F, 256)), dim3(256), 0, s, faces, 3 * F, V, c->flag);
-  int bad = 0;
-  GR_HIP(c, hipMemcpyAsync(&bad, c->flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(k_mesh_bounds, dim3((unsigned)std::min<int64_t>(ceil_div(V, 256), 2048)), dim3(256), 0, s, verts, V,
+                     up + 1);
+  uint32_t got[8];
+  GR_HIP(c, hipMemcpyAsync(got, up, sizeof(got), hipMemcpyDeviceToHost, s));
   GR_HIP(c, hipStreamSynchronize(s));
-  if (bad) return fail(c, GR_EINDEX, "face index outside [0, %lld)", (long long)V);
+  if (got[0]) return fail(c, GR_EINDEX, "face index outside [0, %lld)", (long long)V);
+  // the two axes of largest extent carry the Morton code (16 bits each)
+  float lo[3], ext[3];
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = ordered_float(got[1 + d]);
+    const float hi = ordered_float(got[4 + d]);
+    ext[d] = (hi >= lo[d]) ? hi - lo[d] : 0.0f;  // no finite vertex on this axis: extent 0
+    if (!(ext[d] >= 0.0f) || std::isinf(ext[d])) ext[d] = 0.0f;
+  }
+  int ax0 = 0, ax1 = 1, axs = 2;  // ax0, ax1: largest extents
+  if (ext[axs] > ext[ax0]) std::swap(axs, ax0);
+  if (ext[axs] > ext[ax1]) std::swap(axs, ax1);
+  const float inv0 = ext[ax0] > 0.0f ? 65535.0f / ext[ax0] : 0.0f, inv1 = ext[ax1] > 0.0f ? 65535.0f / ext[ax1] : 0.0f;
+
   const int64_t nblk = ceil_div(F, GR_BLOCK);
   if (c->blk_cap < nblk) {
     if (c->blk) (void)hipFree(c->blk);
@@ -1612,12 +1695,35 @@ int gr_mesh_upload(gr_ctx *c, const float *verts, const int32_t *faces, int64_t 
   }
   if (c->soup_cap < F) {
     if (c->soup) (void)hipFree(c->soup);
-    c->soup = nullptr; c->soup_cap = 0;
+    if (c->orig) (void)hipFree(c->orig);
+    c->soup = nullptr; c->orig = nullptr; c->soup_cap = 0;
     if (hipMalloc(&c->soup, sizeof(float) * 9 * F) != hipSuccess) return fail(c, GR_ENOMEM, "face soup allocation failed");
+    if (hipMalloc(&c->orig, sizeof(int32_t) * F) != hipSuccess) return fail(c, GR_ENOMEM, "face order allocation failed");
     c->soup_cap = F;
   }
-  hipLaunchKernelGGL(k_build_soup, dim3((unsigned)ceil_div(3 * F, 256)), dim3(256), 0, s, verts, faces, F, c->soup);
-  hipLaunchKernelGGL(k_block_bounds, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s, verts, faces, F, c->blk);
+  // Morton codes -> stable radix sort of (code, face) pairs (rocPRIM through hipcub) -> orig[]
+  size_t sort_bytes = 0;
+  GR_HIP(c, hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                               (int32_t *)nullptr, (int32_t *)nullptr, (int)F, 0, 32, s));
+  const size_t arr = ((size_t)F * 4 + 255) / 256 * 256;
+  const size_t need = 3 * arr + sort_bytes + 256;
+  if (c->sort_bytes < need) {
+    GR_HIP(c, hipStreamSynchronize(s));
+    if (c->sort_tmp) (void)hipFree(c->sort_tmp);
+    c->sort_tmp = nullptr; c->sort_bytes = 0;
+    if (hipMalloc(&c->sort_tmp, need) != hipSuccess) return fail(c, GR_ENOMEM, "sort scratch allocation failed");
+    c->sort_bytes = need;
+  }
+  char *base = static_cast<char *>(c->sort_tmp);
+  uint32_t *code_in = reinterpret_cast<uint32_t *>(base), *code_out = reinterpret_cast<uint32_t *>(base + arr);
+  int32_t *idx_in = reinterpret_cast<int32_t *>(base + 2 * arr);
+  void *tmp = base + 3 * arr;
+  hipLaunchKernelGGL(k_face_codes, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s, verts, faces, F, ax0, ax1, lo[ax0], inv0,
+                     lo[ax1], inv1, code_in, idx_in);
+  size_t tb = sort_bytes;
+  GR_HIP(c, hipcub::DeviceRadixSort::SortPairs(tmp, tb, code_in, code_out, idx_in, c->orig, (int)F, 0, 32, s));
+  hipLaunchKernelGGL(k_build_soup, dim3((unsigned)ceil_div(3 * F, 256)), dim3(256), 0, s, verts, faces, c->orig, F, c->soup);
+  hipLaunchKernelGGL(k_block_bounds, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s, c->soup, F, c->blk);
   GR_HIP(c, hipGetLastError());
   c->verts = verts; c->faces = faces; c->V = V; c->F = F;
   return GR_OK;
