@@ -63,6 +63,27 @@ def test_config1_all_views_bit_exact(hip):
     assert (ids >= 0).mean() > 0.5
 
 
+def test_face_order_does_not_matter(hip):
+    """The library re-orders the faces internally (Morton curve of the centroids) and reports the caller's ids: a
+    shuffled face list -- no spatial coherence at all -- gives the same picture, face for face, and stays bit-exact
+    against the oracle run on the shuffled mesh.  Vertices with NaN / inf coordinates and a flat mesh (one axis of
+    zero extent) go through the same ordering code."""
+    (points, faces), cams = synthetic.config1_scene()
+    recs = _records(cams)[:3]
+    base = _check_views(hip, points, faces, recs, 480, 640)
+    perm = np.random.default_rng(11).permutation(faces.shape[0])
+    shuffled = faces[perm]
+    ids = _check_views(hip, points, shuffled, recs, 480, 640)
+    back = np.where(ids >= 0, perm[np.clip(ids, 0, None)], -1)  # shuffled id -> original id
+    np.testing.assert_array_equal(back, base)
+    flat = points.copy()
+    flat[:, 2] = 0.0
+    _check_views(hip, flat, shuffled, recs, 480, 640)
+    broken = np.vstack([points, [[np.nan, 0.0, 0.0], [np.inf, 1.0, 2.0], [0.0, -np.inf, 0.0]]])
+    extra = np.array([[0, 1, len(points)], [2, len(points) + 1, 3], [len(points) + 2, 4, 5]], dtype=faces.dtype)
+    _check_views(hip, broken, np.vstack([shuffled, extra]), recs, 480, 640)
+
+
 @pytest.mark.parametrize("scale", [0.25, 0.37, 1.0])
 def test_ragged_sizes_and_scales(hip, scale):
     """h, w not multiples of the 64-pixel tile, and the int(H*s) truncation of cameras.py:179-200."""
