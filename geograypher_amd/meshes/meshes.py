@@ -507,26 +507,41 @@ class TexturedPhotogrammetryMesh:
             chunk = max(int(batch_size), 32)
             chunks = [my_inds[c0 : c0 + chunk] for c0 in range(0, len(my_inds), chunk)]
 
-            def load_chunk(inds):
-                """Label images of one chunk as a pinned (n,h,w) uint8 host tensor (or a device tensor when the
-                segmentor already produces tensors).  Runs on a worker thread: PNG decode and the NN resize of the next
-                chunk overlap the GPU work on the current one (row f4, input pipeline)."""
-                labels = [first_label if i == view_inds[0] else label_fn(i, aggregate_img_scale) for i in inds]
-                if isinstance(labels[0], torch.Tensor):
-                    return torch.stack([l.to(self.backend.device, torch.uint8) for l in labels], dim=0)
-                arr = np.stack([np.asarray(l).astype(np.uint8, copy=False) for l in labels], axis=0)
-                t = torch.from_numpy(arr)
-                if self.backend.device.type == "cuda":
-                    t = t.pin_memory()
-                return t
-
+            # Input pipeline (row f4).  The label images of a chunk are decoded straight into ONE pinned (n,h,w) uint8
+            # staging tensor (no stack / pin copies), by `loader_threads` workers when the segmentor says its lookups
+            # are thread safe (file look-ups and in-memory arrays are; an arbitrary model may not be), while the GPU
+            # works on the previous chunk.
+            import os
             from concurrent.futures import ThreadPoolExecutor
 
-            with ThreadPoolExecutor(max_workers=1) as pool:
-                pending = pool.submit(load_chunk, chunks[0]) if chunks else None
+            thread_safe = bool(getattr(getattr(cameras, "segmentor", None), "thread_safe_lookup", False))
+            n_workers = int(kwargs.pop("loader_threads", min(8, os.cpu_count() or 1) if thread_safe else 1))
+            h0, w0 = np.asarray(first_label).shape[:2] if not isinstance(first_label, torch.Tensor) else first_label.shape[:2]
+            on_gpu = self.backend.device.type == "cuda"
+
+            def one_label(i):
+                return first_label if i == view_inds[0] else label_fn(i, aggregate_img_scale)
+
+            def load_chunk(inds, img_pool):
+                if isinstance(first_label, torch.Tensor):  # the segmentor already produces tensors
+                    return torch.stack([one_label(i).to(self.backend.device, torch.uint8) for i in inds], dim=0)
+                stage = torch.empty((len(inds), h0, w0), dtype=torch.uint8, pin_memory=on_gpu)
+                view = stage.numpy()
+
+                def fill(k):
+                    lab = np.asarray(one_label(inds[k]))
+                    if lab.shape != (h0, w0):
+                        raise ValueError(f"label image of view {inds[k]} has shape {lab.shape}, expected {(h0, w0)}")
+                    view[k] = lab  # casts to uint8 while copying
+
+                list(img_pool.map(fill, range(len(inds))))
+                return stage
+
+            with ThreadPoolExecutor(max_workers=1) as pool, ThreadPoolExecutor(max_workers=max(n_workers, 1)) as img_pool:
+                pending = pool.submit(load_chunk, chunks[0], img_pool) if chunks else None
                 for ci in tqdm(range(len(chunks)), total=len(chunks), desc="Aggregating projected viewpoints"):
                     lab = pending.result()
-                    pending = pool.submit(load_chunk, chunks[ci + 1]) if ci + 1 < len(chunks) else None
+                    pending = pool.submit(load_chunk, chunks[ci + 1], img_pool) if ci + 1 < len(chunks) else None
                     sub = cameras.get_subset_cameras(chunks[ci])
                     if lab.device.type != self.backend.device.type:
                         lab = lab.to(self.backend.device, non_blocking=True)

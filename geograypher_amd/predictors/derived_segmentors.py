@@ -19,6 +19,8 @@ def _nearest_resize(image: np.ndarray, out_hw) -> np.ndarray:
 class LookUpSegmentor(Segmentor):
     """Reads `<lookup_folder>/<path of the image relative to base_folder>.png` as a class-index image."""
 
+    thread_safe_lookup = True  # stateless file look-ups: the aggregation input pipeline may decode several at once
+
     def __init__(self, base_folder, lookup_folder, num_classes=10):
         self.base_folder = Path(base_folder)
         self.lookup_folder = lookup_folder
@@ -49,6 +51,8 @@ class ArrayLabelSegmentor(Segmentor):
         self.num_classes = num_classes
         self._by_name = None if filenames is None else {str(f): i for i, f in enumerate(filenames)}
         self._cursor = 0
+        # keyed by filename: stateless, several look-ups may run at once; keyed by call order: strictly sequential
+        self.thread_safe_lookup = self._by_name is not None
 
     def _lookup(self, filename):
         if self._by_name is not None and filename is not None and str(filename) in self._by_name:
