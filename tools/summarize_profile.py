@@ -57,10 +57,14 @@ def main():
     path, rows = kernel_stats(raw)
     lines.append(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline   [{tag}]")
     lines.append(f"# source: {path}")
-    lines.append(f"{'kernel':58s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
+    # median from the per-launch trace of the same run (the first launches after a mesh upload run cold and pull the mean up)
+    trace = kernel_trace_durations(raw, "trace")
+    lines.append(f"{'kernel':58s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'median_us':>10s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
     for r in rows[:25]:
+        d = sorted(trace.get(short(r['Name']), []))
+        med = d[len(d) // 2] if d else float("nan")
         lines.append(f"{short(r['Name'])[:58]:58s} {r['Calls']:>7s} {float(r['TotalDurationNs'])/1e6:10.3f} "
-                     f"{float(r['AverageNs'])/1e3:10.2f} {float(r['MinNs'])/1e3:9.2f} {float(r['MaxNs'])/1e3:9.2f} "
+                     f"{float(r['AverageNs'])/1e3:10.2f} {med:10.2f} {float(r['MinNs'])/1e3:9.2f} {float(r['MaxNs'])/1e3:9.2f} "
                      f"{float(r['Percentage']):6.2f}")
     fetch = pmc(raw, "pmc_fetch", "FETCH_SIZE")
     write = pmc(raw, "pmc_write", "WRITE_SIZE")
