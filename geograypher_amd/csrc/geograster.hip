@@ -1037,13 +1037,20 @@ __global__ __launch_bounds__(256) void k_vote_labels(KeyT *__restrict__ winner, 
   if (f >= F) return;
   const KeyT mask = (((KeyT)1) << LB) - 1;
   uint32_t c = 0;
-  for (int v = 0; v < n_views; ++v) {
-    const KeyT key = winner[v * F + f];
-    if (key == 0) continue;
-    winner[v * F + f] = 0;
-    const int l = (int)(key & mask);
-    if (l < C) votes[f * C + l] += 1u;
-    ++c;
+  // eight views' winners are requested together (the kernel is a pure stream over winner[views][F]: memory-level
+  // parallelism, not arithmetic, sets its speed), then consumed in view order
+  for (int v0 = 0; v0 < n_views; v0 += 8) {
+    KeyT key[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) key[k] = (v0 + k < n_views) ? winner[(int64_t)(v0 + k) * F + f] : (KeyT)0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (key[k] == 0) continue;
+      winner[(int64_t)(v0 + k) * F + f] = 0;
+      const int l = (int)(key[k] & mask);
+      if (l < C) votes[f * C + l] += 1u;
+      ++c;
+    }
   }
   if (c) counts[f] += c;
 }
