@@ -1309,6 +1309,8 @@ struct gr_ctx {
   int opt_batch = GR_MAX_BATCH;
   int opt_dbg = 0;
   int opt_direct_cap = 512;  // single-pass binning: entry slots per tile (0 = always use the exact two-pass path)
+  int learned_cap = 0, learned_T = 0;  // slots per tile learned from an overflow, valid for images with learned_T tiles
+  int last_T = 0, last_B = 0;          // tile count and launch-group size of the last raster call
   bool direct_ok = true;     // cleared when a tile overflowed its slots: later calls take the exact path
   bool last_direct = false;
   // winner scratch
@@ -1327,6 +1329,15 @@ struct gr_ctx {
 };
 
 namespace {
+
+// Slots per tile of the single-pass binning for an image of T tiles (0 = exact two-pass binning).  A call that
+// overflowed the configured slots teaches the context the size that image needs (gr_raster_status), as long as the
+// entry memory of a launch group stays within GR_DIRECT_BUDGET; other image sizes keep the configured value.
+#define GR_DIRECT_BUDGET (24ll << 30)
+int direct_cap(const gr_ctx *c, int T) {
+  if (c->opt_direct_cap <= 0 || !c->direct_ok) return 0;
+  return (c->learned_cap > 0 && c->learned_T == T) ? c->learned_cap : c->opt_direct_cap;
+}
 
 int fail(gr_ctx *c, int code, const char *fmt, ...) {
   if (c) {
@@ -1381,9 +1392,10 @@ int grow(gr_ctx *c, T *&ptr, int64_t &have, int64_t want, const char *what) {
 
 int ensure_bins(gr_ctx *c, int n_slots, int T) {
   const int64_t F = c->F > 0 ? c->F : 1;
-  const bool direct = c->opt_direct_cap > 0 && c->direct_ok;
+  const int dcap = direct_cap(c, T);
+  const bool direct = dcap > 0;
   int64_t want_cap = c->ent_cap_request > 0 ? c->ent_cap_request : (F / 2 + 65536);
-  if (direct) want_cap = std::max<int64_t>(want_cap, (int64_t)T * c->opt_direct_cap);
+  if (direct) want_cap = std::max<int64_t>(want_cap, (int64_t)T * dcap);
   // strides only ever grow, so a layout change re-allocates (rare: a larger image, mesh or launch group)
   const int slots = std::max(n_slots, c->slots);
   const int Tcap = std::max(T, c->Tcap);
@@ -1422,7 +1434,7 @@ BinArgs make_args(gr_ctx *c, int h, int w, int slot0) {
   a.twl = GR_TILE_LOG2; a.thl = c->opt_thl;
   a.TX = (w + (1 << a.twl) - 1) >> a.twl; a.TY = (h + (1 << a.thl) - 1) >> a.thl; a.T = a.TX * a.TY; a.Tcap = c->Tcap;
   a.h = h; a.w = w; a.dbg = c->opt_dbg;
-  a.cap_tile = (c->opt_direct_cap > 0 && c->direct_ok) ? c->opt_direct_cap : 0;
+  a.cap_tile = direct_cap(c, a.T);
   return a;
 }
 
@@ -1534,6 +1546,7 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   const int T = ((w + GR_TILE - 1) >> GR_TILE_LOG2) * ((h + (1 << thl) - 1) >> thl);
   rc = ensure_bins(c, B, T);
   if (rc) return rc;
+  c->last_T = T; c->last_B = B;
   const int64_t P = (int64_t)h * w, F = c->F;
   int LB = 0, key64 = 0;
   if (labels) {
@@ -1640,7 +1653,7 @@ int gr_set_option(gr_ctx *c, int key, int value) {
       c->opt_dbg = value; return GR_OK;
     case GR_OPT_DIRECT_CAP:
       if (value < 0 || value > 65536) return fail(c, GR_EINVAL, "slots per tile must be in [0, 65536]");
-      c->opt_direct_cap = value; c->direct_ok = true; return GR_OK;
+      c->opt_direct_cap = value; c->direct_ok = true; c->learned_cap = 0; c->learned_T = 0; return GR_OK;
     default: return fail(c, GR_EINVAL, "unknown option %d", key);
   }
 }
@@ -1750,9 +1763,15 @@ int gr_raster_status(gr_ctx *c, gr_raster_stats *o) {
   o->records = (int64_t)st[0]; o->entries = (int64_t)st[1]; o->max_entries = (int64_t)st[2];
   o->entry_cap = c->ent_cap; o->overflow = (int32_t)st[3];
   if (st[3] && c->last_direct) {
-    c->direct_ok = false;  // a tile outgrew its fixed segment: the retry bins exactly (count, scan, fill)
+    // A tile outgrew its fixed segment.  The counters kept counting, so the need is known: the retry uses segments of
+    // that size if a launch group's entry memory stays within budget, and bins exactly (count, scan, fill) otherwise.
+    const int used = direct_cap(c, c->last_T);
+    const int64_t need = ((int64_t)st[2] + (int64_t)st[2] / 8 + 16 + 63) / 64 * 64;
+    const int64_t bytes = need * 64 * (int64_t)c->last_T * (int64_t)std::max(c->last_B, 1);
+    if (need <= 16384 && bytes <= GR_DIRECT_BUDGET) { c->learned_cap = (int)need; c->learned_T = c->last_T; }
+    else c->direct_ok = false;
     return fail(c, GR_EOVERFLOW, "single-pass binning overflow: a tile received %llu entries (slots per tile %d); "
-                "retry the call", st[2], c->opt_direct_cap);
+                "retry the call", st[2], used);
   }
   if (st[3]) {
     // grow on the next call: exact need is known

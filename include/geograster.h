@@ -92,7 +92,9 @@ enum {
   GR_OPT_BATCH = 3,         /* views per launch group, 1..64 (default 64)                                    */
   GR_OPT_DIRECT_CAP = 6,    /* single-pass binning: entry slots per tile (default 512); 0 = always bin exactly
                                (count, scan, fill).  A tile that outgrows its slots is reported by
-                               gr_raster_status (GR_EOVERFLOW); the context then bins exactly from the retry on */
+                               gr_raster_status (GR_EOVERFLOW); the retry uses segments of the size that image needs
+                               (remembered for images of the same tile count) or, beyond 16384 slots / 24 GB of
+                               entry memory per launch group, bins exactly                                     */
   GR_OPT_DEBUG = 99         /* timing-only ablation mask for tools/ab_raster.py: OUTPUTS BECOME WRONG         */
 };
 int gr_set_option(gr_ctx *ctx, int key, int value);

@@ -177,13 +177,24 @@ def test_many_views_in_one_call_cross_batch_boundary(hip, batch):
         hip.set_option(3, 64)
 
 
-def test_single_pass_binning_overflow_falls_back_to_exact(hip):
-    """Eight entry slots per tile are far too few for the C1 views: the overflow is reported, the retry bins exactly and
-    must reproduce the oracle."""
+def test_single_pass_binning_overflow_learns_or_falls_back(hip):
+    """Eight entry slots per tile are far too few for the C1 views: the overflow is reported with the size the image
+    needs and the retry (single-pass binning with segments of that size) must reproduce the oracle.  20 000 faces stacked
+    in ONE tile need more slots than a segment may have: that retry bins exactly (two-pass), same results."""
     (points, faces), cams = synthetic.config1_scene()
     hip.set_option(6, 8)
     ids = _check_views(hip, points, faces, _records(cams), 480, 640)
     assert hip.last_stats["overflow"] == 0 and (ids >= 0).mean() > 0.5
+    hip.set_option(6, 512)
+    n = 20000
+    rng = np.random.default_rng(5)
+    centre = rng.uniform(-0.2, 0.2, size=(n, 1, 3)) * np.array([1.0, 1.0, 0.0]) + np.array([0.0, 0.0, 1.0]) * rng.uniform(-1, 0, size=(n, 1, 1))
+    tri = centre + rng.uniform(-0.15, 0.15, size=(n, 3, 3)) * np.array([1.0, 1.0, 0.0])
+    points2 = tri.reshape(-1, 3)
+    faces2 = np.arange(3 * n).reshape(n, 3)
+    cams2 = synthetic.camera_set_from_poses([synthetic.nadir_pose(0, 0, 5.0)], f=300.0, width=64, height=64)
+    ids2 = _check_views(hip, points2, faces2, _records(cams2), 64, 64)
+    assert hip.last_stats["overflow"] == 0 and hip.last_stats["entries"] > 16384 and (ids2 >= 0).mean() > 0.2
     hip.set_option(6, 512)
 
 
