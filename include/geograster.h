@@ -102,7 +102,9 @@ int gr_get_stage_times(gr_ctx *ctx, gr_stage_times *out_h);
 
 /* mesh -- replaces the per-view mesh + colour upload of meshes.py:1776-1817 (plotter.clear/add_mesh) and the
  * coordinate hand-over of meshes.py:1641-1676.  verts: V x 3 fp32 in the cameras' local frame; faces: F x 3 int32.
- * Borrowed: the caller keeps both alive until the next upload or gr_ctx_destroy.  Validates 0 <= index < V. */
+ * Borrowed: the caller keeps both alive until the next upload or gr_ctx_destroy.  Validates 0 <= index < V
+ * (GR_EINDEX).  The library keeps its own de-indexed copy of the faces, ordered along a Morton curve of their
+ * centroids; every id it reports is an index into the caller's `faces`, whatever their order.  Synchronises `stream`. */
 int gr_mesh_upload(gr_ctx *ctx, const float *verts, const int32_t *faces, int64_t V, int64_t F, void *stream);
 
 /* pix2face -- replaces meshes.py:1776-1836 (encode ids, VTK render, decode, background mask) for n_views
