@@ -1394,22 +1394,19 @@ int ensure_bins(gr_ctx *c, int n_slots, int T) {
   const int64_t F = c->F > 0 ? c->F : 1;
   const int dcap = direct_cap(c, T);
   const bool direct = dcap > 0;
-  int64_t want_cap = c->ent_cap_request > 0 ? c->ent_cap_request : (F / 2 + 65536);
-  if (direct) want_cap = std::max<int64_t>(want_cap, (int64_t)T * dcap);
-  // strides only ever grow, so a layout change re-allocates (rare: a larger image, mesh or launch group)
-  const int slots = std::max(n_slots, c->slots);
-  const int Tcap = std::max(T, c->Tcap);
-  const int64_t cap = std::max(want_cap, c->ent_cap);
-  const int64_t ctrl_stride = ((GR_CTRL_HDR + 4 * (int64_t)Tcap) + 63) / 64 * 64;
-  const int64_t work_stride = std::max<int64_t>(ceil_div(F, GR_BLOCK) + 4, c->work_stride);
-  const int64_t rec_F = std::max<int64_t>(F, c->rec_F);
-  int rc = grow(c, c->ctrl, c->ctrl_have, ctrl_stride * slots, "bin control");
-  if (!rc) rc = grow(c, c->comp, c->comp_have, 4 * cap * slots, "entry list");
-  if (!rc) rc = grow(c, c->work, c->work_have, work_stride * slots, "work list");
-  if (!rc && !direct) rc = grow(c, c->rec, c->rec_have, 4 * rec_F * slots, "record planes");  // exact path only
+  int64_t cap = c->ent_cap_request > 0 ? c->ent_cap_request : (F / 2 + 65536);
+  if (direct) cap = std::max<int64_t>(cap, (int64_t)T * dcap);
+  // The layout (strides) is that of THIS call; a buffer is re-allocated only when the call needs more elements than the
+  // buffer has (a huge image with a small launch group and a small image with a full one share the same memory).
+  const int64_t ctrl_stride = ((GR_CTRL_HDR + 4 * (int64_t)T) + 63) / 64 * 64;
+  const int64_t work_stride = ceil_div(F, GR_BLOCK) + 4;
+  int rc = grow(c, c->ctrl, c->ctrl_have, ctrl_stride * n_slots, "bin control");
+  if (!rc) rc = grow(c, c->comp, c->comp_have, 4 * cap * n_slots, "entry list");
+  if (!rc) rc = grow(c, c->work, c->work_have, work_stride * n_slots, "work list");
+  if (!rc && !direct) rc = grow(c, c->rec, c->rec_have, 4 * F * n_slots, "record planes");  // exact path only
   if (rc) return rc;
-  c->slots = slots; c->Tcap = Tcap; c->ent_cap = cap; c->ctrl_stride = ctrl_stride; c->work_stride = work_stride;
-  if (!direct) { c->rec_F = rec_F; c->rec_stride = 4 * rec_F; }
+  c->slots = n_slots; c->Tcap = T; c->ent_cap = cap; c->ctrl_stride = ctrl_stride; c->work_stride = work_stride;
+  c->rec_F = F; c->rec_stride = 4 * F;
   return GR_OK;
 }
 
@@ -1541,9 +1538,13 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   if (!cams) return fail(c, GR_EINVAL, "null cams");
   if (n_views == 0) return GR_OK;
   GR_HIP(c, hipSetDevice(c->device));
-  const int B = n_views < c->opt_batch ? n_views : c->opt_batch;
+  int B = n_views < c->opt_batch ? n_views : c->opt_batch;
   const int thl = c->opt_thl;
   const int T = ((w + GR_TILE - 1) >> GR_TILE_LOG2) * ((h + (1 << thl) - 1) >> thl);
+  {  // very large images: fewer views per launch group, so that the fixed tile segments stay within the scratch budget
+    const int64_t per_slot = (int64_t)T * direct_cap(c, T) * 64;
+    if (per_slot > 0) B = (int)std::max<int64_t>(1, std::min<int64_t>(B, GR_DIRECT_BUDGET / per_slot));
+  }
   rc = ensure_bins(c, B, T);
   if (rc) return rc;
   c->last_T = T; c->last_B = B;

@@ -84,6 +84,25 @@ def test_face_order_does_not_matter(hip):
     _check_views(hip, broken, np.vstack([shuffled, extra]), recs, 480, 640)
 
 
+def test_maximum_image_size(hip, raster_variant):
+    """16384 x 16384, the largest image the library accepts (guard band, GR_MAX_DIM): 131 072 tiles.  The fixed tile
+    segments of a full launch group would not fit the scratch budget; the group shrinks instead.  One size larger is
+    refused."""
+    if raster_variant != "tile32_direct":
+        pytest.skip("one variant is enough for a 268-megapixel view")
+    (points, faces), _ = synthetic.config1_scene()
+    cams = synthetic.camera_set_from_poses([synthetic.nadir_pose(3.0, -2.0, 40.0, yaw_deg=20.0)] * 2, f=8000.0,
+                                           width=16384, height=16384)
+    recs = _records(cams)
+    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+    ids = hip.raster_face_ids(recs, 16384, 16384)
+    want = oracle_c.raster(points, faces, recs[0], 16384, 16384)
+    assert torch.equal(ids[0].cpu(), torch.from_numpy(want)) and torch.equal(ids[1], ids[0])
+    assert (want >= 0).mean() > 0.5
+    with pytest.raises((ValueError, RuntimeError)):
+        hip.raster_face_ids(recs, 16385, 16384)
+
+
 @pytest.mark.parametrize("scale", [0.25, 0.37, 1.0])
 def test_ragged_sizes_and_scales(hip, scale):
     """h, w not multiples of the 64-pixel tile, and the int(H*s) truncation of cameras.py:179-200."""
