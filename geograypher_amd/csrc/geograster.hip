@@ -8,7 +8,7 @@
 // LDS-resident depth|id tile per workgroup, wave ballot/popcount compaction of surviving faces and global
 // atomicMax/atomicAdd for bins and per-face winners.
 //
-// Rule-set R0-R6 is implemented here independently of oracle/oracle_raster.c; tests demand equality.
+// Rule-set R0-R7 is implemented here independently of oracle/oracle_raster.c; tests demand equality.
 // Compile with -ffp-contract=off: every floating-point operation below is individually rounded on purpose.
 
 #include <hip/hip_runtime.h>
@@ -32,13 +32,13 @@
 #define GR_TILE 64          // tile edge in pixels (one workgroup rasterizes one 64x64 tile out of LDS)
 #define GR_TILE_LOG2 6
 #define GR_MAX_BATCH 64     // views per launch group (amortises kernel boundaries and per-launch tails)
-#define GR_CTRL_HDR 4       // ctrl words before the tile arrays: rec_count, total_entries, overflow, work_count
+#define GR_CTRL_HDR 8       // ctrl words before the tile arrays: rec_count, total_entries, overflow, work_count, clip_count
 #define GR_MAX_DIM 16384    // h, w limit (guard band and 16-bit bbox packing)
 
 namespace {
 
 struct BinArgs {
-  uint32_t *ctrl;        // [slot][GR_CTRL_HDR + 4*Tcap]  rec_count,total,overflow,pad | cntS[T] | cntB[T] | offset[T] | curB[T]
+  uint32_t *ctrl;        // [slot][GR_CTRL_HDR + 4*Tcap]  rec_count,total,overflow,work_count,clip_count,- | cntS[T] | cntB[T] | offset[T] | curB[T]
                          //   cntS: entries whose list position was handed out in k_setup_cull (faces touching <= 2x2 tiles)
                          //   cntB: entries of larger faces, placed by k_fill_compile behind the cntS block of their tile (exact path)
   int4 *rec;             // [slot][4][F]  plane0 {X0,Y0,X1,Y1} plane1 {X2,Y2,iz0,face} plane2 {A,B,jmin|jmax<<16,imin|imax<<16}
@@ -47,6 +47,7 @@ struct BinArgs {
   const int32_t *orig;   // [F] soup position -> face id of the caller's mesh
   const float4 *blk;     // [ceil(F/64)] bounding sphere (centre, radius) of each block of GR_BLOCK faces, local frame
   uint32_t *work;        // [slot][work_stride] blocks of this view that passed the frustum test (ctrl[3] = count)
+  uint32_t *clip;        // [slot][F] soup faces that straddle the near plane / guard band (R7; ctrl[4] = count)
   int64_t work_stride;
   int4 *comp;            // [slot][ent_cap][4]  compiled (face, tile) entries grouped by tile, 64-byte slots (13 words used)
   unsigned long long *stats;  // [4] records, entries, max_entries, overflow (accumulated over the call)
@@ -69,6 +70,7 @@ struct Vtx {
   int X, Y;
   float iz;
   bool valid;
+  bool front, finite;  // q_z > near; camera-space point finite (R7: which invalid faces are clipped instead of dropped)
 };
 
 // R1 -- vertex transform, fp32, each operation individually rounded
@@ -85,6 +87,8 @@ __device__ __forceinline__ Vtx project_vertex(const float *__restrict__ p, const
   m0 = cam[2] * dx; m1 = cam[5] * dy; m2 = cam[8] * dz;
   const float qz = (m0 + m1) + m2;
   v.valid = qz > cam[15];
+  v.front = v.valid;
+  v.finite = isfinite(qx) && isfinite(qy) && isfinite(qz);
   const float iz = 1.0f / qz;  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
   const float fx = cam[12] * qx;
   const float fy = cam[12] * qy;
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
   const int64_t f = (int64_t)blk_next * GR_BLOCK + lane;
   if (wi + wstep < n_work) blk_next = work[wi + wstep];
 
-  bool keep = false;
+  bool keep = false, clip_me = false;
   int4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0};
   int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
   if (f < a.F) {
@@ -299,6 +303,8 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
     Vtx v0 = project_vertex(sp, cam);
     Vtx v1 = project_vertex(sp + 3, cam);
     Vtx v2 = project_vertex(sp + 6, cam);
+    clip_me = !(v0.valid && v1.valid && v2.valid) && (v0.front || v1.front || v2.front) && v0.finite && v1.finite &&
+              v2.finite;
     if (v0.valid && v1.valid && v2.valid) {
       long long area2 = (long long)(v1.X - v0.X) * (long long)(v2.Y - v0.Y) -
                         (long long)(v2.X - v0.X) * (long long)(v1.Y - v0.Y);
@@ -332,6 +338,15 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
         }
       }
     }
+  }
+  // R7: faces that straddle the near plane or the guard band go to the view's clip list (k_clip_faces)
+  const unsigned long long mc = __ballot(clip_me);
+  if (mc) {
+    const int lead = __ffsll((long long)mc) - 1;
+    uint32_t cb = 0;
+    if (lane == lead) cb = atomicAdd(&ctrl[4], (uint32_t)__popcll(mc));
+    cb = __shfl(cb, lead);
+    if (clip_me) a.clip[(int64_t)slot * a.F + cb + __popcll(mc & ((1ull << lane) - 1ull))] = (uint32_t)f;
   }
   // wave-level compaction of survivors
   const unsigned long long m = __ballot(keep);
@@ -592,6 +607,155 @@ __global__ __launch_bounds__(256) void k_fill_compile(BinArgs a) {
         if (idx < a.ent_cap) compile_entry(comp + idx * 4, p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH);
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K3c  R7: faces that straddle the near plane or the guard band (the view's clip list, filled by K1) are clipped in
+//      camera space -- Sutherland-Hodgman against z >= near and |s| <= 16383 px, double precision, every operation
+//      individually rounded, crossings always computed from the inside vertex (two faces sharing an edge get the same
+//      new vertex) -- and the fan of the clipped polygon is binned like any other triangle, with the face's id.  Rare
+//      (a camera inside the scene, faces larger than the guard band): one thread per face, plain atomics, local arrays.
+//      The oracle's orc_clip_face is the same code in C.
+// ------------------------------------------------------------------------------------------------------------------
+struct P3 { double x, y, z; };
+
+__device__ __forceinline__ double clip_plane(const double *pl, P3 p) {
+  const double t1 = pl[0] * p.x, t2 = pl[1] * p.y, t3 = pl[2] * p.z;
+  return ((t1 + t2) + t3) + pl[3];
+}
+
+__device__ __forceinline__ P3 clip_cross(P3 in, double din, P3 out, double dout) {
+  const double t = din / (din - dout);
+  const double ex = out.x - in.x, ey = out.y - in.y, ez = out.z - in.z;
+  const double px = t * ex, py = t * ey, pz = t * ez;
+  P3 r;
+  r.x = in.x + px; r.y = in.y + py; r.z = in.z + pz;
+  return r;
+}
+
+// one triangle of a clipped face: R2 / R4 set-up from three snapped vertices, then binning (no wave aggregation)
+template <bool DIRECT>
+__device__ void emit_triangle(const BinArgs &a, int slot, uint32_t *ctrl, Vtx v0, Vtx v1, Vtx v2, int face) {
+  long long area2 = (long long)(v1.X - v0.X) * (long long)(v2.Y - v0.Y) - (long long)(v2.X - v0.X) * (long long)(v1.Y - v0.Y);
+  if (area2 == 0) return;
+  if (area2 < 0) { Vtx t = v1; v1 = v2; v2 = t; area2 = -area2; }
+  const int Xmin = imin3(v0.X, v1.X, v2.X), Xmax = imax3(v0.X, v1.X, v2.X);
+  const int Ymin = imin3(v0.Y, v1.Y, v2.Y), Ymax = imax3(v0.Y, v1.Y, v2.Y);
+  int jmin = (Xmin - 128 + 255) >> 8, jmax = (Xmax - 128) >> 8;
+  int imin = (Ymin - 128 + 255) >> 8, imax = (Ymax - 128) >> 8;
+  jmin = max(jmin, 0); imin = max(imin, 0);
+  jmax = min(jmax, a.w - 1); imax = min(imax, a.h - 1);
+  if (jmin > jmax || imin > imax) return;
+  const double d1 = (double)v1.iz - (double)v0.iz;
+  const double d2 = (double)v2.iz - (double)v0.iz;
+  const double a2 = (double)area2;
+  double n1, n2;
+  n1 = d1 * (double)(v2.Y - v0.Y); n2 = d2 * (double)(v1.Y - v0.Y);
+  const float A = (float)((n1 - n2) / a2);
+  n1 = d2 * (double)(v1.X - v0.X); n2 = d1 * (double)(v2.X - v0.X);
+  const float B = (float)((n1 - n2) / a2);
+  const int4 r0 = make_int4(v0.X, v0.Y, v1.X, v1.Y);
+  const int4 r1 = make_int4(v2.X, v2.Y, __float_as_int(v0.iz), face);
+  const int4 r2 = make_int4(__float_as_int(A), __float_as_int(B), jmin | (jmax << 16), imin | (imax << 16));
+  const int tx0 = jmin >> a.twl, tx1 = jmax >> a.twl, ty0 = imin >> a.thl, ty1 = imax >> a.thl;
+  uint32_t *cntS = ctrl + GR_CTRL_HDR;
+  uint32_t *cntB = cntS + a.Tcap;
+  if (DIRECT) {
+    int4 *comp = a.comp + slot * a.ent_cap * 4;
+    for (int ty = ty0; ty <= ty1; ++ty)
+      for (int tx = tx0; tx <= tx1; ++tx) {
+        const int t = ty * a.TX + tx;
+        const uint32_t pos = atomicAdd(&cntS[t], 1u);
+        if (pos < (uint32_t)a.cap_tile) compile_entry(comp + ((int64_t)t * a.cap_tile + pos) * 4, r0, r1, r2, tx << a.twl,
+                                                      ty << a.thl, 1 << a.twl, 1 << a.thl);
+        else ctrl[2] = 1u;
+      }
+  } else {
+    const uint32_t s = atomicAdd(&ctrl[0], 1u);
+    if ((int64_t)s >= a.F) { atomicMax(&a.stats[3], 1ull); return; }  // more records than faces: the call is rejected
+    const bool small_fp = (tx1 - tx0 <= 1) && (ty1 - ty0 <= 1);
+    int4 r3 = {0, 0, 0, 0};
+    if (small_fp) {
+      r3.x = (int)atomicAdd(&cntS[ty0 * a.TX + tx0], 1u);
+      if (tx1 > tx0) r3.y = (int)atomicAdd(&cntS[ty0 * a.TX + tx1], 1u);
+      if (ty1 > ty0) r3.z = (int)atomicAdd(&cntS[ty1 * a.TX + tx0], 1u);
+      if (tx1 > tx0 && ty1 > ty0) r3.w = (int)atomicAdd(&cntS[ty1 * a.TX + tx1], 1u);
+    } else {
+      for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&cntB[ty * a.TX + tx], 1u);
+    }
+    int4 *rec = a.rec + slot * a.rec_stride;
+    rec[s] = r0; rec[a.F + s] = r1; rec[2 * a.F + s] = r2; rec[3 * a.F + s] = r3;
+  }
+}
+
+template <bool DIRECT>
+__global__ __launch_bounds__(256) void k_clip_faces(const float *__restrict__ cams, BinArgs a) {
+  const int slot = blockIdx.y;
+  const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
+  uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  const int64_t n_clip = min((int64_t)ctrl[4], a.F);
+  const float fe = cam[12], cxp = cam[13], cyp = cam[14], nearp = cam[15];
+  if (!(nearp > 0.0f) || !(fe > 0.0f) || !isfinite(fe) || !isfinite(cxp) || !isfinite(cyp)) return;
+  constexpr double G = 16383.0;
+  const double planes[5][4] = {
+      {0.0, 0.0, 1.0, -(double)nearp},
+      {-(double)fe, 0.0, G - (double)cxp, 0.0},
+      {(double)fe, 0.0, G + (double)cxp, 0.0},
+      {0.0, -(double)fe, G - (double)cyp, 0.0},
+      {0.0, (double)fe, G + (double)cyp, 0.0},
+  };
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_clip; i += (int64_t)gridDim.x * 256) {
+    const int64_t f = a.clip[(int64_t)slot * a.F + i];
+    const float *sp = a.soup + 9 * f;
+    P3 pa[8], pb[8];
+    for (int k = 0; k < 3; ++k) {  // the first half of R1
+      const float *p = sp + 3 * k;
+      const float dx = p[0] - cam[9], dy = p[1] - cam[10], dz = p[2] - cam[11];
+      float m0, m1, m2;
+      m0 = cam[0] * dx; m1 = cam[3] * dy; m2 = cam[6] * dz;
+      pa[k].x = (double)((m0 + m1) + m2);
+      m0 = cam[1] * dx; m1 = cam[4] * dy; m2 = cam[7] * dz;
+      pa[k].y = (double)((m0 + m1) + m2);
+      m0 = cam[2] * dx; m1 = cam[5] * dy; m2 = cam[8] * dz;
+      pa[k].z = (double)((m0 + m1) + m2);
+    }
+    int n = 3;
+    bool bad = false;
+    for (int pl = 0; pl < 5 && n > 0; ++pl) {
+      int m = 0;
+      for (int e = 0; e < n; ++e) {
+        const P3 S = pa[e], E = pa[(e + 1) % n];
+        const double dS = clip_plane(planes[pl], S), dE = clip_plane(planes[pl], E);
+        const bool inS = dS >= 0.0, inE = dE >= 0.0;
+        if (inS && inE) { if (m < 8) pb[m] = E; ++m; }
+        else if (inS && !inE) { if (m < 8) pb[m] = clip_cross(S, dS, E, dE); ++m; }
+        else if (!inS && inE) { if (m < 8) pb[m] = clip_cross(E, dE, S, dS); ++m; if (m < 8) pb[m] = E; ++m; }
+      }
+      if (m > 8) { bad = true; break; }
+      n = m;
+      for (int e = 0; e < n; ++e) pa[e] = pb[e];
+    }
+    if (bad || n < 3) continue;
+    Vtx poly[8];
+    for (int e = 0; e < n; ++e) {
+      const float qx = (float)pa[e].x, qy = (float)pa[e].y, qz = (float)pa[e].z;
+      if (!(qz > 0.0f)) { bad = true; break; }
+      const float iz = 1.0f / qz;
+      const float fx = fe * qx;
+      const float fy = fe * qy;
+      const float sx = cxp + fx * iz;
+      const float sy = cyp + fy * iz;
+      if (!(fabsf(sx) < 16384.0f) || !(fabsf(sy) < 16384.0f)) { bad = true; break; }
+      poly[e].X = (int)floorf(sx * 256.0f + 0.5f);
+      poly[e].Y = (int)floorf(sy * 256.0f + 0.5f);
+      poly[e].iz = iz;
+      poly[e].valid = true; poly[e].front = true; poly[e].finite = true;
+    }
+    if (bad) continue;
+    const int face = a.orig[f];
+    for (int k = 1; k + 1 < n; ++k) emit_triangle<DIRECT>(a, slot, ctrl, poly[0], poly[k], poly[k + 1], face);
   }
 }
 
@@ -1293,6 +1457,8 @@ struct gr_ctx {
   int4 *comp = nullptr;
   uint32_t *work = nullptr;
   int64_t work_stride = 0;
+  uint32_t *clip = nullptr;   // [slot][F] clip lists (R7)
+  int64_t clip_have = 0;
   float4 *blk = nullptr;
   int64_t blk_cap = 0;
   float *soup = nullptr;
@@ -1403,6 +1569,7 @@ int ensure_bins(gr_ctx *c, int n_slots, int T) {
   int rc = grow(c, c->ctrl, c->ctrl_have, ctrl_stride * n_slots, "bin control");
   if (!rc) rc = grow(c, c->comp, c->comp_have, 4 * cap * n_slots, "entry list");
   if (!rc) rc = grow(c, c->work, c->work_have, work_stride * n_slots, "work list");
+  if (!rc) rc = grow(c, c->clip, c->clip_have, F * n_slots, "clip list");
   if (!rc && !direct) rc = grow(c, c->rec, c->rec_have, 4 * F * n_slots, "record planes");  // exact path only
   if (rc) return rc;
   c->slots = n_slots; c->Tcap = T; c->ent_cap = cap; c->ctrl_stride = ctrl_stride; c->work_stride = work_stride;
@@ -1428,6 +1595,7 @@ BinArgs make_args(gr_ctx *c, int h, int w, int slot0) {
   a.ctrl = c->ctrl + slot0 * a.ctrl_stride; a.rec = c->rec + slot0 * a.rec_stride;
   a.comp = c->comp + slot0 * a.ent_cap * 4; a.work = c->work + slot0 * a.work_stride;
   a.stats = c->stats; a.blk = c->blk; a.soup = c->soup; a.orig = c->orig;
+  a.clip = c->clip + slot0 * c->F;
   a.twl = GR_TILE_LOG2; a.thl = c->opt_thl;
   a.TX = (w + (1 << a.twl) - 1) >> a.twl; a.TY = (h + (1 << a.thl) - 1) >> a.thl; a.T = a.TX * a.TY; a.Tcap = c->Tcap;
   a.h = h; a.w = w; a.dbg = c->opt_dbg;
@@ -1443,12 +1611,15 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, hip
     Timed t(c, s, ST_SETUP);
     const int nblk = (int)ceil_div(c->F, GR_BLOCK);
     hipLaunchKernelGGL(k_cull_blocks, dim3((unsigned)ceil_div(nblk, 256), nb), dim3(256), 0, s, cams, a, nblk);
-    if (a.cap_tile > 0)
+    if (a.cap_tile > 0) {
       hipLaunchKernelGGL(k_setup_cull<true>, dim3((unsigned)std::min((nblk + 3) / 4, 1024), nb), dim3(256), 0, s, c->verts,
                          c->faces, cams, a);
-    else
+      hipLaunchKernelGGL(k_clip_faces<true>, dim3(16, nb), dim3(256), 0, s, cams, a);
+    } else {
       hipLaunchKernelGGL(k_setup_cull<false>, dim3((unsigned)std::min((nblk + 3) / 4, 1024), nb), dim3(256), 0, s, c->verts,
                          c->faces, cams, a);
+      hipLaunchKernelGGL(k_clip_faces<false>, dim3(16, nb), dim3(256), 0, s, cams, a);
+    }
   }
   c->last_direct = a.cap_tile > 0;
   if (a.cap_tile > 0) {
@@ -1619,6 +1790,7 @@ int gr_ctx_destroy(gr_ctx *c) {
   if (c->rec) (void)hipFree(c->rec);
   if (c->comp) (void)hipFree(c->comp);
   if (c->work) (void)hipFree(c->work);
+  if (c->clip) (void)hipFree(c->clip);
   if (c->winner) (void)hipFree(c->winner);
   if (c->sort_tmp) (void)hipFree(c->sort_tmp);
   if (c->blk) (void)hipFree(c->blk);

@@ -109,7 +109,7 @@ int gr_mesh_upload(gr_ctx *ctx, const float *verts, const int32_t *faces, int64_
 
 /* pix2face -- replaces meshes.py:1776-1836 (encode ids, VTK render, decode, background mask) for n_views
  * cameras of equal image size.  ids: n_views x h x w int32, background -1.  depth (may be NULL): n_views x h x w
- * fp32 camera-space depth of the visible face, +inf for background.  Rule-set: DESIGN.md R0-R6. */
+ * fp32 camera-space depth of the visible face, +inf for background.  Rule-set: DESIGN.md R0-R7. */
 int gr_raster_face_ids(gr_ctx *ctx, const float *cams, int n_views, int h, int w, int32_t *ids, float *depth,
                        void *stream);
 int gr_raster_status(gr_ctx *ctx, gr_raster_stats *out_h); /* synchronises `stream` of the last raster call */

@@ -10,7 +10,7 @@
  * from this image: vtk==9.2.6 driven through pyvista==0.42.2 (poetry.lock:3361-3362, 2342-2343), i.e. an
  * OpenGL polygon rasterizer.  What is restated here is the *published* algorithm of that stage (OpenGL 4.6
  * core spec 14.6.1 "Basic Polygon Rasterization": point sampling at pixel centres, a consistent
- * shared-edge fill rule, nearest-depth-wins with window-space-linear depth) as the fixed rule-set R0-R6 of
+ * shared-edge fill rule, nearest-depth-wins with window-space-linear depth) as the fixed rule-set R0-R7 of
  * DESIGN.md.  The HIP kernels implement the same rule-set independently; tests require bit equality.
  *
  * PARITY STATUS: pinned to the reference's own known-answer tests for this stage
@@ -80,12 +80,8 @@ typedef struct {
 static inline int32_t orc_min3(int32_t a, int32_t b, int32_t c) { int32_t m = a < b ? a : b; return m < c ? m : c; }
 static inline int32_t orc_max3(int32_t a, int32_t b, int32_t c) { int32_t m = a > b ? a : b; return m > c ? m : c; }
 
-/* R2 + R4 setup. Returns 0 when the face is discarded. */
-static int orc_setup(const float *verts, const int32_t *face, const float *cam, int h, int w, orc_tri *t) {
-  orc_vtx v0 = orc_project(verts + 3 * (int64_t)face[0], cam);
-  orc_vtx v1 = orc_project(verts + 3 * (int64_t)face[1], cam);
-  orc_vtx v2 = orc_project(verts + 3 * (int64_t)face[2], cam);
-  if (!(v0.valid && v1.valid && v2.valid)) return 0;
+/* R2 + R4 setup from three snapped vertices. Returns 0 when the triangle is discarded. */
+static int orc_setup_snapped(orc_vtx v0, orc_vtx v1, orc_vtx v2, int h, int w, orc_tri *t) {
   int64_t area2 = (int64_t)(v1.X - v0.X) * (int64_t)(v2.Y - v0.Y) - (int64_t)(v2.X - v0.X) * (int64_t)(v1.Y - v0.Y);
   if (area2 == 0) return 0;
   if (area2 < 0) { orc_vtx s = v1; v1 = v2; v2 = s; area2 = -area2; } /* both windings are drawn */
@@ -115,6 +111,112 @@ static int orc_setup(const float *verts, const int32_t *face, const float *cam, 
   double Bd = (n1 - n2) / a2;
   t->iz0 = v0.iz; t->A = (float)Ad; t->B = (float)Bd;
   return 1;
+}
+
+/* R7: a face that is partly in front of the near plane or partly inside the guard band is CLIPPED, as the OpenGL
+ * pipeline clips primitives to the view volume (OpenGL 4.6 core 13.7), instead of being dropped: Sutherland-Hodgman in
+ * camera space against the near plane z >= near and the four guard planes |s| <= 16383 px (one pixel inside the
+ * validity limit of R1, so that the rounded projections of the new vertices stay valid), in that order, in double
+ * precision with every operation individually rounded.  A crossing is always computed from the inside vertex towards
+ * the outside one, so two faces that share an edge compute the same new vertex.  The clipped polygon (<= 8 vertices)
+ * is rounded to fp32 camera-space points, projected like R1, and drawn as a triangle fan; every triangle of the fan
+ * carries the face's id and its own 1/z plane (R4).  Faces entirely behind the near plane, faces with a non-finite
+ * vertex and cameras with near <= 0 or f_eff <= 0 keep the old rule: dropped.  Returns the number of triangles. */
+#define ORC_CLIP_G 16383.0
+typedef struct { double x, y, z; } orc_p3;
+
+static void orc_camspace(const float *p, const float *cam, float q[3]) { /* the first half of R1 */
+  float dx = p[0] - cam[9];
+  float dy = p[1] - cam[10];
+  float dz = p[2] - cam[11];
+  float m0, m1, m2;
+  m0 = cam[0] * dx; m1 = cam[3] * dy; m2 = cam[6] * dz;
+  q[0] = (m0 + m1) + m2;
+  m0 = cam[1] * dx; m1 = cam[4] * dy; m2 = cam[7] * dz;
+  q[1] = (m0 + m1) + m2;
+  m0 = cam[2] * dx; m1 = cam[5] * dy; m2 = cam[8] * dz;
+  q[2] = (m0 + m1) + m2;
+}
+
+static inline double orc_plane(const double *pl, orc_p3 p) {
+  double t1 = pl[0] * p.x, t2 = pl[1] * p.y, t3 = pl[2] * p.z;
+  return ((t1 + t2) + t3) + pl[3];
+}
+
+static inline orc_p3 orc_cross(orc_p3 in, double din, orc_p3 out, double dout) { /* from the inside vertex */
+  double t = din / (din - dout);
+  orc_p3 r;
+  double ex = out.x - in.x, ey = out.y - in.y, ez = out.z - in.z;
+  double px = t * ex, py = t * ey, pz = t * ez;
+  r.x = in.x + px; r.y = in.y + py; r.z = in.z + pz;
+  return r;
+}
+
+static int orc_clip_face(const float *verts, const int32_t *face, const float *cam, orc_vtx out[8]) {
+  float q[3][3];
+  for (int k = 0; k < 3; ++k) orc_camspace(verts + 3 * (int64_t)face[k], cam, q[k]);
+  const float fe = cam[12], cxp = cam[13], cyp = cam[14], nearp = cam[15];
+  if (!(nearp > 0.0f) || !(fe > 0.0f) || !isfinite(fe) || !isfinite(cxp) || !isfinite(cyp)) return 0;
+  int front = 0;
+  for (int k = 0; k < 3; ++k) {
+    if (!isfinite(q[k][0]) || !isfinite(q[k][1]) || !isfinite(q[k][2])) return 0;
+    if (q[k][2] > nearp) ++front;
+  }
+  if (front == 0) return 0;
+  const double planes[5][4] = {
+      {0.0, 0.0, 1.0, -(double)nearp},
+      {-(double)fe, 0.0, ORC_CLIP_G - (double)cxp, 0.0},
+      {(double)fe, 0.0, ORC_CLIP_G + (double)cxp, 0.0},
+      {0.0, -(double)fe, ORC_CLIP_G - (double)cyp, 0.0},
+      {0.0, (double)fe, ORC_CLIP_G + (double)cyp, 0.0},
+  };
+  orc_p3 a[8], b[8];
+  int n = 3;
+  for (int k = 0; k < 3; ++k) { a[k].x = q[k][0]; a[k].y = q[k][1]; a[k].z = q[k][2]; }
+  for (int pl = 0; pl < 5 && n > 0; ++pl) {
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+      orc_p3 S = a[i], E = a[(i + 1) % n];
+      double dS = orc_plane(planes[pl], S), dE = orc_plane(planes[pl], E);
+      int inS = dS >= 0.0, inE = dE >= 0.0;
+      if (inS && inE) { if (m < 8) b[m] = E; ++m; }
+      else if (inS && !inE) { if (m < 8) b[m] = orc_cross(S, dS, E, dE); ++m; }
+      else if (!inS && inE) { if (m < 8) b[m] = orc_cross(E, dE, S, dS); ++m; if (m < 8) b[m] = E; ++m; }
+    }
+    if (m > 8) return 0; /* cannot happen for a convex polygon and five planes */
+    n = m;
+    for (int i = 0; i < n; ++i) a[i] = b[i];
+  }
+  if (n < 3) return 0;
+  for (int i = 0; i < n; ++i) {
+    float qx = (float)a[i].x, qy = (float)a[i].y, qz = (float)a[i].z;
+    if (!(qz > 0.0f)) return 0;
+    float iz = 1.0f / qz;
+    float fx = fe * qx;
+    float fy = fe * qy;
+    float sx = cxp + fx * iz;
+    float sy = cyp + fy * iz;
+    if (!(fabsf(sx) < ORC_GUARD) || !(fabsf(sy) < ORC_GUARD)) return 0;
+    out[i].X = (int32_t)floorf(sx * 256.0f + 0.5f);
+    out[i].Y = (int32_t)floorf(sy * 256.0f + 0.5f);
+    out[i].iz = iz;
+    out[i].valid = 1;
+  }
+  return n;
+}
+
+/* All triangles a face contributes (R2/R4 set up): one when its three vertices are valid, the fan of its clipped
+ * polygon (R7) when some are not, none when it is dropped.  t: room for 6. */
+static int orc_face_tris(const float *verts, const int32_t *face, const float *cam, int h, int w, orc_tri *t) {
+  orc_vtx v0 = orc_project(verts + 3 * (int64_t)face[0], cam);
+  orc_vtx v1 = orc_project(verts + 3 * (int64_t)face[1], cam);
+  orc_vtx v2 = orc_project(verts + 3 * (int64_t)face[2], cam);
+  if (v0.valid && v1.valid && v2.valid) return orc_setup_snapped(v0, v1, v2, h, w, t);
+  orc_vtx poly[8];
+  int n = orc_clip_face(verts, face, cam, poly);
+  int count = 0;
+  for (int k = 1; k + 1 < n; ++k) count += orc_setup_snapped(poly[0], poly[k], poly[k + 1], h, w, t + count);
+  return count;
 }
 
 /* R3: edge k runs from vertex a=k to b=(k+1)%3; returns 1 when pixel centre (Px,Py) is covered */
@@ -165,8 +267,10 @@ int orc_raster_spec(const float *verts, const int32_t *faces, int64_t V, int64_t
   int64_t n = (int64_t)h * w;
   for (int64_t p = 0; p < n; ++p) { ids[p] = -1; zbuf[p] = 0; }
   for (int64_t f = 0; f < F; ++f) {
-    orc_tri t;
-    if (!orc_setup(verts, faces + 3 * f, cam, h, w, &t)) continue;
+   orc_tri tris[6];
+   const int ntri = orc_face_tris(verts, faces + 3 * f, cam, h, w, tris);
+   for (int it = 0; it < ntri; ++it) {
+    const orc_tri t = tris[it];
     int own[3] = {orc_owns(&t, 0), orc_owns(&t, 1), orc_owns(&t, 2)};
     for (int32_t i = t.imin; i <= t.imax; ++i) {
       for (int32_t j = t.jmin; j <= t.jmax; ++j) {
@@ -180,6 +284,7 @@ int orc_raster_spec(const float *verts, const int32_t *faces, int64_t V, int64_t
         orc_resolve(zbuf, ids, (int64_t)i * w + j, orc_zbits(&t, Px, Py), (int32_t)f);
       }
     }
+   }
   }
   orc_finish(zbuf, ids, depth, n);
   return 0;
@@ -192,8 +297,10 @@ int orc_raster_fast(const float *verts, const int32_t *faces, int64_t V, int64_t
   int64_t n = (int64_t)h * w;
   for (int64_t p = 0; p < n; ++p) { ids[p] = -1; zbuf[p] = 0; }
   for (int64_t f = 0; f < F; ++f) {
-    orc_tri t;
-    if (!orc_setup(verts, faces + 3 * f, cam, h, w, &t)) continue;
+   orc_tri tris[6];
+   const int ntri = orc_face_tris(verts, faces + 3 * f, cam, h, w, tris);
+   for (int it = 0; it < ntri; ++it) {
+    const orc_tri t = tris[it];
     int64_t bias[3], stepx[3], e_row[3];
     int32_t Px0 = t.jmin * ORC_SUB + ORC_HALF;
     for (int k = 0; k < 3; ++k) {
@@ -213,6 +320,7 @@ int orc_raster_fast(const float *verts, const int32_t *faces, int64_t V, int64_t
         orc_resolve(zbuf, ids, p, orc_zbits(&t, j * ORC_SUB + ORC_HALF, Py), (int32_t)f);
       }
     }
+   }
   }
   orc_finish(zbuf, ids, depth, n);
   return 0;

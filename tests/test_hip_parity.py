@@ -116,14 +116,15 @@ def test_ragged_sizes_and_scales(hip, scale):
 @pytest.mark.parametrize("seed", range(3))
 def test_triangle_soup_occlusion_degenerates_behind_camera(hip, seed):
     """Random overlapping triangles of every size: sub-pixel slivers, triangles larger than a tile (64-bit edge path),
-    coincident depths, zero-area faces, faces behind / straddling the camera plane."""
+    coincident depths, zero-area faces, faces behind / straddling the camera plane (the large ones among the latter pass
+    right in front of the lens and cover most of the picture once they are clipped instead of dropped)."""
     rng = np.random.default_rng(seed)
     n = 3000
     centers = rng.uniform(-30, 30, (n, 1, 3)) * np.array([1, 1, 0.3])
     size = np.exp(rng.uniform(np.log(0.02), np.log(40.0), (n, 1, 1)))
     tri = centers + rng.normal(0, 1, (n, 3, 3)) * size
     tri[:50, :, 2] = 45.0                       # behind the camera (camera at z = 40 looking down)
-    tri[50:100, 0, 2] = 45.0                    # straddling the camera plane -> discarded as a whole
+    tri[50:100, 0, 2] = 45.0                    # straddling the camera plane -> clipped at the near plane (R7)
     tri[100:120, 2] = tri[100:120, 1]           # zero area
     tri[120:140] = tri[140:160]                 # coincident faces: lower id wins
     points = tri.reshape(-1, 3)
@@ -132,7 +133,36 @@ def test_triangle_soup_occlusion_degenerates_behind_camera(hip, seed):
              synthetic.look_at((60, 10, 25), (0, 0, 0), up_hint=(0, 0, 1))]
     cams = synthetic.camera_set_from_poses(poses, f=300.0, width=333, height=251)
     ids = _check_views(hip, points, faces, _records(cams, near=0.5), 251, 333, depth=True)
-    assert len(np.unique(ids)) > 20
+    assert len(np.unique(ids)) >= 3
+
+
+def test_clipping_near_plane_and_guard_band(hip):
+    """R7.  A ground plane of two 1 km triangles seen from 2 m above it, looking at the horizon: every vertex is either
+    behind the camera or far outside the guard band, the clipped faces fill the picture below the horizon, and the
+    depth of the bottom-centre pixel is the analytic one.  Then a camera in the middle of a dense terrain (faces pass
+    behind and beside the lens at every distance), and a camera whose near plane cuts the C1 plane obliquely."""
+    pts = np.array([[-500, -500, 0], [500, -500, 0], [500, 500, 0], [-500, 500, 0]], dtype=np.float64)
+    quad = np.array([[0, 1, 2], [0, 2, 3]])
+    pose = synthetic.look_at((0.0, 0.0, 2.0), (0.0, 100.0, 2.0), up_hint=(0, 0, 1))
+    cams = synthetic.camera_set_from_poses([pose], f=300.0, width=320, height=240)
+    recs = _records(cams, near=0.1)
+    hip.upload_mesh(pts.astype(np.float32), quad.astype(np.int32))
+    ids, dep = hip.raster_face_ids(recs, 240, 320, want_depth=True)
+    want, wdep = oracle_c.raster(pts, quad, recs[0], 240, 320, want_depth=True)
+    np.testing.assert_array_equal(ids[0].cpu().numpy(), want)
+    np.testing.assert_array_equal(dep[0].cpu().numpy().view(np.int32), wdep.view(np.int32))
+    rows = np.nonzero((want >= 0).any(axis=1))[0]
+    assert rows[0] == 121 and rows[-1] == 239 and (want[121:] >= 0).all() and (want[:120] == -1).all()
+    assert abs(wdep[239, 160] - 2.0 * 300.0 / 119.5) < 1e-3
+
+    (points, faces), _ = synthetic.config1_scene()
+    poses = [synthetic.look_at((1.0, 2.0, 0.9), (30.0, 20.0, 0.0), up_hint=(0, 0, 1)),
+             synthetic.look_at((-3.0, 0.5, 0.7), (0.0, 40.0, 5.0), up_hint=(0, 0, 1)),
+             synthetic.nadir_pose(0.0, 0.0, 0.8, tilt_x_deg=70.0)]
+    cams = synthetic.camera_set_from_poses(poses, f=250.0, width=333, height=251)
+    for near in (0.05, 0.7):
+        ids = _check_views(hip, points, faces, _records(cams, near=near), 251, 333, depth=True)
+        assert (ids >= 0).mean() > 0.3
 
 
 @pytest.mark.parametrize("seed", range(12))

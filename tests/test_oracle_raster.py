@@ -38,15 +38,76 @@ def _project_f32(p, cam):
     return int(np.floor(f32(sx * f32(256.0)) + f32(0.5))), int(np.floor(f32(sy * f32(256.0)) + f32(0.5))), iz
 
 
+def _clip_python(pts, cam):
+    """R7 in Python floats (IEEE doubles, one rounding per operation): the clipped polygon of a face as snapped
+    (X, Y, iz) vertices, [] when the face is dropped."""
+    f32 = np.float32
+    q = []
+    for p in pts:
+        d = [f32(p[i]) - cam[9 + i] for i in range(3)]
+        q.append([f32(f32(cam[c] * d[0] + cam[3 + c] * d[1]) + cam[6 + c] * d[2]) for c in range(3)])
+    fe, cxp, cyp, near = cam[12], cam[13], cam[14], cam[15]
+    if not (near > 0 and fe > 0 and np.isfinite(fe) and np.isfinite(cxp) and np.isfinite(cyp)):
+        return []
+    if not all(np.isfinite(c) for v in q for c in v) or not any(v[2] > near for v in q):
+        return []
+    G = 16383.0
+    planes = [(0.0, 0.0, 1.0, -float(near)), (-float(fe), 0.0, G - float(cxp), 0.0), (float(fe), 0.0, G + float(cxp), 0.0),
+              (0.0, -float(fe), G - float(cyp), 0.0), (0.0, float(fe), G + float(cyp), 0.0)]
+    poly = [tuple(float(c) for c in v) for v in q]
+
+    def dist(pl, P):
+        return ((pl[0] * P[0] + pl[1] * P[1]) + pl[2] * P[2]) + pl[3]
+
+    def cross(inside, din, outside, dout):
+        t = din / (din - dout)
+        return tuple(inside[k] + t * (outside[k] - inside[k]) for k in range(3))
+
+    for pl in planes:
+        out = []
+        for i in range(len(poly)):
+            S, E = poly[i], poly[(i + 1) % len(poly)]
+            dS, dE = dist(pl, S), dist(pl, E)
+            if dS >= 0 and dE >= 0:
+                out.append(E)
+            elif dS >= 0:
+                out.append(cross(S, dS, E, dE))
+            elif dE >= 0:
+                out.append(cross(E, dE, S, dS))
+                out.append(E)
+        poly = out
+        if not poly:
+            return []
+    if len(poly) < 3:
+        return []
+    snapped = []
+    for P in poly:
+        qx, qy, qz = f32(P[0]), f32(P[1]), f32(P[2])
+        if not qz > 0:
+            return []
+        iz = f32(1.0) / qz
+        sx = cxp + f32(f32(fe * qx) * iz)
+        sy = cyp + f32(f32(fe * qy) * iz)
+        if not (abs(sx) < 16384 and abs(sy) < 16384):
+            return []
+        snapped.append((int(np.floor(f32(sx * f32(256.0)) + f32(0.5))), int(np.floor(f32(sy * f32(256.0)) + f32(0.5))), iz))
+    return snapped
+
+
 def _spec_python(verts, faces, cam, h, w):
-    """Exact coverage + top-left rule + R4 depth, straight from DESIGN.md, with Python ints."""
+    """Exact coverage + top-left rule + R4 depth (+ R7 clipping), straight from DESIGN.md, with Python ints."""
     f32 = np.float32
     ids = np.full((h, w), -1, dtype=np.int64)
     zb = np.zeros((h, w), dtype=np.int64)
+    work = []
     for f, tri in enumerate(faces):
         v = [_project_f32(verts[i], cam) for i in tri]
         if any(x is None for x in v):
-            continue
+            poly = _clip_python([verts[i] for i in tri], cam)
+            work += [(f, [poly[0], poly[k], poly[k + 1]]) for k in range(1, len(poly) - 1)]
+        else:
+            work.append((f, v))
+    for f, v in work:
         (X0, Y0, z0), (X1, Y1, z1), (X2, Y2, z2) = v
         area2 = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0)
         if area2 == 0:
@@ -130,6 +191,37 @@ def test_pixel_centres_on_edges_follow_top_left_rule():
     assert ids.min() >= 0
     # each pixel centre on the shared diagonal belongs to exactly one triangle, and both triangles own pixels
     assert set(np.unique(ids)) == {0, 1}
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_clipping_c_oracle_equals_python_spec(seed):
+    """R7: a camera in the middle of the soup -- faces straddle the near plane and run far outside the guard band; the C
+    oracle (both forms) and the Python restatement agree pixel for pixel."""
+    rng = np.random.default_rng(100 + seed)
+    verts, faces = _random_soup(rng, 40, spread=4.0, zspread=2.5)
+    h, w = 20, 28
+    cam = _cam(h, w, f=14.0, pos=(0.3, -0.2, 0.4), near=0.05 if seed % 2 else 0.6)
+    got = oracle_c.raster(verts, faces, cam, h, w, spec=True)
+    want = _spec_python(verts, faces, cam, h, w)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(oracle_c.raster(verts, faces, cam, h, w), got)
+    clipped = sum(1 for tri in faces if any(_project_f32(verts[i], cam) is None for i in tri) and _clip_python([verts[i] for i in tri], cam))
+    assert clipped >= 5 and (got >= 0).sum() > 100
+
+
+def test_clipping_ground_plane_to_the_horizon():
+    """Two 1 km triangles seen from 2 m above them, looking at the horizon: every vertex is behind the camera or outside
+    the guard band; clipped, the ground fills the picture below the horizon with the analytic depth."""
+    pts = np.array([[-500, -500, 0], [500, -500, 0], [500, 500, 0], [-500, 500, 0]], dtype=np.float64)
+    quad = np.array([[0, 1, 2], [0, 2, 3]])
+    pose = synthetic.look_at((0.0, 0.0, 2.0), (0.0, 100.0, 2.0), up_hint=(0, 0, 1))
+    cams = synthetic.camera_set_from_poses([pose], f=300.0, width=320, height=240)
+    rec = cams.get_raster_records(1.0, near=0.1)[0]
+    ids, dep = oracle_c.raster(pts, quad, rec, 240, 320, want_depth=True)
+    np.testing.assert_array_equal(oracle_c.raster(pts, quad, rec, 240, 320, spec=True), ids)
+    assert (ids[121:] >= 0).all() and (ids[:120] == -1).all()
+    for row in (130, 180, 239):
+        assert abs(dep[row, 160] - 2.0 * 300.0 / (row + 0.5 - 120.0)) < 2e-3 * dep[row, 160]
 
 
 def test_background_degenerate_and_behind_camera():
