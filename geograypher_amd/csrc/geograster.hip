@@ -691,56 +691,69 @@ __device__ void emit_triangle(const BinArgs &a, int slot, uint32_t *ctrl, Vtx v0
 }
 
 template <bool DIRECT>
-__global__ __launch_bounds__(256) void k_clip_faces(const float *__restrict__ cams, BinArgs a) {
-  const int slot = blockIdx.y;
+__global__ __launch_bounds__(64) void k_clip_faces(const float *__restrict__ cams, BinArgs a) {
+  // polygon buffers in LDS, one column per thread (dynamically indexed local arrays would put the kernel on scratch
+  // memory, which costs every launch ~10 us even when the clip lists are empty)
+  __shared__ double px[2][8][64], py[2][8][64], pz[2][8][64];
+  __shared__ int sX[8][64], sY[8][64];
+  __shared__ float sZ[8][64];
+  const int slot = blockIdx.y, tid = threadIdx.x;
   const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
   uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
   const int64_t n_clip = min((int64_t)ctrl[4], a.F);
+  if ((int64_t)blockIdx.x * 64 >= n_clip) return;  // the usual case: nothing to clip in this view
   const float fe = cam[12], cxp = cam[13], cyp = cam[14], nearp = cam[15];
   if (!(nearp > 0.0f) || !(fe > 0.0f) || !isfinite(fe) || !isfinite(cxp) || !isfinite(cyp)) return;
   constexpr double G = 16383.0;
-  const double planes[5][4] = {
-      {0.0, 0.0, 1.0, -(double)nearp},
-      {-(double)fe, 0.0, G - (double)cxp, 0.0},
-      {(double)fe, 0.0, G + (double)cxp, 0.0},
-      {0.0, -(double)fe, G - (double)cyp, 0.0},
-      {0.0, (double)fe, G + (double)cyp, 0.0},
-  };
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_clip; i += (int64_t)gridDim.x * 256) {
+  for (int64_t i = (int64_t)blockIdx.x * 64 + tid; i < n_clip; i += (int64_t)gridDim.x * 64) {
     const int64_t f = a.clip[(int64_t)slot * a.F + i];
     const float *sp = a.soup + 9 * f;
-    P3 pa[8], pb[8];
+#pragma unroll
     for (int k = 0; k < 3; ++k) {  // the first half of R1
       const float *p = sp + 3 * k;
       const float dx = p[0] - cam[9], dy = p[1] - cam[10], dz = p[2] - cam[11];
       float m0, m1, m2;
       m0 = cam[0] * dx; m1 = cam[3] * dy; m2 = cam[6] * dz;
-      pa[k].x = (double)((m0 + m1) + m2);
+      px[0][k][tid] = (double)((m0 + m1) + m2);
       m0 = cam[1] * dx; m1 = cam[4] * dy; m2 = cam[7] * dz;
-      pa[k].y = (double)((m0 + m1) + m2);
+      py[0][k][tid] = (double)((m0 + m1) + m2);
       m0 = cam[2] * dx; m1 = cam[5] * dy; m2 = cam[8] * dz;
-      pa[k].z = (double)((m0 + m1) + m2);
+      pz[0][k][tid] = (double)((m0 + m1) + m2);
     }
-    int n = 3;
+    int n = 3, cur = 0;
     bool bad = false;
-    for (int pl = 0; pl < 5 && n > 0; ++pl) {
+#pragma unroll
+    for (int pl = 0; pl < 5; ++pl) {
+      // plane pl:  a x + b y + c z + d >= 0   (near plane, then sx <= G, sx >= -G, sy <= G, sy >= -G)
+      const double pa = pl == 1 ? -(double)fe : pl == 2 ? (double)fe : 0.0;
+      const double pb = pl == 3 ? -(double)fe : pl == 4 ? (double)fe : 0.0;
+      const double pc = pl == 0 ? 1.0 : pl == 1 ? G - (double)cxp : pl == 2 ? G + (double)cxp : pl == 3 ? G - (double)cyp
+                                                                                                        : G + (double)cyp;
+      const double pd = pl == 0 ? -(double)nearp : 0.0;
+      const double plane[4] = {pa, pb, pc, pd};
+      if (n == 0 || bad) break;
       int m = 0;
       for (int e = 0; e < n; ++e) {
-        const P3 S = pa[e], E = pa[(e + 1) % n];
-        const double dS = clip_plane(planes[pl], S), dE = clip_plane(planes[pl], E);
+        const int e1 = (e + 1) % n;
+        const P3 S = {px[cur][e][tid], py[cur][e][tid], pz[cur][e][tid]};
+        const P3 E = {px[cur][e1][tid], py[cur][e1][tid], pz[cur][e1][tid]};
+        const double dS = clip_plane(plane, S), dE = clip_plane(plane, E);
         const bool inS = dS >= 0.0, inE = dE >= 0.0;
-        if (inS && inE) { if (m < 8) pb[m] = E; ++m; }
-        else if (inS && !inE) { if (m < 8) pb[m] = clip_cross(S, dS, E, dE); ++m; }
-        else if (!inS && inE) { if (m < 8) pb[m] = clip_cross(E, dE, S, dS); ++m; if (m < 8) pb[m] = E; ++m; }
+        P3 o0 = E, o1 = E;
+        int cnt = 0;
+        if (inS && inE) { cnt = 1; }
+        else if (inS && !inE) { o0 = clip_cross(S, dS, E, dE); cnt = 1; }
+        else if (!inS && inE) { o0 = clip_cross(E, dE, S, dS); cnt = 2; }
+        if (cnt >= 1) { if (m < 8) { px[cur ^ 1][m][tid] = o0.x; py[cur ^ 1][m][tid] = o0.y; pz[cur ^ 1][m][tid] = o0.z; } ++m; }
+        if (cnt == 2) { if (m < 8) { px[cur ^ 1][m][tid] = o1.x; py[cur ^ 1][m][tid] = o1.y; pz[cur ^ 1][m][tid] = o1.z; } ++m; }
       }
-      if (m > 8) { bad = true; break; }
+      if (m > 8) bad = true;
       n = m;
-      for (int e = 0; e < n; ++e) pa[e] = pb[e];
+      cur ^= 1;
     }
     if (bad || n < 3) continue;
-    Vtx poly[8];
     for (int e = 0; e < n; ++e) {
-      const float qx = (float)pa[e].x, qy = (float)pa[e].y, qz = (float)pa[e].z;
+      const float qx = (float)px[cur][e][tid], qy = (float)py[cur][e][tid], qz = (float)pz[cur][e][tid];
       if (!(qz > 0.0f)) { bad = true; break; }
       const float iz = 1.0f / qz;
       const float fx = fe * qx;
@@ -748,14 +761,20 @@ __global__ __launch_bounds__(256) void k_clip_faces(const float *__restrict__ ca
       const float sx = cxp + fx * iz;
       const float sy = cyp + fy * iz;
       if (!(fabsf(sx) < 16384.0f) || !(fabsf(sy) < 16384.0f)) { bad = true; break; }
-      poly[e].X = (int)floorf(sx * 256.0f + 0.5f);
-      poly[e].Y = (int)floorf(sy * 256.0f + 0.5f);
-      poly[e].iz = iz;
-      poly[e].valid = true; poly[e].front = true; poly[e].finite = true;
+      sX[e][tid] = (int)floorf(sx * 256.0f + 0.5f);
+      sY[e][tid] = (int)floorf(sy * 256.0f + 0.5f);
+      sZ[e][tid] = iz;
     }
     if (bad) continue;
     const int face = a.orig[f];
-    for (int k = 1; k + 1 < n; ++k) emit_triangle<DIRECT>(a, slot, ctrl, poly[0], poly[k], poly[k + 1], face);
+    Vtx v0;
+    v0.X = sX[0][tid]; v0.Y = sY[0][tid]; v0.iz = sZ[0][tid]; v0.valid = v0.front = v0.finite = true;
+    for (int k = 1; k + 1 < n; ++k) {
+      Vtx v1 = v0, v2 = v0;
+      v1.X = sX[k][tid]; v1.Y = sY[k][tid]; v1.iz = sZ[k][tid];
+      v2.X = sX[k + 1][tid]; v2.Y = sY[k + 1][tid]; v2.iz = sZ[k + 1][tid];
+      emit_triangle<DIRECT>(a, slot, ctrl, v0, v1, v2, face);
+    }
   }
 }
 
@@ -1614,11 +1633,11 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, hip
     if (a.cap_tile > 0) {
       hipLaunchKernelGGL(k_setup_cull<true>, dim3((unsigned)std::min((nblk + 3) / 4, 1024), nb), dim3(256), 0, s, c->verts,
                          c->faces, cams, a);
-      hipLaunchKernelGGL(k_clip_faces<true>, dim3(16, nb), dim3(256), 0, s, cams, a);
+      hipLaunchKernelGGL(k_clip_faces<true>, dim3(8, nb), dim3(64), 0, s, cams, a);
     } else {
       hipLaunchKernelGGL(k_setup_cull<false>, dim3((unsigned)std::min((nblk + 3) / 4, 1024), nb), dim3(256), 0, s, c->verts,
                          c->faces, cams, a);
-      hipLaunchKernelGGL(k_clip_faces<false>, dim3(16, nb), dim3(256), 0, s, cams, a);
+      hipLaunchKernelGGL(k_clip_faces<false>, dim3(8, nb), dim3(64), 0, s, cams, a);
     }
   }
   c->last_direct = a.cap_tile > 0;
