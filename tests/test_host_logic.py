@@ -107,6 +107,33 @@ def test_index_label_fast_path_matches_reference(golden, oracle_backend_cls):
     _same(np.stack(list(mesh.project_images(seg_set))), golden["project_onehot"])
 
 
+def test_lookup_segmentor_png_files_through_the_threaded_loader(golden, oracle_backend_cls, tmp_path):
+    """LookUpSegmentor (derived_segmentors.py:32-51): `<lookup>/<image path relative to base>.png` class-index files, read by
+    the aggregation input pipeline (several files at once) -- same numbers as the in-memory labels, and the nearest-neighbour
+    resize of a scaled look-up keeps the class indices."""
+    from PIL import Image
+
+    from geograypher_amd.predictors import LookUpSegmentor
+
+    labels = golden["label_inds"]
+    mesh, cs = _golden_scene(golden, oracle_backend_cls, golden["onehot"])
+    base, lookup = tmp_path / "images", tmp_path / "labels"
+    for i, cam in enumerate(cs.cameras):
+        cam.image_filename = base / "flight_a" / f"{i}.png"
+        (lookup / "flight_a").mkdir(parents=True, exist_ok=True)
+        Image.fromarray(labels[i].astype(np.uint8)).save(lookup / "flight_a" / f"{i}.png")
+    seg = LookUpSegmentor(base, lookup, num_classes=golden["onehot"].shape[-1])
+    assert seg.thread_safe_lookup
+    seg_set = SegmentorPhotogrammetryCameraSet(cs, seg)
+    np.testing.assert_array_equal(seg_set.get_label_index_image(2), labels[2])
+    avg, info = mesh.aggregate_projected_images(seg_set, loader_threads=3)
+    _same(avg, golden["agg_onehot_average"])
+    _same(info["projection_counts"], golden["agg_onehot_counts"])
+    half = seg.segment_image_indices(None, filename=cs.cameras[1].image_filename, image_scale=0.5)
+    h, w = labels[1].shape
+    assert half.shape == (int(h * 0.5), int(w * 0.5)) and set(np.unique(half)) <= set(np.unique(labels[1]))
+
+
 def test_camera_helpers_match_reference(golden):
     for H, W, s, h, w in golden["image_sizes"]:
         cam = PhotogrammetryCamera(None, np.eye(4), 100.0, 0, 0, int(W), int(H))
