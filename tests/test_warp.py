@@ -185,6 +185,39 @@ def test_warp_dewarp_image(kind, request, tmp_path, gradient, w2i, k1, relations
     assert relationship(dewarped.mean(), gradient.mean())
 
 
+@pytest.mark.parametrize("delete", list(__import__("itertools").combinations(["b1", "b2", "k1", "k2", "k3", "k4", "p1", "p2"], 2))[::3])
+@pytest.mark.parametrize("w2i,k1,relationship", [(True, 1, operator.lt), (True, -1, operator.gt), (False, 1, operator.gt),
+                                                 (False, -1, operator.lt)])
+@pytest.mark.parametrize("downsample", [1, 2])
+def test_dropped_parameters(request, tmp_path, gradient, delete, w2i, k1, relationship, downsample):
+    """tests/test_derived_cameras.py:213-247: distortion parameters missing from the dict count as zero (every third of the
+    28 pairs the reference drops; k1 is set again afterwards, as there)."""
+    cameras = _metashape_set(tmp_path)
+    camera = simplify_camera(cameras.cameras[0], gradient, delete=delete)
+    camera.distortion_params["k1"] = k1
+    dewarped = cameras.warp_dewarp_image(camera, gradient, warped_to_ideal=w2i, inversion_downsample=downsample,
+                                         backend=_backend("oracle", request))
+    assert dewarped.shape == gradient.shape
+    assert relationship(dewarped.mean(), gradient.mean())
+
+
+@pytest.mark.parametrize("downsample", [1, 2])
+def test_inverse_map_interpolation(downsample):
+    """tests/test_indexing.py:7-66: a simple mapping is reversed; samples nobody maps to are -1."""
+    from geograypher_amd.utils.indexing import inverse_map_interpolation
+
+    imap = np.repeat(np.arange(2, 7)[:, None], 6, axis=1)
+    jmap = np.repeat(np.array([[0, 1, 2, 3, 4, 6]]), 5, axis=0)
+    inv_imap, inv_jmap = inverse_map_interpolation(np.stack([imap, jmap], axis=0), downsample=downsample)
+    i_expected = np.repeat(np.array([-1, -1, 0, 1, 2], dtype=float)[:, None], 6, axis=1)
+    j_expected = np.array([[-1] * 6, [-1] * 6, [0, 1, 2, 3, 4, 4.5], [0, 1, 2, 3, 4, 4.5], [0, 1, 2, 3, 4, 4.5]], dtype=float)
+    if downsample == 2:
+        i_expected[:, -1] = -1
+        j_expected[:, -1] = -1
+    assert np.allclose(inv_imap, i_expected)
+    assert np.allclose(inv_jmap, j_expected)
+
+
 @pytest.mark.parametrize("kind", BACKENDS)
 @pytest.mark.parametrize("k1", [1.0, 0.0, -1.0])
 @pytest.mark.parametrize("w2i", [True, False])
