@@ -45,6 +45,16 @@ def parse_args():
     return ap.parse_args()
 
 
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def torch_hash32(x):
     import torch
 
@@ -242,7 +252,7 @@ def main():
             "cores": int(used),
             "kind": "port",
             "sample": f"{n_sample} C2 views at 4000x3000 ({n_sample // per_pass} passes of {per_pass}, one view per thread) on "
-                      f"{used} threads of {cores} cores in {tc:.1f} s; single thread: {P / t1 / 1e6:.1f} Mpix/s",
+                      f"{used} threads of {cores} cores ({_cpu_model()}) in {tc:.1f} s; single thread: {P / t1 / 1e6:.1f} Mpix/s",
             "views_per_s": round(n_sample / tc, 3),
         }
 
