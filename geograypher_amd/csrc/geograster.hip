@@ -1244,18 +1244,25 @@ __global__ __launch_bounds__(256) void k_vote_values(uint32_t *__restrict__ winn
   const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (f >= F) return;
   uint32_t c = 0;
-  for (int v = 0; v < n_views; ++v) {
-    const uint32_t key = winner[v * F + f];
-    if (key == 0) continue;
-    winner[v * F + f] = 0;
-    const double *row = img + ((int64_t)v * P + (key - 1)) * C;
-    bool any_finite = false;
-    for (int ch = 0; ch < C; ++ch) {
-      const double x = row[ch];
-      if (isfinite(x)) any_finite = true;
-      if (!isnan(x)) sums[f * C + ch] += x;  // nansum: NaN counts as 0 (meshes.py:2060-2062)
+  for (int v0 = 0; v0 < n_views; v0 += 8) {  // eight views' winners are requested together, then consumed in view order
+    uint32_t keyv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) keyv[k] = (v0 + k < n_views) ? winner[(int64_t)(v0 + k) * F + f] : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t key = keyv[k];
+      if (key == 0) continue;
+      const int v = v0 + k;
+      winner[(int64_t)v * F + f] = 0;
+      const double *row = img + ((int64_t)v * P + (key - 1)) * C;
+      bool any_finite = false;
+      for (int ch = 0; ch < C; ++ch) {
+        const double x = row[ch];
+        if (isfinite(x)) any_finite = true;
+        if (!isnan(x)) sums[f * C + ch] += x;  // nansum: NaN counts as 0 (meshes.py:2060-2062)
+      }
+      if (any_finite) ++c;
     }
-    if (any_finite) ++c;
   }
   if (c) counts[f] += c;
 }
