@@ -1030,6 +1030,17 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
     if (a.dbg & 4) cnt = 0;
     const int4 *comp = a.comp + (slot * a.ent_cap + beg) * 4;
 
+    if (!FUSE && cnt == 0) {  // empty tile (a view that overhangs the mesh): background, without the LDS round trip
+      const int col = tid & (TW - 1), gx = px0 + col;
+      if (gx < a.w && !(a.dbg & 2)) {
+        for (int row = tid >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
+          const int64_t p = plane + (int64_t)(py0 + row) * a.w + gx;
+          if (out.ids) out.ids[p] = -1;
+          if (out.depth) out.depth[p] = INFINITY;
+        }
+      }
+      return;
+    }
     {  // zero the tile: 16-byte LDS stores
       static_assert(NKEYS % 2 == 0, "key pairs");
       ulonglong2 *k2 = reinterpret_cast<ulonglong2 *>(keys);
