@@ -32,6 +32,7 @@
 #define GR_TILE 64          // tile edge in pixels (one workgroup rasterizes one 64x64 tile out of LDS)
 #define GR_TILE_LOG2 6
 #define GR_MAX_BATCH 64     // views per launch group (amortises kernel boundaries and per-launch tails)
+#define GR_ENT_Q 3          // int4 per compiled (face, tile) entry: 48 bytes, 12 words
 #define GR_CTRL_HDR 8       // ctrl words before the tile arrays: rec_count, total_entries, overflow, work_count, clip_count
 #define GR_MAX_DIM 16384    // h, w limit (guard band and 16-bit bbox packing)
 
@@ -49,7 +50,7 @@ struct BinArgs {
   uint32_t *work;        // [slot][work_stride] blocks of this view that passed the frustum test (ctrl[3] = count)
   uint32_t *clip;        // [slot][F] soup faces that straddle the near plane / guard band (R7; ctrl[4] = count)
   int64_t work_stride;
-  int4 *comp;            // [slot][ent_cap][4]  compiled (face, tile) entries grouped by tile, 64-byte slots (13 words used)
+  int4 *comp;            // [slot][ent_cap][GR_ENT_Q]  compiled (face, tile) entries grouped by tile, 48 bytes each
   unsigned long long *stats;  // [4] records, entries, max_entries, overflow (accumulated over the call)
   int64_t ctrl_stride;   // words per slot
   int64_t rec_stride;    // int4 per slot (= 3*F)
@@ -278,8 +279,6 @@ __device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, const int4
 template <bool DIRECT>
 __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ verts, const int32_t *__restrict__ faces,
                                                     const float *__restrict__ cams, BinArgs a) {
-  // single-pass binning: per-wave staging rows for the transposed entry stores (5 x 16 B per lane: 64 B + bank padding)
-  __shared__ int4 stage[DIRECT ? 4 : 1][DIRECT ? 64 : 1][5];
   const int slot = blockIdx.y;
   const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
   uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
@@ -381,43 +380,30 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
   r3.y = (int)(__shfl(b1, l1) + (uint32_t)k1);
   r3.z = (int)(__shfl(b2, l2) + (uint32_t)k2);
   r3.w = (int)(__shfl(b3, l3) + (uint32_t)k3);
-  if (DIRECT) {
-    int4 *comp = a.comp + slot * a.ent_cap * 4;
+  if (DIRECT && keep) {
+    int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
     const int TW = 1 << a.twl, TH = 1 << a.thl;
-    const int wv = threadIdx.x >> 6;
-    // Faces over at most 2x2 tiles: tile k of the footprint is compiled by the face's lane into the wave's LDS staging
-    // rows, then FOUR lanes store one entry (16 bytes each): every store instruction writes whole 64-byte entries
-    // instead of a 16-byte piece of 64 different ones (the scattered partial writes cost 2 us per C2 view).
+    if (small_fp) {
+      // faces over at most 2x2 tiles: positions came from the wave-aggregated counters; the lanes of a group hold
+      // consecutive positions of the same tile segment, so their 48-byte entries are written side by side
 #pragma unroll 1
-    for (int k = 0; k < 4; ++k) {
-      const int tx = tx0 + (k & 1), ty = ty0 + (k >> 1);
-      const bool need = small_fp && tx <= tx1 && ty <= ty1;
-      if (__ballot(need) == 0ull) continue;
-      uint32_t idx = 0xFFFFFFFFu;
-      if (need) {
+      for (int k = 0; k < 4; ++k) {
+        const int tx = tx0 + (k & 1), ty = ty0 + (k >> 1);
+        if (tx > tx1 || ty > ty1) continue;
         const uint32_t pos = (uint32_t)(k == 0 ? r3.x : k == 1 ? r3.y : k == 2 ? r3.z : r3.w);
-        if (pos < (uint32_t)a.cap_tile) {
-          compile_entry(&stage[wv][lane][0], r0, r1, r2, tx << a.twl, ty << a.thl, TW, TH);
-          idx = (uint32_t)(ty * a.TX + tx) * (uint32_t)a.cap_tile + pos;
-        } else {
-          ctrl[2] = 1u;
-        }
+        if (pos < (uint32_t)a.cap_tile)
+          compile_entry(comp + ((int64_t)(ty * a.TX + tx) * a.cap_tile + pos) * GR_ENT_Q, r0, r1, r2, tx << a.twl, ty << a.thl,
+                        TW, TH);
+        else ctrl[2] = 1u;
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int e = 16 * j + (lane >> 2), q = lane & 3;
-        const uint32_t di = (uint32_t)__shfl((int)idx, e);
-        if (di != 0xFFFFFFFFu) comp[(int64_t)di * 4 + q] = stage[wv][e][q];
-      }
-    }
-    if (keep && !small_fp) {  // faces over more than 2x2 tiles (rare): one plain atomic and a direct store per tile
+    } else {  // faces over more than 2x2 tiles (rare): one plain atomic per tile
 #pragma unroll 1
       for (int ty = ty0; ty <= ty1; ++ty) {
 #pragma unroll 1
         for (int tx = tx0; tx <= tx1; ++tx) {
           const int t = ty * a.TX + tx;
           const uint32_t pos = atomicAdd(&cntS[t], 1u);
-          if (pos < (uint32_t)a.cap_tile) compile_entry(comp + ((int64_t)t * a.cap_tile + pos) * 4, r0, r1, r2, tx << a.twl,
+          if (pos < (uint32_t)a.cap_tile) compile_entry(comp + ((int64_t)t * a.cap_tile + pos) * GR_ENT_Q, r0, r1, r2, tx << a.twl,
                                                         ty << a.thl, TW, TH);
           else ctrl[2] = 1u;
         }
@@ -509,19 +495,20 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(BinArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K3  per (face, tile) entry: re-base the face's edge functions to the tile origin and store the 64-byte "compiled"
+// K3  per (face, tile) entry: re-base the face's edge functions to the tile origin and store the 48-byte "compiled"
 //     entry at its place in the tile's list.  grid (G, views), grid-stride over the surviving records.
 //       E_k(x, y) = C_k + A_k x + B_k y,  x, y = tile-local pixel;  covered <=> all E_k >= 0 (fill rule folded in C_k)
 //     All 64-bit set-up arithmetic happens here, once per entry, at full occupancy; the tile rasterizer then only
 //     streams entries (no index indirection, no 64-bit multiplies).  Entries whose edge values could leave int32
 //     inside the tile keep their vertices instead and are walked with 64-bit adds (flag bit 31 of the Yw word).
 //     List positions of <= 2x2-tile faces come from K1 (plain stores); larger faces take one cursor atomic per tile.
-//     Only 12 words of an entry travel to the lanes that walk its scanlines (each is one ds_bpermute per 64 items, and
-//     the LDS pipe is the tile kernel's bottleneck), so A_k / 256 and B_k / 256 (|.| < 2^15) are packed in pairs:
+//     An entry is 12 words (48 bytes): all of them travel to the lanes that walk its scanlines (one ds_bpermute each per
+//     64 items, and the LDS pipe is the tile kernel's bottleneck), so A_k / 256 and B_k / 256 (|.| < 2^15) are packed in
+//     pairs and the small fields ride in the spare top bytes of the two 24-bit offsets:
 //       word  0..3   C0 C1 C2 a0|a1<<16          | X0 Y0 X1 Y1      (64-bit form)
 //       word  4..7   a2|b0<<16 b1|b2<<16 iz0 zA  | X2 Y2 iz0 zA
-//       word  8..11  zB X0rel Yw ~face           (Px - X0 = 256 x + X0rel;  Yw = Y0rel (24 bit) | ilo<<24 | 64-bit flag<<31)
-//       word 12      bbox = jlo | jhi<<8 | ilo<<16 | ihi<<24   (row count; the 64-bit form also walks jlo..jhi)
+//       word  8..11  zB Xw Yw ~face              (Px - X0 = 256 x + X0rel;  Xw = X0rel (24 bit) | rows in tile << 24;
+//                                                 Yw = Y0rel (24 bit) | first row ilo << 24 | 64-bit flag << 31)
 // ------------------------------------------------------------------------------------------------------------------
 // Faces whose snapped bounding box is smaller than GR_FAST_EXT sub-pixels (93 px) take a short form of the set-up: the
 // face overlaps the tile, so every pixel the tile rasterizer can probe (x in [-2, TW+2], y in [0, TH]) lies within
@@ -542,16 +529,16 @@ __device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, const int4
   const int t1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
   const int t2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
   const int ext = max(imax3(X0, X1, X2) - imin3(X0, X1, X2), imax3(Y0, Y1, Y2) - imin3(Y0, Y1, Y2));
-  const int box = jlo | (jhi << 8) | (ilo << 16) | (ihi << 24);
   const int yw = ((Pyo - Y0) & 0xFFFFFF) | (ilo << 24);  // |Pyo - Y0| < 2^23 inside the guard band
+  const int nr = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;   // rows of the entry in this tile (<= 64)
+  const int xw = ((Pxo - X0) & 0xFFFFFF) | (nr << 24);
   if (ext < GR_FAST_EXT) {
     const int c0 = __mul24(dx0, Pyo - Y0) - __mul24(dy0, Pxo - X0) + t0;
     const int c1 = __mul24(dx1, Pyo - Y1) - __mul24(dy1, Pxo - X1) + t1;
     const int c2 = __mul24(dx2, Pyo - Y2) - __mul24(dy2, Pxo - X2) + t2;
     dst[0] = make_int4(c0, c1, c2, pack16(-dy0, -dy1));
     dst[1] = make_int4(pack16(-dy2, dx0), pack16(dx1, dx2), p1.z, p2.x);
-    dst[2] = make_int4(p2.y, Pxo - X0, yw, (int)~(uint32_t)p1.w);
-    dst[3] = make_int4(box, 0, 0, 0);
+    dst[2] = make_int4(p2.y, xw, yw, (int)~(uint32_t)p1.w);
     return;
   }
   const long long b0 = t0, b1 = t1, b2 = t2;
@@ -575,8 +562,7 @@ __device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, const int4
     dst[0] = make_int4(X0, Y0, X1, Y1);
     dst[1] = make_int4(X2, Y2, p1.z, p2.x);
   }
-  dst[2] = make_int4(p2.y, Pxo - X0, yw | (small ? 0 : (int)0x80000000), (int)~(uint32_t)p1.w);
-  dst[3] = make_int4(box, 0, 0, 0);
+  dst[2] = make_int4(p2.y, xw, yw | (small ? 0 : (int)0x80000000), (int)~(uint32_t)p1.w);
 }
 
 __global__ __launch_bounds__(256) void k_fill_compile(BinArgs a) {
@@ -587,7 +573,7 @@ __global__ __launch_bounds__(256) void k_fill_compile(BinArgs a) {
   const uint32_t *off = ctrl + GR_CTRL_HDR + 2 * a.Tcap;
   uint32_t *cur = ctrl + GR_CTRL_HDR + 3 * a.Tcap;
   const int4 *rec0 = a.rec + slot * a.rec_stride;
-  int4 *comp = a.comp + slot * a.ent_cap * 4;
+  int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
   const int TW = 1 << a.twl, TH = 1 << a.thl;
   for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n_rec; r += gridDim.x * 256) {
     const int4 p0 = rec0[r], p1 = rec0[a.F + r], p2 = rec0[2 * a.F + r];
@@ -604,7 +590,7 @@ __global__ __launch_bounds__(256) void k_fill_compile(BinArgs a) {
         const int k = ((ty - ty0) << 1) | (tx - tx0);
         const uint32_t pk = (uint32_t)(k == 0 ? pos.x : k == 1 ? pos.y : k == 2 ? pos.z : pos.w);
         const int64_t idx = small_fp ? (int64_t)off[t] + pk : (int64_t)off[t] + cntS[t] + atomicAdd(&cur[t], 1u);
-        if (idx < a.ent_cap) compile_entry(comp + idx * 4, p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH);
+        if (idx < a.ent_cap) compile_entry(comp + idx * GR_ENT_Q, p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH);
       }
     }
   }
@@ -662,12 +648,12 @@ __device__ void emit_triangle(const BinArgs &a, int slot, uint32_t *ctrl, Vtx v0
   uint32_t *cntS = ctrl + GR_CTRL_HDR;
   uint32_t *cntB = cntS + a.Tcap;
   if (DIRECT) {
-    int4 *comp = a.comp + slot * a.ent_cap * 4;
+    int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
     for (int ty = ty0; ty <= ty1; ++ty)
       for (int tx = tx0; tx <= tx1; ++tx) {
         const int t = ty * a.TX + tx;
         const uint32_t pos = atomicAdd(&cntS[t], 1u);
-        if (pos < (uint32_t)a.cap_tile) compile_entry(comp + ((int64_t)t * a.cap_tile + pos) * 4, r0, r1, r2, tx << a.twl,
+        if (pos < (uint32_t)a.cap_tile) compile_entry(comp + ((int64_t)t * a.cap_tile + pos) * GR_ENT_Q, r0, r1, r2, tx << a.twl,
                                                       ty << a.thl, 1 << a.twl, 1 << a.thl);
         else ctrl[2] = 1u;
       }
@@ -783,7 +769,7 @@ __global__ __launch_bounds__(64) void k_clip_faces(const float *__restrict__ cam
 //     depth|id keys (u64: 1/z bits << 32 | ~face) live in LDS; visibility is resolved with ds_max_u64, so the result
 //     does not depend on list order.  Between the two workgroup barriers (keys zeroed / keys complete) every wave
 //     works on its own, without further synchronisation:
-//       phase 1  each lane streams ONE compiled entry of the tile's list (13 words) into registers; in single-pass
+//       phase 1  each lane streams ONE compiled entry of the tile's list (12 words) into registers; in single-pass
 //                mode the first 64 slots of the tile's segment are requested before the tile's count is known;
 //       phase 2  the entries' row counts are prefix-summed with DPP moves: the wave's work is total_rows
 //                (entry, row) items, taken 64 at a time; an item finds its entry through the wave's LDS mailboxes
@@ -879,12 +865,12 @@ __device__ __forceinline__ int wave_incl_max(int x) {
   return x;
 }
 
-// Phases 2-3 of the tile rasterizer for the 64 entries a wave holds in registers (s0..s3, nrows per lane).
+// Phases 2-3 of the tile rasterizer for the 64 entries a wave holds in registers (s0..s2, nrows per lane).
 // tab: the wave's 64 mailbox words in LDS (zeroed with the tile), gen: the wave's batch counter (mailbox generation).
 template <int TWL>
 __device__ __forceinline__ void raster_wave_entries(unsigned long long *keys, uint32_t *tab, uint32_t &gen, const int4 s0,
-                                                    const int4 s1, const int4 s2, const int4 s3, const int nrows,
-                                                    const int lane, const int px0, const int py0, const int dbg) {
+                                                    const int4 s1, const int4 s2, const int nrows, const int lane,
+                                                    const int px0, const int py0, const int dbg) {
   constexpr int TW = 1 << TWL;
     // ---- phase 2: wave-local scan of the row counts: item q belongs to the entry with excl <= q < excl + nrows ------------
     const int incl = wave_incl_scan(nrows);
@@ -914,11 +900,12 @@ __device__ __forceinline__ void raster_wave_entries(unsigned long long *keys, ui
       const int w3 = __shfl(s0.w, t), w4 = __shfl(s1.x, t), w5 = __shfl(s1.y, t);
       const float iz0 = __int_as_float(__shfl(s1.z, t)), zA = __int_as_float(__shfl(s1.w, t)),
                   zB = __int_as_float(__shfl(s2.x, t));
-      const int X0rel = __shfl(s2.y, t), yw = __shfl(s2.z, t);
+      const int xw = __shfl(s2.y, t), yw = __shfl(s2.z, t);
       uint32_t key_lo = (uint32_t)__shfl(s2.w, t);
       // consume the last ds_bpermute result here: otherwise the compiler parks its s_waitcnt lgkmcnt(0) inside the pixel
       // loop, where it would also wait for the previous iteration's ds_max_u64 and serialise the LDS atomics
       asm volatile("" : "+v"(key_lo));
+      const int X0rel = (xw << 8) >> 8;
       const int Y0rel = (yw << 8) >> 8, ilo = (yw >> 24) & 0x3F;
       const int y = ilo + (q - et);
       const float m1 = zB * (float)(y * 256 + Y0rel);
@@ -951,10 +938,11 @@ __device__ __forceinline__ void raster_wave_entries(unsigned long long *keys, ui
         }
       }
       if (__ballot(big) != 0ull) {
-        const int bbox = __shfl(s3.x, t);  // rare path: one more word for the column range
         if (big) {  // 64-bit form: words 0..5 hold the snapped vertices
           const int X0 = C0, Y0 = C1, X1 = C2, Y1 = w3, X2 = w4, Y2 = w5;
-          const int jlo = bbox & 0xFF, jhi = (bbox >> 8) & 0xFF;
+          // column range: pixel centres inside the face's bounding box, clipped to the tile (R2)
+          const int jlo = max(((imin3(X0, X1, X2) - 128 + 255) >> 8) - px0, 0);
+          const int jhi = min(((imax3(X0, X1, X2) - 128) >> 8) - px0, TW - 1);
           const int dx0 = X1 - X0, dy0 = Y1 - Y0, dx1 = X2 - X1, dy1 = Y2 - Y1, dx2 = X0 - X2, dy2 = Y0 - Y2;
           const long long b0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;
           const long long b1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
@@ -1008,10 +996,10 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
   const bool spec = a.cap_tile >= (int)GR_SPEC && e_first < GR_SPEC;
   // this lane's entry; deliberately left undefined where no entry is loaded (such lanes have no rows and are never a
   // shuffle source): a zero initialiser would cost a register copy -- and a wait -- right behind the early loads
-  int4 s0, s1, s2, s3;
+  int4 s0, s1, s2;
   if (spec) {
-    const int4 *cs = a.comp + (slot * a.ent_cap + (int64_t)tile * a.cap_tile + e_first) * 4;
-    s0 = cs[0]; s1 = cs[1]; s2 = cs[2]; s3.x = cs[3].x;
+    const int4 *cs = a.comp + (slot * a.ent_cap + (int64_t)tile * a.cap_tile + e_first) * GR_ENT_Q;
+    s0 = cs[0]; s1 = cs[1]; s2 = cs[2];
   }
   {
     const int tx = tile % a.TX, ty = tile / a.TX;
@@ -1028,7 +1016,7 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
       else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
     }
     if (a.dbg & 4) cnt = 0;
-    const int4 *comp = a.comp + (slot * a.ent_cap + beg) * 4;
+    const int4 *comp = a.comp + (slot * a.ent_cap + beg) * GR_ENT_Q;
 
     if (!FUSE && cnt == 0) {  // empty tile (a view that overhangs the mesh): background, without the LDS round trip
       const int col = tid & (TW - 1), gx = px0 + col;
@@ -1056,23 +1044,21 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
     {
       int nrows = 0;
       if (e_first < cnt) {
-        if (!spec) { s0 = comp[e_first * 4 + 0]; s1 = comp[e_first * 4 + 1]; s2 = comp[e_first * 4 + 2]; s3.x = comp[e_first * 4 + 3].x; }
-        const int jlo = s3.x & 0xFF, jhi = (s3.x >> 8) & 0xFF, ilo = (s3.x >> 16) & 0xFF, ihi = (s3.x >> 24) & 0x7F;
-        nrows = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;
+        if (!spec) { s0 = comp[e_first * GR_ENT_Q + 0]; s1 = comp[e_first * GR_ENT_Q + 1]; s2 = comp[e_first * GR_ENT_Q + 2]; }
+        nrows = (s2.y >> 24) & 0x7F;
       }
-      raster_wave_entries<TWL>(keys, tab, gen, s0, s1, s2, s3, nrows, lane, px0, py0, a.dbg);
+      raster_wave_entries<TWL>(keys, tab, gen, s0, s1, s2, nrows, lane, px0, py0, a.dbg);
     }
 #pragma unroll 1
     for (uint32_t c0 = NT; c0 < cnt; c0 += NT) {
       const uint32_t e = c0 + e_first;
-      int4 t0, t1, t2, t3;
+      int4 t0, t1, t2;
       int nrows = 0;
       if (e < cnt) {
-        t0 = comp[e * 4 + 0]; t1 = comp[e * 4 + 1]; t2 = comp[e * 4 + 2]; t3.x = comp[e * 4 + 3].x;
-        const int jlo = t3.x & 0xFF, jhi = (t3.x >> 8) & 0xFF, ilo = (t3.x >> 16) & 0xFF, ihi = (t3.x >> 24) & 0x7F;
-        nrows = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;
+        t0 = comp[e * GR_ENT_Q + 0]; t1 = comp[e * GR_ENT_Q + 1]; t2 = comp[e * GR_ENT_Q + 2];
+        nrows = (t2.y >> 24) & 0x7F;
       }
-      raster_wave_entries<TWL>(keys, tab, gen, t0, t1, t2, t3, nrows, lane, px0, py0, a.dbg);
+      raster_wave_entries<TWL>(keys, tab, gen, t0, t1, t2, nrows, lane, px0, py0, a.dbg);
     }
     // fused projection: the label bytes of this wave's rows are requested BEFORE the barrier (coalesced 64-byte row
     // segments, all RW loads in flight at once), so the candidates' atomics in the epilogue never wait on a dependent load
@@ -1604,7 +1590,7 @@ int ensure_bins(gr_ctx *c, int n_slots, int T) {
   const int64_t ctrl_stride = ((GR_CTRL_HDR + 4 * (int64_t)T) + 63) / 64 * 64;
   const int64_t work_stride = ceil_div(F, GR_BLOCK) + 4;
   int rc = grow(c, c->ctrl, c->ctrl_have, ctrl_stride * n_slots, "bin control");
-  if (!rc) rc = grow(c, c->comp, c->comp_have, 4 * cap * n_slots, "entry list");
+  if (!rc) rc = grow(c, c->comp, c->comp_have, GR_ENT_Q * cap * n_slots, "entry list");
   if (!rc) rc = grow(c, c->work, c->work_have, work_stride * n_slots, "work list");
   if (!rc) rc = grow(c, c->clip, c->clip_have, F * n_slots, "clip list");
   if (!rc && !direct) rc = grow(c, c->rec, c->rec_have, 4 * F * n_slots, "record planes");  // exact path only
@@ -1630,7 +1616,7 @@ BinArgs make_args(gr_ctx *c, int h, int w, int slot0) {
   a.ctrl_stride = c->ctrl_stride; a.rec_stride = c->rec_stride; a.ent_cap = c->ent_cap; a.F = c->F;
   a.work_stride = c->work_stride;
   a.ctrl = c->ctrl + slot0 * a.ctrl_stride; a.rec = c->rec + slot0 * a.rec_stride;
-  a.comp = c->comp + slot0 * a.ent_cap * 4; a.work = c->work + slot0 * a.work_stride;
+  a.comp = c->comp + slot0 * a.ent_cap * GR_ENT_Q; a.work = c->work + slot0 * a.work_stride;
   a.stats = c->stats; a.blk = c->blk; a.soup = c->soup; a.orig = c->orig;
   a.clip = c->clip + slot0 * c->F;
   a.twl = GR_TILE_LOG2; a.thl = c->opt_thl;
@@ -1750,7 +1736,7 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   const int thl = c->opt_thl;
   const int T = ((w + GR_TILE - 1) >> GR_TILE_LOG2) * ((h + (1 << thl) - 1) >> thl);
   {  // very large images: fewer views per launch group, so that the fixed tile segments stay within the scratch budget
-    const int64_t per_slot = (int64_t)T * direct_cap(c, T) * 64;
+    const int64_t per_slot = (int64_t)T * direct_cap(c, T) * (16 * GR_ENT_Q);
     if (per_slot > 0) B = (int)std::max<int64_t>(1, std::min<int64_t>(B, GR_DIRECT_BUDGET / per_slot));
   }
   rc = ensure_bins(c, B, T);
@@ -1977,7 +1963,7 @@ int gr_raster_status(gr_ctx *c, gr_raster_stats *o) {
     // that size if a launch group's entry memory stays within budget, and bins exactly (count, scan, fill) otherwise.
     const int used = direct_cap(c, c->last_T);
     const int64_t need = ((int64_t)st[2] + (int64_t)st[2] / 8 + 16 + 63) / 64 * 64;
-    const int64_t bytes = need * 64 * (int64_t)c->last_T * (int64_t)std::max(c->last_B, 1);
+    const int64_t bytes = need * (16 * GR_ENT_Q) * (int64_t)c->last_T * (int64_t)std::max(c->last_B, 1);
     if (need <= 16384 && bytes <= GR_DIRECT_BUDGET) { c->learned_cap = (int)need; c->learned_T = c->last_T; }
     else c->direct_ok = false;
     return fail(c, GR_EOVERFLOW, "single-pass binning overflow: a tile received %llu entries (slots per tile %d); "
