@@ -51,6 +51,7 @@ struct BinArgs {
   uint32_t *clip;        // [slot][F] soup faces that straddle the near plane / guard band (R7; ctrl[4] = count)
   int64_t work_stride;
   int4 *comp;            // [slot][ent_cap][GR_ENT_Q]  compiled (face, tile) entries grouped by tile, 48 bytes each
+  uint8_t *nrow8;        // [slot][ent_cap] rows of each entry inside its tile (the tile kernel's scan input: a compact stream)
   unsigned long long *stats;  // [4] records, entries, max_entries, overflow (accumulated over the call)
   int64_t ctrl_stride;   // words per slot
   int64_t rec_stride;    // int4 per slot (= 3*F)
@@ -60,6 +61,9 @@ struct BinArgs {
   int h, w;
   int twl, thl;          // log2 of the tile width / height in pixels
   int cap_tile;          // > 0: single-pass binning, every tile owns cap_tile entry slots (list base = tile * cap_tile)
+  unsigned long long *stamps;  // diagnostic builds only (var bit 256): per-phase cycle sums of the tile kernel
+  int pf_dist;           // tiles between a workgroup and the one it warms L2 for (multiple of 8)
+  int var;               // kernel variant bits (GR_OPT_VARIANT): 1 v2 tile kernel, 2 16-byte id stores, 4 entry prefetch
   int dbg;               // timing-only ablation mask (GR_OPT_DEBUG): 1 skip scanline loop, 2 skip id stores, 4 skip triangles,
                          // fused epilogue: 8 skip winner atomics, 16 skip label loads
 };
@@ -269,8 +273,8 @@ __global__ __launch_bounds__(256) void k_cull_blocks(const float *__restrict__ c
   if (keep) a.work[(int64_t)slot * a.work_stride + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)b;
 }
 
-__device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, const int4 p0, const int4 p1, const int4 p2,
-                                              int px0, int py0, int TW, int TH);
+__device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, uint8_t *__restrict__ nr8, const int4 p0, const int4 p1,
+                                              const int4 p2, int px0, int py0, int TW, int TH);
 
 // DIRECT = true: single-pass binning.  Every tile owns a fixed segment of a.cap_tile entries; the list position
 // returned by the (wave-aggregated) tile counter is final, so the compiled entry is written straight from here and
@@ -382,6 +386,7 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
   r3.w = (int)(__shfl(b3, l3) + (uint32_t)k3);
   if (DIRECT && keep) {
     int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
+    uint8_t *nr8 = a.nrow8 + slot * a.ent_cap;
     const int TW = 1 << a.twl, TH = 1 << a.thl;
     if (small_fp) {
       // faces over at most 2x2 tiles: positions came from the wave-aggregated counters; the lanes of a group hold
@@ -391,10 +396,10 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
         const int tx = tx0 + (k & 1), ty = ty0 + (k >> 1);
         if (tx > tx1 || ty > ty1) continue;
         const uint32_t pos = (uint32_t)(k == 0 ? r3.x : k == 1 ? r3.y : k == 2 ? r3.z : r3.w);
-        if (pos < (uint32_t)a.cap_tile)
-          compile_entry(comp + ((int64_t)(ty * a.TX + tx) * a.cap_tile + pos) * GR_ENT_Q, r0, r1, r2, tx << a.twl, ty << a.thl,
-                        TW, TH);
-        else ctrl[2] = 1u;
+        if (pos < (uint32_t)a.cap_tile) {
+          const int64_t idx = (int64_t)(ty * a.TX + tx) * a.cap_tile + pos;
+          compile_entry(comp + idx * GR_ENT_Q, nr8 + idx, r0, r1, r2, tx << a.twl, ty << a.thl, TW, TH);
+        } else ctrl[2] = 1u;
       }
     } else {  // faces over more than 2x2 tiles (rare): one plain atomic per tile
 #pragma unroll 1
@@ -403,9 +408,10 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
         for (int tx = tx0; tx <= tx1; ++tx) {
           const int t = ty * a.TX + tx;
           const uint32_t pos = atomicAdd(&cntS[t], 1u);
-          if (pos < (uint32_t)a.cap_tile) compile_entry(comp + ((int64_t)t * a.cap_tile + pos) * GR_ENT_Q, r0, r1, r2, tx << a.twl,
-                                                        ty << a.thl, TW, TH);
-          else ctrl[2] = 1u;
+          if (pos < (uint32_t)a.cap_tile) {
+            const int64_t idx = (int64_t)t * a.cap_tile + pos;
+            compile_entry(comp + idx * GR_ENT_Q, nr8 + idx, r0, r1, r2, tx << a.twl, ty << a.thl, TW, TH);
+          } else ctrl[2] = 1u;
         }
       }
     }
@@ -518,8 +524,8 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(BinArgs a) {
 // Larger faces take the general form below (identical coverage: both forms are exact).
 #define GR_FAST_EXT 24000
 __device__ __forceinline__ int pack16(int lo, int hi) { return (lo & 0xFFFF) | (hi << 16); }
-__device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, const int4 p0, const int4 p1, const int4 p2,
-                                              int px0, int py0, int TW, int TH) {
+__device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, uint8_t *__restrict__ nr8, const int4 p0, const int4 p1,
+                                              const int4 p2, int px0, int py0, int TW, int TH) {
   const int X0 = p0.x, Y0 = p0.y, X1 = p0.z, Y1 = p0.w, X2 = p1.x, Y2 = p1.y;
   const int Pxo = px0 * 256 + 128, Pyo = py0 * 256 + 128;  // centre of the tile's first pixel
   const int jlo = max((p2.z & 0xFFFF) - px0, 0), jhi = min((int)((uint32_t)p2.z >> 16) - px0, TW - 1);
@@ -532,6 +538,7 @@ __device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, const int4
   const int yw = ((Pyo - Y0) & 0xFFFFFF) | (ilo << 24);  // |Pyo - Y0| < 2^23 inside the guard band
   const int nr = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;   // rows of the entry in this tile (<= 64)
   const int xw = ((Pxo - X0) & 0xFFFFFF) | (nr << 24);
+  *nr8 = (uint8_t)nr;
   if (ext < GR_FAST_EXT) {
     const int c0 = __mul24(dx0, Pyo - Y0) - __mul24(dy0, Pxo - X0) + t0;
     const int c1 = __mul24(dx1, Pyo - Y1) - __mul24(dy1, Pxo - X1) + t1;
@@ -574,6 +581,7 @@ __global__ __launch_bounds__(256) void k_fill_compile(BinArgs a) {
   uint32_t *cur = ctrl + GR_CTRL_HDR + 3 * a.Tcap;
   const int4 *rec0 = a.rec + slot * a.rec_stride;
   int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
+  uint8_t *nr8 = a.nrow8 + slot * a.ent_cap;
   const int TW = 1 << a.twl, TH = 1 << a.thl;
   for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n_rec; r += gridDim.x * 256) {
     const int4 p0 = rec0[r], p1 = rec0[a.F + r], p2 = rec0[2 * a.F + r];
@@ -590,7 +598,7 @@ __global__ __launch_bounds__(256) void k_fill_compile(BinArgs a) {
         const int k = ((ty - ty0) << 1) | (tx - tx0);
         const uint32_t pk = (uint32_t)(k == 0 ? pos.x : k == 1 ? pos.y : k == 2 ? pos.z : pos.w);
         const int64_t idx = small_fp ? (int64_t)off[t] + pk : (int64_t)off[t] + cntS[t] + atomicAdd(&cur[t], 1u);
-        if (idx < a.ent_cap) compile_entry(comp + idx * GR_ENT_Q, p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH);
+        if (idx < a.ent_cap) compile_entry(comp + idx * GR_ENT_Q, nr8 + idx, p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH);
       }
     }
   }
@@ -649,13 +657,15 @@ __device__ void emit_triangle(const BinArgs &a, int slot, uint32_t *ctrl, Vtx v0
   uint32_t *cntB = cntS + a.Tcap;
   if (DIRECT) {
     int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
+    uint8_t *nr8 = a.nrow8 + slot * a.ent_cap;
     for (int ty = ty0; ty <= ty1; ++ty)
       for (int tx = tx0; tx <= tx1; ++tx) {
         const int t = ty * a.TX + tx;
         const uint32_t pos = atomicAdd(&cntS[t], 1u);
-        if (pos < (uint32_t)a.cap_tile) compile_entry(comp + ((int64_t)t * a.cap_tile + pos) * GR_ENT_Q, r0, r1, r2, tx << a.twl,
-                                                      ty << a.thl, 1 << a.twl, 1 << a.thl);
-        else ctrl[2] = 1u;
+        if (pos < (uint32_t)a.cap_tile) {
+          const int64_t idx = (int64_t)t * a.cap_tile + pos;
+          compile_entry(comp + idx * GR_ENT_Q, nr8 + idx, r0, r1, r2, tx << a.twl, ty << a.thl, 1 << a.twl, 1 << a.thl);
+        } else ctrl[2] = 1u;
       }
   } else {
     const uint32_t s = atomicAdd(&ctrl[0], 1u);
@@ -865,6 +875,76 @@ __device__ __forceinline__ int wave_incl_max(int x) {
   return x;
 }
 
+// Phase 3 for ONE work item: scanline `q - et` of the entry whose 12 words the lane holds (however they got there).
+template <int TWL>
+__device__ __forceinline__ void raster_item(unsigned long long *keys, const int C0, const int C1, const int C2, const int w3,
+                                            const int w4, const int w5, const float iz0, const float zA, const float zB,
+                                            const int xw, const int yw, const uint32_t key_lo, const int q, const int et,
+                                            const bool live, const int px0, const int py0) {
+  constexpr int TW = 1 << TWL;
+  const int X0rel = (xw << 8) >> 8;
+  const int Y0rel = (yw << 8) >> 8, ilo = (yw >> 24) & 0x3F;
+  const int y = ilo + (q - et);
+  const float m1 = zB * (float)(y * 256 + Y0rel);
+  const bool big = live && (yw < 0);
+  if (live && !big) {
+    // exact covered span [xs, xe] of this scanline: each edge E(x) = E(0) + A x >= 0 bounds x from one side
+    // (the three edges bound the span completely: the face's bounding box is not needed here)
+    const int A0 = (w3 << 16) >> 8, A1 = (w3 >> 16) << 8, A2 = (w4 << 16) >> 8;   // 256 * signed 16-bit halves
+    const int B0 = (w4 >> 16) << 8, B1 = (w5 << 16) >> 8, B2 = (w5 >> 16) << 8;
+    int xs = 0, xe = TW - 1;
+    span_clip<TW>(C0 + __mul24(B0, y), A0, xs, xe);
+    span_clip<TW>(C1 + __mul24(B1, y), A1, xs, xe);
+    span_clip<TW>(C2 + __mul24(B2, y), A2, xs, xe);
+    // two pixels per step with packed fp32 math (v_pk_mul_f32 / v_pk_add_f32: same IEEE results as the scalar
+    // forms, R4 op for op).  float(P_x - X0) advances by exact float adds (integers below 2^24).  An odd span's
+    // spare slot is steered to the row's padding key (column TW), which nobody reads.
+    if (xs <= xe) {
+      const f32x2 zA2 = {zA, zA}, m12 = {m1, m1}, iz2 = {iz0, iz0}, step = {512.0f, 512.0f};
+      const float fx0 = (float)(xs * 256 + X0rel);
+      f32x2 fx = {fx0, fx0 + 256.0f};
+      unsigned long long *kp = keys + lds_idx<TWL>(y, xs);
+      unsigned long long *const pad = keys + lds_idx<TWL>(y, TW);
+      unsigned long long *const kend = keys + lds_idx<TWL>(y, xe);
+      for (; kp <= kend; kp += 2, fx += step) {
+        const f32x2 z = iz2 + (zA2 * fx + m12);
+        const int zb0 = max(__float_as_int(z.x), 1), zb1 = max(__float_as_int(z.y), 1);
+        atomicMax(kp, ((unsigned long long)(uint32_t)zb0 << 32) | key_lo);
+        atomicMax(kp < kend ? kp + 1 : pad, ((unsigned long long)(uint32_t)zb1 << 32) | key_lo);
+      }
+    }
+  }
+  if (__ballot(big) != 0ull) {
+    if (big) {  // 64-bit form: words 0..5 hold the snapped vertices
+      const int X0 = C0, Y0 = C1, X1 = C2, Y1 = w3, X2 = w4, Y2 = w5;
+      // column range: pixel centres inside the face's bounding box, clipped to the tile (R2)
+      const int jlo = max(((imin3(X0, X1, X2) - 128 + 255) >> 8) - px0, 0);
+      const int jhi = min(((imax3(X0, X1, X2) - 128) >> 8) - px0, TW - 1);
+      const int dx0 = X1 - X0, dy0 = Y1 - Y0, dx1 = X2 - X1, dy1 = Y2 - Y1, dx2 = X0 - X2, dy2 = Y0 - Y2;
+      const long long b0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;
+      const long long b1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
+      const long long b2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
+      const long long Py = (long long)(py0 + y) * 256 + 128;
+      const long long Px = (long long)(px0 + jlo) * 256 + 128;
+      long long e0 = (long long)dx0 * (Py - Y0) - (long long)dy0 * (Px - X0) + b0;
+      long long e1 = (long long)dx1 * (Py - Y1) - (long long)dy1 * (Px - X1) + b1;
+      long long e2 = (long long)dx2 * (Py - Y2) - (long long)dy2 * (Px - X2) + b2;
+      const long long a0 = -(long long)dy0 * 256, a1 = -(long long)dy1 * 256, a2 = -(long long)dy2 * 256;
+      int fxi = jlo * 256 + X0rel;
+      for (int x = jlo; x <= jhi; ++x, e0 += a0, e1 += a1, e2 += a2, fxi += 256) {
+        if ((e0 | e1 | e2) >= 0) {
+          const float m0 = zA * (float)fxi;
+          const float s = m0 + m1;
+          const float z = iz0 + s;
+          const int zb = max(__float_as_int(z), 1);
+          const unsigned long long key = ((unsigned long long)(uint32_t)zb << 32) | key_lo;
+          atomicMax(&keys[lds_idx<TWL>(y, x)], key);
+        }
+      }
+    }
+  }
+}
+
 // Phases 2-3 of the tile rasterizer for the 64 entries a wave holds in registers (s0..s2, nrows per lane).
 // tab: the wave's 64 mailbox words in LDS (zeroed with the tile), gen: the wave's batch counter (mailbox generation).
 template <int TWL>
@@ -905,68 +985,67 @@ __device__ __forceinline__ void raster_wave_entries(unsigned long long *keys, ui
       // consume the last ds_bpermute result here: otherwise the compiler parks its s_waitcnt lgkmcnt(0) inside the pixel
       // loop, where it would also wait for the previous iteration's ds_max_u64 and serialise the LDS atomics
       asm volatile("" : "+v"(key_lo));
-      const int X0rel = (xw << 8) >> 8;
-      const int Y0rel = (yw << 8) >> 8, ilo = (yw >> 24) & 0x3F;
-      const int y = ilo + (q - et);
-      const float m1 = zB * (float)(y * 256 + Y0rel);
-      const bool big = live && (yw < 0);
-      if (live && !big) {
-        // exact covered span [xs, xe] of this scanline: each edge E(x) = E(0) + A x >= 0 bounds x from one side
-        // (the three edges bound the span completely: the face's bounding box is not needed here)
-        const int A0 = (w3 << 16) >> 8, A1 = (w3 >> 16) << 8, A2 = (w4 << 16) >> 8;   // 256 * signed 16-bit halves
-        const int B0 = (w4 >> 16) << 8, B1 = (w5 << 16) >> 8, B2 = (w5 >> 16) << 8;
-        int xs = 0, xe = TW - 1;
-        span_clip<TW>(C0 + __mul24(B0, y), A0, xs, xe);
-        span_clip<TW>(C1 + __mul24(B1, y), A1, xs, xe);
-        span_clip<TW>(C2 + __mul24(B2, y), A2, xs, xe);
-        // two pixels per step with packed fp32 math (v_pk_mul_f32 / v_pk_add_f32: same IEEE results as the scalar
-        // forms, R4 op for op).  float(P_x - X0) advances by exact float adds (integers below 2^24).  An odd span's
-        // spare slot is steered to the row's padding key (column TW), which nobody reads.
-        if (xs <= xe) {
-          const f32x2 zA2 = {zA, zA}, m12 = {m1, m1}, iz2 = {iz0, iz0}, step = {512.0f, 512.0f};
-          const float fx0 = (float)(xs * 256 + X0rel);
-          f32x2 fx = {fx0, fx0 + 256.0f};
-          unsigned long long *kp = keys + lds_idx<TWL>(y, xs);
-          unsigned long long *const pad = keys + lds_idx<TWL>(y, TW);
-          unsigned long long *const kend = keys + lds_idx<TWL>(y, xe);
-          for (; kp <= kend; kp += 2, fx += step) {
-            const f32x2 z = iz2 + (zA2 * fx + m12);
-            const int zb0 = max(__float_as_int(z.x), 1), zb1 = max(__float_as_int(z.y), 1);
-            atomicMax(kp, ((unsigned long long)(uint32_t)zb0 << 32) | key_lo);
-            atomicMax(kp < kend ? kp + 1 : pad, ((unsigned long long)(uint32_t)zb1 << 32) | key_lo);
-          }
-        }
-      }
-      if (__ballot(big) != 0ull) {
-        if (big) {  // 64-bit form: words 0..5 hold the snapped vertices
-          const int X0 = C0, Y0 = C1, X1 = C2, Y1 = w3, X2 = w4, Y2 = w5;
-          // column range: pixel centres inside the face's bounding box, clipped to the tile (R2)
-          const int jlo = max(((imin3(X0, X1, X2) - 128 + 255) >> 8) - px0, 0);
-          const int jhi = min(((imax3(X0, X1, X2) - 128) >> 8) - px0, TW - 1);
-          const int dx0 = X1 - X0, dy0 = Y1 - Y0, dx1 = X2 - X1, dy1 = Y2 - Y1, dx2 = X0 - X2, dy2 = Y0 - Y2;
-          const long long b0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;
-          const long long b1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
-          const long long b2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
-          const long long Py = (long long)(py0 + y) * 256 + 128;
-          const long long Px = (long long)(px0 + jlo) * 256 + 128;
-          long long e0 = (long long)dx0 * (Py - Y0) - (long long)dy0 * (Px - X0) + b0;
-          long long e1 = (long long)dx1 * (Py - Y1) - (long long)dy1 * (Px - X1) + b1;
-          long long e2 = (long long)dx2 * (Py - Y2) - (long long)dy2 * (Px - X2) + b2;
-          const long long a0 = -(long long)dy0 * 256, a1 = -(long long)dy1 * 256, a2 = -(long long)dy2 * 256;
-          int fxi = jlo * 256 + X0rel;
-          for (int x = jlo; x <= jhi; ++x, e0 += a0, e1 += a1, e2 += a2, fxi += 256) {
-            if ((e0 | e1 | e2) >= 0) {
-              const float m0 = zA * (float)fxi;
-              const float s = m0 + m1;
-              const float z = iz0 + s;
-              const int zb = max(__float_as_int(z), 1);
-              const unsigned long long key = ((unsigned long long)(uint32_t)zb << 32) | key_lo;
-              atomicMax(&keys[lds_idx<TWL>(y, x)], key);
-            }
-          }
-        }
-      }
+      raster_item<TWL>(keys, C0, C1, C2, w3, w4, w5, iz0, zA, zB, xw, yw, key_lo, q, et, live, px0, py0);
     }
+}
+
+// v2 of phases 2-3: the (up to 64) entries of one CHUNK of the tile's list stay in memory; every wave of the workgroup
+// scans the same 64 row counts (one byte per lane from the nrow8 stream), the chunk's 64-item batches are dealt to the
+// waves round-robin (batch b -> wave (b + rot) % NW: an average C2 tile has 6.5 batches, so 7 are issued instead of the
+// 8 that a per-wave split of the ENTRIES costs), and an item's 12 entry words arrive through the vector memory pipe
+// (3 x global_load_dwordx4 from the entry of lane t; rows of one entry share the address, the lines sit in L1/L2 after
+// the first touch) instead of 12 ds_bpermute through the LDS pipe, the tile kernel's scarcest resource.
+template <int TWL, int NW, typename EntPtr>
+__device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, uint32_t *tab, uint32_t &gen,
+                                                   EntPtr ent, const int nrows, const int lane,
+                                                   const int first_b, const int px0, const int py0, const int dbg) {
+  const int incl = wave_incl_scan(nrows);
+  int total = __builtin_amdgcn_readlane(incl, 63);
+  const int excl = incl - nrows;
+  if (dbg & 1) total = 0;
+  for (int k0 = first_b * 64; k0 < total; k0 += 64 * NW) {
+    const int q = k0 + lane;
+    ++gen;
+    const int slot = excl - k0;
+    if (nrows > 0 && slot >= 0 && slot < 64) tab[slot] = (gen << 13) | (uint32_t)((lane + 1) << 6) | (uint32_t)slot;
+    const int carry_t = __popcll(__ballot(incl <= k0));  // the entry that holds item k0: it exists (k0 < total)
+    const int carry_e = __builtin_amdgcn_readlane(excl, carry_t & 63);
+    const uint32_t mail = tab[lane];
+    const int m = wave_incl_max((mail >> 13) == gen ? (int)(mail & 0x1FFFu) : 0);
+    const int t = m ? (m >> 6) - 1 : carry_t;  // always an entry of this chunk, also for lanes beyond the last item
+    const int et = m ? k0 + (m & 63) : carry_e;
+    const bool live = q < total;
+    const int4 e0 = ent[(t & 63) * 3], e1 = ent[(t & 63) * 3 + 1], e2 = ent[(t & 63) * 3 + 2];
+    raster_item<TWL>(keys, e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, __int_as_float(e1.z), __int_as_float(e1.w),
+                     __int_as_float(e2.x), e2.y, e2.z, (uint32_t)e2.w, q, et, live, px0, py0);
+  }
+  return (total + 63) >> 6;
+}
+
+// ids-only epilogue with 16-byte stores: a lane owns 4 consecutive pixels of a row (16 lanes per 64-pixel row, NT/16
+// rows per pass); the four low dwords sit 8 bytes apart in LDS, the global store is one dwordx4.
+template <int TWL, int TH, int NT>
+__device__ __forceinline__ void store_ids16(const unsigned long long *keys, const BinArgs &a, int32_t *ids_plane, int te,
+                                            int px0, int py0) {
+  const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
+  const int c4 = (te & 15) * 4, rr = te >> 4;
+  const int gx4 = px0 + c4;
+  const int rows_here = min(TH, a.h - py0);
+  const bool vec = ((a.w & 3) == 0) && ((reinterpret_cast<uintptr_t>(ids_plane) & 15) == 0);
+  if (gx4 >= a.w) return;
+  for (int row = rr; row < rows_here; row += NT / 16) {
+    const uint32_t *kr = klo + 2 * lds_idx<TWL>(row, c4);
+    const int i0 = (int)~kr[0], i1 = (int)~kr[2], i2 = (int)~kr[4], i3 = (int)~kr[6];
+    int32_t *dst = ids_plane + (int64_t)(py0 + row) * a.w + gx4;
+    if (vec) *reinterpret_cast<int4 *>(dst) = make_int4(i0, i1, i2, i3);
+    else {  // volatile: keeps the compiler from merging these with the 16-byte store above (it splits that one)
+      volatile int32_t *d = dst;
+      d[0] = i0;
+      if (gx4 + 1 < a.w) d[1] = i1;
+      if (gx4 + 2 < a.w) d[2] = i2;
+      if (gx4 + 3 < a.w) d[3] = i3;
+    }
+  }
 }
 
 template <int TWL, int THL, int NT, bool FUSE>
@@ -1082,7 +1161,9 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
     if (FUSE) __builtin_amdgcn_s_waitcnt(0x0F70);
 
     // epilogue: whole rows (TW pixels, coalesced); the NW waves interleave over the TH rows
-    if (gx < a.w && !(a.dbg & 2)) {
+    if (!FUSE && out.ids && !out.depth && (a.var & 2) && !(a.dbg & 2)) {
+      store_ids16<TWL, TH, NT>(keys, a, out.ids + plane, te, px0, py0);
+    } else if (gx < a.w && !(a.dbg & 2)) {
       if (!FUSE && out.ids && !out.depth) {
         // ids only (the common case): the key's low dword is ~face, and 0 for an empty pixel, so id = ~low for both;
         // one 4-byte LDS read, one NOT, one store per pixel, the output pointer advances by a constant stride
@@ -1144,6 +1225,587 @@ __global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
           if (out.depth) out.depth[plane + p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
         }
       }
+    }
+  }
+}
+
+// K4 v2  tile rasterizer with memory-resident entries (see raster_chunk_gather).  Same grid, LDS image, barriers and
+//        epilogues as k_raster_rows; what changes is how entries reach the lanes and how the batches are dealt.
+//        a.var (GR_OPT_VARIANT) bit 1: plain epilogue with 16-byte id stores (4 pixels per lane);
+//                               bit 2: touch the first 32 entry slots of the segment before the count is known.
+template <int TWL, int THL, int NT, bool FUSE>
+__global__ __launch_bounds__(NT) void k_raster_tile(BinArgs a, RasterOut out) {
+  constexpr int TW = 1 << TWL, TH = 1 << THL;
+  constexpr int NKEYS = (TW + GR_LDS_PAD) * TH;
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[NKEYS + (NT / 64) * 32];
+
+  const int slot = blockIdx.y;
+  const int tile = blockIdx.x;
+  const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NW = NT / 64;
+  constexpr int ROWS_PER_PASS = NT / TW;
+  constexpr int RW = TH / (NT / 64);
+  const int64_t P = (int64_t)a.h * a.w;
+  const int64_t plane = (int64_t)slot * P;
+  const bool direct = a.cap_tile > 0;
+
+  // single-pass binning: the tile's segment starts at a known address, so the row counts of its first 64 entries (64
+  // bytes) are requested before the count is known -- count and row counts are ONE memory round trip
+  const bool spec = a.cap_tile >= 64;
+  uint32_t nr_first = 0;
+  if (spec) nr_first = a.nrow8[slot * a.ent_cap + (int64_t)tile * a.cap_tile + lane];
+  if (spec && (a.var & 4) && lane < 24 && wv == 0) {  // 32 slots = 24 sectors of 64 bytes: warm L2 for the gather
+    const int4 *cs = a.comp + (slot * a.ent_cap + (int64_t)tile * a.cap_tile) * GR_ENT_Q;
+    int4 touch = cs[lane * 4];
+    asm volatile("" ::"v"(touch.x));
+  }
+  const int tx = tile % a.TX, ty = tile / a.TX;
+  const int px0 = tx << TWL, py0 = ty << THL;
+  uint32_t cnt;
+  int64_t beg;
+  if (direct) {
+    cnt = min(ctrl[GR_CTRL_HDR + tile], (uint32_t)a.cap_tile);
+    beg = (int64_t)tile * a.cap_tile;
+  } else {
+    cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
+    beg = ctrl[GR_CTRL_HDR + 2 * a.Tcap + tile];
+    if (beg >= a.ent_cap) cnt = 0;
+    else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
+  }
+  if (a.dbg & 4) cnt = 0;
+  const int4 *comp = a.comp + (slot * a.ent_cap + beg) * GR_ENT_Q;
+  const uint8_t *nr8 = a.nrow8 + slot * a.ent_cap + beg;
+
+  if (!FUSE && cnt == 0) {  // empty tile (a view that overhangs the mesh): background, without the LDS round trip
+    const int col = tid & (TW - 1), gx = px0 + col;
+    if (gx < a.w && !(a.dbg & 2)) {
+      for (int row = tid >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
+        const int64_t p = plane + (int64_t)(py0 + row) * a.w + gx;
+        if (out.ids) out.ids[p] = -1;
+        if (out.depth) out.depth[p] = INFINITY;
+      }
+    }
+    return;
+  }
+  {  // zero the tile: 16-byte LDS stores (keys + mailboxes)
+    static_assert(NKEYS % 2 == 0, "key pairs");
+    ulonglong2 *k2 = reinterpret_cast<ulonglong2 *>(keys);
+    for (int i = tid; i < (NKEYS + (NT / 64) * 32) / 2; i += NT) k2[i] = make_ulonglong2(0ull, 0ull);
+  }
+  __syncthreads();
+
+  uint32_t *tab = reinterpret_cast<uint32_t *>(keys + NKEYS) + wv * 64;
+  uint32_t gen = 0;
+  int rot = wv;  // this wave's first batch of the current chunk
+  {
+    const uint32_t e = (uint32_t)lane;
+    int nrows = 0;
+    if (e < cnt) nrows = spec ? (int)nr_first : (int)nr8[e];
+    const int nb = raster_chunk_gather<TWL, NW, const int4 *>(keys, tab, gen, comp, nrows, lane, rot, px0, py0, a.dbg);
+    rot = (rot - nb) & (NW - 1);
+  }
+#pragma unroll 1
+  for (uint32_t c0 = 64; c0 < cnt; c0 += 64) {
+    const uint32_t e = c0 + (uint32_t)lane;
+    const int nrows = e < cnt ? (int)nr8[e] : 0;
+    const int nb = raster_chunk_gather<TWL, NW, const int4 *>(keys, tab, gen, comp + (int64_t)c0 * GR_ENT_Q, nrows, lane, rot, px0, py0, a.dbg);
+    rot = (rot - nb) & (NW - 1);
+  }
+
+  int te = tid;
+  asm volatile("" : "+v"(te));  // the epilogue's addresses are derived here, not hoisted above the scanline phase
+  const int col = te & (TW - 1);
+  const int gx = px0 + col;
+  uint32_t lab[RW];
+  if (FUSE && out.labels && gx < a.w && !(a.dbg & 16)) {
+    const int r0 = (te >> 6) * RW;
+    const int rows_here = min(RW, a.h - (py0 + r0));
+    if (rows_here > 0) {
+      const uint8_t *lp = out.labels + plane + (int64_t)(py0 + r0) * a.w + gx;
+#pragma unroll
+      for (int k = 0; k < RW; ++k) lab[k] = (uint32_t)lp[(int64_t)min(k, rows_here - 1) * a.w];
+    }
+  }
+  __syncthreads();
+  if (FUSE) __builtin_amdgcn_s_waitcnt(0x0F70);
+
+  if (!FUSE && out.ids && !out.depth && (a.var & 2) && !(a.dbg & 2)) {
+    store_ids16<TWL, TH, NT>(keys, a, out.ids + plane, te, px0, py0);
+    return;
+  }
+  if (gx < a.w && !(a.dbg & 2)) {
+    if (!FUSE && out.ids && !out.depth) {
+      const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
+      const int rows_here = min(TH, a.h - py0);
+      int32_t *dst = out.ids + plane + (int64_t)(py0 + (te >> TWL)) * a.w + gx;
+      const int64_t dstep = (int64_t)ROWS_PER_PASS * a.w;
+      for (int row = te >> TWL; row < rows_here; row += ROWS_PER_PASS, dst += dstep)
+        *dst = (int32_t)~klo[2 * lds_idx<TWL>(row, col)];
+    } else if (FUSE && !out.depth && TW == 64) {
+      // fused projection epilogue: see k_raster_rows
+      const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
+      const int r0 = (te >> 6) * RW;
+      const int bg = out.compat ? (int)out.F - 1 : -1;
+      const int rows_here = min(RW, a.h - (py0 + r0));
+      int raw = (int32_t)~klo[2 * lds_idx<TWL>(r0, col)];
+      int cur = raw == -1 ? bg : raw;
+      int p1 = (py0 + r0) * a.w + gx + 1;
+      int32_t *idp = out.ids ? out.ids + plane + (p1 - 1) : nullptr;
+      uint32_t *win32 = (uint32_t *)out.winner + slot * out.F;
+      unsigned long long *win64 = (unsigned long long *)out.winner + slot * out.F;
+#pragma unroll
+      for (int k = 0; k < RW; ++k) {
+        if (k >= rows_here) break;
+        const int row = r0 + k;
+        int nraw = -3, nxt = -3;
+        if (row + 1 < TH) {
+          nraw = (int32_t)~klo[2 * lds_idx<TWL>(row + 1, col)];
+          nxt = (py0 + row + 1 >= a.h) ? -2 : (nraw == -1 ? bg : nraw);
+        }
+        const int fr = __builtin_amdgcn_update_dpp(-3, cur, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+        const int fbr = __builtin_amdgcn_update_dpp(-3, nxt, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+        const int fbl = __builtin_amdgcn_update_dpp(-3, nxt, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        if (idp) { *idp = raw; idp += a.w; }
+        if (cur >= 0 && fr != cur && nxt != cur && fbr != cur && fbl != cur && !(a.dbg & 8)) {
+          const int label = min((int)lab[k], out.C);
+          if (out.key64) atomicMax(win64 + cur, ((unsigned long long)(uint32_t)p1 << out.LB) | (unsigned long long)label);
+          else atomicMax(win32 + cur, ((uint32_t)p1 << out.LB) | (uint32_t)label);
+        }
+        p1 += a.w;
+        cur = nxt;
+        raw = nraw;
+      }
+    } else {
+      for (int row = te >> TWL; row < TH; row += ROWS_PER_PASS) {
+        const int gy = py0 + row;
+        if (gy >= a.h) break;
+        const unsigned long long key = keys[lds_idx<TWL>(row, col)];
+        const int64_t p = (int64_t)gy * a.w + gx;
+        const int32_t id = (int32_t)~(uint32_t)key;
+        if (out.ids) out.ids[plane + p] = id;
+        if (out.depth) out.depth[plane + p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
+      }
+    }
+  }
+}
+
+// K4 v3  tile rasterizer with LDS-staged entries: the (up to 64) entries of a chunk are copied once into a 3 KiB LDS
+//        buffer shared by the workgroup (one 16-byte load + one ds_write_b128 per lane of 48 lanes per wave), an item
+//        reads its entry with three ds_read_b128 (12 LDS cycles per 64-item batch instead of the 48 of twelve
+//        ds_bpermute), and the chunk's batches are dealt to the waves round-robin.  LDS: 21.25 KiB -> 7 workgroups/CU.
+template <int TWL, int THL, int NT, bool FUSE>
+__global__ __launch_bounds__(NT) void k_raster_tile_lds(BinArgs a, RasterOut out) {
+  constexpr int TW = 1 << TWL, TH = 1 << THL;
+  constexpr int NKEYS = (TW + GR_LDS_PAD) * TH;
+  constexpr int NW = NT / 64;
+  constexpr int NMAIL = NW * 32;          // u64 units
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[NKEYS + NMAIL + 64 * 6];
+  int4 *ent_lds = reinterpret_cast<int4 *>(keys + NKEYS + NMAIL);
+
+  // views in reverse order (var bit 16): the entries the set-up kernel wrote last are still in the Infinity Cache
+  const int slot = (a.var & 16) ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+  // XCD-aware tile order (var bit 64): workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, observed,
+  // speed only), so XCD x takes the contiguous tiles [x * per, (x + 1) * per): each L2 writes back one compact part of
+  // the id image (pure 64x32-tile stores of a C2 view: 9.1 -> 7.9 us, tools/ubench/store_pattern.hip)
+  int tile = blockIdx.x;
+  if (a.var & 64) {
+    const int per = (a.T + 7) >> 3;
+    tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tile >= a.T) return;
+  }
+  const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int ROWS_PER_PASS = NT / TW;
+  constexpr int RW = TH / (NT / 64);
+  const int64_t P = (int64_t)a.h * a.w;
+  const int64_t plane = (int64_t)slot * P;
+  const bool direct = a.cap_tile > 0;
+  static_assert(NT == 256, "the entry copy deals 48 int4 per wave");
+
+  const bool diag = (a.var & 256) != 0;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
+  if (diag) ts0 = __builtin_amdgcn_s_memtime();
+  const bool spec = a.cap_tile >= 64 && !(a.var & 128);
+  uint32_t nr_first = 0;
+  int4 ex;
+  if (spec) {
+    const int64_t seg = slot * a.ent_cap + (int64_t)tile * a.cap_tile;
+    nr_first = a.nrow8[seg + lane];
+    if (lane < 48) ex = a.comp[seg * GR_ENT_Q + wv * 48 + lane];
+  }
+  const int tx = tile % a.TX, ty = tile / a.TX;
+  const int px0 = tx << TWL, py0 = ty << THL;
+  uint32_t cnt;
+  int64_t beg;
+  if (direct) {
+    cnt = min(ctrl[GR_CTRL_HDR + tile], (uint32_t)a.cap_tile);
+    beg = (int64_t)tile * a.cap_tile;
+  } else {
+    cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
+    beg = ctrl[GR_CTRL_HDR + 2 * a.Tcap + tile];
+    if (beg >= a.ent_cap) cnt = 0;
+    else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
+  }
+  if (a.dbg & 4) cnt = 0;
+  const int4 *comp = a.comp + (slot * a.ent_cap + beg) * GR_ENT_Q;
+  const uint8_t *nr8 = a.nrow8 + slot * a.ent_cap + beg;
+
+  if (!FUSE && cnt == 0) {
+    const int col = tid & (TW - 1), gx = px0 + col;
+    if (gx < a.w && !(a.dbg & 2)) {
+      for (int row = tid >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
+        const int64_t p = plane + (int64_t)(py0 + row) * a.w + gx;
+        if (out.ids) out.ids[p] = -1;
+        if (out.depth) out.depth[p] = INFINITY;
+      }
+    }
+    return;
+  }
+  {
+    static_assert(NKEYS % 2 == 0, "key pairs");
+    ulonglong2 *k2 = reinterpret_cast<ulonglong2 *>(keys);
+    for (int i = tid; i < (NKEYS + NMAIL) / 2; i += NT) k2[i] = make_ulonglong2(0ull, 0ull);
+  }
+  uint32_t *tab = reinterpret_cast<uint32_t *>(keys + NKEYS) + wv * 64;
+  uint32_t gen = 0;
+  int rot = wv;
+  // L2 warm-up for a LATER workgroup (var bit 512): the tile kernel lives on workgroup latency, and 36 % of a wave's life
+  // is the wait for its first chunk (tools/stamp_tile.py).  Wave 0 touches the first chunk, the row counts and the
+  // counter of the tile that a workgroup on the same XCD will start `a.pf_dist` (a multiple of 8) tiles from now; the
+  // loads are consumed in front of the second barrier, a raster phase later, when they have long landed.
+  uint32_t pf = 0;
+  if ((a.var & 512) && spec && wv == 0 && lane < 26) {
+    const int64_t g = (int64_t)slot * a.T + tile + a.pf_dist;
+    const int64_t ps = g / a.T, pt = g - ps * a.T;
+    if (ps < (int64_t)gridDim.y) {
+      const int64_t seg = ps * a.ent_cap + pt * a.cap_tile;
+      const uint32_t *src = lane < 24 ? reinterpret_cast<const uint32_t *>(a.comp + seg * GR_ENT_Q) + lane * 32
+                            : lane == 24 ? reinterpret_cast<const uint32_t *>(a.nrow8 + seg)
+                                         : a.ctrl + ps * a.ctrl_stride + GR_CTRL_HDR + pt;
+      pf = __builtin_nontemporal_load(src);
+    }
+  }
+#pragma unroll 1
+  for (uint32_t c0 = 0; c0 < cnt || c0 == 0; c0 += 64) {
+    // copy the chunk's entries to LDS (entries past the count hold stale data that nobody reads)
+    if (lane < 48) {
+      const uint32_t q = c0 * GR_ENT_Q + wv * 48 + lane;
+      if (!(spec && c0 == 0)) {
+        if (q < cnt * GR_ENT_Q) ex = comp[q];
+      }
+      ent_lds[wv * 48 + lane] = ex;
+    }
+    if (diag && c0 == 0) { __builtin_amdgcn_s_waitcnt(0); ts1 = __builtin_amdgcn_s_memtime(); }
+    __syncthreads();
+    if (diag && c0 == 0) ts2 = __builtin_amdgcn_s_memtime();
+    const uint32_t e = c0 + (uint32_t)lane;
+    int nrows = 0;
+    if (e < cnt) nrows = (spec && c0 == 0) ? (int)nr_first : (int)nr8[e];
+    const int nb = raster_chunk_gather<TWL, NW, const int4 *>(keys, tab, gen, ent_lds, nrows, lane, rot, px0, py0, a.dbg);
+    rot = (rot - nb) & (NW - 1);
+    if (c0 + 64 < cnt) __syncthreads();  // every wave is done with this chunk before it is overwritten
+  }
+
+  int te = tid;
+  asm volatile("" : "+v"(te));
+  const int col = te & (TW - 1);
+  const int gx = px0 + col;
+  uint32_t lab[RW];
+  if (FUSE && out.labels && gx < a.w && !(a.dbg & 16)) {
+    const int r0 = (te >> 6) * RW;
+    const int rows_here = min(RW, a.h - (py0 + r0));
+    if (rows_here > 0) {
+      const uint8_t *lp = out.labels + plane + (int64_t)(py0 + r0) * a.w + gx;
+#pragma unroll
+      for (int k = 0; k < RW; ++k) lab[k] = (uint32_t)lp[(int64_t)min(k, rows_here - 1) * a.w];
+    }
+  }
+  asm volatile("" ::"v"(pf));
+  if (diag) { __builtin_amdgcn_s_waitcnt(0); ts3 = __builtin_amdgcn_s_memtime(); }
+  __syncthreads();
+  if (FUSE) __builtin_amdgcn_s_waitcnt(0x0F70);
+  if (diag) ts4 = __builtin_amdgcn_s_memtime();
+
+  if (!FUSE && out.ids && !out.depth && (a.var & 2) && !(a.dbg & 2)) {
+    store_ids16<TWL, TH, NT>(keys, a, out.ids + plane, te, px0, py0);
+    if (diag) {
+      const unsigned long long ts5 = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_waitcnt(0);
+      const unsigned long long ts6 = __builtin_amdgcn_s_memtime();
+      if (lane == 0) {  // per wave: load wait, barrier A, raster, barrier B, store issue, store completion, waves
+        unsigned long long *st = a.stamps + 8 * ((blockIdx.x * 4 + wv + blockIdx.y * 1031) & 4095);
+        a.stamps = st;
+        atomicAdd(&a.stamps[0], ts1 - ts0); atomicAdd(&a.stamps[1], ts2 - ts1); atomicAdd(&a.stamps[2], ts3 - ts2);
+        atomicAdd(&a.stamps[3], ts4 - ts3); atomicAdd(&a.stamps[4], ts5 - ts4); atomicAdd(&a.stamps[5], ts6 - ts5);
+        atomicAdd(&a.stamps[6], 1ull);
+      }
+    }
+    return;
+  }
+  if (gx < a.w && !(a.dbg & 2)) {
+    if (!FUSE && out.ids && !out.depth) {
+      const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
+      const int rows_here = min(TH, a.h - py0);
+      int32_t *dst = out.ids + plane + (int64_t)(py0 + (te >> TWL)) * a.w + gx;
+      const int64_t dstep = (int64_t)ROWS_PER_PASS * a.w;
+      for (int row = te >> TWL; row < rows_here; row += ROWS_PER_PASS, dst += dstep)
+        *dst = (int32_t)~klo[2 * lds_idx<TWL>(row, col)];
+    } else if (FUSE && !out.depth && TW == 64) {
+      const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
+      const int r0 = (te >> 6) * RW;
+      const int bg = out.compat ? (int)out.F - 1 : -1;
+      const int rows_here = min(RW, a.h - (py0 + r0));
+      int raw = (int32_t)~klo[2 * lds_idx<TWL>(r0, col)];
+      int cur = raw == -1 ? bg : raw;
+      int p1 = (py0 + r0) * a.w + gx + 1;
+      int32_t *idp = out.ids ? out.ids + plane + (p1 - 1) : nullptr;
+      uint32_t *win32 = (uint32_t *)out.winner + slot * out.F;
+      unsigned long long *win64 = (unsigned long long *)out.winner + slot * out.F;
+#pragma unroll
+      for (int k = 0; k < RW; ++k) {
+        if (k >= rows_here) break;
+        const int row = r0 + k;
+        int nraw = -3, nxt = -3;
+        if (row + 1 < TH) {
+          nraw = (int32_t)~klo[2 * lds_idx<TWL>(row + 1, col)];
+          nxt = (py0 + row + 1 >= a.h) ? -2 : (nraw == -1 ? bg : nraw);
+        }
+        const int fr = __builtin_amdgcn_update_dpp(-3, cur, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+        const int fbr = __builtin_amdgcn_update_dpp(-3, nxt, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+        const int fbl = __builtin_amdgcn_update_dpp(-3, nxt, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        if (idp) { *idp = raw; idp += a.w; }
+        if (cur >= 0 && fr != cur && nxt != cur && fbr != cur && fbl != cur && !(a.dbg & 8)) {
+          const int label = min((int)lab[k], out.C);
+          if (out.key64) atomicMax(win64 + cur, ((unsigned long long)(uint32_t)p1 << out.LB) | (unsigned long long)label);
+          else atomicMax(win32 + cur, ((uint32_t)p1 << out.LB) | (uint32_t)label);
+        }
+        p1 += a.w;
+        cur = nxt;
+        raw = nraw;
+      }
+    } else {
+      for (int row = te >> TWL; row < TH; row += ROWS_PER_PASS) {
+        const int gy = py0 + row;
+        if (gy >= a.h) break;
+        const unsigned long long key = keys[lds_idx<TWL>(row, col)];
+        const int64_t p = (int64_t)gy * a.w + gx;
+        const int32_t id = (int32_t)~(uint32_t)key;
+        if (out.ids) out.ids[plane + p] = id;
+        if (out.depth) out.depth[plane + p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
+      }
+    }
+  }
+}
+
+// K4 v4  persistent tile rasterizer: a workgroup walks KT consecutive tiles of one view.  The tile kernel is bound by
+//        latency, not by a pipe (5 instead of 7 resident workgroups per CU cost 40 %; the kernel without any triangle
+//        work -- zero LDS, fetch entries, store ids -- takes 12.7 of its 17.6 us per C2 view): a workgroup that starts,
+//        asks memory for its count and entries, and only then has work, holds 21 KiB of LDS idle for a memory round trip.
+//        Here the counts of all KT tiles arrive with ONE load (lane j keeps tile j's), and the first chunk of tile k+1
+//        (one 16-byte piece per lane, exact: the count is known) is requested before tile k is rasterized and copied to
+//        LDS after tile k's epilogue.  Entries staged in LDS and batches dealt round-robin as in v3; the ids-only
+//        epilogue clears the keys it has just read, so a tile costs two workgroup barriers.
+template <int TWL, int THL, int NT, bool FUSE>
+__global__ __launch_bounds__(NT) void k_raster_tiles(BinArgs a, RasterOut out, int KT) {
+  constexpr int TW = 1 << TWL, TH = 1 << THL;
+  constexpr int NKEYS = (TW + GR_LDS_PAD) * TH;
+  constexpr int NW = NT / 64;
+  constexpr int NMAIL = NW * 32;  // u64 units
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[NKEYS + NMAIL + 64 * 6];
+  int4 *ent_lds = reinterpret_cast<int4 *>(keys + NKEYS + NMAIL);
+  static_assert(NT == 256, "the entry copy deals 48 int4 per wave");
+
+  const int slot = blockIdx.y;
+  const int t0 = blockIdx.x * KT;
+  const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int ROWS_PER_PASS = NT / TW;
+  constexpr int RW = TH / (NT / 64);
+  const int64_t P = (int64_t)a.h * a.w;
+  const int64_t plane = (int64_t)slot * P;
+  const bool direct = a.cap_tile > 0;
+  const int nt = min(KT, a.T - t0);  // tiles of this workgroup
+
+  // counts (and list starts) of this workgroup's tiles: lane j holds tile t0 + j
+  uint32_t cv = 0, bv = 0;
+  if (lane < nt) {
+    if (direct) {
+      cv = min(ctrl[GR_CTRL_HDR + t0 + lane], (uint32_t)a.cap_tile);
+    } else {
+      cv = ctrl[GR_CTRL_HDR + t0 + lane] + ctrl[GR_CTRL_HDR + a.Tcap + t0 + lane];
+      bv = ctrl[GR_CTRL_HDR + 2 * a.Tcap + t0 + lane];
+      if ((int64_t)bv >= a.ent_cap) cv = 0;
+      else if ((int64_t)bv + cv > a.ent_cap) cv = (uint32_t)(a.ent_cap - bv);
+    }
+    if (a.dbg & 4) cv = 0;
+  }
+  // first tile: its segment address is static in single-pass mode, so the first chunk is requested before the counts land
+  const bool spec = a.cap_tile >= 64;
+  {  // zero keys + mailboxes once; later tiles find the keys cleared by the previous epilogue (ids-only) or clear them again
+    static_assert(NKEYS % 2 == 0, "key pairs");
+    ulonglong2 *k2 = reinterpret_cast<ulonglong2 *>(keys);
+    for (int i = tid; i < (NKEYS + NMAIL) / 2; i += NT) k2[i] = make_ulonglong2(0ull, 0ull);
+  }
+  int nrows_cur = 0;
+  {
+    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cv, 0);
+    int4 e0 = make_int4(0, 0, 0, 0);
+    uint32_t n0 = 0;
+    if (spec) {
+      const int64_t seg = slot * a.ent_cap + (int64_t)t0 * a.cap_tile;
+      n0 = a.nrow8[seg + lane];
+      if (lane < 48) e0 = a.comp[seg * GR_ENT_Q + wv * 48 + lane];
+    } else {
+      const int64_t b0 = direct ? (int64_t)t0 * a.cap_tile : (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)bv, 0);
+      if (lane < 48 && (uint32_t)(wv * 48 + lane) < c0 * GR_ENT_Q) e0 = a.comp[(slot * a.ent_cap + b0) * GR_ENT_Q + wv * 48 + lane];
+      if ((uint32_t)lane < c0) n0 = a.nrow8[slot * a.ent_cap + b0 + lane];
+    }
+    if (lane < 48) ent_lds[wv * 48 + lane] = e0;
+    nrows_cur = (uint32_t)lane < c0 ? (int)n0 : 0;
+  }
+  uint32_t *tab = reinterpret_cast<uint32_t *>(keys + NKEYS) + wv * 64;
+  uint32_t gen = 0;
+  int rot = wv;
+  const bool ids16 = !FUSE && out.ids && !out.depth && !(a.dbg & 2);
+
+#pragma unroll 1
+  for (int k = 0; k < nt; ++k) {
+    const int tile = t0 + k;
+    const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)cv, k);
+    const int64_t beg = direct ? (int64_t)tile * a.cap_tile : (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)bv, k);
+    const int4 *comp = a.comp + (slot * a.ent_cap + beg) * GR_ENT_Q;
+    const uint8_t *nr8 = a.nrow8 + slot * a.ent_cap + beg;
+    const int tx = tile % a.TX, ty = tile / a.TX;
+    const int px0 = tx << TWL, py0 = ty << THL;
+    __syncthreads();  // A: keys cleared, this tile's first chunk visible in LDS
+    // request the next tile's first chunk (exact: its count is known): it lands while this tile is rasterized
+    int4 ex_n = make_int4(0, 0, 0, 0);
+    uint32_t nr_n = 0, cn = 0;
+    if (k + 1 < nt) {
+      cn = (uint32_t)__builtin_amdgcn_readlane((int)cv, k + 1);
+      const int64_t bn = direct ? (int64_t)(tile + 1) * a.cap_tile : (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)bv, k + 1);
+      if (lane < 48 && (uint32_t)(wv * 48 + lane) < cn * GR_ENT_Q) ex_n = a.comp[(slot * a.ent_cap + bn) * GR_ENT_Q + wv * 48 + lane];
+      if ((uint32_t)lane < cn) nr_n = a.nrow8[slot * a.ent_cap + bn + lane];
+    }
+    if (cnt > 0) {
+      const int nb = raster_chunk_gather<TWL, NW, const int4 *>(keys, tab, gen, ent_lds, nrows_cur, lane, rot, px0, py0, a.dbg);
+      rot = (rot - nb) & (NW - 1);
+#pragma unroll 1
+      for (uint32_t c0 = 64; c0 < cnt; c0 += 64) {  // long lists: further chunks, fetched in place
+        __syncthreads();
+        const uint32_t q = c0 * GR_ENT_Q + wv * 48 + lane;
+        if (lane < 48 && q < cnt * GR_ENT_Q) ent_lds[wv * 48 + lane] = comp[q];
+        const uint32_t e = c0 + (uint32_t)lane;
+        const int nrows = e < cnt ? (int)nr8[e] : 0;
+        __syncthreads();
+        const int nb2 = raster_chunk_gather<TWL, NW, const int4 *>(keys, tab, gen, ent_lds, nrows, lane, rot, px0, py0, a.dbg);
+        rot = (rot - nb2) & (NW - 1);
+      }
+    }
+
+    int te = tid;
+    asm volatile("" : "+v"(te));
+    const int col = te & (TW - 1);
+    const int gx = px0 + col;
+    uint32_t lab[RW];
+    if (FUSE && out.labels && gx < a.w && !(a.dbg & 16)) {
+      const int r0 = (te >> 6) * RW;
+      const int rows_here = min(RW, a.h - (py0 + r0));
+      if (rows_here > 0) {
+        const uint8_t *lp = out.labels + plane + (int64_t)(py0 + r0) * a.w + gx;
+#pragma unroll
+        for (int kk = 0; kk < RW; ++kk) lab[kk] = (uint32_t)lp[(int64_t)min(kk, rows_here - 1) * a.w];
+      }
+    }
+    __syncthreads();  // B: keys complete, nobody reads this tile's entries any more
+    // the next tile's chunk, requested a whole raster phase ago, goes to LDS BEFORE this tile's stores are issued: the
+    // wait for it must not queue behind stores (loads and stores share one in-order counter)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (lane < 48) ent_lds[wv * 48 + lane] = ex_n;
+    nrows_cur = (uint32_t)lane < cn ? (int)nr_n : 0;
+    if (ids16) {
+      // ids only: 4 pixels per lane, 16-byte stores; the keys just read are cleared for the next tile
+      const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
+      const int c4 = (te & 15) * 4, rr = te >> 4;
+      const int gx4 = px0 + c4;
+      const int rows_here = min(TH, a.h - py0);
+      int32_t *ids_plane = out.ids + plane;
+      const bool vec = ((a.w & 3) == 0) && ((reinterpret_cast<uintptr_t>(ids_plane) & 15) == 0);
+      for (int row = rr; row < TH; row += NT / 16) {
+        unsigned long long *kq = keys + lds_idx<TWL>(row, c4);
+        const uint32_t *kr = klo + 2 * lds_idx<TWL>(row, c4);
+        const int i0 = (int)~kr[0], i1 = (int)~kr[2], i2 = (int)~kr[4], i3 = (int)~kr[6];
+        kq[0] = 0ull; kq[1] = 0ull; kq[2] = 0ull; kq[3] = 0ull;
+        if (row < rows_here && gx4 < a.w) {
+          int32_t *dst = ids_plane + (int64_t)(py0 + row) * a.w + gx4;
+          if (vec) *reinterpret_cast<int4 *>(dst) = make_int4(i0, i1, i2, i3);
+          else {  // volatile: keeps the compiler from merging these with the 16-byte store above (it splits that one)
+            volatile int32_t *d = dst;
+            d[0] = i0;
+            if (gx4 + 1 < a.w) d[1] = i1;
+            if (gx4 + 2 < a.w) d[2] = i2;
+            if (gx4 + 3 < a.w) d[3] = i3;
+          }
+        }
+      }
+      continue;  // barrier A of the next tile orders the clearing against its raster phase
+    }
+    if (FUSE) __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (gx < a.w && !(a.dbg & 2)) {
+      if (FUSE && !out.depth && TW == 64) {
+        // fused projection epilogue: see k_raster_rows
+        const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
+        const int r0 = (te >> 6) * RW;
+        const int bg = out.compat ? (int)out.F - 1 : -1;
+        const int rows_here = min(RW, a.h - (py0 + r0));
+        int raw = (int32_t)~klo[2 * lds_idx<TWL>(r0, col)];
+        int cur = raw == -1 ? bg : raw;
+        int p1 = (py0 + r0) * a.w + gx + 1;
+        int32_t *idp = out.ids ? out.ids + plane + (p1 - 1) : nullptr;
+        uint32_t *win32 = (uint32_t *)out.winner + slot * out.F;
+        unsigned long long *win64 = (unsigned long long *)out.winner + slot * out.F;
+#pragma unroll
+        for (int kk = 0; kk < RW; ++kk) {
+          if (kk >= rows_here) break;
+          const int row = r0 + kk;
+          int nraw = -3, nxt = -3;
+          if (row + 1 < TH) {
+            nraw = (int32_t)~klo[2 * lds_idx<TWL>(row + 1, col)];
+            nxt = (py0 + row + 1 >= a.h) ? -2 : (nraw == -1 ? bg : nraw);
+          }
+          const int fr = __builtin_amdgcn_update_dpp(-3, cur, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+          const int fbr = __builtin_amdgcn_update_dpp(-3, nxt, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+          const int fbl = __builtin_amdgcn_update_dpp(-3, nxt, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+          if (idp) { *idp = raw; idp += a.w; }
+          if (cur >= 0 && fr != cur && nxt != cur && fbr != cur && fbl != cur && !(a.dbg & 8)) {
+            const int label = min((int)lab[kk], out.C);
+            if (out.key64) atomicMax(win64 + cur, ((unsigned long long)(uint32_t)p1 << out.LB) | (unsigned long long)label);
+            else atomicMax(win32 + cur, ((uint32_t)p1 << out.LB) | (uint32_t)label);
+          }
+          p1 += a.w;
+          cur = nxt;
+          raw = nraw;
+        }
+      } else {
+        for (int row = te >> TWL; row < TH; row += ROWS_PER_PASS) {
+          const int gy = py0 + row;
+          if (gy >= a.h) break;
+          const unsigned long long key = keys[lds_idx<TWL>(row, col)];
+          const int64_t p = (int64_t)gy * a.w + gx;
+          const int32_t id = (int32_t)~(uint32_t)key;
+          if (out.ids) out.ids[plane + p] = id;
+          if (out.depth) out.depth[plane + p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
+        }
+      }
+    }
+    if (k + 1 < nt) {
+      __syncthreads();  // C: every wave has read the keys before they are cleared for the next tile
+      ulonglong2 *k2 = reinterpret_cast<ulonglong2 *>(keys);
+      for (int i = tid; i < NKEYS / 2; i += NT) k2[i] = make_ulonglong2(0ull, 0ull);
     }
   }
 }
@@ -1478,6 +2140,8 @@ struct gr_ctx {
   uint32_t *ctrl = nullptr;
   int4 *rec = nullptr;
   int4 *comp = nullptr;
+  uint8_t *nrow8 = nullptr;
+  int64_t nrow_have = 0;
   uint32_t *work = nullptr;
   int64_t work_stride = 0;
   uint32_t *clip = nullptr;   // [slot][F] clip lists (R7)
@@ -1497,6 +2161,10 @@ struct gr_ctx {
   int opt_thl = 5;      // log2 tile height (5 or 6); width is 64.  64x32 tiles: 16 KiB of LDS, 8 workgroups per CU
   int opt_batch = GR_MAX_BATCH;
   int opt_dbg = 0;
+  int opt_var = 3;
+  int opt_pf_dist = 2048;
+  int opt_kt = 4;        // tiles per workgroup of the persistent tile kernel
+  int opt_lds_pad = 0;   // extra dynamic LDS bytes per tile workgroup (occupancy experiments)
   int opt_direct_cap = 512;  // single-pass binning: entry slots per tile (0 = always use the exact two-pass path)
   int learned_cap = 0, learned_T = 0;  // slots per tile learned from an overflow, valid for images with learned_T tiles
   int last_T = 0, last_B = 0;          // tile count and launch-group size of the last raster call
@@ -1591,6 +2259,7 @@ int ensure_bins(gr_ctx *c, int n_slots, int T) {
   const int64_t work_stride = ceil_div(F, GR_BLOCK) + 4;
   int rc = grow(c, c->ctrl, c->ctrl_have, ctrl_stride * n_slots, "bin control");
   if (!rc) rc = grow(c, c->comp, c->comp_have, GR_ENT_Q * cap * n_slots, "entry list");
+  if (!rc) rc = grow(c, c->nrow8, c->nrow_have, cap * n_slots + 64, "entry row counts");
   if (!rc) rc = grow(c, c->work, c->work_have, work_stride * n_slots, "work list");
   if (!rc) rc = grow(c, c->clip, c->clip_have, F * n_slots, "clip list");
   if (!rc && !direct) rc = grow(c, c->rec, c->rec_have, 4 * F * n_slots, "record planes");  // exact path only
@@ -1617,11 +2286,12 @@ BinArgs make_args(gr_ctx *c, int h, int w, int slot0) {
   a.work_stride = c->work_stride;
   a.ctrl = c->ctrl + slot0 * a.ctrl_stride; a.rec = c->rec + slot0 * a.rec_stride;
   a.comp = c->comp + slot0 * a.ent_cap * GR_ENT_Q; a.work = c->work + slot0 * a.work_stride;
-  a.stats = c->stats; a.blk = c->blk; a.soup = c->soup; a.orig = c->orig;
+  a.nrow8 = c->nrow8 + slot0 * a.ent_cap;
+  a.stamps = c->stats + 8; a.stats = c->stats; a.blk = c->blk; a.soup = c->soup; a.orig = c->orig;
   a.clip = c->clip + slot0 * c->F;
   a.twl = GR_TILE_LOG2; a.thl = c->opt_thl;
   a.TX = (w + (1 << a.twl) - 1) >> a.twl; a.TY = (h + (1 << a.thl) - 1) >> a.thl; a.T = a.TX * a.TY; a.Tcap = c->Tcap;
-  a.h = h; a.w = w; a.dbg = c->opt_dbg;
+  a.h = h; a.w = w; a.dbg = c->opt_dbg; a.var = c->opt_var; a.pf_dist = c->opt_pf_dist;
   a.cap_tile = direct_cap(c, a.T);
   return a;
 }
@@ -1668,15 +2338,33 @@ int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStr
   BinArgs a = make_args(c, h, w, slot0);
   {
     Timed t(c, s, ST_RASTER);
-    if (out.labels) {
-      if (a.thl == 6)
-        hipLaunchKernelGGL((k_raster_rows<6, 6, 256, true>), dim3(a.T, nb), dim3(256), 0, s, a, out);
-      else
-        hipLaunchKernelGGL((k_raster_rows<6, 5, 256, true>), dim3(a.T, nb), dim3(256), 0, s, a, out);
-    } else if (a.thl == 6)
-      hipLaunchKernelGGL((k_raster_rows<6, 6, 256, false>), dim3(a.T, nb), dim3(256), 0, s, a, out);
-    else
-      hipLaunchKernelGGL((k_raster_rows<6, 5, 256, false>), dim3(a.T, nb), dim3(256), 0, s, a, out);
+    const dim3 grid(a.T, nb), block(256);
+    if (a.var & 32) {
+      const int KT = c->opt_kt;
+      const dim3 g4((unsigned)((a.T + KT - 1) / KT), nb);
+      if (out.labels) {
+        if (a.thl == 6) hipLaunchKernelGGL((k_raster_tiles<6, 6, 256, true>), g4, block, c->opt_lds_pad, s, a, out, KT);
+        else hipLaunchKernelGGL((k_raster_tiles<6, 5, 256, true>), g4, block, c->opt_lds_pad, s, a, out, KT);
+      } else if (a.thl == 6) hipLaunchKernelGGL((k_raster_tiles<6, 6, 256, false>), g4, block, c->opt_lds_pad, s, a, out, KT);
+      else hipLaunchKernelGGL((k_raster_tiles<6, 5, 256, false>), g4, block, c->opt_lds_pad, s, a, out, KT);
+    } else if (a.var & 8) {
+      const dim3 grid((a.var & 64) ? (unsigned)(((a.T + 7) >> 3) << 3) : (unsigned)a.T, nb);
+      if (out.labels) {
+        if (a.thl == 6) hipLaunchKernelGGL((k_raster_tile_lds<6, 6, 256, true>), grid, block, c->opt_lds_pad, s, a, out);
+        else hipLaunchKernelGGL((k_raster_tile_lds<6, 5, 256, true>), grid, block, c->opt_lds_pad, s, a, out);
+      } else if (a.thl == 6) hipLaunchKernelGGL((k_raster_tile_lds<6, 6, 256, false>), grid, block, c->opt_lds_pad, s, a, out);
+      else hipLaunchKernelGGL((k_raster_tile_lds<6, 5, 256, false>), grid, block, c->opt_lds_pad, s, a, out);
+    } else if (a.var & 1) {
+      if (out.labels) {
+        if (a.thl == 6) hipLaunchKernelGGL((k_raster_tile<6, 6, 256, true>), grid, block, 0, s, a, out);
+        else hipLaunchKernelGGL((k_raster_tile<6, 5, 256, true>), grid, block, 0, s, a, out);
+      } else if (a.thl == 6) hipLaunchKernelGGL((k_raster_tile<6, 6, 256, false>), grid, block, 0, s, a, out);
+      else hipLaunchKernelGGL((k_raster_tile<6, 5, 256, false>), grid, block, 0, s, a, out);
+    } else if (out.labels) {
+      if (a.thl == 6) hipLaunchKernelGGL((k_raster_rows<6, 6, 256, true>), grid, block, 0, s, a, out);
+      else hipLaunchKernelGGL((k_raster_rows<6, 5, 256, true>), grid, block, 0, s, a, out);
+    } else if (a.thl == 6) hipLaunchKernelGGL((k_raster_rows<6, 6, 256, false>), grid, block, 0, s, a, out);
+    else hipLaunchKernelGGL((k_raster_rows<6, 5, 256, false>), grid, block, 0, s, a, out);
     c->prof_raster_launches += 1;
   }
   c->prof_views += nb;
@@ -1793,12 +2481,12 @@ int gr_ctx_create(int device, gr_ctx **out) {
   gr_ctx *c = new (std::nothrow) gr_ctx();
   if (!c) return GR_ENOMEM;
   c->device = device;
-  if (hipMalloc(&c->stats, sizeof(unsigned long long) * 4) != hipSuccess ||
+  if (hipMalloc(&c->stats, sizeof(unsigned long long) * (8 + 8 * 4096)) != hipSuccess ||
       hipMalloc(&c->flag, sizeof(int) * 8) != hipSuccess) {  // flag word + upload scratch (vertex bounds)
     delete c;
     return GR_ENOMEM;
   }
-  (void)hipMemset(c->stats, 0, sizeof(unsigned long long) * 4);
+  (void)hipMemset(c->stats, 0, sizeof(unsigned long long) * (8 + 8 * 4096));
   *out = c;
   return GR_OK;
 }
@@ -1812,6 +2500,7 @@ int gr_ctx_destroy(gr_ctx *c) {
   if (c->ctrl) (void)hipFree(c->ctrl);
   if (c->rec) (void)hipFree(c->rec);
   if (c->comp) (void)hipFree(c->comp);
+  if (c->nrow8) (void)hipFree(c->nrow8);
   if (c->work) (void)hipFree(c->work);
   if (c->clip) (void)hipFree(c->clip);
   if (c->winner) (void)hipFree(c->winner);
@@ -1847,6 +2536,15 @@ int gr_set_option(gr_ctx *c, int key, int value) {
       c->opt_batch = value; return GR_OK;
     case GR_OPT_DEBUG:
       c->opt_dbg = value; return GR_OK;
+    case GR_OPT_VARIANT:
+      c->opt_var = value; return GR_OK;
+    case 98:
+      c->opt_lds_pad = value; return GR_OK;
+    case 97:
+      c->opt_pf_dist = value; return GR_OK;
+    case GR_OPT_TILES_PER_WG:
+      if (value < 1 || value > 64) return fail(c, GR_EINVAL, "tiles per workgroup must be in [1, 64]");
+      c->opt_kt = value; return GR_OK;
     case GR_OPT_DIRECT_CAP:
       if (value < 0 || value > 65536) return fail(c, GR_EINVAL, "slots per tile must be in [0, 65536]");
       c->opt_direct_cap = value; c->direct_ok = true; c->learned_cap = 0; c->learned_T = 0; return GR_OK;
@@ -1869,6 +2567,18 @@ int gr_get_stage_times(gr_ctx *c, gr_stage_times *o) {
   for (auto &sp : c->spans) { c->pool.push_back(sp.a); c->pool.push_back(sp.b); }
   c->spans.clear();
   c->prof_views = 0; c->prof_raster_launches = 0;
+  return GR_OK;
+}
+
+int gr_debug_stamps(gr_ctx *c, unsigned long long *out_h, int reset) {
+  if (!c || !out_h) return GR_EINVAL;
+  GR_HIP(c, hipDeviceSynchronize());
+  std::vector<unsigned long long> tmp(8 * 4096);
+  GR_HIP(c, hipMemcpy(tmp.data(), c->stats + 8, sizeof(unsigned long long) * 8 * 4096, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 8; ++k) out_h[k] = 0;
+  for (int i = 0; i < 4096; ++i)
+    for (int k = 0; k < 8; ++k) out_h[k] += tmp[8 * i + k];
+  if (reset) GR_HIP(c, hipMemset(c->stats + 8, 0, sizeof(unsigned long long) * 8 * 4096));
   return GR_OK;
 }
 

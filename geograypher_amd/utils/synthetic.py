@@ -228,3 +228,90 @@ def synthetic_labels(ids: np.ndarray, view: int, n_classes: int = 4, seed_face: 
     cls = np.where(flip, ((r >> np.uint32(10)) % np.uint32(n_classes)).astype(np.uint8), cls)
     cls = np.where(u >= 990, np.uint8(255), cls)
     return cls.reshape(ids.shape).astype(np.uint8)
+
+
+# ---- hostile workload: terrain + trees (restates geograypher/utils/example_data.py:30-112 without pyvista) ---------------
+def _cylinder(cx, cy, z0, radius, height, resolution=10):
+    """Closed cylinder like `pv.Cylinder(..., resolution=10).triangulate()` of example_data.py:58-66: two n-gon caps
+    (triangle fans) and 2n side triangles.  Returns (points (2n,3), faces (4n-4,3))."""
+    ang = 2 * np.pi * np.arange(resolution) / resolution
+    ring = np.stack([cx + radius * np.cos(ang), cy + radius * np.sin(ang)], axis=1)
+    pts = np.concatenate([np.c_[ring, np.full(resolution, z0)], np.c_[ring, np.full(resolution, z0 + height)]], axis=0)
+    n = resolution
+    k = np.arange(n)
+    k1 = (k + 1) % n
+    side = np.concatenate([np.stack([k, k1, n + k1], axis=1), np.stack([k, n + k1, n + k], axis=1)], axis=0)
+    fan = np.arange(1, n - 1)
+    bottom = np.stack([np.zeros(n - 2, dtype=np.int64), fan + 1, fan], axis=1)
+    top = np.stack([np.full(n - 2, n), n + fan, n + fan + 1], axis=1)
+    return pts, np.concatenate([side, bottom, top], axis=0).astype(np.int64)
+
+
+def _cone(cx, cy, z0, radius, height, resolution=12):
+    """Cone with its apex up, like the `pv.Cone(..., resolution=12).triangulate()` of example_data.py:70-80: n side
+    triangles and an n-gon base (triangle fan).  Returns (points (n+1,3), faces (2n-2,3))."""
+    n = resolution
+    ang = 2 * np.pi * np.arange(n) / n
+    ring = np.stack([cx + radius * np.cos(ang), cy + radius * np.sin(ang), np.full(n, z0)], axis=1)
+    pts = np.concatenate([ring, [[cx, cy, z0 + height]]], axis=0)
+    k = np.arange(n)
+    side = np.stack([k, (k + 1) % n, np.full(n, n)], axis=1)
+    fan = np.arange(1, n - 1)
+    base = np.stack([np.zeros(n - 2, dtype=np.int64), fan + 1, fan], axis=1)
+    return pts, np.concatenate([side, base], axis=0).astype(np.int64)
+
+
+def forest_scene(n_trees: int = 20000, n_side: int = 776, extent: float = 400.0, seed: int = 7):
+    """The C2 terrain with `n_trees` trees on it: a trunk (10-gon cylinder, 36 triangles) carrying a canopy (12-gon
+    cone, 22 triangles), tree heights 8-25 m, canopy radii 1.5-4 m, uniformly scattered (seeded).  What the heightfield
+    alone does not have: depth complexity > 1, triangles from sub-pixel slivers to tile-sized canopy sides, and tiles whose
+    entry lists differ by two orders of magnitude once the cameras are tilted.  Returns (points, faces)."""
+    rng = np.random.default_rng(seed)
+    points, faces = terrain_mesh(n_side, extent)
+    height_fn = _spectrum(1)
+    xy = rng.uniform(-0.48 * extent, 0.48 * extent, size=(n_trees, 2))
+    tall = rng.uniform(8.0, 25.0, n_trees)
+    rad = rng.uniform(1.5, 4.0, n_trees)
+    ground = height_fn(xy[:, 0], xy[:, 1])
+    cp, cf = _cylinder(0.0, 0.0, 0.0, 1.0, 1.0)
+    kp, kf = _cone(0.0, 0.0, 0.0, 1.0, 1.0)
+    # trunks: radius 0.3 m, 40 % of the tree height, sunk 0.5 m into the ground; canopies on top of them
+    trunk_pts = cp[None, :, :] * np.stack([np.full(n_trees, 0.3), np.full(n_trees, 0.3), 0.4 * tall + 0.5], axis=1)[:, None, :]
+    trunk_pts = trunk_pts + np.stack([xy[:, 0], xy[:, 1], ground - 0.5], axis=1)[:, None, :]
+    can_pts = kp[None, :, :] * np.stack([rad, rad, 0.6 * tall], axis=1)[:, None, :]
+    can_pts = can_pts + np.stack([xy[:, 0], xy[:, 1], ground + 0.4 * tall], axis=1)[:, None, :]
+    v0 = points.shape[0]
+    nt, nc = cp.shape[0], kp.shape[0]
+    trunk_faces = cf[None, :, :] + (v0 + nt * np.arange(n_trees))[:, None, None]
+    v1 = v0 + nt * n_trees
+    can_faces = kf[None, :, :] + (v1 + nc * np.arange(n_trees))[:, None, None]
+    all_points = np.concatenate([points, trunk_pts.reshape(-1, 3), can_pts.reshape(-1, 3)], axis=0)
+    all_faces = np.concatenate([faces, trunk_faces.reshape(-1, 3), can_faces.reshape(-1, 3)], axis=0).astype(np.int64)
+    return all_points, all_faces
+
+
+def oblique_cameras(n_views: int = 20, tilt_range=(30.0, 45.0), agl: float = 120.0, f: float = 3000.0, width: int = 4000,
+                    height: int = 3000, seed: int = 8, extent: float = 400.0) -> PhotogrammetryCameraSet:
+    """Cameras over the central part of the terrain, tilted 30-45 degrees off nadir with random headings."""
+    rng = np.random.default_rng(seed)
+    height_fn = _spectrum(1)
+    poses = []
+    for _ in range(n_views):
+        x, y = rng.uniform(-0.25 * extent, 0.25 * extent, 2)
+        ground = float(height_fn(np.array(x), np.array(y)))
+        poses.append(nadir_pose(x, y, ground + agl, yaw_deg=rng.uniform(0, 360), tilt_x_deg=rng.uniform(*tilt_range),
+                                tilt_y_deg=rng.uniform(-5, 5)))
+    return camera_set_from_poses(poses, f=f, width=width, height=height)
+
+
+def config4_cameras(**kw) -> PhotogrammetryCameraSet:
+    """C4: 2000 views = the C3 grid at four altitudes (90 / 110 / 130 / 150 m AGL); view i belongs to GPU i mod world."""
+    return survey_cameras(25, 20, 16.0, 20.0, altitudes=(90.0, 110.0, 130.0, 150.0), **kw)
+
+
+def config5_scene(n_views: int = 2000):
+    """C5: 1582 x 1582 heightfield over 800 m (4 999 122 faces), cameras 6000 x 4000, f = 4500 px, 150 m AGL, 50 x 40 grid
+    (15 m x 18 m spacing), tilt N(0, 5 deg) with seed 6."""
+    points, faces = terrain_mesh(1582, 800.0)
+    cams = survey_cameras(50, 40, 15.0, 18.0, agl=150.0, f=4500.0, width=6000, height=4000, seed=6)
+    return (points, faces), (cams[:n_views] if n_views < len(cams) else cams)

@@ -95,6 +95,9 @@ enum {
                                gr_raster_status (GR_EOVERFLOW); the retry uses segments of the size that image needs
                                (remembered for images of the same tile count) or, beyond 16384 slots / 24 GB of
                                entry memory per launch group, bins exactly                                     */
+  GR_OPT_VARIANT = 7,       /* tile-kernel variant bits for A/B runs (results identical): 1 entries gathered through
+                               vector memory (v2), 2 16-byte id stores, 4 entry prefetch                      */
+  GR_OPT_TILES_PER_WG = 8,  /* persistent tile kernel: consecutive tiles per workgroup, 1..64 (default 4)          */
   GR_OPT_DEBUG = 99         /* timing-only ablation mask for tools/ab_raster.py: OUTPUTS BECOME WRONG         */
 };
 int gr_set_option(gr_ctx *ctx, int key, int value);

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""tools/ab_kernel.py [views] [reps] [variant ...] -- interleaved A/B of tile-kernel variants on the C2 workload, plain
+(pix2face) and fused (raster + label projection), in ONE process.  GPU box only.
+
+A variant is `name:var[:dbg[:thl[:cap[:ldspad[:kt[:batch[:pfd]]]]]]]` (GR_OPT_VARIANT bits, GR_OPT_DEBUG mask, tile height log2, slots per tile).
+Every variant with dbg == 0 must reproduce the first variant's ids and votes bit for bit.  Prints one JSON line per
+variant: median HIP-event stage times in microseconds per view.
+"""
+import json
+import statistics
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from geograypher_amd._hip import HipRaster
+from geograypher_amd.utils import synthetic
+
+H, W, C = 3000, 4000, 4
+DEFAULT = ["v1:0", "v2:1", "v2_st16:3", "v2_st16_pf:7"]
+
+
+def main():
+    nv = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    specs = sys.argv[3:] or DEFAULT
+    variants = []
+    for sp in specs:
+        parts = sp.split(":")
+        name = parts[0]
+        nums = [int(x) for x in parts[1:]] + [None] * 8
+        variants.append((name, nums[0] or 0, nums[1] or 0, nums[2] or 5, 512 if nums[3] is None else nums[3], nums[4] or 0, nums[5] or 4, nums[6] or 64, nums[7] or 2048))
+    points, faces = synthetic.terrain_mesh()
+    cams = synthetic.config2_cameras(50)
+    recs = torch.from_numpy(cams.get_raster_records(1.0, near=1.0)[:nv]).cuda()
+    hip = HipRaster(0)
+    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+    ids = torch.empty((nv, H, W), dtype=torch.int32, device="cuda")
+    labels = torch.randint(0, C, (nv, H, W), dtype=torch.uint8, device="cuda")
+    votes, counts = hip.new_vote_buffers(C)
+    ref_ids = ref_votes = ref_counts = None
+    acc = {v[0]: {"plain": [], "fused": []} for v in variants}
+
+    def setopt(var, dbg, thl, cap, ldspad=0, kt=4, batch=64, pfd=2048):
+        hip.set_option(97, pfd)
+        hip.set_option(3, batch)
+        hip.set_option(98, ldspad)
+        hip.set_option(8, kt)
+        hip.set_option(2, thl)
+        hip.set_option(6, cap)
+        hip.set_option(7, var)
+        hip.set_option(99, dbg)
+
+    for rep in range(reps + 1):
+        for name, var, dbg, thl, cap, ldspad, kt, batch, pfd in variants:
+            setopt(var, dbg, thl, cap, ldspad, kt, batch, pfd)
+            if rep == 0:  # correctness + sizing pass
+                hip.raster_face_ids(recs, H, W, out=ids, check=True)
+                votes.zero_(); counts.zero_()
+                hip.raster_project_labels(recs, labels, C, votes, counts, ids_out=None, check=True)
+                if dbg == 0:
+                    if ref_ids is None:
+                        ref_ids, ref_votes, ref_counts = ids.clone(), votes.clone(), counts.clone()
+                    else:
+                        assert torch.equal(ref_ids, ids), f"{name}: ids differ from {variants[0][0]}"
+                        assert torch.equal(ref_votes, votes) and torch.equal(ref_counts, counts), f"{name}: votes differ"
+                continue
+            for _ in range(2):
+                hip.raster_face_ids(recs, H, W, out=ids, check=False)
+            hip.set_profiling(True)
+            for _ in range(4):
+                hip.raster_face_ids(recs, H, W, out=ids, check=False)
+            st = hip.stage_times()
+            hip.set_profiling(False)
+            acc[name]["plain"].append({k: st[k] / st["views"] * 1e3 for k in ("setup_ms", "scan_ms", "fill_ms", "raster_ms")})
+            hip.raster_project_labels(recs, labels, C, votes, counts, ids_out=None, check=False)
+            hip.set_profiling(True)
+            for _ in range(4):
+                hip.raster_project_labels(recs, labels, C, votes, counts, ids_out=None, check=False)
+            st = hip.stage_times()
+            hip.set_profiling(False)
+            acc[name]["fused"].append({k: st[k] / st["views"] * 1e3 for k in ("setup_ms", "raster_ms", "vote_ms")})
+    setopt(3, 0, 5, 512)
+    for name, var, dbg, thl, cap, ldspad, kt, batch, pfd in variants:
+        out = {"variant": name, "var": var, "dbg": dbg, "thl": thl, "cap": cap, "ldspad": ldspad, "kt": kt, "batch": batch, "pfd": pfd}
+        for kind in ("plain", "fused"):
+            runs = acc[name][kind]
+            out[kind] = {k: round(statistics.median(r[k] for r in runs), 2) for k in runs[0]}
+            out[kind]["raster_min"] = round(min(r["raster_ms"] for r in runs), 2)
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
