@@ -74,6 +74,7 @@ class RasterStats(ctypes.Structure):
         ("max_entries", ctypes.c_int64),
         ("entry_cap", ctypes.c_int64),
         ("overflow", ctypes.c_int32),
+        ("views_done", ctypes.c_int32),
     ]
 
     def as_dict(self):
@@ -247,7 +248,7 @@ class HipRaster:
 
     def set_option(self, key: int, value: int):
         """Tuning knobs of include/geograster.h (GR_OPT_*): 2 tile height log2, 3 views per launch group, 6 single-pass
-        slots per tile (0 = exact binning)."""
+        slots per tile (0 = exact binning), 7 tile-kernel variant bits (64 = XCD-aware tile order)."""
         self._check(self.lib.gr_set_option(self._ctx, int(key), int(value)), "gr_set_option")
 
     def stage_times(self) -> dict:
@@ -282,19 +283,21 @@ class HipRaster:
         elif tuple(out.shape) != (n, h, w) or out.dtype != torch.int32 or not out.is_contiguous():
             raise ValueError("out must be a contiguous int32 tensor of shape (N,h,w)")
         depth = torch.empty((n, h, w), dtype=torch.float32, device=self.device) if want_depth else None
-        for attempt in range(3):
+        v0 = 0
+        for attempt in range(4):
             with torch.cuda.device(self.device):
                 rc = self.lib.gr_raster_face_ids(
-                    self._ctx, cams_t.data_ptr(), n, h, w, out.data_ptr(),
-                    depth.data_ptr() if depth is not None else None, self._stream(),
+                    self._ctx, cams_t[v0:].data_ptr(), n - v0, h, w, out[v0:].data_ptr(),
+                    depth[v0:].data_ptr() if depth is not None else None, self._stream(),
                 )
             self._check(rc, "gr_raster_face_ids")
             if not check:
                 break
             st = RasterStats()
             rc = self.lib.gr_raster_status(self._ctx, ctypes.byref(st))
-            if rc == GR_EOVERFLOW and attempt < 2:
-                continue  # the library has recorded the exact need; the retry re-allocates the bin lists
+            if rc == GR_EOVERFLOW and attempt < 3:
+                v0 += int(st.views_done)  # the library has recorded the need; only the unfinished views are repeated
+                continue
             self._check(rc, "gr_raster_status")
             self.last_stats = st.as_dict()
             break
@@ -445,21 +448,21 @@ class HipRaster:
         if cams_t.shape[0] != n:
             raise ValueError(f"{cams_t.shape[0]} camera records for {n} label images")
         flags = GR_FLAG_NEG1_IS_LAST_FACE if neg1_is_last_face else 0
-        backup = (votes.clone(), counts.clone()) if check else None
-        for attempt in range(3):
+        v0 = 0
+        for attempt in range(4):
             with torch.cuda.device(self.device):
                 rc = self.lib.gr_raster_project_labels_u8(
-                    self._ctx, cams_t.data_ptr(), lab_t.data_ptr(), n, h, w, C, votes.data_ptr(), counts.data_ptr(),
-                    ids_out.data_ptr() if ids_out is not None else None, flags, self._stream(),
+                    self._ctx, cams_t[v0:].data_ptr(), lab_t[v0:].data_ptr(), n - v0, h, w, C, votes.data_ptr(),
+                    counts.data_ptr(), ids_out[v0:].data_ptr() if ids_out is not None else None, flags, self._stream(),
                 )
             self._check(rc, "gr_raster_project_labels_u8")
             if not check:
                 break
             st = RasterStats()
             rc = self.lib.gr_raster_status(self._ctx, ctypes.byref(st))
-            if rc == GR_EOVERFLOW and attempt < 2:
-                votes.copy_(backup[0])
-                counts.copy_(backup[1])
+            if rc == GR_EOVERFLOW and attempt < 3:
+                # the votes of the first views_done views are in; the library skipped the rest on the device
+                v0 += int(st.views_done)
                 continue
             self._check(rc, "gr_raster_status")
             self.last_stats = st.as_dict()

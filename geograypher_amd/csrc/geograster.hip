@@ -1,7 +1,7 @@
 // geograypher_amd/csrc/geograster.hip -- hand-written CDNA4 (gfx950, wave64) kernels + the C ABI of include/geograster.h.
 //
 // Hot path of geograypher re-designed for MI355X (reference lines in include/geograster.h and DESIGN.md):
-//   pix2face            k_setup_cull -> k_scan_tiles -> k_fill_compile -> k_raster_rows  (meshes.py:1776-1836)
+//   pix2face            k_setup_cull -> k_scan_tiles -> k_fill_compile -> k_raster_tile  (meshes.py:1776-1836)
 //   project/aggregate   k_winner_*   -> k_vote_*                                          (meshes.py:1987-2002, 2057-2067)
 //   render_flat gather  k_gather_texture                                                  (meshes.py:1921-1937)
 // No MFMA anywhere: there is no dense contraction on this path.  The work is integer edge functions, an
@@ -52,7 +52,8 @@ struct BinArgs {
   int64_t work_stride;
   int4 *comp;            // [slot][ent_cap][GR_ENT_Q]  compiled (face, tile) entries grouped by tile, 48 bytes each
   uint8_t *nrow8;        // [slot][ent_cap] rows of each entry inside its tile (the tile kernel's scan input: a compact stream)
-  unsigned long long *stats;  // [4] records, entries, max_entries, overflow (accumulated over the call)
+  unsigned long long *stats;  // [5] records, entries, max_entries, overflow, first overflowed launch group (over the call)
+  int group;             // index of this launch group inside the call
   int64_t ctrl_stride;   // words per slot
   int64_t rec_stride;    // int4 per slot (= 3*F)
   int64_t ent_cap;       // entries per slot
@@ -61,9 +62,7 @@ struct BinArgs {
   int h, w;
   int twl, thl;          // log2 of the tile width / height in pixels
   int cap_tile;          // > 0: single-pass binning, every tile owns cap_tile entry slots (list base = tile * cap_tile)
-  unsigned long long *stamps;  // diagnostic builds only (var bit 256): per-phase cycle sums of the tile kernel
-  int pf_dist;           // tiles between a workgroup and the one it warms L2 for (multiple of 8)
-  int var;               // kernel variant bits (GR_OPT_VARIANT): 1 v2 tile kernel, 2 16-byte id stores, 4 entry prefetch
+  int var;               // kernel variant bits (GR_OPT_VARIANT): 64 = XCD-aware tile order
   int dbg;               // timing-only ablation mask (GR_OPT_DEBUG): 1 skip scanline loop, 2 skip id stores, 4 skip triangles,
                          // fused epilogue: 8 skip winner atomics, 16 skip label loads
 };
@@ -451,7 +450,7 @@ __global__ __launch_bounds__(1024) void k_bin_stats(BinArgs a) {
     atomicAdd(&a.stats[0], (unsigned long long)ctrl[0]);
     atomicAdd(&a.stats[1], total);
     atomicMax(&a.stats[2], (unsigned long long)m);  // direct mode: the largest per-tile count
-    if (ovf) atomicMax(&a.stats[3], 1ull);
+    if (ovf) { atomicMax(&a.stats[3], 1ull); atomicMin(&a.stats[4], (unsigned long long)a.group); }
   }
 }
 
@@ -496,7 +495,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(BinArgs a) {
     atomicAdd(&a.stats[0], (unsigned long long)ctrl[0]);
     atomicAdd(&a.stats[1], (unsigned long long)total);
     atomicMax(&a.stats[2], (unsigned long long)total);
-    if (ovf) atomicMax(&a.stats[3], 1ull);
+    if (ovf) { atomicMax(&a.stats[3], 1ull); atomicMin(&a.stats[4], (unsigned long long)a.group); }
   }
 }
 
@@ -539,32 +538,46 @@ __device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, uint8_t *_
   const int nr = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;   // rows of the entry in this tile (<= 64)
   const int xw = ((Pxo - X0) & 0xFFFFFF) | (nr << 24);
   *nr8 = (uint8_t)nr;
+  // Small forms (every face whose edge values stay inside int32 in this tile): the three edge functions in units of 256,
+  //   E'_k(x, y) = C'_k + a_k x + b_k y,  C'_k = floor(C_k / 256), a_k = -dy_k, b_k = dx_k  (|a|, |b| < 2^15),
+  // exact because A_k, B_k are multiples of 256: E_k >= 0 <=> floor(E_k / 256) >= 0 <=> E'_k >= 0.  The edges are stored
+  // in an order the tile kernel relies on: FIRST an edge with a > 0 (it bounds the span from the left), LAST one with
+  // a < 0 (from the right; its magnitude is stored), the remaining one in the middle -- a triangle of non-zero area has
+  // both kinds (the a_k sum to zero).  The plane of 1/z refers to vertex 0 whatever the edge order.
+  int c0, c1, c2;
+  bool small = true;
   if (ext < GR_FAST_EXT) {
-    const int c0 = __mul24(dx0, Pyo - Y0) - __mul24(dy0, Pxo - X0) + t0;
-    const int c1 = __mul24(dx1, Pyo - Y1) - __mul24(dy1, Pxo - X1) + t1;
-    const int c2 = __mul24(dx2, Pyo - Y2) - __mul24(dy2, Pxo - X2) + t2;
-    dst[0] = make_int4(c0, c1, c2, pack16(-dy0, -dy1));
-    dst[1] = make_int4(pack16(-dy2, dx0), pack16(dx1, dx2), p1.z, p2.x);
-    dst[2] = make_int4(p2.y, xw, yw, (int)~(uint32_t)p1.w);
-    return;
+    c0 = __mul24(dx0, Pyo - Y0) - __mul24(dy0, Pxo - X0) + t0;
+    c1 = __mul24(dx1, Pyo - Y1) - __mul24(dy1, Pxo - X1) + t1;
+    c2 = __mul24(dx2, Pyo - Y2) - __mul24(dy2, Pxo - X2) + t2;
+  } else {
+    const long long b0 = t0, b1 = t1, b2 = t2;
+    const long long C0 = (long long)dx0 * (Pyo - Y0) - (long long)dy0 * (Pxo - X0) + b0;
+    const long long C1 = (long long)dx1 * (Pyo - Y1) - (long long)dy1 * (Pxo - X1) + b1;
+    const long long C2 = (long long)dx2 * (Pyo - Y2) - (long long)dy2 * (Pxo - X2) + b2;
+    const long long A0 = -(long long)dy0 * 256, A1 = -(long long)dy1 * 256, A2 = -(long long)dy2 * 256;
+    const long long B0 = (long long)dx0 * 256, B1 = (long long)dx1 * 256, B2 = (long long)dx2 * 256;
+    const long long lim = 0x7FFFFFFFll;
+    const long long m24 = (1ll << 23) - 1;  // |a|, |b| <= 32767 once divided by 256
+    // int32-safe inside this tile, with room for the +-2 pixel reach of the span solver
+    small = (llabs(C0) + (TW + 2) * llabs(A0) + TH * llabs(B0) < lim) &&
+            (llabs(C1) + (TW + 2) * llabs(A1) + TH * llabs(B1) < lim) &&
+            (llabs(C2) + (TW + 2) * llabs(A2) + TH * llabs(B2) < lim) &&
+            llabs(A0) <= m24 && llabs(A1) <= m24 && llabs(A2) <= m24 &&
+            llabs(B0) <= m24 && llabs(B1) <= m24 && llabs(B2) <= m24;
+    c0 = (int)C0; c1 = (int)C1; c2 = (int)C2;
   }
-  const long long b0 = t0, b1 = t1, b2 = t2;
-  const long long C0 = (long long)dx0 * (Pyo - Y0) - (long long)dy0 * (Pxo - X0) + b0;
-  const long long C1 = (long long)dx1 * (Pyo - Y1) - (long long)dy1 * (Pxo - X1) + b1;
-  const long long C2 = (long long)dx2 * (Pyo - Y2) - (long long)dy2 * (Pxo - X2) + b2;
-  const long long A0 = -(long long)dy0 * 256, A1 = -(long long)dy1 * 256, A2 = -(long long)dy2 * 256;
-  const long long B0 = (long long)dx0 * 256, B1 = (long long)dx1 * 256, B2 = (long long)dx2 * 256;
-  const long long lim = 0x7FFFFFFFll;
-  // int32-safe inside this tile, including the +-2 pixel probes of the span solver
-  const long long m24 = (1ll << 23) - 1;  // A, B feed v_mul_i32_i24
-  const bool small = (llabs(C0) + (TW + 2) * llabs(A0) + TH * llabs(B0) < lim) &&
-                     (llabs(C1) + (TW + 2) * llabs(A1) + TH * llabs(B1) < lim) &&
-                     (llabs(C2) + (TW + 2) * llabs(A2) + TH * llabs(B2) < lim) &&
-                     llabs(A0) <= m24 && llabs(A1) <= m24 && llabs(A2) <= m24 &&
-                     llabs(B0) <= m24 && llabs(B1) <= m24 && llabs(B2) <= m24;
-  if (small) {  // |A|, |B| <= m24 and multiples of 256: the quotients fit 16 bits
-    dst[0] = make_int4((int)C0, (int)C1, (int)C2, pack16(-dy0, -dy1));
-    dst[1] = make_int4(pack16(-dy2, dx0), pack16(dx1, dx2), p1.z, p2.x);
+  if (small) {
+    const int a0 = -dy0, a1 = -dy1, a2 = -dy2;
+    const int kf = a0 > 0 ? 0 : (a1 > 0 ? 1 : 2);   // first: a > 0
+    const int kl = a0 < 0 ? 0 : (a1 < 0 ? 1 : 2);   // last: a < 0
+    const int km = 3 - kf - kl;
+    auto pick = [](int k, int v0, int v1, int v2) { return k == 0 ? v0 : (k == 1 ? v1 : v2); };
+    const int cf = pick(kf, c0, c1, c2) >> 8, cm = pick(km, c0, c1, c2) >> 8, cl = pick(kl, c0, c1, c2) >> 8;
+    const int af = pick(kf, a0, a1, a2), am = pick(km, a0, a1, a2), al = pick(kl, a0, a1, a2);
+    const int bf = pick(kf, dx0, dx1, dx2), bm = pick(km, dx0, dx1, dx2), bl = pick(kl, dx0, dx1, dx2);
+    dst[0] = make_int4(cf, cm, cl, pack16(af, am));
+    dst[1] = make_int4(pack16(-al, bf), pack16(bm, bl), p1.z, p2.x);
   } else {
     dst[0] = make_int4(X0, Y0, X1, Y1);
     dst[1] = make_int4(X2, Y2, p1.z, p2.x);
@@ -669,7 +682,7 @@ __device__ void emit_triangle(const BinArgs &a, int slot, uint32_t *ctrl, Vtx v0
       }
   } else {
     const uint32_t s = atomicAdd(&ctrl[0], 1u);
-    if ((int64_t)s >= a.F) { atomicMax(&a.stats[3], 1ull); return; }  // more records than faces: the call is rejected
+    if ((int64_t)s >= a.F) { atomicMax(&a.stats[3], 1ull); atomicMin(&a.stats[4], (unsigned long long)a.group); return; }  // more records than faces: the call is rejected
     const bool small_fp = (tx1 - tx0 <= 1) && (ty1 - ty0 <= 1);
     int4 r3 = {0, 0, 0, 0};
     if (small_fp) {
@@ -775,28 +788,32 @@ __global__ __launch_bounds__(64) void k_clip_faces(const float *__restrict__ cam
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K4  tile rasterizer (the dominant kernel).  grid (T, views), NT threads = NW waves, one TW x TH tile per workgroup.
+// K4  tile rasterizer (the dominant kernel).  grid (T, views), 256 threads = 4 waves, one 64 x TH tile per workgroup.
 //     depth|id keys (u64: 1/z bits << 32 | ~face) live in LDS; visibility is resolved with ds_max_u64, so the result
-//     does not depend on list order.  Between the two workgroup barriers (keys zeroed / keys complete) every wave
-//     works on its own, without further synchronisation:
-//       phase 1  each lane streams ONE compiled entry of the tile's list (12 words) into registers; in single-pass
-//                mode the first 64 slots of the tile's segment are requested before the tile's count is known;
-//       phase 2  the entries' row counts are prefix-summed with DPP moves: the wave's work is total_rows
-//                (entry, row) items, taken 64 at a time; an item finds its entry through the wave's LDS mailboxes
-//                (starts post, items read, a DPP prefix maximum carries the latest start forward) and pulls the
-//                entry's 12 words out of the owning lane's registers (ds_bpermute) -- no LDS staging at all;
+//     does not depend on list order.
+//       phase 1  the tile's list is taken in CHUNKS of 64 entries.  A chunk is copied once into a 3 KiB LDS buffer
+//                shared by the workgroup (one 16-byte load + one ds_write_b128 per lane, 48 lanes per wave); in
+//                single-pass mode the first chunk and its 64 row counts (the nrow8 stream) are requested before the
+//                tile's count is known (the segment address is static: one memory round trip instead of two);
+//       phase 2  every wave prefix-sums the same 64 row counts with DPP moves: the chunk's work is total_rows
+//                (entry, row) items, taken 64 at a time; the 64-item batches are dealt to the waves round-robin (an
+//                average C2 tile has 6.5 batches: 7 are issued, where a per-wave split of the ENTRIES issued 8); an
+//                item finds its entry through the wave's LDS mailboxes (starts post, items read, a DPP prefix
+//                maximum carries the latest start forward) and reads the entry's 12 words with three ds_read_b128
+//                (12 LDS cycles per batch; the register-resident entries of round 1 cost twelve ds_bpermute = 48);
 //       phase 3  ONE SCANLINE OF ONE TRIANGLE PER LANE: the exact covered span [xs, xe] comes from the three edge
 //                inequalities (float reciprocal proposal + exact int32 correction), then the lane walks the span
 //                and issues one ds_max_u64 per covered pixel.  Entries flagged 64-bit take a bounding-box walk
 //                with 64-bit edge adds (same results, exact).
-//     The LDS pipe (atomics AND shuffles) is the kernel's scarcest resource, VALU issue the second.
-//     Epilogue: whole rows, one coalesced 256-byte store per wave-instruction.
+//     What bounds it: the lifetime of a workgroup.  7 workgroups fit a CU (21.25 KiB of LDS each);
+//     a C2 view is 23 tiles per CU, so every microsecond of a workgroup's life costs 3.3 us per view.  The
+//     id stores plus the entry reads alone keep the memory system busy for 12.7 of the 17.5 us.
+//     Epilogues: ids -> 16-byte stores (4 pixels per lane); fused projection -> per-face winners (see fused_winners).
 // ------------------------------------------------------------------------------------------------------------------
-// last-writer-wins candidate (see K5): issue the global atomicMax only when neither the right nor the lower neighbour
-// shows the same face (the fused tile epilogue also looks at the two diagonal neighbours below).  key = (pixel+1) << LB | label  (LB = 0: pixel+1)
-template <typename KeyT>
-__device__ __forceinline__ void winner_pixel(KeyT *__restrict__ winner, int f, int fr, int fb, int64_t p, int label,
-                                              int64_t F, int C, int LB, int compat) {
+// last-writer-wins candidate of the unfused pass (K5): issue the global atomicMax only when neither the right nor the
+// lower neighbour shows the same face.  key = pixel + 1 (the label is looked up by the vote kernel).
+__device__ __forceinline__ void winner_pixel(uint32_t *__restrict__ winner, int f, int fr, int fb, int64_t p, int64_t F,
+                                              int compat) {
   if (compat) {  // meshes.py:1998-2001: index -1 aliases the last face
     const int last = (int)F - 1;
     if (f == -1) f = last;
@@ -805,19 +822,15 @@ __device__ __forceinline__ void winner_pixel(KeyT *__restrict__ winner, int f, i
   }
   if (f < 0 || f >= F) return;
   if (fr == f || fb == f) return;  // a later pixel of the same face exists
-  KeyT key = (KeyT)(p + 1);
-  if (LB) key = (key << LB) | (KeyT)min(label, C);
-  atomicMax(&winner[f], key);
+  atomicMax(&winner[f], (uint32_t)(p + 1));
 }
 
 struct RasterOut {
-  int32_t *ids;    // [slot][h][w] or null
-  float *depth;    // [slot][h][w] or null
-  // fused projection (gr_raster_project_labels_u8): per-face winners straight from the LDS tile
-  const uint8_t *labels;  // [slot][h][w] or null
-  void *winner;           // [slot][F] uint32 / uint64 keys
+  int32_t *ids;      // [slot][h][w] or null
+  float *depth;      // [slot][h][w] or null
+  uint32_t *winner;  // fused projection: [slot][F] keys = (last pixel of the face in the view) + 1, or null
   int64_t F;
-  int C, LB, compat, key64;
+  int compat;        // GR_FLAG_NEG1_IS_LAST_FACE
 };
 
 // LDS image of a tile: rows of TW keys padded by GR_LDS_PAD keys (stride 69 keys = 552 B).  The rows of one triangle
@@ -830,23 +843,42 @@ __device__ __forceinline__ int lds_idx(int row, int col) {
   return __mul24(row, (1 << TWL) + GR_LDS_PAD) + col;
 }
 
-// Integer solution of g(x) = E + A x >= 0 on one scanline, branch-free.  A float reciprocal proposes x0 = floor(-E/A);
-// in the clamped range [-1, TW] the proposal is within one of the true root, so the exact boundary follows from the
-// signs of two exact int32 probes g(x0), g(x0+1):   A >= 0: first covered x = x0 - s0 - s1;   A < 0: last covered
-// x = x0 + 1 + s0 + s1   (s = -1 where the probe is negative, 0 otherwise).  |A| < 2^23 (checked when the entry was
-// compiled), so the products are full-rate 24-bit multiplies.  A == 0 needs no case of its own: the quotient is -inf
-// or NaN for E >= 0 (clamped to x0 = -1: both probes pass, first covered x = -1, no constraint) and +inf for E < 0
-// (x0 = TW, both probes fail, first covered x = TW + 2: the span is empty).
-template <int TW>
-__device__ __forceinline__ void span_clip(int E, int A, int &xs, int &xe) {
-  float q = -(float)E * __builtin_amdgcn_rcpf((float)A);
-  q = fminf(fmaxf(q, -1.0f), (float)TW);  // NaN (A == 0, E == 0) -> -1
-  const int x0 = (int)floorf(q);
-  const int e0 = E + __mul24(A, x0);
-  const int u = (e0 >> 31) + ((e0 + A) >> 31);
-  const int lo = max(xs, x0 - u), hi = min(xe, x0 + 1 + u);
-  xs = A < 0 ? xs : lo;
-  xe = A < 0 ? hi : xe;
+// floor(E / m) for an integer edge value E (|E| < 2^23 wherever the result matters) and an edge slope magnitude
+// 0 <= m < 2^15, clamped to [-66, 65] (-67 / 66 with the correction): the scanline solver of the tile kernel.
+//   g = (E + 0.5) * rcp(m) in fp32.  (E + 0.5) / m is never an integer and at least 0.5 / m away from one; the fp32 error
+//   of g (v_rcp_f32: 1 ulp, one rounded multiply) is below 66 * 1.8e-7 = 1.2e-5 wherever |g| <= 66.  For m <= 16000
+//   the gap is 3.1e-5: floor(g) IS floor(E / m) -- checked exhaustively on the CPU against integer division with the
+//   reciprocal perturbed by up to 3.5 ulp (tests/test_span_floor.py) -- so no probe of the edge function is needed.
+//   CORR (m up to 32767): one exact remainder puts a proposal that is off by one right.
+//   m == 0 (an edge parallel to the scanline): g = +-inf, clamped to "no constraint" / "empty" by the sign of E.
+#define GR_FLOOR_NOCORR_MAX 16000
+template <bool CORR>
+__device__ __forceinline__ int edge_floor(int E, int m, float mf) {
+  float g = ((float)E + 0.5f) * __builtin_amdgcn_rcpf(mf);
+  g = __builtin_amdgcn_fmed3f(g, -66.0f, 65.0f);
+  int fl = (int)floorf(g);
+  if (CORR) {
+    const int rem = E - __mul24(fl, m);
+    fl += (rem >= m ? 1 : 0) - (rem < 0 ? 1 : 0);
+  }
+  return fl;
+}
+
+// exact covered span [xs, xe] of scanline y: the first edge (a > 0) bounds it from the left, x >= ceil(-E'/a) =
+// -floor(E'/a); the last (a < 0) from the right, x <= floor(E'/|a|); the middle one does either (a == 0 works as either)
+template <int TW, bool CORR>
+__device__ __forceinline__ void span_solve(int C0, int C1, int C2, int w3, int w4, int w5, int y, int &xs, int &xe) {
+  const int a0 = w3 & 0xFFFF, a1 = w3 >> 16, m2 = w4 & 0xFFFF;
+  const int b0 = w4 >> 16, b1 = (w5 << 16) >> 16, b2 = w5 >> 16;
+  const int m1 = a1 < 0 ? -a1 : a1;
+  const int f0 = edge_floor<CORR>(C0 + __mul24(b0, y), a0, (float)a0);
+  const int f1 = edge_floor<CORR>(C1 + __mul24(b1, y), m1, (float)m1);
+  const int f2 = edge_floor<CORR>(C2 + __mul24(b2, y), m2, (float)m2);
+  xs = max(0, -f0);
+  xe = min(TW - 1, f2);
+  const int lo = max(xs, -f1), hi = min(xe, f1);
+  xs = a1 > 0 ? lo : xs;
+  xe = a1 > 0 ? xe : hi;
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -887,15 +919,17 @@ __device__ __forceinline__ void raster_item(unsigned long long *keys, const int 
   const int y = ilo + (q - et);
   const float m1 = zB * (float)(y * 256 + Y0rel);
   const bool big = live && (yw < 0);
-  if (live && !big) {
-    // exact covered span [xs, xe] of this scanline: each edge E(x) = E(0) + A x >= 0 bounds x from one side
-    // (the three edges bound the span completely: the face's bounding box is not needed here)
-    const int A0 = (w3 << 16) >> 8, A1 = (w3 >> 16) << 8, A2 = (w4 << 16) >> 8;   // 256 * signed 16-bit halves
-    const int B0 = (w4 >> 16) << 8, B1 = (w5 << 16) >> 8, B2 = (w5 >> 16) << 8;
-    int xs = 0, xe = TW - 1;
-    span_clip<TW>(C0 + __mul24(B0, y), A0, xs, xe);
-    span_clip<TW>(C1 + __mul24(B1, y), A1, xs, xe);
-    span_clip<TW>(C2 + __mul24(B2, y), A2, xs, xe);
+  const bool small_item = live && !big;
+  // slopes beyond GR_FLOOR_NOCORR_MAX (edges taller than 62 pixels) take the span solver with the exact correction; the
+  // choice is made per wave so that the usual case carries no extra instructions
+  const bool wide = small_item && (max(max(w3 & 0xFFFF, w4 & 0xFFFF), abs(w3 >> 16)) > GR_FLOOR_NOCORR_MAX);
+  int xs = 0, xe = -1;
+  if (__ballot(wide) != 0ull) {
+    if (small_item) span_solve<TW, true>(C0, C1, C2, w3, w4, w5, y, xs, xe);
+  } else {
+    if (small_item) span_solve<TW, false>(C0, C1, C2, w3, w4, w5, y, xs, xe);
+  }
+  if (small_item) {
     // two pixels per step with packed fp32 math (v_pk_mul_f32 / v_pk_add_f32: same IEEE results as the scalar
     // forms, R4 op for op).  float(P_x - X0) advances by exact float adds (integers below 2^24).  An odd span's
     // spare slot is steered to the row's padding key (column TW), which nobody reads.
@@ -945,56 +979,9 @@ __device__ __forceinline__ void raster_item(unsigned long long *keys, const int 
   }
 }
 
-// Phases 2-3 of the tile rasterizer for the 64 entries a wave holds in registers (s0..s2, nrows per lane).
-// tab: the wave's 64 mailbox words in LDS (zeroed with the tile), gen: the wave's batch counter (mailbox generation).
-template <int TWL>
-__device__ __forceinline__ void raster_wave_entries(unsigned long long *keys, uint32_t *tab, uint32_t &gen, const int4 s0,
-                                                    const int4 s1, const int4 s2, const int nrows, const int lane,
-                                                    const int px0, const int py0, const int dbg) {
-  constexpr int TW = 1 << TWL;
-    // ---- phase 2: wave-local scan of the row counts: item q belongs to the entry with excl <= q < excl + nrows ------------
-    const int incl = wave_incl_scan(nrows);
-    int total = __builtin_amdgcn_readlane(incl, 63);
-    const int excl = incl - nrows;
-    if (dbg & 1) total = 0;
-    // ---- phase 3: one scanline of one triangle per lane -------------------------------------------------------------------
-    for (int k0 = 0; k0 < total; k0 += 64) {
-      const int q = k0 + lane;
-      // Item -> entry.  Every entry that STARTS inside this batch posts (its lane, its start slot) into the start slot's
-      // mailbox (one masked LDS write), every item lane reads its own mailbox (one LDS read), and a DPP prefix maximum
-      // carries the latest start forward: two LDS operations instead of a six-step ds_bpermute search.  Mailboxes are
-      // never cleared: a word counts only if it carries this batch's generation.  Items before the first start of the
-      // batch belong to the entry that holds item k0 (wave-uniform: the entries ending at or before k0 are counted).
-      ++gen;
-      const int slot = excl - k0;
-      if (nrows > 0 && slot >= 0 && slot < 64) tab[slot] = (gen << 13) | (uint32_t)((lane + 1) << 6) | (uint32_t)slot;
-      const int carry_t = __popcll(__ballot(incl <= k0));
-      const int carry_e = __builtin_amdgcn_readlane(excl, carry_t & 63);
-      const uint32_t mail = tab[lane];
-      const int m = wave_incl_max((mail >> 13) == gen ? (int)(mail & 0x1FFFu) : 0);
-      const int t = m ? (m >> 6) - 1 : carry_t;
-      const int et = m ? k0 + (m & 63) : carry_e;
-      const bool live = q < total;
-      // fetch the entry from lane t's registers (ds_bpermute: no LDS storage) -- 12 words
-      const int C0 = __shfl(s0.x, t), C1 = __shfl(s0.y, t), C2 = __shfl(s0.z, t);
-      const int w3 = __shfl(s0.w, t), w4 = __shfl(s1.x, t), w5 = __shfl(s1.y, t);
-      const float iz0 = __int_as_float(__shfl(s1.z, t)), zA = __int_as_float(__shfl(s1.w, t)),
-                  zB = __int_as_float(__shfl(s2.x, t));
-      const int xw = __shfl(s2.y, t), yw = __shfl(s2.z, t);
-      uint32_t key_lo = (uint32_t)__shfl(s2.w, t);
-      // consume the last ds_bpermute result here: otherwise the compiler parks its s_waitcnt lgkmcnt(0) inside the pixel
-      // loop, where it would also wait for the previous iteration's ds_max_u64 and serialise the LDS atomics
-      asm volatile("" : "+v"(key_lo));
-      raster_item<TWL>(keys, C0, C1, C2, w3, w4, w5, iz0, zA, zB, xw, yw, key_lo, q, et, live, px0, py0);
-    }
-}
-
-// v2 of phases 2-3: the (up to 64) entries of one CHUNK of the tile's list stay in memory; every wave of the workgroup
-// scans the same 64 row counts (one byte per lane from the nrow8 stream), the chunk's 64-item batches are dealt to the
-// waves round-robin (batch b -> wave (b + rot) % NW: an average C2 tile has 6.5 batches, so 7 are issued instead of the
-// 8 that a per-wave split of the ENTRIES costs), and an item's 12 entry words arrive through the vector memory pipe
-// (3 x global_load_dwordx4 from the entry of lane t; rows of one entry share the address, the lines sit in L1/L2 after
-// the first touch) instead of 12 ds_bpermute through the LDS pipe, the tile kernel's scarcest resource.
+// Phases 2-3 for one CHUNK of up to 64 entries staged in LDS (`ent`, 48 bytes each).  Every wave of the workgroup scans
+// the same 64 row counts; batch b of the chunk belongs to wave (b + rot) % NW.  tab: the wave's 64 mailbox words in LDS,
+// gen: the wave's batch counter (mailbox generation).  Returns the number of batches of the chunk.
 template <int TWL, int NW, typename EntPtr>
 __device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, uint32_t *tab, uint32_t &gen,
                                                    EntPtr ent, const int nrows, const int lane,
@@ -1022,244 +1009,142 @@ __device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, uin
   return (total + 63) >> 6;
 }
 
-// ids-only epilogue with 16-byte stores: a lane owns 4 consecutive pixels of a row (16 lanes per 64-pixel row, NT/16
-// rows per pass); the four low dwords sit 8 bytes apart in LDS, the global store is one dwordx4.
+// ids-only epilogue.  16-byte stores where the rows allow it: a lane owns 4 consecutive pixels of a row (16 lanes per
+// 64-pixel row, 16 rows per pass); the four low dwords sit 8 bytes apart in LDS (two ds_read2_b32), id = ~low (0 for an
+// empty pixel -> -1).  Images whose width is not a multiple of 4 take one pixel per lane.
 template <int TWL, int TH, int NT>
-__device__ __forceinline__ void store_ids16(const unsigned long long *keys, const BinArgs &a, int32_t *ids_plane, int te,
-                                            int px0, int py0) {
+__device__ __forceinline__ void store_ids(const unsigned long long *keys, const BinArgs &a, int32_t *ids_plane, int te,
+                                          int px0, int py0) {
   const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
-  const int c4 = (te & 15) * 4, rr = te >> 4;
-  const int gx4 = px0 + c4;
   const int rows_here = min(TH, a.h - py0);
   const bool vec = ((a.w & 3) == 0) && ((reinterpret_cast<uintptr_t>(ids_plane) & 15) == 0);
-  if (gx4 >= a.w) return;
-  for (int row = rr; row < rows_here; row += NT / 16) {
-    const uint32_t *kr = klo + 2 * lds_idx<TWL>(row, c4);
-    const int i0 = (int)~kr[0], i1 = (int)~kr[2], i2 = (int)~kr[4], i3 = (int)~kr[6];
-    int32_t *dst = ids_plane + (int64_t)(py0 + row) * a.w + gx4;
-    if (vec) *reinterpret_cast<int4 *>(dst) = make_int4(i0, i1, i2, i3);
-    else {  // volatile: keeps the compiler from merging these with the 16-byte store above (it splits that one)
-      volatile int32_t *d = dst;
-      d[0] = i0;
-      if (gx4 + 1 < a.w) d[1] = i1;
-      if (gx4 + 2 < a.w) d[2] = i2;
-      if (gx4 + 3 < a.w) d[3] = i3;
+  if (vec) {
+    const int c4 = (te & 15) * 4, rr = te >> 4;
+    const int gx4 = px0 + c4;
+    if (gx4 >= a.w) return;
+    int32_t *dst = ids_plane + (int64_t)(py0 + rr) * a.w + gx4;
+    const int64_t dstep = (int64_t)(NT / 16) * a.w;
+    for (int row = rr; row < rows_here; row += NT / 16, dst += dstep) {
+      const uint32_t *kr = klo + 2 * lds_idx<TWL>(row, c4);
+      *reinterpret_cast<int4 *>(dst) = make_int4((int)~kr[0], (int)~kr[2], (int)~kr[4], (int)~kr[6]);
     }
+  } else {
+    constexpr int TW = 1 << TWL;
+    const int col = te & (TW - 1), gx = px0 + col;
+    if (gx >= a.w) return;
+    int32_t *dst = ids_plane + (int64_t)(py0 + (te >> TWL)) * a.w + gx;
+    const int64_t dstep = (int64_t)(NT / TW) * a.w;
+    for (int row = te >> TWL; row < rows_here; row += NT / TW, dst += dstep) *dst = (int32_t)~klo[2 * lds_idx<TWL>(row, col)];
   }
 }
 
-template <int TWL, int THL, int NT, bool FUSE>
-__global__ __launch_bounds__(NT) void k_raster_rows(BinArgs a, RasterOut out) {
-  constexpr int TW = 1 << TWL, TH = 1 << THL;
-  // the kernel's only LDS: the tile's keys (17.25 KiB for 64x32) + 64 mailbox words per wave (1 KiB) -> 8 workgroups/CU
-  constexpr int NKEYS = (TW + GR_LDS_PAD) * TH;
-  __shared__ __attribute__((aligned(16))) unsigned long long keys[NKEYS + (NT / 64) * 32];
-
-  const int slot = blockIdx.y;
-  const int tile = blockIdx.x;
-  const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int NW = NT / 64;
-  constexpr int ROWS_PER_PASS = NT / TW;
-  constexpr int RW = TH / (NT / 64);
-  const int64_t P = (int64_t)a.h * a.w;
-  const int64_t plane = (int64_t)slot * P;
-
-  // Single-pass binning: the tile's segment starts at a known address, so its first GR_SPEC entries are requested before
-  // its count is known (count read and entry read are ONE memory round trip instead of two dependent ones; most tiles
-  // hold fewer entries than that).  Slots beyond the count hold stale data and are dropped.
-  constexpr uint32_t GR_SPEC = 64;
-  const uint32_t e_first = (uint32_t)(lane * NW + wv);
-  const bool direct = a.cap_tile > 0;
-  const bool spec = a.cap_tile >= (int)GR_SPEC && e_first < GR_SPEC;
-  // this lane's entry; deliberately left undefined where no entry is loaded (such lanes have no rows and are never a
-  // shuffle source): a zero initialiser would cost a register copy -- and a wait -- right behind the early loads
-  int4 s0, s1, s2;
-  if (spec) {
-    const int4 *cs = a.comp + (slot * a.ent_cap + (int64_t)tile * a.cap_tile + e_first) * GR_ENT_Q;
-    s0 = cs[0]; s1 = cs[1]; s2 = cs[2];
-  }
-  {
-    const int tx = tile % a.TX, ty = tile / a.TX;
-    const int px0 = tx << TWL, py0 = ty << THL;
-    uint32_t cnt;
-    int64_t beg;
-    if (direct) {
-      cnt = min(ctrl[GR_CTRL_HDR + tile], (uint32_t)a.cap_tile);
-      beg = (int64_t)tile * a.cap_tile;
-    } else {
-      cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
-      beg = ctrl[GR_CTRL_HDR + 2 * a.Tcap + tile];
-      if (beg >= a.ent_cap) cnt = 0;
-      else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
-    }
-    if (a.dbg & 4) cnt = 0;
-    const int4 *comp = a.comp + (slot * a.ent_cap + beg) * GR_ENT_Q;
-
-    if (!FUSE && cnt == 0) {  // empty tile (a view that overhangs the mesh): background, without the LDS round trip
-      const int col = tid & (TW - 1), gx = px0 + col;
-      if (gx < a.w && !(a.dbg & 2)) {
-        for (int row = tid >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
-          const int64_t p = plane + (int64_t)(py0 + row) * a.w + gx;
-          if (out.ids) out.ids[p] = -1;
-          if (out.depth) out.depth[p] = INFINITY;
-        }
-      }
-      return;
-    }
-    {  // zero the tile: 16-byte LDS stores
-      static_assert(NKEYS % 2 == 0, "key pairs");
-      ulonglong2 *k2 = reinterpret_cast<ulonglong2 *>(keys);
-      for (int i = tid; i < (NKEYS + (NT / 64) * 32) / 2; i += NT) k2[i] = make_ulonglong2(0ull, 0ull);  // keys + mailboxes
-    }
-    __syncthreads();
-
-    // entries are dealt round-robin to the NW waves (entry e -> wave e % NW) so that a short list still feeds every wave
-    uint32_t *tab = reinterpret_cast<uint32_t *>(keys + NKEYS) + wv * 64;
-    uint32_t gen = 0;
-    // ---- phase 1: one compiled entry per lane, kept in registers.  The first NT entries (nearly always all of them) are
-    //      handled outside the loop so that the early-requested registers are used where they landed.
-    {
-      int nrows = 0;
-      if (e_first < cnt) {
-        if (!spec) { s0 = comp[e_first * GR_ENT_Q + 0]; s1 = comp[e_first * GR_ENT_Q + 1]; s2 = comp[e_first * GR_ENT_Q + 2]; }
-        nrows = (s2.y >> 24) & 0x7F;
-      }
-      raster_wave_entries<TWL>(keys, tab, gen, s0, s1, s2, nrows, lane, px0, py0, a.dbg);
-    }
-#pragma unroll 1
-    for (uint32_t c0 = NT; c0 < cnt; c0 += NT) {
-      const uint32_t e = c0 + e_first;
-      int4 t0, t1, t2;
-      int nrows = 0;
-      if (e < cnt) {
-        t0 = comp[e * GR_ENT_Q + 0]; t1 = comp[e * GR_ENT_Q + 1]; t2 = comp[e * GR_ENT_Q + 2];
-        nrows = (t2.y >> 24) & 0x7F;
-      }
-      raster_wave_entries<TWL>(keys, tab, gen, t0, t1, t2, nrows, lane, px0, py0, a.dbg);
-    }
-    // fused projection: the label bytes of this wave's rows are requested BEFORE the barrier (coalesced 64-byte row
-    // segments, all RW loads in flight at once), so the candidates' atomics in the epilogue never wait on a dependent load
-    int te = tid;
-    asm volatile("" : "+v"(te));  // the epilogue's addresses are derived here, not hoisted above the scanline phase
-    const int col = te & (TW - 1);
-    const int gx = px0 + col;
-    uint32_t lab[RW];
-    if (FUSE && out.labels && gx < a.w && !(a.dbg & 16)) {
-      const int r0 = (te >> 6) * RW;
-      const int rows_here = min(RW, a.h - (py0 + r0));
-      if (rows_here > 0) {  // straight-line loads (rows below the image re-read the last valid row: never used)
-        const uint8_t *lp = out.labels + plane + (int64_t)(py0 + r0) * a.w + gx;
+// Fused projection epilogue (aggregate_projected_images fast path): the last pixel, in row-major order, of every face
+// the tile shows goes to winner[face] with a global atomicMax of pixel + 1 -- meshes.py:1987-2001, where numpy's fancy
+// assignment lets the last pixel of a face win.  A pixel can only be that last pixel if none of right / below-left /
+// below / below-right shows the same face (a face's consecutive scanlines touch at least diagonally unless it is a steep
+// sliver; extra candidates are harmless): 1.7 candidates per visible face on C2.  What makes this epilogue cheap is
+// its LATENCY (a workgroup's lifetime is the kernel's currency): a lane owns 4 consecutive pixels of two rows, ALL its
+// LDS reads -- the rows and the rows below them -- are issued up front, the neighbours across lanes come from DPP row
+// shifts (a 16-lane DPP row is exactly one 64-pixel tile row: lanes outside keep the `old` operand, "differs"), and
+// nothing waits on global memory: the label of the winning pixel is looked up by the vote kernel.  Background needs no
+// mapping here: the tile was filled with the id that background aliases (F - 1 with GR_FLAG_NEG1_IS_LAST_FACE, else
+// -1, which no candidate test accepts).  Unknown neighbours count as "differs": -3 across a tile edge, -2 outside the
+// image (EDGE tiles only).
+template <int TWL, int TH, int NT, bool EDGE>
+__device__ __forceinline__ void fused_winners(const unsigned long long *keys, const BinArgs &a, uint32_t *__restrict__ win,
+                                              int te, int px0, int py0, int dbg) {
+  static_assert(TWL == 6 && NT == 256, "16 lanes x 4 pixels per tile row");
+  const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
+  const int c4 = (te & 15) * 4, rr = te >> 4;
+  constexpr int NPASS = TH / 16;
 #pragma unroll
-        for (int k = 0; k < RW; ++k) lab[k] = (uint32_t)lp[(int64_t)min(k, rows_here - 1) * a.w];
-      }
-    }
-    __syncthreads();
-    // the label bytes are waited for HERE, once (vmcnt(0), other counters untouched): left to the compiler, the wait lands
-    // inside the row loop, where it would also wait for the previous row's winner atomics and serialise them
-    if (FUSE) __builtin_amdgcn_s_waitcnt(0x0F70);
-
-    // epilogue: whole rows (TW pixels, coalesced); the NW waves interleave over the TH rows
-    if (!FUSE && out.ids && !out.depth && (a.var & 2) && !(a.dbg & 2)) {
-      store_ids16<TWL, TH, NT>(keys, a, out.ids + plane, te, px0, py0);
-    } else if (gx < a.w && !(a.dbg & 2)) {
-      if (!FUSE && out.ids && !out.depth) {
-        // ids only (the common case): the key's low dword is ~face, and 0 for an empty pixel, so id = ~low for both;
-        // one 4-byte LDS read, one NOT, one store per pixel, the output pointer advances by a constant stride
-        const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
-        const int rows_here = min(TH, a.h - py0);
-        int32_t *dst = out.ids + plane + (int64_t)(py0 + (te >> TWL)) * a.w + gx;
-        const int64_t dstep = (int64_t)ROWS_PER_PASS * a.w;
-        for (int row = te >> TWL; row < rows_here; row += ROWS_PER_PASS, dst += dstep)
-          *dst = (int32_t)~klo[2 * lds_idx<TWL>(row, col)];
-      } else if (FUSE && !out.depth && TW == 64) {
-        // Fused projection epilogue.  Each wave owns TH/NW CONSECUTIVE rows: the row below is read from LDS once and
-        // becomes the current row of the next step; the right and the two diagonal neighbours come from the adjacent
-        // lanes (DPP wave shifts), so a pixel costs one 4-byte LDS read.  A pixel is a candidate for its face's last
-        // pixel only if none of right / below-left / below / below-right shows the same face (a face's consecutive
-        // scanlines touch at least diagonally unless it is a steep sliver; extra candidates are harmless).  Unknown
-        // neighbours count as "differs": -3 across a tile edge or next to a lane outside the image (a DPP read from
-        // a disabled lane keeps the old value), -2 below the last image row.  Background is mapped to the face it
-        // aliases (meshes.py:1998-2001) once, when the row is read.
-        const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
-        const int r0 = (te >> 6) * RW;
-        const int bg = out.compat ? (int)out.F - 1 : -1;
-        const int rows_here = min(RW, a.h - (py0 + r0));          // rows of this wave inside the image (wave-uniform)
-        int raw = (int32_t)~klo[2 * lds_idx<TWL>(r0, col)];
-        int cur = raw == -1 ? bg : raw;
-        int p1 = (py0 + r0) * a.w + gx + 1;                        // linear pixel index + 1 (h, w <= 16384)
-        int32_t *idp = out.ids ? out.ids + plane + (p1 - 1) : nullptr;
-        uint32_t *win32 = (uint32_t *)out.winner + slot * out.F;
-        unsigned long long *win64 = (unsigned long long *)out.winner + slot * out.F;
+  for (int g = 0; g < NPASS; g += 2) {
+    int cur[2][4], bel[2][4];
 #pragma unroll
-        for (int k = 0; k < RW; ++k) {
-          if (k >= rows_here) break;
-          const int row = r0 + k;
-          int nraw = -3, nxt = -3;
-          if (row + 1 < TH) {
-            nraw = (int32_t)~klo[2 * lds_idx<TWL>(row + 1, col)];
-            nxt = (py0 + row + 1 >= a.h) ? -2 : (nraw == -1 ? bg : nraw);
-          }
-          const int fr = __builtin_amdgcn_update_dpp(-3, cur, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-          const int fbr = __builtin_amdgcn_update_dpp(-3, nxt, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-          const int fbl = __builtin_amdgcn_update_dpp(-3, nxt, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-          if (idp) { *idp = raw; idp += a.w; }
-          if (cur >= 0 && fr != cur && nxt != cur && fbr != cur && fbl != cur && !(a.dbg & 8)) {
-            const int label = min((int)lab[k], out.C);
-            if (out.key64) atomicMax(win64 + cur, ((unsigned long long)(uint32_t)p1 << out.LB) | (unsigned long long)label);
-            else atomicMax(win32 + cur, ((uint32_t)p1 << out.LB) | (uint32_t)label);
-          }
-          p1 += a.w;
-          cur = nxt;
-          raw = nraw;
-        }
+    for (int u = 0; u < 2; ++u) {
+      const int r = rr + (g + u) * 16;
+      const uint32_t *kr = klo + 2 * lds_idx<TWL>(r, c4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cur[u][j] = (int)~kr[2 * j];
+      if (r + 1 < TH) {
+        const uint32_t *kb = klo + 2 * lds_idx<TWL>(r + 1, c4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bel[u][j] = (int)~kb[2 * j];
       } else {
-        for (int row = te >> TWL; row < TH; row += ROWS_PER_PASS) {
-          const int gy = py0 + row;
-          if (gy >= a.h) break;
-          const unsigned long long key = keys[lds_idx<TWL>(row, col)];
-          const int64_t p = (int64_t)gy * a.w + gx;
-          const int32_t id = (int32_t)~(uint32_t)key;  // low dword = ~face, 0 when empty: ~0 = -1
-          if (out.ids) out.ids[plane + p] = id;
-          if (out.depth) out.depth[plane + p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bel[u][j] = -3;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int r = rr + (g + u) * 16;
+      const int gy = py0 + r;
+      if (EDGE && gy >= a.h) continue;
+      int c[5], b[6];  // c[j]: this row, b[j + 1]: the row below, j = -1 .. 4
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { c[j] = cur[u][j]; b[j + 1] = bel[u][j]; }
+      if (EDGE && gy + 1 >= a.h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j + 1] = -2;
+      }
+      c[4] = __builtin_amdgcn_update_dpp(-3, c[0], 0x101 /* row_shl:1: lane + 1 */, 0xf, 0xf, false);
+      b[5] = __builtin_amdgcn_update_dpp(-3, b[1], 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+      b[0] = __builtin_amdgcn_update_dpp(-3, b[4], 0x111 /* row_shr:1: lane - 1 */, 0xf, 0xf, false);
+      const int p1 = gy * a.w + px0 + c4 + 1;  // linear pixel index + 1 of the lane's first pixel (h, w <= 16384)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int f = c[j];
+        bool cand = f >= 0 && b[j] != f && b[j + 1] != f;
+        if (EDGE) {
+          const int gx = px0 + c4 + j;
+          cand = cand && gx < a.w && (gx + 1 >= a.w || (c[j + 1] != f && b[j + 2] != f));
+        } else {
+          cand = cand && c[j + 1] != f && b[j + 2] != f;
         }
+        if (cand && !(dbg & 8)) atomicMax(win + f, (uint32_t)(p1 + j));
       }
     }
   }
 }
 
-// K4 v2  tile rasterizer with memory-resident entries (see raster_chunk_gather).  Same grid, LDS image, barriers and
-//        epilogues as k_raster_rows; what changes is how entries reach the lanes and how the batches are dealt.
-//        a.var (GR_OPT_VARIANT) bit 1: plain epilogue with 16-byte id stores (4 pixels per lane);
-//                               bit 2: touch the first 32 entry slots of the segment before the count is known.
 template <int TWL, int THL, int NT, bool FUSE>
 __global__ __launch_bounds__(NT) void k_raster_tile(BinArgs a, RasterOut out) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   constexpr int NKEYS = (TW + GR_LDS_PAD) * TH;
-  __shared__ __attribute__((aligned(16))) unsigned long long keys[NKEYS + (NT / 64) * 32];
+  constexpr int NW = NT / 64;
+  constexpr int NMAIL = NW * 32;  // u64 units: 64 mailbox words per wave
+  // the kernel's only LDS: keys (17.25 KiB for 64x32) + mailboxes (1 KiB) + one chunk of entries (3 KiB) -> 7 workgroups/CU
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[NKEYS + NMAIL + 64 * 6];
+  int4 *ent_lds = reinterpret_cast<int4 *>(keys + NKEYS + NMAIL);
+  static_assert(NT == 256, "the entry copy deals 48 int4 to each of 4 waves");
+  static_assert(NKEYS % 2 == 0 && TH % 32 == 0, "key pairs; two 16-row passes per fused group");
 
   const int slot = blockIdx.y;
-  const int tile = blockIdx.x;
+  // XCD-aware tile order (GR_OPT_VARIANT bit 64): workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8,
+  // observed, speed only), so XCD x takes the contiguous tiles [x * per, (x + 1) * per)
+  int tile = blockIdx.x;
+  if (a.var & 64) {
+    const int per = (a.T + 7) >> 3;
+    tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tile >= a.T) return;
+  }
   const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int NW = NT / 64;
   constexpr int ROWS_PER_PASS = NT / TW;
-  constexpr int RW = TH / (NT / 64);
   const int64_t P = (int64_t)a.h * a.w;
   const int64_t plane = (int64_t)slot * P;
   const bool direct = a.cap_tile > 0;
 
-  // single-pass binning: the tile's segment starts at a known address, so the row counts of its first 64 entries (64
-  // bytes) are requested before the count is known -- count and row counts are ONE memory round trip
+  // single-pass binning: the segment address is static, so the first chunk (entries and row counts) is requested before
+  // the tile's count is known; slots beyond the count hold stale data that nobody reads
   const bool spec = a.cap_tile >= 64;
   uint32_t nr_first = 0;
-  if (spec) nr_first = a.nrow8[slot * a.ent_cap + (int64_t)tile * a.cap_tile + lane];
-  if (spec && (a.var & 4) && lane < 24 && wv == 0) {  // 32 slots = 24 sectors of 64 bytes: warm L2 for the gather
-    const int4 *cs = a.comp + (slot * a.ent_cap + (int64_t)tile * a.cap_tile) * GR_ENT_Q;
-    int4 touch = cs[lane * 4];
-    asm volatile("" ::"v"(touch.x));
+  int4 ex;
+  if (spec) {
+    const int64_t seg = slot * a.ent_cap + (int64_t)tile * a.cap_tile;
+    nr_first = a.nrow8[seg + lane];
+    if (lane < 48) ex = a.comp[seg * GR_ENT_Q + wv * 48 + lane];
   }
   const int tx = tile % a.TX, ty = tile / a.TX;
   const int px0 = tx << TWL, py0 = ty << THL;
@@ -1289,218 +1174,24 @@ __global__ __launch_bounds__(NT) void k_raster_tile(BinArgs a, RasterOut out) {
     }
     return;
   }
-  {  // zero the tile: 16-byte LDS stores (keys + mailboxes)
-    static_assert(NKEYS % 2 == 0, "key pairs");
+  {  // fill the tile (16-byte LDS stores): depth 0 | the id background stands for; mailboxes zero
+    const int bg = (FUSE && out.compat) ? (int)out.F - 1 : -1;
+    const unsigned long long fill = (unsigned long long)(uint32_t)~bg;
     ulonglong2 *k2 = reinterpret_cast<ulonglong2 *>(keys);
-    for (int i = tid; i < (NKEYS + (NT / 64) * 32) / 2; i += NT) k2[i] = make_ulonglong2(0ull, 0ull);
+    for (int i = tid; i < NKEYS / 2; i += NT) k2[i] = make_ulonglong2(fill, fill);
+    for (int i = tid; i < NMAIL / 2; i += NT) k2[NKEYS / 2 + i] = make_ulonglong2(0ull, 0ull);
   }
-  __syncthreads();
-
   uint32_t *tab = reinterpret_cast<uint32_t *>(keys + NKEYS) + wv * 64;
   uint32_t gen = 0;
   int rot = wv;  // this wave's first batch of the current chunk
-  {
-    const uint32_t e = (uint32_t)lane;
-    int nrows = 0;
-    if (e < cnt) nrows = spec ? (int)nr_first : (int)nr8[e];
-    const int nb = raster_chunk_gather<TWL, NW, const int4 *>(keys, tab, gen, comp, nrows, lane, rot, px0, py0, a.dbg);
-    rot = (rot - nb) & (NW - 1);
-  }
-#pragma unroll 1
-  for (uint32_t c0 = 64; c0 < cnt; c0 += 64) {
-    const uint32_t e = c0 + (uint32_t)lane;
-    const int nrows = e < cnt ? (int)nr8[e] : 0;
-    const int nb = raster_chunk_gather<TWL, NW, const int4 *>(keys, tab, gen, comp + (int64_t)c0 * GR_ENT_Q, nrows, lane, rot, px0, py0, a.dbg);
-    rot = (rot - nb) & (NW - 1);
-  }
-
-  int te = tid;
-  asm volatile("" : "+v"(te));  // the epilogue's addresses are derived here, not hoisted above the scanline phase
-  const int col = te & (TW - 1);
-  const int gx = px0 + col;
-  uint32_t lab[RW];
-  if (FUSE && out.labels && gx < a.w && !(a.dbg & 16)) {
-    const int r0 = (te >> 6) * RW;
-    const int rows_here = min(RW, a.h - (py0 + r0));
-    if (rows_here > 0) {
-      const uint8_t *lp = out.labels + plane + (int64_t)(py0 + r0) * a.w + gx;
-#pragma unroll
-      for (int k = 0; k < RW; ++k) lab[k] = (uint32_t)lp[(int64_t)min(k, rows_here - 1) * a.w];
-    }
-  }
-  __syncthreads();
-  if (FUSE) __builtin_amdgcn_s_waitcnt(0x0F70);
-
-  if (!FUSE && out.ids && !out.depth && (a.var & 2) && !(a.dbg & 2)) {
-    store_ids16<TWL, TH, NT>(keys, a, out.ids + plane, te, px0, py0);
-    return;
-  }
-  if (gx < a.w && !(a.dbg & 2)) {
-    if (!FUSE && out.ids && !out.depth) {
-      const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
-      const int rows_here = min(TH, a.h - py0);
-      int32_t *dst = out.ids + plane + (int64_t)(py0 + (te >> TWL)) * a.w + gx;
-      const int64_t dstep = (int64_t)ROWS_PER_PASS * a.w;
-      for (int row = te >> TWL; row < rows_here; row += ROWS_PER_PASS, dst += dstep)
-        *dst = (int32_t)~klo[2 * lds_idx<TWL>(row, col)];
-    } else if (FUSE && !out.depth && TW == 64) {
-      // fused projection epilogue: see k_raster_rows
-      const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
-      const int r0 = (te >> 6) * RW;
-      const int bg = out.compat ? (int)out.F - 1 : -1;
-      const int rows_here = min(RW, a.h - (py0 + r0));
-      int raw = (int32_t)~klo[2 * lds_idx<TWL>(r0, col)];
-      int cur = raw == -1 ? bg : raw;
-      int p1 = (py0 + r0) * a.w + gx + 1;
-      int32_t *idp = out.ids ? out.ids + plane + (p1 - 1) : nullptr;
-      uint32_t *win32 = (uint32_t *)out.winner + slot * out.F;
-      unsigned long long *win64 = (unsigned long long *)out.winner + slot * out.F;
-#pragma unroll
-      for (int k = 0; k < RW; ++k) {
-        if (k >= rows_here) break;
-        const int row = r0 + k;
-        int nraw = -3, nxt = -3;
-        if (row + 1 < TH) {
-          nraw = (int32_t)~klo[2 * lds_idx<TWL>(row + 1, col)];
-          nxt = (py0 + row + 1 >= a.h) ? -2 : (nraw == -1 ? bg : nraw);
-        }
-        const int fr = __builtin_amdgcn_update_dpp(-3, cur, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-        const int fbr = __builtin_amdgcn_update_dpp(-3, nxt, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-        const int fbl = __builtin_amdgcn_update_dpp(-3, nxt, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-        if (idp) { *idp = raw; idp += a.w; }
-        if (cur >= 0 && fr != cur && nxt != cur && fbr != cur && fbl != cur && !(a.dbg & 8)) {
-          const int label = min((int)lab[k], out.C);
-          if (out.key64) atomicMax(win64 + cur, ((unsigned long long)(uint32_t)p1 << out.LB) | (unsigned long long)label);
-          else atomicMax(win32 + cur, ((uint32_t)p1 << out.LB) | (uint32_t)label);
-        }
-        p1 += a.w;
-        cur = nxt;
-        raw = nraw;
-      }
-    } else {
-      for (int row = te >> TWL; row < TH; row += ROWS_PER_PASS) {
-        const int gy = py0 + row;
-        if (gy >= a.h) break;
-        const unsigned long long key = keys[lds_idx<TWL>(row, col)];
-        const int64_t p = (int64_t)gy * a.w + gx;
-        const int32_t id = (int32_t)~(uint32_t)key;
-        if (out.ids) out.ids[plane + p] = id;
-        if (out.depth) out.depth[plane + p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
-      }
-    }
-  }
-}
-
-// K4 v3  tile rasterizer with LDS-staged entries: the (up to 64) entries of a chunk are copied once into a 3 KiB LDS
-//        buffer shared by the workgroup (one 16-byte load + one ds_write_b128 per lane of 48 lanes per wave), an item
-//        reads its entry with three ds_read_b128 (12 LDS cycles per 64-item batch instead of the 48 of twelve
-//        ds_bpermute), and the chunk's batches are dealt to the waves round-robin.  LDS: 21.25 KiB -> 7 workgroups/CU.
-template <int TWL, int THL, int NT, bool FUSE>
-__global__ __launch_bounds__(NT) void k_raster_tile_lds(BinArgs a, RasterOut out) {
-  constexpr int TW = 1 << TWL, TH = 1 << THL;
-  constexpr int NKEYS = (TW + GR_LDS_PAD) * TH;
-  constexpr int NW = NT / 64;
-  constexpr int NMAIL = NW * 32;          // u64 units
-  __shared__ __attribute__((aligned(16))) unsigned long long keys[NKEYS + NMAIL + 64 * 6];
-  int4 *ent_lds = reinterpret_cast<int4 *>(keys + NKEYS + NMAIL);
-
-  // views in reverse order (var bit 16): the entries the set-up kernel wrote last are still in the Infinity Cache
-  const int slot = (a.var & 16) ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
-  // XCD-aware tile order (var bit 64): workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, observed,
-  // speed only), so XCD x takes the contiguous tiles [x * per, (x + 1) * per): each L2 writes back one compact part of
-  // the id image (pure 64x32-tile stores of a C2 view: 9.1 -> 7.9 us, tools/ubench/store_pattern.hip)
-  int tile = blockIdx.x;
-  if (a.var & 64) {
-    const int per = (a.T + 7) >> 3;
-    tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (tile >= a.T) return;
-  }
-  const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int ROWS_PER_PASS = NT / TW;
-  constexpr int RW = TH / (NT / 64);
-  const int64_t P = (int64_t)a.h * a.w;
-  const int64_t plane = (int64_t)slot * P;
-  const bool direct = a.cap_tile > 0;
-  static_assert(NT == 256, "the entry copy deals 48 int4 per wave");
-
-  const bool diag = (a.var & 256) != 0;
-  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
-  if (diag) ts0 = __builtin_amdgcn_s_memtime();
-  const bool spec = a.cap_tile >= 64 && !(a.var & 128);
-  uint32_t nr_first = 0;
-  int4 ex;
-  if (spec) {
-    const int64_t seg = slot * a.ent_cap + (int64_t)tile * a.cap_tile;
-    nr_first = a.nrow8[seg + lane];
-    if (lane < 48) ex = a.comp[seg * GR_ENT_Q + wv * 48 + lane];
-  }
-  const int tx = tile % a.TX, ty = tile / a.TX;
-  const int px0 = tx << TWL, py0 = ty << THL;
-  uint32_t cnt;
-  int64_t beg;
-  if (direct) {
-    cnt = min(ctrl[GR_CTRL_HDR + tile], (uint32_t)a.cap_tile);
-    beg = (int64_t)tile * a.cap_tile;
-  } else {
-    cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
-    beg = ctrl[GR_CTRL_HDR + 2 * a.Tcap + tile];
-    if (beg >= a.ent_cap) cnt = 0;
-    else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
-  }
-  if (a.dbg & 4) cnt = 0;
-  const int4 *comp = a.comp + (slot * a.ent_cap + beg) * GR_ENT_Q;
-  const uint8_t *nr8 = a.nrow8 + slot * a.ent_cap + beg;
-
-  if (!FUSE && cnt == 0) {
-    const int col = tid & (TW - 1), gx = px0 + col;
-    if (gx < a.w && !(a.dbg & 2)) {
-      for (int row = tid >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
-        const int64_t p = plane + (int64_t)(py0 + row) * a.w + gx;
-        if (out.ids) out.ids[p] = -1;
-        if (out.depth) out.depth[p] = INFINITY;
-      }
-    }
-    return;
-  }
-  {
-    static_assert(NKEYS % 2 == 0, "key pairs");
-    ulonglong2 *k2 = reinterpret_cast<ulonglong2 *>(keys);
-    for (int i = tid; i < (NKEYS + NMAIL) / 2; i += NT) k2[i] = make_ulonglong2(0ull, 0ull);
-  }
-  uint32_t *tab = reinterpret_cast<uint32_t *>(keys + NKEYS) + wv * 64;
-  uint32_t gen = 0;
-  int rot = wv;
-  // L2 warm-up for a LATER workgroup (var bit 512): the tile kernel lives on workgroup latency, and 36 % of a wave's life
-  // is the wait for its first chunk (tools/stamp_tile.py).  Wave 0 touches the first chunk, the row counts and the
-  // counter of the tile that a workgroup on the same XCD will start `a.pf_dist` (a multiple of 8) tiles from now; the
-  // loads are consumed in front of the second barrier, a raster phase later, when they have long landed.
-  uint32_t pf = 0;
-  if ((a.var & 512) && spec && wv == 0 && lane < 26) {
-    const int64_t g = (int64_t)slot * a.T + tile + a.pf_dist;
-    const int64_t ps = g / a.T, pt = g - ps * a.T;
-    if (ps < (int64_t)gridDim.y) {
-      const int64_t seg = ps * a.ent_cap + pt * a.cap_tile;
-      const uint32_t *src = lane < 24 ? reinterpret_cast<const uint32_t *>(a.comp + seg * GR_ENT_Q) + lane * 32
-                            : lane == 24 ? reinterpret_cast<const uint32_t *>(a.nrow8 + seg)
-                                         : a.ctrl + ps * a.ctrl_stride + GR_CTRL_HDR + pt;
-      pf = __builtin_nontemporal_load(src);
-    }
-  }
 #pragma unroll 1
   for (uint32_t c0 = 0; c0 < cnt || c0 == 0; c0 += 64) {
-    // copy the chunk's entries to LDS (entries past the count hold stale data that nobody reads)
     if (lane < 48) {
       const uint32_t q = c0 * GR_ENT_Q + wv * 48 + lane;
-      if (!(spec && c0 == 0)) {
-        if (q < cnt * GR_ENT_Q) ex = comp[q];
-      }
+      if (!(spec && c0 == 0) && q < cnt * GR_ENT_Q) ex = comp[q];
       ent_lds[wv * 48 + lane] = ex;
     }
-    if (diag && c0 == 0) { __builtin_amdgcn_s_waitcnt(0); ts1 = __builtin_amdgcn_s_memtime(); }
-    __syncthreads();
-    if (diag && c0 == 0) ts2 = __builtin_amdgcn_s_memtime();
+    __syncthreads();  // keys filled, chunk visible
     const uint32_t e = c0 + (uint32_t)lane;
     int nrows = 0;
     if (e < cnt) nrows = (spec && c0 == 0) ? (int)nr_first : (int)nr8[e];
@@ -1510,328 +1201,54 @@ __global__ __launch_bounds__(NT) void k_raster_tile_lds(BinArgs a, RasterOut out
   }
 
   int te = tid;
-  asm volatile("" : "+v"(te));
-  const int col = te & (TW - 1);
-  const int gx = px0 + col;
-  uint32_t lab[RW];
-  if (FUSE && out.labels && gx < a.w && !(a.dbg & 16)) {
-    const int r0 = (te >> 6) * RW;
-    const int rows_here = min(RW, a.h - (py0 + r0));
-    if (rows_here > 0) {
-      const uint8_t *lp = out.labels + plane + (int64_t)(py0 + r0) * a.w + gx;
-#pragma unroll
-      for (int k = 0; k < RW; ++k) lab[k] = (uint32_t)lp[(int64_t)min(k, rows_here - 1) * a.w];
-    }
-  }
-  asm volatile("" ::"v"(pf));
-  if (diag) { __builtin_amdgcn_s_waitcnt(0); ts3 = __builtin_amdgcn_s_memtime(); }
-  __syncthreads();
-  if (FUSE) __builtin_amdgcn_s_waitcnt(0x0F70);
-  if (diag) ts4 = __builtin_amdgcn_s_memtime();
-
-  if (!FUSE && out.ids && !out.depth && (a.var & 2) && !(a.dbg & 2)) {
-    store_ids16<TWL, TH, NT>(keys, a, out.ids + plane, te, px0, py0);
-    if (diag) {
-      const unsigned long long ts5 = __builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_s_waitcnt(0);
-      const unsigned long long ts6 = __builtin_amdgcn_s_memtime();
-      if (lane == 0) {  // per wave: load wait, barrier A, raster, barrier B, store issue, store completion, waves
-        unsigned long long *st = a.stamps + 8 * ((blockIdx.x * 4 + wv + blockIdx.y * 1031) & 4095);
-        a.stamps = st;
-        atomicAdd(&a.stamps[0], ts1 - ts0); atomicAdd(&a.stamps[1], ts2 - ts1); atomicAdd(&a.stamps[2], ts3 - ts2);
-        atomicAdd(&a.stamps[3], ts4 - ts3); atomicAdd(&a.stamps[4], ts5 - ts4); atomicAdd(&a.stamps[5], ts6 - ts5);
-        atomicAdd(&a.stamps[6], 1ull);
-      }
-    }
-    return;
-  }
-  if (gx < a.w && !(a.dbg & 2)) {
-    if (!FUSE && out.ids && !out.depth) {
-      const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
-      const int rows_here = min(TH, a.h - py0);
-      int32_t *dst = out.ids + plane + (int64_t)(py0 + (te >> TWL)) * a.w + gx;
-      const int64_t dstep = (int64_t)ROWS_PER_PASS * a.w;
-      for (int row = te >> TWL; row < rows_here; row += ROWS_PER_PASS, dst += dstep)
-        *dst = (int32_t)~klo[2 * lds_idx<TWL>(row, col)];
-    } else if (FUSE && !out.depth && TW == 64) {
-      const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
-      const int r0 = (te >> 6) * RW;
-      const int bg = out.compat ? (int)out.F - 1 : -1;
-      const int rows_here = min(RW, a.h - (py0 + r0));
-      int raw = (int32_t)~klo[2 * lds_idx<TWL>(r0, col)];
-      int cur = raw == -1 ? bg : raw;
-      int p1 = (py0 + r0) * a.w + gx + 1;
-      int32_t *idp = out.ids ? out.ids + plane + (p1 - 1) : nullptr;
-      uint32_t *win32 = (uint32_t *)out.winner + slot * out.F;
-      unsigned long long *win64 = (unsigned long long *)out.winner + slot * out.F;
-#pragma unroll
-      for (int k = 0; k < RW; ++k) {
-        if (k >= rows_here) break;
-        const int row = r0 + k;
-        int nraw = -3, nxt = -3;
-        if (row + 1 < TH) {
-          nraw = (int32_t)~klo[2 * lds_idx<TWL>(row + 1, col)];
-          nxt = (py0 + row + 1 >= a.h) ? -2 : (nraw == -1 ? bg : nraw);
-        }
-        const int fr = __builtin_amdgcn_update_dpp(-3, cur, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-        const int fbr = __builtin_amdgcn_update_dpp(-3, nxt, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-        const int fbl = __builtin_amdgcn_update_dpp(-3, nxt, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-        if (idp) { *idp = raw; idp += a.w; }
-        if (cur >= 0 && fr != cur && nxt != cur && fbr != cur && fbl != cur && !(a.dbg & 8)) {
-          const int label = min((int)lab[k], out.C);
-          if (out.key64) atomicMax(win64 + cur, ((unsigned long long)(uint32_t)p1 << out.LB) | (unsigned long long)label);
-          else atomicMax(win32 + cur, ((uint32_t)p1 << out.LB) | (uint32_t)label);
-        }
-        p1 += a.w;
-        cur = nxt;
-        raw = nraw;
-      }
-    } else {
-      for (int row = te >> TWL; row < TH; row += ROWS_PER_PASS) {
-        const int gy = py0 + row;
-        if (gy >= a.h) break;
-        const unsigned long long key = keys[lds_idx<TWL>(row, col)];
-        const int64_t p = (int64_t)gy * a.w + gx;
-        const int32_t id = (int32_t)~(uint32_t)key;
-        if (out.ids) out.ids[plane + p] = id;
-        if (out.depth) out.depth[plane + p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
-      }
-    }
-  }
-}
-
-// K4 v4  persistent tile rasterizer: a workgroup walks KT consecutive tiles of one view.  The tile kernel is bound by
-//        latency, not by a pipe (5 instead of 7 resident workgroups per CU cost 40 %; the kernel without any triangle
-//        work -- zero LDS, fetch entries, store ids -- takes 12.7 of its 17.6 us per C2 view): a workgroup that starts,
-//        asks memory for its count and entries, and only then has work, holds 21 KiB of LDS idle for a memory round trip.
-//        Here the counts of all KT tiles arrive with ONE load (lane j keeps tile j's), and the first chunk of tile k+1
-//        (one 16-byte piece per lane, exact: the count is known) is requested before tile k is rasterized and copied to
-//        LDS after tile k's epilogue.  Entries staged in LDS and batches dealt round-robin as in v3; the ids-only
-//        epilogue clears the keys it has just read, so a tile costs two workgroup barriers.
-template <int TWL, int THL, int NT, bool FUSE>
-__global__ __launch_bounds__(NT) void k_raster_tiles(BinArgs a, RasterOut out, int KT) {
-  constexpr int TW = 1 << TWL, TH = 1 << THL;
-  constexpr int NKEYS = (TW + GR_LDS_PAD) * TH;
-  constexpr int NW = NT / 64;
-  constexpr int NMAIL = NW * 32;  // u64 units
-  __shared__ __attribute__((aligned(16))) unsigned long long keys[NKEYS + NMAIL + 64 * 6];
-  int4 *ent_lds = reinterpret_cast<int4 *>(keys + NKEYS + NMAIL);
-  static_assert(NT == 256, "the entry copy deals 48 int4 per wave");
-
-  const int slot = blockIdx.y;
-  const int t0 = blockIdx.x * KT;
-  const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int ROWS_PER_PASS = NT / TW;
-  constexpr int RW = TH / (NT / 64);
-  const int64_t P = (int64_t)a.h * a.w;
-  const int64_t plane = (int64_t)slot * P;
-  const bool direct = a.cap_tile > 0;
-  const int nt = min(KT, a.T - t0);  // tiles of this workgroup
-
-  // counts (and list starts) of this workgroup's tiles: lane j holds tile t0 + j
-  uint32_t cv = 0, bv = 0;
-  if (lane < nt) {
-    if (direct) {
-      cv = min(ctrl[GR_CTRL_HDR + t0 + lane], (uint32_t)a.cap_tile);
-    } else {
-      cv = ctrl[GR_CTRL_HDR + t0 + lane] + ctrl[GR_CTRL_HDR + a.Tcap + t0 + lane];
-      bv = ctrl[GR_CTRL_HDR + 2 * a.Tcap + t0 + lane];
-      if ((int64_t)bv >= a.ent_cap) cv = 0;
-      else if ((int64_t)bv + cv > a.ent_cap) cv = (uint32_t)(a.ent_cap - bv);
-    }
-    if (a.dbg & 4) cv = 0;
-  }
-  // first tile: its segment address is static in single-pass mode, so the first chunk is requested before the counts land
-  const bool spec = a.cap_tile >= 64;
-  {  // zero keys + mailboxes once; later tiles find the keys cleared by the previous epilogue (ids-only) or clear them again
-    static_assert(NKEYS % 2 == 0, "key pairs");
-    ulonglong2 *k2 = reinterpret_cast<ulonglong2 *>(keys);
-    for (int i = tid; i < (NKEYS + NMAIL) / 2; i += NT) k2[i] = make_ulonglong2(0ull, 0ull);
-  }
-  int nrows_cur = 0;
-  {
-    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cv, 0);
-    int4 e0 = make_int4(0, 0, 0, 0);
-    uint32_t n0 = 0;
-    if (spec) {
-      const int64_t seg = slot * a.ent_cap + (int64_t)t0 * a.cap_tile;
-      n0 = a.nrow8[seg + lane];
-      if (lane < 48) e0 = a.comp[seg * GR_ENT_Q + wv * 48 + lane];
-    } else {
-      const int64_t b0 = direct ? (int64_t)t0 * a.cap_tile : (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)bv, 0);
-      if (lane < 48 && (uint32_t)(wv * 48 + lane) < c0 * GR_ENT_Q) e0 = a.comp[(slot * a.ent_cap + b0) * GR_ENT_Q + wv * 48 + lane];
-      if ((uint32_t)lane < c0) n0 = a.nrow8[slot * a.ent_cap + b0 + lane];
-    }
-    if (lane < 48) ent_lds[wv * 48 + lane] = e0;
-    nrows_cur = (uint32_t)lane < c0 ? (int)n0 : 0;
-  }
-  uint32_t *tab = reinterpret_cast<uint32_t *>(keys + NKEYS) + wv * 64;
-  uint32_t gen = 0;
-  int rot = wv;
-  const bool ids16 = !FUSE && out.ids && !out.depth && !(a.dbg & 2);
-
-#pragma unroll 1
-  for (int k = 0; k < nt; ++k) {
-    const int tile = t0 + k;
-    const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)cv, k);
-    const int64_t beg = direct ? (int64_t)tile * a.cap_tile : (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)bv, k);
-    const int4 *comp = a.comp + (slot * a.ent_cap + beg) * GR_ENT_Q;
-    const uint8_t *nr8 = a.nrow8 + slot * a.ent_cap + beg;
-    const int tx = tile % a.TX, ty = tile / a.TX;
-    const int px0 = tx << TWL, py0 = ty << THL;
-    __syncthreads();  // A: keys cleared, this tile's first chunk visible in LDS
-    // request the next tile's first chunk (exact: its count is known): it lands while this tile is rasterized
-    int4 ex_n = make_int4(0, 0, 0, 0);
-    uint32_t nr_n = 0, cn = 0;
-    if (k + 1 < nt) {
-      cn = (uint32_t)__builtin_amdgcn_readlane((int)cv, k + 1);
-      const int64_t bn = direct ? (int64_t)(tile + 1) * a.cap_tile : (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)bv, k + 1);
-      if (lane < 48 && (uint32_t)(wv * 48 + lane) < cn * GR_ENT_Q) ex_n = a.comp[(slot * a.ent_cap + bn) * GR_ENT_Q + wv * 48 + lane];
-      if ((uint32_t)lane < cn) nr_n = a.nrow8[slot * a.ent_cap + bn + lane];
-    }
-    if (cnt > 0) {
-      const int nb = raster_chunk_gather<TWL, NW, const int4 *>(keys, tab, gen, ent_lds, nrows_cur, lane, rot, px0, py0, a.dbg);
-      rot = (rot - nb) & (NW - 1);
-#pragma unroll 1
-      for (uint32_t c0 = 64; c0 < cnt; c0 += 64) {  // long lists: further chunks, fetched in place
-        __syncthreads();
-        const uint32_t q = c0 * GR_ENT_Q + wv * 48 + lane;
-        if (lane < 48 && q < cnt * GR_ENT_Q) ent_lds[wv * 48 + lane] = comp[q];
-        const uint32_t e = c0 + (uint32_t)lane;
-        const int nrows = e < cnt ? (int)nr8[e] : 0;
-        __syncthreads();
-        const int nb2 = raster_chunk_gather<TWL, NW, const int4 *>(keys, tab, gen, ent_lds, nrows, lane, rot, px0, py0, a.dbg);
-        rot = (rot - nb2) & (NW - 1);
-      }
-    }
-
-    int te = tid;
-    asm volatile("" : "+v"(te));
-    const int col = te & (TW - 1);
-    const int gx = px0 + col;
-    uint32_t lab[RW];
-    if (FUSE && out.labels && gx < a.w && !(a.dbg & 16)) {
-      const int r0 = (te >> 6) * RW;
-      const int rows_here = min(RW, a.h - (py0 + r0));
-      if (rows_here > 0) {
-        const uint8_t *lp = out.labels + plane + (int64_t)(py0 + r0) * a.w + gx;
-#pragma unroll
-        for (int kk = 0; kk < RW; ++kk) lab[kk] = (uint32_t)lp[(int64_t)min(kk, rows_here - 1) * a.w];
-      }
-    }
-    __syncthreads();  // B: keys complete, nobody reads this tile's entries any more
-    // the next tile's chunk, requested a whole raster phase ago, goes to LDS BEFORE this tile's stores are issued: the
-    // wait for it must not queue behind stores (loads and stores share one in-order counter)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    if (lane < 48) ent_lds[wv * 48 + lane] = ex_n;
-    nrows_cur = (uint32_t)lane < cn ? (int)nr_n : 0;
-    if (ids16) {
-      // ids only: 4 pixels per lane, 16-byte stores; the keys just read are cleared for the next tile
-      const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
-      const int c4 = (te & 15) * 4, rr = te >> 4;
-      const int gx4 = px0 + c4;
-      const int rows_here = min(TH, a.h - py0);
-      int32_t *ids_plane = out.ids + plane;
-      const bool vec = ((a.w & 3) == 0) && ((reinterpret_cast<uintptr_t>(ids_plane) & 15) == 0);
-      for (int row = rr; row < TH; row += NT / 16) {
-        unsigned long long *kq = keys + lds_idx<TWL>(row, c4);
-        const uint32_t *kr = klo + 2 * lds_idx<TWL>(row, c4);
-        const int i0 = (int)~kr[0], i1 = (int)~kr[2], i2 = (int)~kr[4], i3 = (int)~kr[6];
-        kq[0] = 0ull; kq[1] = 0ull; kq[2] = 0ull; kq[3] = 0ull;
-        if (row < rows_here && gx4 < a.w) {
-          int32_t *dst = ids_plane + (int64_t)(py0 + row) * a.w + gx4;
-          if (vec) *reinterpret_cast<int4 *>(dst) = make_int4(i0, i1, i2, i3);
-          else {  // volatile: keeps the compiler from merging these with the 16-byte store above (it splits that one)
-            volatile int32_t *d = dst;
-            d[0] = i0;
-            if (gx4 + 1 < a.w) d[1] = i1;
-            if (gx4 + 2 < a.w) d[2] = i2;
-            if (gx4 + 3 < a.w) d[3] = i3;
-          }
-        }
-      }
-      continue;  // barrier A of the next tile orders the clearing against its raster phase
-    }
-    if (FUSE) __builtin_amdgcn_s_waitcnt(0x0F70);
-    if (gx < a.w && !(a.dbg & 2)) {
-      if (FUSE && !out.depth && TW == 64) {
-        // fused projection epilogue: see k_raster_rows
-        const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
-        const int r0 = (te >> 6) * RW;
-        const int bg = out.compat ? (int)out.F - 1 : -1;
-        const int rows_here = min(RW, a.h - (py0 + r0));
-        int raw = (int32_t)~klo[2 * lds_idx<TWL>(r0, col)];
-        int cur = raw == -1 ? bg : raw;
-        int p1 = (py0 + r0) * a.w + gx + 1;
-        int32_t *idp = out.ids ? out.ids + plane + (p1 - 1) : nullptr;
-        uint32_t *win32 = (uint32_t *)out.winner + slot * out.F;
-        unsigned long long *win64 = (unsigned long long *)out.winner + slot * out.F;
-#pragma unroll
-        for (int kk = 0; kk < RW; ++kk) {
-          if (kk >= rows_here) break;
-          const int row = r0 + kk;
-          int nraw = -3, nxt = -3;
-          if (row + 1 < TH) {
-            nraw = (int32_t)~klo[2 * lds_idx<TWL>(row + 1, col)];
-            nxt = (py0 + row + 1 >= a.h) ? -2 : (nraw == -1 ? bg : nraw);
-          }
-          const int fr = __builtin_amdgcn_update_dpp(-3, cur, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-          const int fbr = __builtin_amdgcn_update_dpp(-3, nxt, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-          const int fbl = __builtin_amdgcn_update_dpp(-3, nxt, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-          if (idp) { *idp = raw; idp += a.w; }
-          if (cur >= 0 && fr != cur && nxt != cur && fbr != cur && fbl != cur && !(a.dbg & 8)) {
-            const int label = min((int)lab[kk], out.C);
-            if (out.key64) atomicMax(win64 + cur, ((unsigned long long)(uint32_t)p1 << out.LB) | (unsigned long long)label);
-            else atomicMax(win32 + cur, ((uint32_t)p1 << out.LB) | (uint32_t)label);
-          }
-          p1 += a.w;
-          cur = nxt;
-          raw = nraw;
-        }
-      } else {
-        for (int row = te >> TWL; row < TH; row += ROWS_PER_PASS) {
-          const int gy = py0 + row;
-          if (gy >= a.h) break;
+  asm volatile("" : "+v"(te));  // the epilogue's addresses are derived here, not hoisted above the scanline phase
+  __syncthreads();              // keys complete
+  if (a.dbg & 2) return;
+  if (FUSE) {
+    uint32_t *win = out.winner + slot * out.F;
+    const bool edge = px0 + TW > a.w || py0 + TH + 1 > a.h;
+    if (edge) fused_winners<TWL, TH, NT, true>(keys, a, win, te, px0, py0, a.dbg);
+    else fused_winners<TWL, TH, NT, false>(keys, a, win, te, px0, py0, a.dbg);
+    if (out.ids) {  // the id image as well (rare): background is where no fragment landed (depth bits 0)
+      const int col = te & (TW - 1), gx = px0 + col;
+      if (gx < a.w)
+        for (int row = te >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
           const unsigned long long key = keys[lds_idx<TWL>(row, col)];
-          const int64_t p = (int64_t)gy * a.w + gx;
-          const int32_t id = (int32_t)~(uint32_t)key;
-          if (out.ids) out.ids[plane + p] = id;
-          if (out.depth) out.depth[plane + p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
+          out.ids[plane + (int64_t)(py0 + row) * a.w + gx] = (key >> 32) ? (int32_t)~(uint32_t)key : -1;
         }
+    }
+  } else if (out.ids && !out.depth) {
+    store_ids<TWL, TH, NT>(keys, a, out.ids + plane, te, px0, py0);
+  } else {
+    const int col = te & (TW - 1), gx = px0 + col;
+    if (gx < a.w)
+      for (int row = te >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
+        const unsigned long long key = keys[lds_idx<TWL>(row, col)];
+        const int64_t p = plane + (int64_t)(py0 + row) * a.w + gx;
+        if (out.ids) out.ids[p] = (int32_t)~(uint32_t)key;  // low dword = ~face, 0 when empty: ~0 = -1
+        if (out.depth) out.depth[p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
       }
-    }
-    if (k + 1 < nt) {
-      __syncthreads();  // C: every wave has read the keys before they are cleared for the next tile
-      ulonglong2 *k2 = reinterpret_cast<ulonglong2 *>(keys);
-      for (int i = tid; i < NKEYS / 2; i += NT) k2[i] = make_ulonglong2(0ull, 0ull);
-    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K5  last-writer-wins winners.  Four pixels per thread.  A pixel can only be its face's LAST pixel in row-major
-//     order if neither its right nor its lower neighbour shows the same face, so only those candidates issue the
-//     global atomicMax (~1-3 per visible face instead of ~80).  key = (pixel+1) << LB | label  (LB = 0: pixel+1).
+// K5  last-writer-wins winners from id images already in memory (the unfused path).  Four pixels per thread.  A pixel
+//     can only be its face's LAST pixel in row-major order if neither its right nor its lower neighbour shows the same
+//     face, so only those candidates issue the global atomicMax (~1-3 per visible face instead of ~80).  key = pixel + 1.
 // ------------------------------------------------------------------------------------------------------------------
 // grid (ceil(w/1024), ceil(h/WIN_ROWS), views): a thread owns 4 consecutive columns and walks WIN_ROWS rows downwards;
-// the row below is loaded once and becomes the current row of the next step (16-byte id loads, 4-byte label loads).
+// the row below is loaded once and becomes the current row of the next step (16-byte id loads).
 #define WIN_ROWS 16
-template <typename KeyT>
-__global__ __launch_bounds__(256) void k_winner(const int32_t *__restrict__ ids, const uint8_t *__restrict__ labels,
-                                                KeyT *__restrict__ winner, int64_t F, int h, int w, int C, int LB,
-                                                int compat) {
+__global__ __launch_bounds__(256) void k_winner(const int32_t *__restrict__ ids, uint32_t *__restrict__ winner, int64_t F,
+                                                int h, int w, int compat) {
   const int slot = blockIdx.z;
   const int y0 = blockIdx.y * WIN_ROWS;
   const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (x0 >= w) return;
   const int64_t P = (int64_t)h * w;
   const int32_t *img = ids + slot * P;
-  const uint8_t *lab = LB ? labels + slot * P : nullptr;
-  KeyT *win = winner + slot * F;
-  const bool vec = ((w & 3) == 0) && ((reinterpret_cast<uintptr_t>(img) & 15) == 0) &&
-                   (!LB || (reinterpret_cast<uintptr_t>(lab) & 3) == 0);
+  uint32_t *win = winner + slot * F;
+  const bool vec = ((w & 3) == 0) && ((reinterpret_cast<uintptr_t>(img) & 15) == 0);
   auto load_row = [&](int y, int (&f)[5]) {
     const int32_t *row = img + (int64_t)y * w;
     if (vec) {
@@ -1850,47 +1267,45 @@ __global__ __launch_bounds__(256) void k_winner(const int32_t *__restrict__ ids,
     const bool has_below = (y + 1 < h);
     if (has_below) load_row(y + 1, nxt);
     else { nxt[0] = nxt[1] = nxt[2] = nxt[3] = nxt[4] = -2; }
-    int l[4] = {0, 0, 0, 0};
-    if (LB) {
-      const uint8_t *lrow = lab + (int64_t)y * w;
-      if (vec) {
-        const uchar4 q = *reinterpret_cast<const uchar4 *>(lrow + x0);
-        l[0] = q.x; l[1] = q.y; l[2] = q.z; l[3] = q.w;
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (x0 + k < w) l[k] = lrow[x0 + k];
-      }
-    }
     const int64_t p0 = (int64_t)y * w + x0;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (x0 + k < w) winner_pixel<KeyT>(win, cur[k], cur[k + 1], nxt[k], p0 + k, l[k], F, C, LB, compat);
+      if (x0 + k < w) winner_pixel(win, cur[k], cur[k + 1], nxt[k], p0 + k, F, compat);
 #pragma unroll
     for (int k = 0; k < 5; ++k) cur[k] = nxt[k];
   }
 }
 
-// K6  per-face vote: one thread per face walks the views of the batch IN ORDER (deterministic, no atomics needed:
-//     a face belongs to exactly one thread).  votes[f][label] += 1, counts[f] += 1; winners are cleared for reuse.
-template <typename KeyT>
-__global__ __launch_bounds__(256) void k_vote_labels(KeyT *__restrict__ winner, int n_views, int64_t F, int C, int LB,
-                                                     uint32_t *__restrict__ votes, uint32_t *__restrict__ counts) {
+// K6  per-face vote: one thread per face walks the views of the launch group IN ORDER (deterministic, no atomics needed:
+//     a face belongs to exactly one thread).  The label of the winning pixel is looked up here (one byte per visible
+//     face and view; neighbouring faces win neighbouring pixels): votes[f][label] += 1, counts[f] += 1; a label >= C
+//     (255 = ignore) is an all-zero one-hot row that still counts (predictors/segmentor.py:37-69).  Winners are
+//     cleared for reuse.
+__global__ __launch_bounds__(256) void k_vote_labels(uint32_t *__restrict__ winner, const uint8_t *__restrict__ labels,
+                                                     int n_views, int64_t F, int64_t P, int C,
+                                                     uint32_t *__restrict__ votes, uint32_t *__restrict__ counts,
+                                                     const unsigned long long *__restrict__ stats, int group) {
   const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (f >= F) return;
-  const KeyT mask = (((KeyT)1) << LB) - 1;
+  // a launch group whose binning overflowed (and every group after it) must not vote: its winners are incomplete.  The
+  // caller learns how many views were folded in (gr_raster_status: views_done) and repeats the call for the rest.
+  const bool skip = stats != nullptr && stats[4] <= (unsigned long long)group;
   uint32_t c = 0;
-  // eight views' winners are requested together (the kernel is a pure stream over winner[views][F]: memory-level
-  // parallelism, not arithmetic, sets its speed), then consumed in view order
+  // eight views' winners are requested together (the kernel is a stream over winner[views][F]: memory-level
+  // parallelism, not arithmetic, sets its speed), then their labels, then the votes in view order
   for (int v0 = 0; v0 < n_views; v0 += 8) {
-    KeyT key[8];
+    uint32_t key[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) key[k] = (v0 + k < n_views) ? winner[(int64_t)(v0 + k) * F + f] : (KeyT)0;
+    for (int k = 0; k < 8; ++k) key[k] = (v0 + k < n_views) ? winner[(int64_t)(v0 + k) * F + f] : 0u;
+    uint32_t lab[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lab[k] = (key[k] && !skip) ? (uint32_t)labels[(int64_t)(v0 + k) * P + (key[k] - 1)] : 0u;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       if (key[k] == 0) continue;
       winner[(int64_t)(v0 + k) * F + f] = 0;
-      const int l = (int)(key[k] & mask);
-      if (l < C) votes[f * C + l] += 1u;
+      if (skip) continue;
+      if ((int)lab[k] < C) votes[f * C + lab[k]] += 1u;
       ++c;
     }
   }
@@ -2161,13 +1576,12 @@ struct gr_ctx {
   int opt_thl = 5;      // log2 tile height (5 or 6); width is 64.  64x32 tiles: 16 KiB of LDS, 8 workgroups per CU
   int opt_batch = GR_MAX_BATCH;
   int opt_dbg = 0;
-  int opt_var = 3;
-  int opt_pf_dist = 2048;
-  int opt_kt = 4;        // tiles per workgroup of the persistent tile kernel
-  int opt_lds_pad = 0;   // extra dynamic LDS bytes per tile workgroup (occupancy experiments)
+  int opt_var = 0;
+  int opt_lds_pad = 0;   // extra dynamic LDS bytes per tile workgroup (occupancy experiments, GR_OPT_DEBUG_LDS)
   int opt_direct_cap = 512;  // single-pass binning: entry slots per tile (0 = always use the exact two-pass path)
   int learned_cap = 0, learned_T = 0;  // slots per tile learned from an overflow, valid for images with learned_T tiles
   int last_T = 0, last_B = 0;          // tile count and launch-group size of the last raster call
+  int last_n_views = 0;
   bool direct_ok = true;     // cleared when a tile overflowed its slots: later calls take the exact path
   bool last_direct = false;
   // winner scratch
@@ -2287,18 +1701,20 @@ BinArgs make_args(gr_ctx *c, int h, int w, int slot0) {
   a.ctrl = c->ctrl + slot0 * a.ctrl_stride; a.rec = c->rec + slot0 * a.rec_stride;
   a.comp = c->comp + slot0 * a.ent_cap * GR_ENT_Q; a.work = c->work + slot0 * a.work_stride;
   a.nrow8 = c->nrow8 + slot0 * a.ent_cap;
-  a.stamps = c->stats + 8; a.stats = c->stats; a.blk = c->blk; a.soup = c->soup; a.orig = c->orig;
+  a.stats = c->stats; a.blk = c->blk; a.soup = c->soup; a.orig = c->orig;
   a.clip = c->clip + slot0 * c->F;
   a.twl = GR_TILE_LOG2; a.thl = c->opt_thl;
   a.TX = (w + (1 << a.twl) - 1) >> a.twl; a.TY = (h + (1 << a.thl) - 1) >> a.thl; a.T = a.TX * a.TY; a.Tcap = c->Tcap;
-  a.h = h; a.w = w; a.dbg = c->opt_dbg; a.var = c->opt_var; a.pf_dist = c->opt_pf_dist;
+  a.h = h; a.w = w; a.dbg = c->opt_dbg; a.var = c->opt_var;
   a.cap_tile = direct_cap(c, a.T);
+  a.group = 0;
   return a;
 }
 
 // stage 1 of a launch group: cull, set up and bin `nb` views (camera records `cams`) into scratch slots slot0..
-int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, hipStream_t s) {
+int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int group, hipStream_t s) {
   BinArgs a = make_args(c, h, w, slot0);
+  a.group = group;
   GR_HIP(c, hipMemsetAsync(a.ctrl, 0, sizeof(uint32_t) * c->ctrl_stride * nb, s));
   {
     Timed t(c, s, ST_SETUP);
@@ -2338,33 +1754,13 @@ int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStr
   BinArgs a = make_args(c, h, w, slot0);
   {
     Timed t(c, s, ST_RASTER);
-    const dim3 grid(a.T, nb), block(256);
-    if (a.var & 32) {
-      const int KT = c->opt_kt;
-      const dim3 g4((unsigned)((a.T + KT - 1) / KT), nb);
-      if (out.labels) {
-        if (a.thl == 6) hipLaunchKernelGGL((k_raster_tiles<6, 6, 256, true>), g4, block, c->opt_lds_pad, s, a, out, KT);
-        else hipLaunchKernelGGL((k_raster_tiles<6, 5, 256, true>), g4, block, c->opt_lds_pad, s, a, out, KT);
-      } else if (a.thl == 6) hipLaunchKernelGGL((k_raster_tiles<6, 6, 256, false>), g4, block, c->opt_lds_pad, s, a, out, KT);
-      else hipLaunchKernelGGL((k_raster_tiles<6, 5, 256, false>), g4, block, c->opt_lds_pad, s, a, out, KT);
-    } else if (a.var & 8) {
-      const dim3 grid((a.var & 64) ? (unsigned)(((a.T + 7) >> 3) << 3) : (unsigned)a.T, nb);
-      if (out.labels) {
-        if (a.thl == 6) hipLaunchKernelGGL((k_raster_tile_lds<6, 6, 256, true>), grid, block, c->opt_lds_pad, s, a, out);
-        else hipLaunchKernelGGL((k_raster_tile_lds<6, 5, 256, true>), grid, block, c->opt_lds_pad, s, a, out);
-      } else if (a.thl == 6) hipLaunchKernelGGL((k_raster_tile_lds<6, 6, 256, false>), grid, block, c->opt_lds_pad, s, a, out);
-      else hipLaunchKernelGGL((k_raster_tile_lds<6, 5, 256, false>), grid, block, c->opt_lds_pad, s, a, out);
-    } else if (a.var & 1) {
-      if (out.labels) {
-        if (a.thl == 6) hipLaunchKernelGGL((k_raster_tile<6, 6, 256, true>), grid, block, 0, s, a, out);
-        else hipLaunchKernelGGL((k_raster_tile<6, 5, 256, true>), grid, block, 0, s, a, out);
-      } else if (a.thl == 6) hipLaunchKernelGGL((k_raster_tile<6, 6, 256, false>), grid, block, 0, s, a, out);
-      else hipLaunchKernelGGL((k_raster_tile<6, 5, 256, false>), grid, block, 0, s, a, out);
-    } else if (out.labels) {
-      if (a.thl == 6) hipLaunchKernelGGL((k_raster_rows<6, 6, 256, true>), grid, block, 0, s, a, out);
-      else hipLaunchKernelGGL((k_raster_rows<6, 5, 256, true>), grid, block, 0, s, a, out);
-    } else if (a.thl == 6) hipLaunchKernelGGL((k_raster_rows<6, 6, 256, false>), grid, block, 0, s, a, out);
-    else hipLaunchKernelGGL((k_raster_rows<6, 5, 256, false>), grid, block, 0, s, a, out);
+    const dim3 grid((a.var & 64) ? (unsigned)(((a.T + 7) >> 3) << 3) : (unsigned)a.T, nb), block(256);
+    const size_t pad = (size_t)c->opt_lds_pad;
+    if (out.winner) {
+      if (a.thl == 6) hipLaunchKernelGGL((k_raster_tile<6, 6, 256, true>), grid, block, pad, s, a, out);
+      else hipLaunchKernelGGL((k_raster_tile<6, 5, 256, true>), grid, block, pad, s, a, out);
+    } else if (a.thl == 6) hipLaunchKernelGGL((k_raster_tile<6, 6, 256, false>), grid, block, pad, s, a, out);
+    else hipLaunchKernelGGL((k_raster_tile<6, 5, 256, false>), grid, block, pad, s, a, out);
     c->prof_raster_launches += 1;
   }
   c->prof_views += nb;
@@ -2379,31 +1775,25 @@ int check_common(gr_ctx *c, int n_views, int h, int w) {
   return GR_OK;
 }
 
-int label_bits(int C) {
-  int lb = 1;
-  while ((1 << lb) < C + 1) ++lb;
-  return lb;
-}
-
-template <typename KeyT>
-int project_labels_t(gr_ctx *c, const int32_t *ids, const uint8_t *labels, int n_views, int h, int w, int C, int LB,
-                     uint32_t *votes, uint32_t *counts, int flags, hipStream_t s) {
+// unfused label projection for id images already in memory: winner pass + vote pass per launch group
+int project_labels(gr_ctx *c, const int32_t *ids, const uint8_t *labels, int n_views, int h, int w, int C, uint32_t *votes,
+                   uint32_t *counts, int flags, hipStream_t s) {
   const int64_t P = (int64_t)h * w, F = c->F;
   const int B = n_views < GR_MAX_BATCH ? n_views : GR_MAX_BATCH;
-  int rc = ensure_winner(c, sizeof(KeyT) * (size_t)F * B);
+  int rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F * B);
   if (rc) return rc;
-  KeyT *win = (KeyT *)c->winner;
+  uint32_t *win = (uint32_t *)c->winner;
   for (int v0 = 0; v0 < n_views; v0 += B) {
     const int nb = (n_views - v0) < B ? (n_views - v0) : B;
     {
       Timed t(c, s, ST_PROJECT);
-      hipLaunchKernelGGL(k_winner<KeyT>, dim3((unsigned)ceil_div(ceil_div(w, 4), 256), (unsigned)ceil_div(h, WIN_ROWS), nb), dim3(256), 0, s, ids + v0 * P,
-                         labels + v0 * P, win, F, h, w, C, LB, (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0);
+      hipLaunchKernelGGL(k_winner, dim3((unsigned)ceil_div(ceil_div(w, 4), 256), (unsigned)ceil_div(h, WIN_ROWS), nb), dim3(256), 0,
+                         s, ids + v0 * P, win, F, h, w, (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0);
     }
     {
       Timed t(c, s, ST_VOTE);
-      hipLaunchKernelGGL(k_vote_labels<KeyT>, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s, win, nb, F, C, LB,
-                         votes, counts);
+      hipLaunchKernelGGL(k_vote_labels, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s, win, labels + v0 * P, nb, F, P, C,
+                         votes, counts, (const unsigned long long *)nullptr, 0);
     }
   }
   GR_HIP(c, hipGetLastError());
@@ -2431,35 +1821,30 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   if (rc) return rc;
   c->last_T = T; c->last_B = B;
   const int64_t P = (int64_t)h * w, F = c->F;
-  int LB = 0, key64 = 0;
   if (labels) {
-    LB = label_bits(C);
-    key64 = (((P + 1) << LB) <= 0xFFFFFFFFll) ? 0 : 1;
-    rc = ensure_winner(c, (key64 ? sizeof(unsigned long long) : sizeof(uint32_t)) * (size_t)F * B);
+    rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F * B);
     if (rc) return rc;
   }
   c->last_stream = s;
   GR_HIP(c, hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 4, s));
+  GR_HIP(c, hipMemsetAsync(c->stats + 4, 0xFF, sizeof(unsigned long long), s));  // first overflowed group: none
+  c->last_n_views = n_views;
   for (int v0 = 0; v0 < n_views; v0 += B) {
     const int nb = (n_views - v0) < B ? (n_views - v0) : B;
-    rc = bin_batch(c, cams + (int64_t)v0 * GR_CAM_FLOATS, nb, h, w, 0, s);
+    rc = bin_batch(c, cams + (int64_t)v0 * GR_CAM_FLOATS, nb, h, w, 0, v0 / B, s);
     if (rc) return rc;
     RasterOut out;
     out.ids = ids ? ids + v0 * P : nullptr;
     out.depth = depth ? depth + v0 * P : nullptr;
-    out.labels = labels ? labels + v0 * P : nullptr;
-    out.winner = c->winner; out.F = F; out.C = C; out.LB = LB; out.key64 = key64;
+    out.winner = labels ? (uint32_t *)c->winner : nullptr;
+    out.F = F;
     out.compat = (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0;
     rc = tile_batch(c, nb, h, w, 0, out, s);
     if (rc) return rc;
     if (labels) {
       Timed t(c, s, ST_VOTE);
-      if (key64)
-        hipLaunchKernelGGL(k_vote_labels<unsigned long long>, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s,
-                           (unsigned long long *)c->winner, nb, F, C, LB, votes, counts);
-      else
-        hipLaunchKernelGGL(k_vote_labels<uint32_t>, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s,
-                           (uint32_t *)c->winner, nb, F, C, LB, votes, counts);
+      hipLaunchKernelGGL(k_vote_labels, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s, (uint32_t *)c->winner,
+                         labels + v0 * P, nb, F, P, C, votes, counts, (const unsigned long long *)c->stats, v0 / B);
       GR_HIP(c, hipGetLastError());
     }
   }
@@ -2481,12 +1866,12 @@ int gr_ctx_create(int device, gr_ctx **out) {
   gr_ctx *c = new (std::nothrow) gr_ctx();
   if (!c) return GR_ENOMEM;
   c->device = device;
-  if (hipMalloc(&c->stats, sizeof(unsigned long long) * (8 + 8 * 4096)) != hipSuccess ||
+  if (hipMalloc(&c->stats, sizeof(unsigned long long) * 8) != hipSuccess ||
       hipMalloc(&c->flag, sizeof(int) * 8) != hipSuccess) {  // flag word + upload scratch (vertex bounds)
     delete c;
     return GR_ENOMEM;
   }
-  (void)hipMemset(c->stats, 0, sizeof(unsigned long long) * (8 + 8 * 4096));
+  (void)hipMemset(c->stats, 0, sizeof(unsigned long long) * 8);
   *out = c;
   return GR_OK;
 }
@@ -2538,13 +1923,9 @@ int gr_set_option(gr_ctx *c, int key, int value) {
       c->opt_dbg = value; return GR_OK;
     case GR_OPT_VARIANT:
       c->opt_var = value; return GR_OK;
-    case 98:
+    case GR_OPT_DEBUG_LDS:
+      if (value < 0 || value > 65536) return fail(c, GR_EINVAL, "extra LDS bytes must be in [0, 65536]");
       c->opt_lds_pad = value; return GR_OK;
-    case 97:
-      c->opt_pf_dist = value; return GR_OK;
-    case GR_OPT_TILES_PER_WG:
-      if (value < 1 || value > 64) return fail(c, GR_EINVAL, "tiles per workgroup must be in [1, 64]");
-      c->opt_kt = value; return GR_OK;
     case GR_OPT_DIRECT_CAP:
       if (value < 0 || value > 65536) return fail(c, GR_EINVAL, "slots per tile must be in [0, 65536]");
       c->opt_direct_cap = value; c->direct_ok = true; c->learned_cap = 0; c->learned_T = 0; return GR_OK;
@@ -2567,18 +1948,6 @@ int gr_get_stage_times(gr_ctx *c, gr_stage_times *o) {
   for (auto &sp : c->spans) { c->pool.push_back(sp.a); c->pool.push_back(sp.b); }
   c->spans.clear();
   c->prof_views = 0; c->prof_raster_launches = 0;
-  return GR_OK;
-}
-
-int gr_debug_stamps(gr_ctx *c, unsigned long long *out_h, int reset) {
-  if (!c || !out_h) return GR_EINVAL;
-  GR_HIP(c, hipDeviceSynchronize());
-  std::vector<unsigned long long> tmp(8 * 4096);
-  GR_HIP(c, hipMemcpy(tmp.data(), c->stats + 8, sizeof(unsigned long long) * 8 * 4096, hipMemcpyDeviceToHost));
-  for (int k = 0; k < 8; ++k) out_h[k] = 0;
-  for (int i = 0; i < 4096; ++i)
-    for (int k = 0; k < 8; ++k) out_h[k] += tmp[8 * i + k];
-  if (reset) GR_HIP(c, hipMemset(c->stats + 8, 0, sizeof(unsigned long long) * 8 * 4096));
   return GR_OK;
 }
 
@@ -2663,11 +2032,15 @@ int gr_raster_face_ids(gr_ctx *c, const float *cams, int n_views, int h, int w, 
 
 int gr_raster_status(gr_ctx *c, gr_raster_stats *o) {
   if (!c || !o) return GR_EINVAL;
-  unsigned long long st[4] = {0, 0, 0, 0};
+  unsigned long long st[5] = {0, 0, 0, 0, 0};
   GR_HIP(c, hipMemcpyAsync(st, c->stats, sizeof(st), hipMemcpyDeviceToHost, c->last_stream));
   GR_HIP(c, hipStreamSynchronize(c->last_stream));
   o->records = (int64_t)st[0]; o->entries = (int64_t)st[1]; o->max_entries = (int64_t)st[2];
   o->entry_cap = c->ent_cap; o->overflow = (int32_t)st[3];
+  // views of the last call whose results are complete: every launch group in front of the first one that overflowed
+  o->views_done = st[3] ? (int32_t)std::min<unsigned long long>(st[4] * (unsigned long long)std::max(c->last_B, 1),
+                                                                (unsigned long long)c->last_n_views)
+                        : c->last_n_views;
   if (st[3] && c->last_direct) {
     // A tile outgrew its fixed segment.  The counters kept counting, so the need is known: the retry uses segments of
     // that size if a launch group's entry memory stays within budget, and bins exactly (count, scan, fill) otherwise.
@@ -2710,11 +2083,7 @@ int gr_project_labels_u8(gr_ctx *c, const int32_t *ids, const uint8_t *labels, i
   if (n_views == 0) return GR_OK;
   hipStream_t s = (hipStream_t)stream;
   GR_HIP(c, hipSetDevice(c->device));
-  const int LB = label_bits(C);
-  const int64_t P = (int64_t)h * w;
-  if (((P + 1) << LB) <= 0xFFFFFFFFll)
-    return project_labels_t<uint32_t>(c, ids, labels, n_views, h, w, C, LB, votes, counts, flags, s);
-  return project_labels_t<unsigned long long>(c, ids, labels, n_views, h, w, C, LB, votes, counts, flags, s);
+  return project_labels(c, ids, labels, n_views, h, w, C, votes, counts, flags, s);
 }
 
 int gr_project_values_f64(gr_ctx *c, const int32_t *ids, const double *img, int n_views, int h, int w, int C,
@@ -2735,8 +2104,8 @@ int gr_project_values_f64(gr_ctx *c, const int32_t *ids, const double *img, int 
     const int nb = (n_views - v0) < B ? (n_views - v0) : B;
     {
       Timed t(c, s, ST_PROJECT);
-      hipLaunchKernelGGL(k_winner<uint32_t>, dim3((unsigned)ceil_div(ceil_div(w, 4), 256), (unsigned)ceil_div(h, WIN_ROWS), nb), dim3(256), 0, s, ids + v0 * P,
-                         (const uint8_t *)nullptr, win, F, h, w, C, 0, (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0);
+      hipLaunchKernelGGL(k_winner, dim3((unsigned)ceil_div(ceil_div(w, 4), 256), (unsigned)ceil_div(h, WIN_ROWS), nb), dim3(256), 0, s, ids + v0 * P, win, F, h, w,
+                         (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0);
     }
     {
       Timed t(c, s, ST_VOTE);
@@ -2762,8 +2131,8 @@ int gr_project_view_f64(gr_ctx *c, const int32_t *ids, const double *img, int h,
   uint32_t *win = (uint32_t *)c->winner;
   {
     Timed t(c, s, ST_PROJECT);
-    hipLaunchKernelGGL(k_winner<uint32_t>, dim3((unsigned)ceil_div(ceil_div(w, 4), 256), (unsigned)ceil_div(h, WIN_ROWS), 1), dim3(256), 0, s, ids,
-                       (const uint8_t *)nullptr, win, F, h, w, C, 0, (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0);
+    hipLaunchKernelGGL(k_winner, dim3((unsigned)ceil_div(ceil_div(w, 4), 256), (unsigned)ceil_div(h, WIN_ROWS), 1), dim3(256), 0, s, ids, win, F, h, w,
+                         (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0);
   }
   {
     Timed t(c, s, ST_VOTE);
@@ -2848,8 +2217,7 @@ int gr_project_index_pairs(gr_ctx *c, const int32_t *ids, const double *img, int
     const int nb = (n_views - v0) < B ? (n_views - v0) : B;
     {
       Timed t(c, s, ST_PROJECT);
-      hipLaunchKernelGGL(k_winner<uint32_t>, dim3((unsigned)ceil_div(ceil_div(w, 4), 256), (unsigned)ceil_div(h, WIN_ROWS), nb),
-                         dim3(256), 0, s, ids + v0 * P, (const uint8_t *)nullptr, win, F, h, w, 1, 0,
+      hipLaunchKernelGGL(k_winner, dim3((unsigned)ceil_div(ceil_div(w, 4), 256), (unsigned)ceil_div(h, WIN_ROWS), nb), dim3(256), 0, s, ids + v0 * P, win, F, h, w,
                          (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0);
     }
     {

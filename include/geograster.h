@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GR_VERSION 100 /* 0.1.0 */
+#define GR_VERSION 110 /* 0.1.1: gr_raster_stats.views_done, 32-bit pixel-only winner keys */
 
 enum {
   GR_OK = 0,
@@ -73,6 +73,7 @@ typedef struct gr_raster_stats {
   int64_t max_entries;  /* largest per-view entry count seen (capacity needed)                 */
   int64_t entry_cap;    /* current per-view capacity                                           */
   int32_t overflow;     /* != 0: some view exceeded entry_cap, output incomplete               */
+  int32_t views_done;   /* leading views of the last call whose outputs / votes are complete    */
 } gr_raster_stats;
 
 int gr_version(void);
@@ -95,9 +96,8 @@ enum {
                                gr_raster_status (GR_EOVERFLOW); the retry uses segments of the size that image needs
                                (remembered for images of the same tile count) or, beyond 16384 slots / 24 GB of
                                entry memory per launch group, bins exactly                                     */
-  GR_OPT_VARIANT = 7,       /* tile-kernel variant bits for A/B runs (results identical): 1 entries gathered through
-                               vector memory (v2), 2 16-byte id stores, 4 entry prefetch                      */
-  GR_OPT_TILES_PER_WG = 8,  /* persistent tile kernel: consecutive tiles per workgroup, 1..64 (default 4)          */
+  GR_OPT_VARIANT = 7,       /* tile-kernel variant bits for A/B runs (results identical): 64 = XCD-aware tile order */
+  GR_OPT_DEBUG_LDS = 98,    /* extra dynamic LDS bytes per tile workgroup: lowers occupancy (timing experiments)     */
   GR_OPT_DEBUG = 99         /* timing-only ablation mask for tools/ab_raster.py: OUTPUTS BECOME WRONG         */
 };
 int gr_set_option(gr_ctx *ctx, int key, int value);
@@ -142,8 +142,10 @@ int gr_project_view_f64(gr_ctx *ctx, const int32_t *ids, const double *img, int 
 
 /* fused pix2face + project_labels (ids never leave the chip unless ids_or_null != NULL): the
  * aggregate_projected_images fast path, meshes.py:2004-2084 over n_views cameras.  The tile rasterizer's epilogue feeds
- * the per-face winners straight from its LDS tile.  If gr_raster_status afterwards reports GR_EOVERFLOW the votes of
- * this call are incomplete: restore votes/counts to their state before the call and call again. */
+ * the per-face winners straight from its LDS tile.  If gr_raster_status afterwards reports GR_EOVERFLOW, the votes of the
+ * first gr_raster_stats.views_done views HAVE been folded into votes/counts and those of the remaining views have
+ * not (the launch group that overflowed and every later one are skipped on the device): call again with the camera
+ * records and label images from view `views_done` on.  No rollback of votes/counts is needed. */
 int gr_raster_project_labels_u8(gr_ctx *ctx, const float *cams, const uint8_t *labels, int n_views, int h, int w,
                                 int C, uint32_t *votes, uint32_t *counts, int32_t *ids_or_null, int flags,
                                 void *stream);

@@ -13,14 +13,10 @@ from oracle import oracle_c, oracle_np
 
 pytestmark = pytest.mark.gpu
 
-# every raster test runs against each tile-kernel variant (include/geograster.h GR_OPT_*): results must not change
-# (tile height log2, single-pass slots per tile: 0 = exact two-pass binning): results must not depend on the knobs
-# plus the tile-kernel generation (GR_OPT_VARIANT: 0 = entries in registers / ds_bpermute, 3 = entries gathered through
-# vector memory + 16-byte id stores, 7 = + entry prefetch)
-VARIANTS = {"tile32_direct": (5, 512, 3), "tile64_direct": (6, 512, 3), "tile32_exact": (5, 0, 3), "tile64_exact": (6, 0, 7),
-            "tile32_direct_v1": (5, 512, 2), "tile64_exact_v1": (6, 0, 0), "tile32_direct_v3": (5, 512, 10),
-            "tile64_exact_v3": (6, 0, 8), "tile32_direct_v4": (5, 512, 32), "tile64_exact_v4": (6, 0, 32),
-            "tile32_exact_v4": (5, 0, 32)}
+# every raster test runs against each setting of the tuning knobs (include/geograster.h GR_OPT_*): tile height log2,
+# single-pass slots per tile (0 = exact two-pass binning), tile order (GR_OPT_VARIANT 64 = XCD-aware) -- results must
+# not depend on them
+VARIANTS = {"tile32_direct": (5, 512, 0), "tile64_direct": (6, 512, 64), "tile32_exact": (5, 0, 64), "tile64_exact": (6, 0, 0)}
 
 
 @pytest.fixture(params=list(VARIANTS), autouse=True)
@@ -32,7 +28,7 @@ def raster_variant(request, hip):
     yield request.param
     hip.set_option(2, 5)
     hip.set_option(6, 512)
-    hip.set_option(7, 3)
+    hip.set_option(7, 0)
 
 
 def _same(a, b):

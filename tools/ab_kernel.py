@@ -19,7 +19,7 @@ from geograypher_amd._hip import HipRaster
 from geograypher_amd.utils import synthetic
 
 H, W, C = 3000, 4000, 4
-DEFAULT = ["v1:0", "v2:1", "v2_st16:3", "v2_st16_pf:7"]
+DEFAULT = ["base:0", "xcd:64"]
 
 
 def main():
@@ -44,10 +44,8 @@ def main():
     acc = {v[0]: {"plain": [], "fused": []} for v in variants}
 
     def setopt(var, dbg, thl, cap, ldspad=0, kt=4, batch=64, pfd=2048):
-        hip.set_option(97, pfd)
         hip.set_option(3, batch)
         hip.set_option(98, ldspad)
-        hip.set_option(8, kt)
         hip.set_option(2, thl)
         hip.set_option(6, cap)
         hip.set_option(7, var)
@@ -82,7 +80,7 @@ def main():
             st = hip.stage_times()
             hip.set_profiling(False)
             acc[name]["fused"].append({k: st[k] / st["views"] * 1e3 for k in ("setup_ms", "raster_ms", "vote_ms")})
-    setopt(3, 0, 5, 512)
+    setopt(0, 0, 5, 512)
     for name, var, dbg, thl, cap, ldspad, kt, batch, pfd in variants:
         out = {"variant": name, "var": var, "dbg": dbg, "thl": thl, "cap": cap, "ldspad": ldspad, "kt": kt, "batch": batch, "pfd": pfd}
         for kind in ("plain", "fused"):
