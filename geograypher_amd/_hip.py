@@ -206,6 +206,8 @@ class HipRaster:
         self._ctx = handle
         self._verts = None
         self._faces = None
+        self.last_retries = 0
+        self.last_stats = {}
         self.n_faces = 0
         self.n_verts = 0
 
@@ -284,6 +286,7 @@ class HipRaster:
             raise ValueError("out must be a contiguous int32 tensor of shape (N,h,w)")
         depth = torch.empty((n, h, w), dtype=torch.float32, device=self.device) if want_depth else None
         v0 = 0
+        self.last_retries = 0
         for attempt in range(4):
             with torch.cuda.device(self.device):
                 rc = self.lib.gr_raster_face_ids(
@@ -297,6 +300,7 @@ class HipRaster:
             rc = self.lib.gr_raster_status(self._ctx, ctypes.byref(st))
             if rc == GR_EOVERFLOW and attempt < 3:
                 v0 += int(st.views_done)  # the library has recorded the need; only the unfinished views are repeated
+                self.last_retries += 1
                 continue
             self._check(rc, "gr_raster_status")
             self.last_stats = st.as_dict()
@@ -449,6 +453,7 @@ class HipRaster:
             raise ValueError(f"{cams_t.shape[0]} camera records for {n} label images")
         flags = GR_FLAG_NEG1_IS_LAST_FACE if neg1_is_last_face else 0
         v0 = 0
+        self.last_retries = 0
         for attempt in range(4):
             with torch.cuda.device(self.device):
                 rc = self.lib.gr_raster_project_labels_u8(
@@ -463,6 +468,7 @@ class HipRaster:
             if rc == GR_EOVERFLOW and attempt < 3:
                 # the votes of the first views_done views are in; the library skipped the rest on the device
                 v0 += int(st.views_done)
+                self.last_retries += 1
                 continue
             self._check(rc, "gr_raster_status")
             self.last_stats = st.as_dict()

@@ -196,7 +196,8 @@ class PhotogrammetryCamera:
         return {"position": position, "focal_point": focal_point, "up": up, "view_angle": view_angle}
 
     def get_raster_record(
-        self, image_scale: float = 1.0, near: float = 1e-3, principal_point: str = "center"
+        self, image_scale: float = 1.0, near: float = 1e-3, principal_point: str = "center", origin=None,
+        focal_scaling: str = "scaled",
     ) -> np.ndarray:
         """Pack this view into the 16-float record of include/geograster.h.
 
@@ -205,20 +206,34 @@ class PhotogrammetryCamera:
         (cameras.py:469-475, meshes.py:1801, 1820-1822).  principal_point="center" reproduces that (cx, cy ignored
         exactly as the reference's pyvista path does); "intrinsics" places it at (w/2 + cx*s, h/2 + cy*s), the
         convention of the reference's PyTorch3D plugin (derived_meshes.py:772-780) scaled to the window.
+
+        origin: float64 point subtracted from the camera position before the fp32 cast (the mesh class subtracts the
+            same point from the vertices: ECEF-magnitude coordinates keep their metres, VTK does the same with its
+            automatic VBO shift).
+        focal_scaling: "scaled" = f * h / image_height (what the pyvista camera's vertical view angle gives in an
+            (h, w) window); "unscaled" reproduces the PyTorch3D plugin, which hands the FULL-resolution focal length and
+            principal point to a down-scaled image (derived_meshes.py:686-692, 772-780: `focal_length=camera.f`,
+            `image_size` scaled) -- a bug-compatibility switch, only meaningful with principal_point="intrinsics".
         """
         h, w = self.get_image_size(image_scale)
         T = np.asarray(self.cam_to_world_transform, dtype=np.float64)
-        f_eff = float(self.f) * h / float(self.image_height)
+        if focal_scaling == "scaled":
+            f_eff = float(self.f) * h / float(self.image_height)
+        elif focal_scaling == "unscaled":
+            f_eff = float(self.f)
+        else:
+            raise ValueError(f"focal_scaling must be 'scaled' or 'unscaled', not {focal_scaling!r}")
         if principal_point == "center":
             cxp, cyp = w / 2.0, h / 2.0
         elif principal_point == "intrinsics":
-            cxp = w / 2.0 + float(self.cx) * h / float(self.image_height)
-            cyp = h / 2.0 + float(self.cy) * h / float(self.image_height)
+            k = 1.0 if focal_scaling == "unscaled" else h / float(self.image_height)
+            cxp = w / 2.0 + float(self.cx) * k
+            cyp = h / 2.0 + float(self.cy) * k
         else:
             raise ValueError(f"principal_point must be 'center' or 'intrinsics', not {principal_point!r}")
         rec = np.empty(16, dtype=np.float32)
         rec[0:9] = T[:3, :3].reshape(9)
-        rec[9:12] = T[:3, 3]
+        rec[9:12] = T[:3, 3] if origin is None else T[:3, 3] - np.asarray(origin, dtype=np.float64)
         rec[12] = f_eff
         rec[13] = cxp
         rec[14] = cyp
@@ -362,7 +377,8 @@ class PhotogrammetryCameraSet:
         return self._local_to_epsg_4978_transform
 
     def get_raster_records(
-        self, image_scale: float = 1.0, near: Union[float, List[float]] = 1e-3, principal_point: str = "center"
+        self, image_scale: float = 1.0, near: Union[float, List[float]] = 1e-3, principal_point: str = "center",
+        origin=None, focal_scaling: str = "scaled",
     ) -> np.ndarray:
         """(N,16) float32 records for the HIP rasterizer; all cameras must share one image size."""
         nears = [near] * len(self.cameras) if np.isscalar(near) else list(near)
@@ -370,7 +386,8 @@ class PhotogrammetryCameraSet:
         if len(sizes) > 1:
             raise ValueError("Not all cameras have the same image size")
         return np.stack(
-            [cam.get_raster_record(image_scale, nr, principal_point) for cam, nr in zip(self.cameras, nears)], axis=0
+            [cam.get_raster_record(image_scale, nr, principal_point, origin, focal_scaling)
+             for cam, nr in zip(self.cameras, nears)], axis=0
         )
 
     # -- distortion (the warp stage itself is the "next" row f1 of SURVEY.md section 8) -------------------------------

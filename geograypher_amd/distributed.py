@@ -42,3 +42,23 @@ def all_reduce_votes(votes, counts, group=None):
     votes.copy_(packed[:, :C])
     counts.copy_(packed[:, C])
     return votes, counts
+
+
+def all_reduce_sums(sums, counts, group=None):
+    """Float-image aggregation (meshes.py:2057-2067: nansum of the projections + per-face view counts): sums (F,C)
+    float64 and counts (F,) int32 of all ranks are added in place with ONE collective over a packed [F x (C+1)] float64
+    buffer (the counts ride along as float64: exact below 2^53).  Sums of doubles depend on the order of addition only in
+    the last bits (1e-16 relative; the north star's tolerance is 1e-5)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return sums, counts
+    F, C = sums.shape
+    packed = torch.empty((F, C + 1), dtype=torch.float64, device=sums.device)
+    packed[:, :C] = sums
+    packed[:, C] = counts.to(torch.float64)
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    sums.copy_(packed[:, :C])
+    counts.copy_(packed[:, C].to(counts.dtype))
+    return sums, counts

@@ -63,6 +63,20 @@ class LocalMesh:
             self._bounds = np.array([lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]], dtype=np.float64)
         return self._bounds
 
+    def origin(self) -> np.ndarray:
+        """float64 point the rasterizer's fp32 frame is centred on.  The kernels compute p - t in fp32, so coordinates
+        of ECEF magnitude (6.4e6 m: fp32 ulp 0.5 m) must be re-centred before the cast -- VTK does the same with its
+        automatic VBO shift/scale.  Meshes whose coordinates are already small (|x| < 4096: ulp <= 0.5 mm) keep the
+        frame they have; otherwise the origin is the bounding-box centre rounded to whole metres."""
+        if getattr(self, "_origin", None) is None:
+            b = self.bounds()
+            finite = np.all(np.isfinite(b))
+            if finite and np.max(np.abs(b)) >= 4096.0:
+                self._origin = np.round(np.array([(b[0] + b[1]) / 2, (b[2] + b[3]) / 2, (b[4] + b[5]) / 2]))
+            else:
+                self._origin = np.zeros(3)
+        return self._origin
+
 
 def _parse_mesh(mesh) -> typing.Tuple[np.ndarray, np.ndarray]:
     """Accept (points, faces), a pyvista-like object (.points/.faces), or a .npz file with those two arrays."""
@@ -278,7 +292,7 @@ class TexturedPhotogrammetryMesh:
         T = np.eye(4) if T is None else np.asarray(T, dtype=np.float64)
         key = hashlib.sha1(T.tobytes()).hexdigest()
         cache = self.__dict__.setdefault("_local_mesh_cache", {})
-        if not inplace and key in cache and cache[key][0] is self.points:
+        if not inplace and key in cache and cache[key][0] is self.points and cache[key][1].faces is self.faces:
             return cache[key][1]  # the reference transforms the whole mesh again for every call (meshes.py:1659-1666)
         epsg_4978_to_camera = np.linalg.inv(T)
         pts = np.asarray(self.points, dtype=np.float64)
@@ -294,13 +308,20 @@ class TexturedPhotogrammetryMesh:
         return mesh
 
     def _ensure_uploaded(self, mesh: LocalMesh):
-        key = (id(self.faces), mesh.key if mesh.key is not None else id(mesh.points))
-        if self._uploaded_key != key:
-            self.backend.upload_mesh(mesh.points.astype(np.float32), mesh.faces.astype(np.int32))
-            self._uploaded_key = key
+        """Upload `mesh` unless the device already holds exactly these arrays.  The cache holds strong references and
+        compares identity (`is`) of the point and face arrays: a different array -- also one that happens to reuse the
+        id() of a freed temporary -- is always uploaded again."""
+        held = self._uploaded_key
+        if held is None or held[0] is not mesh.points or held[1] is not mesh.faces:
+            origin = mesh.origin()
+            pts = np.asarray(mesh.points, dtype=np.float64)
+            if np.any(origin != 0.0):
+                pts = pts - origin
+            self.backend.upload_mesh(pts.astype(np.float32), mesh.faces.astype(np.int32))
+            self._uploaded_key = (mesh.points, mesh.faces)
 
     # -- pix2face ------------------------------------------------------------------------------------------------
-    def _raster_records(self, cameras, mesh, render_img_scale, near=None, principal_point="center"):
+    def _raster_records(self, cameras, mesh, render_img_scale, near=None, principal_point="center", focal_scaling="scaled"):
         """Upload the local mesh if needed and pack the (N,16) camera records; returns (records, (h, w))."""
         if isinstance(cameras, PhotogrammetryCamera):
             cameras = PhotogrammetryCameraSet([cameras], local_to_epsg_4978_transform=cameras._local_to_epsg_4978_transform)
@@ -314,12 +335,14 @@ class TexturedPhotogrammetryMesh:
             near = vtk_like_near_planes(
                 np.stack([np.asarray(c.cam_to_world_transform, dtype=np.float64) for c in cameras.cameras]), mesh.bounds()
             )
-        records = cameras.get_raster_records(render_img_scale, near=near, principal_point=principal_point)
+        records = cameras.get_raster_records(render_img_scale, near=near, principal_point=principal_point,
+                                             origin=mesh.origin(), focal_scaling=focal_scaling)
         return records, cameras.cameras[0].get_image_size(render_img_scale)
 
-    def _pix2face_device(self, cameras, mesh, render_img_scale, near=None, principal_point="center"):
+    def _pix2face_device(self, cameras, mesh, render_img_scale, near=None, principal_point="center", focal_scaling="scaled"):
         """(N,h,w) int32 device tensor of face ids for a camera or camera set."""
-        records, (h, w) = self._raster_records(cameras, mesh, render_img_scale, near=near, principal_point=principal_point)
+        records, (h, w) = self._raster_records(cameras, mesh, render_img_scale, near=near, principal_point=principal_point,
+                                               focal_scaling=focal_scaling)
         return self.backend.raster_face_ids(records, h, w)
 
     def pix2face(
@@ -334,6 +357,7 @@ class TexturedPhotogrammetryMesh:
         return_tensor: bool = False,
         near: typing.Union[None, float, typing.List[float]] = None,
         principal_point: str = "center",
+        focal_scaling: str = "scaled",
     ):
         """Face hit by the ray through each pixel, per camera (reference: meshes.py:1678-1856).
 
@@ -342,6 +366,10 @@ class TexturedPhotogrammetryMesh:
         device tensor is returned instead (no host copy).  `save_to_cache` / `cache_folder` are accepted for API
         compatibility and unused, as in the reference's own GPU plugin (derived_meshes.py:665-668): rasterizing on
         the GPU is faster than reading a cached array from disk.
+
+        `principal_point="intrinsics"` + `focal_scaling="unscaled"` reproduces the reference's PyTorch3D plugin
+        (derived_meshes.py:686-692, 772-780), including its use of the full-resolution focal length on a down-scaled
+        image; the defaults reproduce the pyvista path (cameras.py:446-477).
         """
         if distortion_set is None and apply_distortion:
             self.logger.warning("Distortion requested but no distortion parameters provided. Skipping")
@@ -349,7 +377,8 @@ class TexturedPhotogrammetryMesh:
         single = isinstance(cameras, PhotogrammetryCamera)
         if not single and not isinstance(cameras, PhotogrammetryCameraSet):
             raise TypeError()
-        ids = self._pix2face_device(cameras, mesh, render_img_scale, near=near, principal_point=principal_point)
+        ids = self._pix2face_device(cameras, mesh, render_img_scale, near=near, principal_point=principal_point,
+                                    focal_scaling=focal_scaling)
         if apply_distortion:
             # reference: meshes.py:1842-1854.  A base camera set raises NotImplementedError here, as the reference does
             cams = [cameras] if single else cameras.cameras
@@ -480,7 +509,8 @@ class TexturedPhotogrammetryMesh:
         `SegmentorPhotogrammetryCameraSet`) and `return_all` is False, face ids and vote histograms stay on the GPU:
         per view one winner pass + one vote pass in uint32 (bit-exact, order independent), one finalize at the end.
         `distributed=True` (inside an initialised torch.distributed job): this rank handles views rank::world and the
-        per-face votes are summed with ONE all-reduce (RCCL over xGMI) before finalising.
+        per-face votes (index labels: [F x (C+1)] int32, bit-identical for every world size) or sums + counts (float
+        images: [F x (C+1)] float64) are added with ONE all-reduce (RCCL over xGMI) before finalising.
         """
         from geograypher_amd import distributed as dist_utils
 
@@ -494,7 +524,18 @@ class TexturedPhotogrammetryMesh:
         batch_stop = max(len(cameras) - batch_size + 1, 1)
         view_inds = [i for s in range(0, batch_stop, batch_size) for i in range(s, s + batch_size)]
 
+        loader_threads = kwargs.pop("loader_threads", None)
+        unknown = [k for k in kwargs if k not in _PIX2FACE_KWARGS]
+        if unknown:
+            raise TypeError(f"pix2face() got an unexpected keyword argument {unknown[0]!r}")
+        # The fused path rasterizes with the plain pinhole records.  Whatever else pix2face honours -- a distortion set
+        # (unless explicitly switched off), an explicit mesh -- goes through pix2face itself: ids per chunk from
+        # `pix2face(return_tensor=True, **kwargs)`, then the unfused winner + vote kernels.
+        wants_warp = kwargs.get("distortion_set") is not None and kwargs.get("apply_distortion", True)
+        fused_ok = not wants_warp and kwargs.get("mesh") is None
         label_fn = getattr(cameras, "get_label_index_image", None) if not return_all else None
+        if label_fn is not None and int(cameras.n_image_channels()) > 255:
+            label_fn = None  # class indices do not fit the uint8 label images of the fast path
         first_label = label_fn(view_inds[0], aggregate_img_scale) if label_fn is not None else None
 
         if first_label is not None:
@@ -515,23 +556,38 @@ class TexturedPhotogrammetryMesh:
             from concurrent.futures import ThreadPoolExecutor
 
             thread_safe = bool(getattr(getattr(cameras, "segmentor", None), "thread_safe_lookup", False))
-            n_workers = int(kwargs.pop("loader_threads", min(8, os.cpu_count() or 1) if thread_safe else 1))
-            h0, w0 = np.asarray(first_label).shape[:2] if not isinstance(first_label, torch.Tensor) else first_label.shape[:2]
+            n_workers = int(loader_threads if loader_threads is not None else (min(8, os.cpu_count() or 1) if thread_safe else 1))
+            # the label images must have the size the camera records are built for (the reference fails with a shape
+            # error in `textured_faces[flat_pix2face] = flat_img` otherwise, meshes.py:1998-2001)
+            h0, w0 = cameras.cameras[view_inds[0]].get_image_size(aggregate_img_scale)
             on_gpu = self.backend.device.type == "cuda"
+
+            def check_shape(shape, i):
+                if tuple(shape[:2]) != (h0, w0):
+                    raise ValueError(
+                        f"label image of view {i} has shape {tuple(shape[:2])}, but the camera renders {(h0, w0)} at "
+                        f"aggregate_img_scale={aggregate_img_scale}"
+                    )
 
             def one_label(i):
                 return first_label if i == view_inds[0] else label_fn(i, aggregate_img_scale)
 
             def load_chunk(inds, img_pool):
                 if isinstance(first_label, torch.Tensor):  # the segmentor already produces tensors
-                    return torch.stack([one_label(i).to(self.backend.device, torch.uint8) for i in inds], dim=0)
+                    labs = [one_label(i) for i in inds]
+                    for i, lab in zip(inds, labs):
+                        check_shape(lab.shape, i)
+                    labs = [torch.where((lab < 0) | (lab > 255), torch.full_like(lab, 255), lab)
+                            if lab.dtype != torch.uint8 else lab for lab in labs]
+                    return torch.stack([lab.to(self.backend.device, torch.uint8) for lab in labs], dim=0)
                 stage = torch.empty((len(inds), h0, w0), dtype=torch.uint8, pin_memory=on_gpu)
                 view = stage.numpy()
 
                 def fill(k):
                     lab = np.asarray(one_label(inds[k]))
-                    if lab.shape != (h0, w0):
-                        raise ValueError(f"label image of view {inds[k]} has shape {lab.shape}, expected {(h0, w0)}")
+                    check_shape(lab.shape, inds[k])
+                    if lab.dtype != np.uint8:  # an index outside [0, 255] is no class: the ignore value, not a wrapped class
+                        lab = np.where((lab < 0) | (lab > 255), 255, lab)
                     view[k] = lab  # casts to uint8 while copying
 
                 list(img_pool.map(fill, range(len(inds))))
@@ -545,11 +601,21 @@ class TexturedPhotogrammetryMesh:
                     sub = cameras.get_subset_cameras(chunks[ci])
                     if lab.device.type != self.backend.device.type:
                         lab = lab.to(self.backend.device, non_blocking=True)
-                    # fused: face ids stay in the rasterizer's LDS tiles, only per-face winners reach HBM
-                    records, _ = self._raster_records(sub, mesh, aggregate_img_scale, **_raster_kwargs(kwargs))
-                    self.backend.raster_project_labels(
-                        records, lab, C, votes, counts, neg1_is_last_face=self.neg1_is_last_face
-                    )
+                    if fused_ok:
+                        # fused: face ids stay in the rasterizer's LDS tiles, only per-face winners reach HBM
+                        records, _ = self._raster_records(sub, mesh, aggregate_img_scale, **_raster_kwargs(kwargs))
+                        self.backend.raster_project_labels(
+                            records, lab, C, votes, counts, neg1_is_last_face=self.neg1_is_last_face
+                        )
+                    else:
+                        p2f_kwargs = {k: v for k, v in kwargs.items() if k in _PIX2FACE_KWARGS}
+                        p2f_kwargs.setdefault("mesh", mesh)
+                        ids = self.pix2face(cameras=sub, render_img_scale=aggregate_img_scale, return_tensor=True, **p2f_kwargs)
+                        if isinstance(ids, np.ndarray):
+                            ids = self.backend._dev(ids.astype(np.int32), torch.int32)
+                        if tuple(ids.shape[-2:]) != (h0, w0):
+                            raise ValueError(f"pix2face returned {tuple(ids.shape[-2:])} ids for {(h0, w0)} label images")
+                        self.backend.project_labels(ids, lab, C, votes, counts, neg1_is_last_face=self.neg1_is_last_face)
             if distributed and world > 1:
                 dist_utils.all_reduce_votes(votes, counts)
             avg, summed, cnt = self.backend.finalize_votes(votes, counts)
@@ -559,13 +625,21 @@ class TexturedPhotogrammetryMesh:
             }
 
         # ---- general path: float images; nansum + finite-row counts accumulate on device (meshes.py:2057-2067) ----------
-        if distributed and world > 1:
-            raise NotImplementedError("distributed aggregation is implemented for class-index label images")
-        all_projections = [] if return_all else None
         single_view = len(view_inds) == 1
+        shard = distributed and world > 1 and not single_view
+        if shard and return_all:
+            raise NotImplementedError("return_all keeps every view's projection: not available with distributed=True")
+        all_projections = [] if return_all else None
         sums = counts = first = None
-        gen = self._iter_view_inputs(cameras, batch_size, aggregate_img_scale, check_null_image, kwargs)
-        for _, ids, img, n_channels in tqdm(gen, total=len(cameras), desc="Aggregating projected viewpoints"):
+        if shard:  # this rank's views; the per-view arithmetic does not depend on the other views
+            my_cams = cameras.get_subset_cameras(view_inds[rank::world])
+            gen = self._iter_view_inputs(my_cams, 1, aggregate_img_scale, check_null_image, kwargs) if len(my_cams) else iter(())
+            total = len(my_cams)
+        else:
+            gen = self._iter_view_inputs(cameras, batch_size, aggregate_img_scale, check_null_image, kwargs)
+            total = len(cameras)
+        n_channels = None
+        for _, ids, img, n_channels in tqdm(gen, total=total, desc="Aggregating projected viewpoints"):
             if sums is None:
                 sums = torch.zeros((n_faces, n_channels), dtype=torch.float64, device=self.backend.device)
                 counts = torch.zeros((n_faces,), dtype=torch.int32, device=self.backend.device)
@@ -579,6 +653,13 @@ class TexturedPhotogrammetryMesh:
                 first = proj if first is None else first
             if img is not None:
                 self.backend.project_values(ids, img, sums, counts, neg1_is_last_face=self.neg1_is_last_face)
+        if shard:
+            if sums is None:  # a rank without views still takes part in the collective
+                n_channels = int(np.asarray(cameras.get_image_by_index(view_inds[0], aggregate_img_scale)).reshape(
+                    cameras.cameras[view_inds[0]].get_image_size(aggregate_img_scale) + (-1,)).shape[-1])
+                sums = torch.zeros((n_faces, n_channels), dtype=torch.float64, device=self.backend.device)
+                counts = torch.zeros((n_faces,), dtype=torch.int32, device=self.backend.device)
+            dist_utils.all_reduce_sums(sums, counts)
         avg, summed, cnt = self.backend.finalize_sums(sums, counts)
         avg, summed, cnt = _to_host(avg), _to_host(summed), _to_host(cnt)
         if single_view:
@@ -719,8 +800,12 @@ class TexturedPhotogrammetryMesh:
                 Image.fromarray(rendered).save(str(output_filename.with_suffix(".tif")), compression="tiff_deflate")
 
 
+_FUSED_KWARGS = ("near", "principal_point", "focal_scaling")
+_PIX2FACE_KWARGS = _FUSED_KWARGS + ("mesh", "save_to_cache", "cache_folder", "distortion_set", "apply_distortion")
+
+
 def _raster_kwargs(kwargs: dict) -> dict:
-    return {k: kwargs[k] for k in ("near", "principal_point") if k in kwargs}
+    return {k: kwargs[k] for k in _FUSED_KWARGS if k in kwargs}
 
 
 # device -> host through pinned memory.  A pageable destination moves at ~10 GB/s on the MI355X host link, a pinned one

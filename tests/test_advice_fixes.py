@@ -1,0 +1,165 @@
+"""Host-logic regressions found by the round-1 review, driven through the product's mesh class on the
+oracle backend: the aggregation fast path must honour every pix2face keyword, coordinates of ECEF magnitude must survive
+the fp32 cast, the upload cache must not alias arrays, label images are checked before they reach the device."""
+import numpy as np
+import pytest
+
+from geograypher_amd.cameras import SegmentorPhotogrammetryCameraSet
+from geograypher_amd.cameras.cameras import PhotogrammetryCamera, PhotogrammetryCameraSet
+from geograypher_amd.meshes import TexturedPhotogrammetryMesh
+from geograypher_amd.predictors import ArrayLabelSegmentor
+from geograypher_amd.utils import synthetic
+from oracle import oracle_np
+
+
+def _small_scene(n_views=3, size=(120, 160), f=125.0):
+    (points, faces), cams = synthetic.config1_scene()
+    cams = cams[0:n_views]
+    for c in cams.cameras:
+        c.image_width, c.image_height, c.image_size, c.f = size[1], size[0], size, f
+    return points, faces, cams
+
+
+def _same(a, b):
+    np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+    np.testing.assert_array_equal(np.nan_to_num(a, nan=-7.0), np.nan_to_num(b, nan=-7.0))
+
+
+def test_fast_path_with_distortion_set_equals_general_path(tmp_path, oracle_backend_cls):
+    """aggregate_projected_images(..., distortion_set=cameras) on a segmentor set: the votes must come from the WARPED id
+    images, exactly as the float-image path (and the reference, meshes.py:2033 -> 1981 -> pix2face(**kwargs)) does."""
+    from tests.test_warp import _metashape_set, simplify_camera
+
+    mesh, _ = synthetic.make_simple_mesh(pixels=[], color=None)
+    be = oracle_backend_cls()
+    tm = TexturedPhotogrammetryMesh(mesh=mesh, log_level="ERROR", backend=be)
+    cameras = _metashape_set(tmp_path)
+    sensor = 65
+    camera = simplify_camera(cameras.cameras[0], image=np.ones((sensor, sensor, 3)))
+    camera.distortion_params["k1"] = -0.05
+    cameras._local_to_epsg_4978_transform = np.eye(4)
+    HT = synthetic.downward_view(scene_width=4, focal=camera.f, sensor_width=sensor)
+    camera.cam_to_world_transform, camera.world_to_cam_transform = HT, np.linalg.inv(HT)
+    orig = cameras.warp_dewarp_image
+    cameras.warp_dewarp_image = lambda *a, **k: orig(*a, backend=be, **k)
+    one = cameras[0:1]
+    one.warp_dewarp_image = cameras.warp_dewarp_image
+    C = 3
+    rng = np.random.default_rng(3)
+    labels = [rng.integers(0, C, size=(sensor, sensor)).astype(np.uint8)]
+    seg = ArrayLabelSegmentor(labels, C, filenames=[camera.image_filename])
+    seg_set = SegmentorPhotogrammetryCameraSet(one, seg)
+    seg_set.warp_dewarp_image = cameras.warp_dewarp_image
+
+    warped = tm.pix2face(one, distortion_set=cameras, apply_distortion=True)
+    ideal = tm.pix2face(one, apply_distortion=False)
+    assert (warped != ideal).mean() > 0.05  # the warp matters in this scene
+    fast, info = tm.aggregate_projected_images(seg_set, distortion_set=cameras)
+    want = oracle_np.project_image(warped[0].astype(np.int64), oracle_np.inds_to_one_hot(labels[0], C).astype(float),
+                                   mesh[1].shape[0], neg1_is_last_face=True)
+    _same(fast, want)
+    # switching the warp off explicitly takes the fused path and gives the un-warped votes
+    plain, _ = tm.aggregate_projected_images(seg_set, distortion_set=cameras, apply_distortion=False)
+    want_plain = oracle_np.project_image(ideal[0].astype(np.int64), oracle_np.inds_to_one_hot(labels[0], C).astype(float),
+                                         mesh[1].shape[0], neg1_is_last_face=True)
+    _same(plain, want_plain)
+    assert np.nansum(np.abs(np.nan_to_num(fast) - np.nan_to_num(plain))) > 0
+
+
+def test_unknown_keyword_is_refused_like_pix2face_would(oracle_backend_cls):
+    points, faces, cams = _small_scene(2)
+    tm = TexturedPhotogrammetryMesh((points, faces), log_level="ERROR", backend=oracle_backend_cls())
+    labels = [np.zeros((120, 160), dtype=np.uint8)] * 2
+    seg_set = SegmentorPhotogrammetryCameraSet(cams, ArrayLabelSegmentor(labels, 2, filenames=[c.image_filename for c in cams.cameras]))
+    with pytest.raises(TypeError, match="unexpected keyword"):
+        tm.aggregate_projected_images(seg_set, not_a_pix2face_argument=1)
+
+
+def test_ecef_magnitude_coordinates_survive_the_fp32_cast(oracle_backend_cls):
+    """A mesh + cameras translated by an ECEF-sized offset render the same ids as at the origin: the mesh class
+    re-centres both in float64 before the fp32 cast (without it 6.4e6 m coordinates snap to a 0.5 m lattice)."""
+    points, faces, cams = _small_scene(3)
+    q = 2.0**-16  # quantise so that the translation below is exact in float64
+    points = np.round(points / q) * q
+    for c in cams.cameras:
+        T = np.array(c.cam_to_world_transform, dtype=np.float64)
+        T[:3, 3] = np.round(T[:3, 3] / q) * q
+        c.cam_to_world_transform, c.world_to_cam_transform = T, np.linalg.inv(T)
+    be0, be1 = oracle_backend_cls(), oracle_backend_cls()
+    near = 0.05
+    base = TexturedPhotogrammetryMesh((points, faces), log_level="ERROR", backend=be0).pix2face(cams, apply_distortion=False, near=near)
+    offset = np.array([-2_517_000.0, -4_198_000.0, 4_076_000.0])  # a point on the WGS84 ellipsoid, whole metres
+    moved_cams = []
+    for c in cams.cameras:
+        T = np.array(c.cam_to_world_transform, dtype=np.float64)
+        T[:3, 3] += offset
+        moved_cams.append(PhotogrammetryCamera(c.image_filename, T, c.f, c.cx, c.cy, c.image_width, c.image_height,
+                                               local_to_epsg_4978_transform=np.eye(4)))
+    moved_set = PhotogrammetryCameraSet(moved_cams, local_to_epsg_4978_transform=np.eye(4))
+    moved_mesh = TexturedPhotogrammetryMesh((points + offset, faces), log_level="ERROR", backend=be1)
+    assert np.array_equal((points + offset) - offset, points)
+    moved = moved_mesh.pix2face(moved_set, apply_distortion=False, near=near)
+    np.testing.assert_array_equal(moved, base)
+    assert (base >= 0).mean() > 0.5
+    assert np.abs(be1.verts).max() < 4096  # what reached the device is centred
+    assert np.abs(be0.verts - points.astype(np.float32)).max() == 0  # small coordinates are left where they are
+
+
+def test_upload_cache_follows_array_identity(oracle_backend_cls):
+    points, faces, cams = _small_scene(1)
+    be = oracle_backend_cls()
+    tm = TexturedPhotogrammetryMesh((points, faces), log_level="ERROR", backend=be)
+    a = tm.pix2face(cams, apply_distortion=False)
+    tm.pix2face(cams, apply_distortion=False)
+    assert be.uploads == 1  # same arrays, same transform: no second upload
+    tm.points = tm.points + np.array([0.0, 0.0, -3.0])  # a new points array
+    b = tm.pix2face(cams, apply_distortion=False)
+    assert be.uploads == 2 and not np.array_equal(a, b)
+    # explicit meshes built from temporaries: every call uploads what it was given
+    for dz in (0.0, -5.0):
+        got = tm.pix2face(cams, mesh=(points + np.array([0.0, 0.0, dz]), faces), apply_distortion=False)
+        want = TexturedPhotogrammetryMesh((points + np.array([0.0, 0.0, dz]), faces), log_level="ERROR",
+                                          backend=oracle_backend_cls()).pix2face(cams, apply_distortion=False)
+        np.testing.assert_array_equal(got, want)
+    assert be.uploads == 4
+    tm.faces = tm.faces[::-1].copy()  # new face array, same points
+    tm.pix2face(cams, apply_distortion=False)
+    assert be.uploads == 5
+
+
+def test_label_images_are_checked(oracle_backend_cls):
+    points, faces, cams = _small_scene(2)
+    tm = TexturedPhotogrammetryMesh((points, faces), log_level="ERROR", backend=oracle_backend_cls())
+    names = [c.image_filename for c in cams.cameras]
+    wrong = [np.zeros((100, 160), dtype=np.uint8)] * 2
+    with pytest.raises(ValueError, match="label image of view"):
+        tm.aggregate_projected_images(SegmentorPhotogrammetryCameraSet(cams, ArrayLabelSegmentor(wrong, 3, filenames=names)))
+    # class indices beyond 255 (or negative) are no class: they must not wrap into a valid one
+    ids = tm.pix2face(cams, apply_distortion=False)
+    rng = np.random.default_rng(0)
+    lab32 = [rng.integers(0, 3, size=(120, 160)).astype(np.int32) for _ in range(2)]
+    lab32[0][::3, ::2] = 256 + 1  # would wrap to class 1 as uint8
+    lab32[1][::5, ::3] = -2       # would wrap to 254
+    seg = ArrayLabelSegmentor(lab32, 3, filenames=names)
+    avg, info = tm.aggregate_projected_images(SegmentorPhotogrammetryCameraSet(cams, seg))
+    want_sum = np.zeros((faces.shape[0], 3))
+    want_cnt = np.zeros(faces.shape[0])
+    for v in range(2):
+        lab = np.where((lab32[v] < 0) | (lab32[v] > 255), 255, lab32[v])
+        proj = oracle_np.project_image(ids[v], oracle_np.inds_to_one_hot(lab, 3).astype(float), faces.shape[0], True)
+        want_sum += np.nan_to_num(proj)
+        want_cnt += np.isfinite(proj).any(axis=1)
+    _same(info["projection_counts"], want_cnt)
+    _same(np.nan_to_num(info["summed_projections"]), want_sum * (want_cnt[:, None] > 0))
+
+
+def test_pytorch3d_plugin_focal_length_switch():
+    """derived_meshes.py:686-692, 772-780: the plugin gives the FULL-resolution focal length and principal point to a
+    down-scaled image."""
+    cam = PhotogrammetryCamera(None, np.eye(4), f=3000.0, cx=12.0, cy=-7.0, image_width=4000, image_height=3000)
+    rec = cam.get_raster_record(0.25, near=1.0, principal_point="intrinsics", focal_scaling="unscaled")
+    assert rec[12] == 3000.0 and rec[13] == 500.0 + 12.0 and rec[14] == 375.0 - 7.0
+    rec = cam.get_raster_record(0.25, near=1.0, principal_point="intrinsics")
+    assert rec[12] == 750.0 and rec[13] == 500.0 + 3.0 and rec[14] == 375.0 - 1.75
+    with pytest.raises(ValueError):
+        cam.get_raster_record(focal_scaling="half")

@@ -117,3 +117,58 @@ def test_mesh_class_distributed_aggregation_equals_single_process(tmp_path):
         np.testing.assert_array_equal(np.isnan(got), np.isnan(want_avg))
         np.testing.assert_array_equal(np.nan_to_num(got), np.nan_to_num(want_avg))
         np.testing.assert_array_equal(np.load(tmp_path / f"cnt_{r}.npy"), want_cnt)
+
+
+def _float_worker(rank, world, port, out_dir):
+    """aggregate_projected_images(distributed=True) for FLOAT images (meshes.py:2057-2067: nansum + finite-row counts):
+    every rank projects its views, ONE all-reduce of the packed [F x (C+1)] float64 sums + counts."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from geograypher_amd.cameras.cameras import PhotogrammetryCameraSet
+        from geograypher_amd.meshes import TexturedPhotogrammetryMesh
+        from geograypher_amd.utils import synthetic
+        from tests.oracle_backend import OracleBackend
+
+        (points, faces), cams = synthetic.config1_scene()
+        cams = cams[0:5]
+        for c in cams.cameras:
+            c.image_width, c.image_height, c.image_size, c.f = 96, 72, (72, 96), 75.0
+
+        class ImageSet(PhotogrammetryCameraSet):
+            def get_image_by_index(self, index, image_scale=1.0):
+                rng = np.random.default_rng(100 + int(Path_name(self.cameras[index])))
+                img = rng.random((72, 96, 3))
+                img[rng.random((72, 96)) < 0.05] = np.nan  # unknown pixels
+                return img
+
+        def Path_name(cam):
+            return str(cam.image_filename).split("_")[-1].split(".")[0]
+
+        img_set = ImageSet(cams.cameras, local_to_epsg_4978_transform=np.eye(4))
+        mesh = TexturedPhotogrammetryMesh((points, faces), log_level="ERROR", backend=OracleBackend())
+        avg, info = mesh.aggregate_projected_images(img_set, distributed=True, apply_distortion=False)
+        np.save(os.path.join(out_dir, f"favg_{rank}.npy"), avg)
+        np.save(os.path.join(out_dir, f"fcnt_{rank}.npy"), info["projection_counts"])
+        np.save(os.path.join(out_dir, f"fsum_{rank}.npy"), info["summed_projections"])
+        if rank == 0:
+            avg1, info1 = mesh.aggregate_projected_images(img_set, distributed=False, apply_distortion=False)
+            np.save(os.path.join(out_dir, "favg_single.npy"), avg1)
+            np.save(os.path.join(out_dir, "fcnt_single.npy"), info1["projection_counts"])
+            np.save(os.path.join(out_dir, "fsum_single.npy"), info1["summed_projections"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_float_image_aggregation_distributed_equals_single_process(tmp_path):
+    world = 2
+    mp.spawn(_float_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want_avg, want_cnt = np.load(tmp_path / "favg_single.npy"), np.load(tmp_path / "fcnt_single.npy")
+    want_sum = np.load(tmp_path / "fsum_single.npy")
+    assert np.nansum(want_cnt) > 1000 and np.nanmax(want_cnt) >= 3
+    for r in range(world):
+        np.testing.assert_array_equal(np.load(tmp_path / f"fcnt_{r}.npy"), want_cnt)
+        np.testing.assert_allclose(np.load(tmp_path / f"fsum_{r}.npy"), want_sum, rtol=1e-12, atol=0, equal_nan=True)
+        np.testing.assert_allclose(np.load(tmp_path / f"favg_{r}.npy"), want_avg, rtol=1e-12, atol=0, equal_nan=True)  # north star: 1e-5
