@@ -12,7 +12,8 @@ _lib = None
 
 def build(force: bool = False):
     """Compile the C oracle with gcc (building the checker is not using it)."""
-    if force or not _SO.is_file() or _SO.stat().st_mtime < (_DIR / "oracle_raster.c").stat().st_mtime:
+    newest = max((_DIR / f).stat().st_mtime for f in ("oracle_raster.c", "oracle_envelope.c", "Makefile"))
+    if force or not _SO.is_file() or _SO.stat().st_mtime < newest:
         subprocess.run(["make", "-C", str(_DIR), "-B" if force else "-s"], check=True, capture_output=True)
     return _SO
 
@@ -31,6 +32,11 @@ def lib():
         L.orc_raster_views.argtypes = [vp, vp, i64, i64, vp, i32, i32, i32, vp, i32]
         L.orc_project_labels.restype = i32
         L.orc_project_labels.argtypes = [vp, vp, i32, i32, i64, i32, i32, vp, vp, vp]
+        f64 = ctypes.c_double
+        L.orc_envelope.restype = i32
+        L.orc_envelope.argtypes = [vp, vp, i64, vp, i32, i32, f64, f64, vp, vp, vp, vp, vp, vp]
+        L.orc_raster_float.restype = i32
+        L.orc_raster_float.argtypes = [vp, vp, i64, vp, i32, i32, vp, vp]
         _lib = L
     return _lib
 
@@ -74,3 +80,35 @@ def project_labels(ids, labels, n_faces, C, votes, counts, neg1_is_last_face=Tru
     rc = lib().orc_project_labels(_p(ids), _p(labels), h, w, n_faces, C, 1 if neg1_is_last_face else 0, _p(votes),
                                   _p(counts), _p(winner))
     assert rc == 0
+
+
+ENVELOPE_DELTA = 1.0 / 256 + 2e-3   # pixels: one sub-pixel step of an 8-bit grid + the fp32 transform error at f = 4000 px
+ENVELOPE_GAP = 1e-5                 # relative depth gap below which the nearer of two faces is an implementation choice
+
+
+def envelope(verts, faces, cam, h, w, delta=ENVELOPE_DELTA, gap_rel=ENVELOPE_GAP):
+    """Classify every pixel of one view (oracle_envelope.c::orc_envelope): returns (cls (h,w) uint8 with 0 = background
+    under every conforming rasterizer, 1 = the face in `ids` under every conforming rasterizer, 2 = implementation-
+    defined; ids (h,w) int32; number of faces that straddle the near plane and were not classified)."""
+    verts = np.ascontiguousarray(verts, dtype=np.float32)
+    faces = np.ascontiguousarray(faces, dtype=np.int32)
+    cam = np.ascontiguousarray(cam, dtype=np.float32).reshape(16)
+    cls = np.empty((h, w), dtype=np.uint8)
+    ids = np.empty((h, w), dtype=np.int32)
+    zA, zB = np.empty((h, w), dtype=np.float64), np.empty((h, w), dtype=np.float64)
+    fA, sure = np.empty((h, w), dtype=np.int32), np.empty((h, w), dtype=np.uint8)
+    n = lib().orc_envelope(_p(verts), _p(faces), faces.shape[0], _p(cam), h, w, float(delta), float(gap_rel), _p(cls),
+                           _p(ids), _p(zA), _p(zB), _p(fA), _p(sure))
+    return cls, ids, n
+
+
+def raster_float(verts, faces, cam, h, w):
+    """The second, independently written rasterizer (un-snapped float64, closed triangles, ties -> higher id):
+    returns ((h,w) int32 ids, number of faces skipped because they reach behind the near plane)."""
+    verts = np.ascontiguousarray(verts, dtype=np.float32)
+    faces = np.ascontiguousarray(faces, dtype=np.int32)
+    cam = np.ascontiguousarray(cam, dtype=np.float32).reshape(16)
+    ids = np.empty((h, w), dtype=np.int32)
+    zbuf = np.empty((h, w), dtype=np.float64)
+    n = lib().orc_raster_float(_p(verts), _p(faces), faces.shape[0], _p(cam), h, w, _p(ids), _p(zbuf))
+    return ids, n
