@@ -44,6 +44,7 @@ EXPORTED_SYMBOLS = (
     "gr_count_pairs",
     "gr_warp_nearest_i32",
     "gr_warp_f64",
+    "gr_invert_distortion_f64",
     "gr_finalize_votes",
     "gr_finalize_sums_f64",
     "gr_argmax_nonzero_f64",
@@ -139,6 +140,8 @@ def load_library() -> ctypes.CDLL:
     lib.gr_warp_nearest_i32.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, ctypes.c_int32, i32, f64, f64, vp, vp]
     lib.gr_warp_f64.restype = i32
     lib.gr_warp_f64.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32, f64, vp, vp]
+    lib.gr_invert_distortion_f64.restype = i32
+    lib.gr_invert_distortion_f64.argtypes = [vp, ctypes.POINTER(f64), i32, i32, f64, i32, f64, vp, vp, vp]
     lib.gr_finalize_votes.restype = i32
     lib.gr_finalize_votes.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp]
     lib.gr_finalize_sums_f64.restype = i32
@@ -483,6 +486,25 @@ class HipRaster:
         if m.ndim != 3 or m.shape[0] != 2:
             raise ValueError(f"sampling map must be (2, H, W), got {tuple(m.shape)}")
         return m
+
+    LENS_PARAMS = ("f", "cx", "cy", "image_width", "image_height", "k1", "k2", "k3", "k4", "p1", "p2", "b1", "b2")
+
+    def invert_distortion(self, params: dict, h: int, w: int, image_scale: float = 1.0, max_iters: int = 12,
+                          fill: float = -1.0):
+        """(2, h, w) float64 device map: for every pixel of the warped image the position to sample in the ideal image
+        (gr_invert_distortion_f64: dense Newton inverse of the Metashape lens model; replaces the host griddata inversion
+        of cameras.py:1045-1062)."""
+        torch = _torch()
+        unknown = set(params) - set(self.LENS_PARAMS)
+        if unknown:
+            raise ValueError(f"Unexpected distortion params found: {sorted(unknown)}")
+        par = (ctypes.c_double * 13)(*[float(params.get(k, 0.0)) for k in self.LENS_PARAMS])
+        out = torch.empty((2, h, w), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gr_invert_distortion_f64(self._ctx, par, int(h), int(w), float(image_scale), int(max_iters),
+                                                   float(fill), out[0].data_ptr(), out[1].data_ptr(), self._stream())
+        self._check(rc, "gr_invert_distortion_f64")
+        return out
 
     def warp_image(self, input_image, map_t, order: int = 1, fill_value: float = 0.0,
                    reference_float_roundtrip: bool = False):

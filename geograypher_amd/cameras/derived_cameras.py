@@ -64,6 +64,17 @@ class MetashapeCameraSet(PhotogrammetryCameraSet):
             local_to_epsg_4978_transform=chunk_to_epsg4978,
         )
 
+    def distortion_model(self, camera: PhotogrammetryCamera) -> dict:
+        """The Metashape frame-camera model of `ideal_to_warped` as parameters for the device inversion
+        (`gr_invert_distortion_f64`); same checks as the forward model (derived_cameras.py:176-181)."""
+        params = sorted(camera.distortion_params.keys())
+        if not set(params) <= set(["b1", "b2", "k1", "k2", "k3", "k4", "p1", "p2"]):
+            raise ValueError(f"Unexpected distortion params found: {params}")
+        model = {"f": camera.f, "cx": camera.cx, "cy": camera.cy, "image_width": camera.image_width,
+                 "image_height": camera.image_height, "k1": camera.distortion_params["k1"]}
+        model.update({k: v for k, v in camera.distortion_params.items() if k != "k1"})
+        return model
+
     def ideal_to_warped(self, camera: PhotogrammetryCamera, xpix: np.ndarray, ypix: np.ndarray):
         """Metashape frame-camera model: ideal pinhole pixels -> distorted image pixels
         (reference: derived_cameras.py:163-208; k1..k4 radial, p1, p2 tangential, b1, b2 affinity/skew; the

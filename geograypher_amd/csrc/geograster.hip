@@ -1420,6 +1420,63 @@ __global__ __launch_bounds__(256) void k_warp_f64(const double *__restrict__ in,
   out[i] = v;
 }
 
+// K8b  inverse of the Metashape frame-camera model (row f1).  The reference inverts the lens model numerically ONCE per
+//      distortion key on the host: scipy griddata over every 8th pixel of the forward map (cameras.py:1045-1062,
+//      utils/indexing.py:87-150) -- minutes at 5280 x 3956, and 0.02 px off the true inverse (the piecewise-linear
+//      interpolation error of its 8-pixel triangles).  Here every pixel (i, j) of the warped image solves
+//      forward(row, col) = (i, j) by Newton's method in float64 with the analytic Jacobian of
+//      derived_cameras.py:163-208, from the identity guess: quadratic convergence, 1e-13 px after at most 8 steps for
+//      the distortions photogrammetry lenses have.  `fill` where the solution lies outside the ideal image or the
+//      iteration has not converged.  par: f, cx, cy, image_width, image_height, k1..k4, p1, p2, b1, b2.
+struct LensModel { double f, cx, cy, W, H, k1, k2, k3, k4, p1, p2, b1, b2; };
+
+// model and its Jacobian at the ORIGINAL-resolution ideal pixel (xp, yp): (u, v) = distorted pixel
+__device__ __forceinline__ void lens_forward(const LensModel &m, double xp, double yp, double &u, double &v, double &ux,
+                                             double &uy, double &vx, double &vy) {
+  const double x = (xp - m.W * 0.5) / m.f, y = (yp - m.H * 0.5) / m.f;
+  const double r2 = x * x + y * y;
+  const double R = 1.0 + r2 * (m.k1 + r2 * (m.k2 + r2 * (m.k3 + r2 * m.k4)));
+  const double Rp = 2.0 * (m.k1 + r2 * (2.0 * m.k2 + r2 * (3.0 * m.k3 + r2 * 4.0 * m.k4)));  // dR/dx = Rp x, dR/dy = Rp y
+  const double xd = x * R + (m.p1 * (r2 + 2.0 * x * x) + 2.0 * m.p2 * x * y);
+  const double yd = y * R + (m.p2 * (r2 + 2.0 * y * y) + 2.0 * m.p1 * x * y);
+  const double xdx = R + x * x * Rp + 6.0 * m.p1 * x + 2.0 * m.p2 * y, xdy = x * y * Rp + 2.0 * m.p1 * y + 2.0 * m.p2 * x;
+  const double ydx = x * y * Rp + 2.0 * m.p2 * x + 2.0 * m.p1 * y, ydy = R + y * y * Rp + 6.0 * m.p2 * y + 2.0 * m.p1 * x;
+  u = m.W * 0.5 + m.cx + xd * m.f + xd * m.b1 + yd * m.b2;
+  v = m.H * 0.5 + m.cy + yd * m.f;
+  const double inv_f = 1.0 / m.f;  // d x / d xp
+  ux = ((m.f + m.b1) * xdx + m.b2 * ydx) * inv_f; uy = ((m.f + m.b1) * xdy + m.b2 * ydy) * inv_f;
+  vx = m.f * ydx * inv_f; vy = m.f * ydy * inv_f;
+}
+
+__global__ __launch_bounds__(256) void k_invert_distortion(LensModel m, int h, int w, double scale, int unit_scale,
+                                                           int iters, double fill, double *__restrict__ map_r,
+                                                           double *__restrict__ map_c) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (int64_t)h * w) return;
+  const int i = (int)(p / w), j = (int)(p - (int64_t)i * w);
+  // the forward map of cameras.py:1012-1043: at scale 1 the model is evaluated at the pixel index itself, otherwise at the
+  // original-resolution position (index + 0.5) / scale of the scaled pixel's centre, and its result is scaled back
+  const double off = unit_scale ? 0.0 : 0.5, s = unit_scale ? 1.0 : scale, inv_s = 1.0 / s;
+  double r = (double)i, c = (double)j;
+  double er = 0.0, ec = 0.0;
+  for (int it = 0; it <= iters; ++it) {
+    double u, v, ux, uy, vx, vy;
+    lens_forward(m, (c + off) * inv_s, (r + off) * inv_s, u, v, ux, uy, vx, vy);
+    er = v * s - (double)i; ec = u * s - (double)j;  // residual in pixels of the scaled warped image
+    if (it == iters) break;
+    // d(row', col') / d(row, col): the scale factors cancel
+    const double det = vy * ux - vx * uy;
+    if (!(fabs(det) > 1e-300)) break;
+    double dr = (ux * er - vx * ec) / det, dc = (vy * ec - uy * er) / det;
+    dr = fmin(fmax(dr, -(double)h), (double)h); dc = fmin(fmax(dc, -(double)w), (double)w);
+    r -= dr; c -= dc;
+  }
+  const double tol = 1e-9 * (double)max(h, w);
+  const bool ok = fabs(er) < tol && fabs(ec) < tol && r >= 0.0 && r <= (double)(h - 1) && c >= 0.0 && c <= (double)(w - 1);
+  map_r[p] = ok ? r : fill;
+  map_c[p] = ok ? c : fill;
+}
+
 // K9  save_renders epilogue (row f2): gather the face texture and cast it the way meshes.py:2325-2337 does --
 //     values < 0, > 255 or non-finite (and pixels without a face) become `null_value`, the rest is truncated to uint8.
 __global__ __launch_bounds__(256) void k_gather_texture_u8(const int32_t *__restrict__ ids, int64_t n_pix,
@@ -2177,6 +2234,24 @@ int gr_warp_f64(gr_ctx *c, const double *in, int h_in, int w_in, int C, const do
   const int64_t n = (int64_t)h_out * w_out;
   hipLaunchKernelGGL(k_warp_f64, dim3((unsigned)ceil_div(n * C, 256)), dim3(256), 0, s, in, h_in, w_in, C, map_rows,
                      map_cols, n, order, fill, out);
+  GR_HIP(c, hipGetLastError());
+  return GR_OK;
+}
+
+int gr_invert_distortion_f64(gr_ctx *c, const double *par_h, int h, int w, double image_scale, int max_iters, double fill,
+                              double *map_rows, double *map_cols, void *stream) {
+  if (!c) return GR_EINVAL;
+  if (!par_h || !map_rows || !map_cols || h <= 0 || w <= 0 || !(image_scale > 0.0) || max_iters < 1 || max_iters > 64)
+    return fail(c, GR_EINVAL, "bad lens-inversion args");
+  if (!(par_h[0] > 0.0) || !(par_h[3] > 0.0) || !(par_h[4] > 0.0)) return fail(c, GR_EINVAL, "focal length and image size must be positive");
+  hipStream_t s = (hipStream_t)stream;
+  GR_HIP(c, hipSetDevice(c->device));
+  LensModel m = {par_h[0], par_h[1], par_h[2], par_h[3], par_h[4], par_h[5], par_h[6], par_h[7], par_h[8], par_h[9], par_h[10],
+                 par_h[11], par_h[12]};
+  const int64_t n = (int64_t)h * w;
+  const int unit = fabs(image_scale - 1.0) <= 1e-8 + 1e-5 * 1.0 ? 1 : 0;  // numpy.isclose(image_scale, 1.0), cameras.py:1012
+  hipLaunchKernelGGL(k_invert_distortion, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, m, h, w, image_scale, unit,
+                     max_iters, fill, map_rows, map_cols);
   GR_HIP(c, hipGetLastError());
   return GR_OK;
 }

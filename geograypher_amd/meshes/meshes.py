@@ -393,6 +393,7 @@ class TexturedPhotogrammetryMesh:
                     fill_value=-1,
                     interpolation_order=0,
                     image_scale=render_img_scale,
+                    backend=self.backend,
                 )
                 warped.append(out_i if isinstance(out_i, torch.Tensor) else torch.as_tensor(np.asarray(out_i)))
             out = torch.stack([w.to(torch.int32) for w in warped], dim=0)

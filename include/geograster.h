@@ -182,6 +182,17 @@ int gr_warp_nearest_i32(gr_ctx *ctx, const int32_t *in, int h_in, int w_in, cons
 int gr_warp_f64(gr_ctx *ctx, const double *in, int h_in, int w_in, int C, const double *map_rows, const double *map_cols,
                 int h_out, int w_out, int order, double fill, double *out, void *stream);
 
+/* inverse of the lens model (row f1) -- replaces the host-side inversion of the forward distortion map by
+ * scipy.interpolate.griddata on every `inversion_downsample`-th pixel (cameras.py:1045-1062, utils/indexing.py:87-150;
+ * minutes at full resolution) with a dense Newton solve on the device: for every pixel (i, j) of the warped image of size
+ * h x w (= int(image_height * image_scale) x int(image_width * image_scale)) the fractional pixel (row, col) of the
+ * ideal image that the Metashape frame-camera model (derived_cameras.py:163-208) sends there, `fill` where that lies
+ * outside the ideal image.  par_h (HOST pointer, 13 doubles): f, cx, cy, image_width, image_height, k1, k2, k3, k4, p1,
+ * p2, b1, b2.  The forward map follows cameras.py:1012-1043 (model evaluated at the pixel index at scale 1, at
+ * (index + 0.5) / scale otherwise).  map_rows / map_cols: h x w f64, the layout gr_warp_* consume. */
+int gr_invert_distortion_f64(gr_ctx *ctx, const double *par_h, int h, int w, double image_scale, int max_iters,
+                             double fill, double *map_rows, double *map_cols, void *stream);
+
 /* finalise -- meshes.py:2069-2082: summed[counts==0] = NaN; average = summed / counts.
  * votes_u32 (F x C) is converted to f64 `summed`; average and summed are F x C f64, counts_f64 is F f64. */
 int gr_finalize_votes(gr_ctx *ctx, const uint32_t *votes, const uint32_t *counts, int64_t F, int C, double *average,

@@ -61,3 +61,54 @@ def inside_mask(inverse_map, in_shape):
     "grid-constant" boundary modes agree)."""
     r, c = inverse_map
     return (r >= 0) & (r <= in_shape[0] - 1) & (c >= 0) & (c <= in_shape[1] - 1)
+
+
+# ---- inverse of the lens model (checker of gr_invert_distortion_f64) -----------------------------------------------------
+def metashape_forward(params, xpix, ypix):
+    """derived_cameras.py:163-208 restated: ideal pinhole pixel -> distorted image pixel.
+    params: dict with f, cx, cy, image_width, image_height and any of k1..k4, p1, p2, b1, b2."""
+    f, W, H = params["f"], params["image_width"], params["image_height"]
+    x = (xpix - W / 2.0) / f
+    y = (ypix - H / 2.0) / f
+    g = params.get
+    r2 = x * x + y * y
+    radial = 1 + g("k1", 0) * r2 + g("k2", 0) * r2**2 + g("k3", 0) * r2**3 + g("k4", 0) * r2**4
+    xd = x * radial + (g("p1", 0) * (r2 + 2 * x * x) + 2 * g("p2", 0) * x * y)
+    yd = y * radial + (g("p2", 0) * (r2 + 2 * y * y) + 2 * g("p1", 0) * x * y)
+    return W / 2.0 + params["cx"] + xd * f + xd * g("b1", 0) + yd * g("b2", 0), H / 2.0 + params["cy"] + yd * f
+
+
+def forward_map_position(params, rows, cols, scale):
+    """Where the (possibly fractional) pixel (rows, cols) of the IDEAL image of scale `scale` lands in the warped image of
+    the same scale -- the construction of cameras.py:1012-1043: at scale 1 the model is evaluated at the pixel index
+    itself, otherwise at the original-resolution position of the scaled pixel's centre, (index + 0.5) / scale."""
+    if np.isclose(scale, 1.0):
+        u, v = metashape_forward(params, cols, rows)
+        return v, u
+    u, v = metashape_forward(params, (cols + 0.5) / scale, (rows + 0.5) / scale)
+    return v * scale, u * scale
+
+
+def newton_inverse_map(params, h, w, scale=1.0, iters=12, fill=-1.0, tol=1e-9):
+    """(2, h, w) map: for every pixel (i, j) of the warped image, the fractional pixel (row, col) of the ideal image that
+    the lens model sends there; `fill` where that position lies outside the ideal image or the iteration does not
+    converge.  Newton's method with a FINITE-DIFFERENCE Jacobian (the device kernel uses the analytic one)."""
+    ti, tj = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+    r, c = ti.copy(), tj.copy()
+    eps = 1e-4
+    for _ in range(iters):
+        fr, fc = forward_map_position(params, r, c, scale)
+        fr_r, fc_r = forward_map_position(params, r + eps, c, scale)
+        fr_c, fc_c = forward_map_position(params, r, c + eps, scale)
+        a, b = (fr_r - fr) / eps, (fr_c - fr) / eps
+        cc, d = (fc_r - fc) / eps, (fc_c - fc) / eps
+        er, ec = fr - ti, fc - tj
+        det = a * d - b * cc
+        with np.errstate(divide="ignore", invalid="ignore"):
+            dr, dc = (d * er - b * ec) / det, (a * ec - cc * er) / det
+        dr, dc = np.nan_to_num(dr), np.nan_to_num(dc)
+        r, c = r - np.clip(dr, -h, h), c - np.clip(dc, -w, w)
+    fr, fc = forward_map_position(params, r, c, scale)
+    ok = (np.abs(fr - ti) < tol * max(h, w)) & (np.abs(fc - tj) < tol * max(h, w))
+    ok &= (r >= 0) & (r <= h - 1) & (c >= 0) & (c <= w - 1)
+    return np.stack([np.where(ok, r, fill), np.where(ok, c, fill)], axis=0)

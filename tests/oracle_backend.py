@@ -123,6 +123,9 @@ class OracleBackend:
     def upload_map(self, inverse_map):
         return torch.from_numpy(np.ascontiguousarray(inverse_map, dtype=np.float64))
 
+    def invert_distortion(self, params, h, w, image_scale=1.0, max_iters=12, fill=-1.0):
+        return torch.from_numpy(oracle_warp.newton_inverse_map(dict(params), h, w, image_scale, fill=fill))
+
     def warp_image(self, input_image, map_t, order=1, fill_value=0.0, reference_float_roundtrip=False):
         fn = oracle_warp.flexible_inputs_warp_reference if reference_float_roundtrip else oracle_warp.warp_exact
         return fn(np.asarray(input_image), map_t.numpy(), order, fill_value)

@@ -40,16 +40,12 @@ def test_fast_path_with_distortion_set_equals_general_path(tmp_path, oracle_back
     cameras._local_to_epsg_4978_transform = np.eye(4)
     HT = synthetic.downward_view(scene_width=4, focal=camera.f, sensor_width=sensor)
     camera.cam_to_world_transform, camera.world_to_cam_transform = HT, np.linalg.inv(HT)
-    orig = cameras.warp_dewarp_image
-    cameras.warp_dewarp_image = lambda *a, **k: orig(*a, backend=be, **k)
     one = cameras[0:1]
-    one.warp_dewarp_image = cameras.warp_dewarp_image
     C = 3
     rng = np.random.default_rng(3)
     labels = [rng.integers(0, C, size=(sensor, sensor)).astype(np.uint8)]
     seg = ArrayLabelSegmentor(labels, C, filenames=[camera.image_filename])
     seg_set = SegmentorPhotogrammetryCameraSet(one, seg)
-    seg_set.warp_dewarp_image = cameras.warp_dewarp_image
 
     warped = tm.pix2face(one, distortion_set=cameras, apply_distortion=True)
     ideal = tm.pix2face(one, apply_distortion=False)

@@ -77,26 +77,87 @@ def test_ideal_to_warped_matches_reference(tmp_path, golden_cameras):
         cams.ideal_to_warped(cam, np.zeros(1), np.zeros(1))
 
 
-@pytest.mark.parametrize("scale,ds", [(1.0, 8), (0.5, 2)])
-def test_distortion_maps_match_reference(tmp_path, golden_warp, scale, ds):
+@pytest.mark.parametrize("kind", BACKENDS)
+@pytest.mark.parametrize("scale,ds,tol", [(1.0, 8, 0.025), (0.5, 2, 0.004)])
+def test_distortion_maps_match_reference(kind, request, tmp_path, golden_warp, scale, ds, tol):
+    """The forward map is bit-equal to the REAL reference's.  The inverse is the dense Newton solve on the device instead of
+    the reference's griddata over every `ds`-th pixel: the two differ by the interpolation error of the reference's
+    triangles -- at most 0.023 px at downsample 8 and 0.003 px at 2 on this lens (k1 = -0.05, f = 100, 97 px sensor),
+    which is exactly how far the REFERENCE's inverse is from satisfying forward(inverse(p)) = p; ours satisfies it to
+    1e-9 px.  Every pixel the reference can invert (inside the hull of its samples), the dense inverse can too."""
     cams = _metashape_set(tmp_path)
     n = int(golden_warp["sensor"])
     cam = simplify_camera(cams.cameras[0], np.ones((n, n, 3)))
     cam.distortion_params["k1"] = float(golden_warp["k1"])
-    cams.make_distortion_map(cam, ds, scale)
+    cams.make_distortion_map(cam, ds, scale, backend=_backend(kind, request))
     key = cams.distortion_key(cam.distortion_params, scale)
     tag = f"s{int(scale * 100)}_d{ds}"
     np.testing.assert_array_equal(cams._maps_ideal_to_warped[key], golden_warp[f"i2w_{tag}"])
-    np.testing.assert_allclose(cams._maps_warped_to_ideal[key], golden_warp[f"w2i_{tag}"], rtol=0, atol=1e-9)
+    ours, ref = cams._maps_warped_to_ideal[key], golden_warp[f"w2i_{tag}"]
+    assert ours.shape == ref.shape and ours.dtype == np.float64
+    ref_valid, our_valid = ref[0] != -1, ours[0] != -1
+    assert np.all(our_valid[ref_valid]) and our_valid.mean() > 0.9
+    diff = np.abs(ours - ref)[:, ref_valid]
+    assert diff.max() < tol, diff.max()
+    # the defining property, which the reference's inverse meets only to `tol`: forward(inverse(p)) == p
+    model = cams.distortion_model(cam)
+    h = w = int(n * scale)
+    ti, tj = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    fr, fc = oracle_warp.forward_map_position(model, ours[0], ours[1], scale)
+    assert np.abs(fr - ti)[our_valid].max() < 1e-9 and np.abs(fc - tj)[our_valid].max() < 1e-9
+    rr, rc = oracle_warp.forward_map_position(model, ref[0], ref[1], scale)
+    assert 0.1 * tol < max(np.abs(rr - ti)[ref_valid].max(), np.abs(rc - tj)[ref_valid].max()) < tol
 
 
-def test_full_model_maps_match_reference(tmp_path, golden_warp):
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_full_model_maps_match_reference(kind, request, tmp_path, golden_warp):
+    """All eight parameters of the XML's lens (k1..k4, p1, p2, b1, b2; cx, cy != 0) at scale 0.02: forward map bit-equal
+    to the reference; the inverse round-trips through the full model (the reference's own inverse, griddata over a
+    2 x 2 sample grid at downsample 64, is no yardstick here)."""
     cams = _metashape_set(tmp_path)
     cam = cams.cameras[0]
-    cams.make_distortion_map(cam, 64, 0.02)
+    cams.make_distortion_map(cam, 64, 0.02, backend=_backend(kind, request))
     key = cams.distortion_key(cam.distortion_params, 0.02)
     np.testing.assert_array_equal(cams._maps_ideal_to_warped[key], golden_warp["full_i2w_s2"])
-    np.testing.assert_allclose(cams._maps_warped_to_ideal[key], golden_warp["full_w2i_s2"], rtol=0, atol=1e-7)
+    inv = cams._maps_warped_to_ideal[key]
+    assert inv.shape == golden_warp["full_w2i_s2"].shape
+    ok = inv[0] != -1
+    assert ok.mean() > 0.8  # the border of the warped image is mapped from outside the ideal one
+    h, w = inv.shape[1:]
+    ti, tj = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    fr, fc = oracle_warp.forward_map_position(cams.distortion_model(cam), inv[0], inv[1], 0.02)
+    assert np.abs(fr - ti)[ok].max() < 1e-9 and np.abs(fc - tj)[ok].max() < 1e-9
+    # the forward map of the reference and the forward model of the oracle are the same function
+    r, c = np.meshgrid(np.arange(h, dtype=float), np.arange(w, dtype=float), indexing="ij")
+    gr, gc = oracle_warp.forward_map_position(cams.distortion_model(cam), r, c, 0.02)
+    np.testing.assert_allclose(np.stack([gr, gc]), golden_warp["full_i2w_s2"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_device_inverse_equals_the_numpy_newton_inverse_and_round_trips_at_full_size(hip, tmp_path):
+    """k_invert_distortion (analytic Jacobian) against the numpy solver (finite differences) on the XML's full lens at a
+    size the CPU finishes in seconds, then the round trip forward(inverse(p)) = p at the sensor's full 5280 x 3956."""
+    cams = _metashape_set(tmp_path)
+    cam = cams.cameras[0]
+    model = cams.distortion_model(cam)
+    for scale in (0.1, 0.25):
+        h, w = cam.get_image_size(scale)
+        got = hip.invert_distortion(model, h, w, scale).cpu().numpy()
+        want = oracle_warp.newton_inverse_map(model, h, w, scale)
+        np.testing.assert_array_equal(got[0] == -1, want[0] == -1)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-8)
+    h, w = cam.get_image_size(1.0)
+    assert (h, w) == (3956, 5280)
+    inv = hip.invert_distortion(model, h, w, 1.0)
+    ok = inv[0] != -1
+    assert float(ok.double().mean()) > 0.8
+    inv_np = inv.cpu().numpy()
+    ti, tj = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    fr, fc = oracle_warp.forward_map_position(model, inv_np[0], inv_np[1], 1.0)
+    okn = ok.cpu().numpy()
+    assert np.abs(fr - ti)[okn].max() < 1e-8 and np.abs(fc - tj)[okn].max() < 1e-8
+    # pixels the lens maps from outside the ideal image are `fill`; the corners of a barrel-corrected image are among them
+    assert inv_np[0].min() == -1.0 or okn.all()
 
 
 # ---- oracle pinned to the real flexible_inputs_warp -------------------------------------------------------------------------
@@ -201,23 +262,6 @@ def test_dropped_parameters(request, tmp_path, gradient, delete, w2i, k1, relati
     assert relationship(dewarped.mean(), gradient.mean())
 
 
-@pytest.mark.parametrize("downsample", [1, 2])
-def test_inverse_map_interpolation(downsample):
-    """tests/test_indexing.py:7-66: a simple mapping is reversed; samples nobody maps to are -1."""
-    from geograypher_amd.utils.indexing import inverse_map_interpolation
-
-    imap = np.repeat(np.arange(2, 7)[:, None], 6, axis=1)
-    jmap = np.repeat(np.array([[0, 1, 2, 3, 4, 6]]), 5, axis=0)
-    inv_imap, inv_jmap = inverse_map_interpolation(np.stack([imap, jmap], axis=0), downsample=downsample)
-    i_expected = np.repeat(np.array([-1, -1, 0, 1, 2], dtype=float)[:, None], 6, axis=1)
-    j_expected = np.array([[-1] * 6, [-1] * 6, [0, 1, 2, 3, 4, 4.5], [0, 1, 2, 3, 4, 4.5], [0, 1, 2, 3, 4, 4.5]], dtype=float)
-    if downsample == 2:
-        i_expected[:, -1] = -1
-        j_expected[:, -1] = -1
-    assert np.allclose(inv_imap, i_expected)
-    assert np.allclose(inv_jmap, j_expected)
-
-
 @pytest.mark.parametrize("kind", BACKENDS)
 @pytest.mark.parametrize("k1", [1.0, 0.0, -1.0])
 @pytest.mark.parametrize("w2i", [True, False])
@@ -236,15 +280,16 @@ def test_mask_image(kind, request, tmp_path, k1, w2i):
 
 @pytest.mark.parametrize("w2i,k1,relationship", [(True, 0, operator.eq), (True, 0.5, operator.lt), (True, -0.5, operator.gt),
                                                  (False, 0, operator.eq), (False, 0.5, operator.gt), (False, -0.5, operator.lt)])
-def test_warp_dewarp_pixels(tmp_path, w2i, k1, relationship):
+def test_warp_dewarp_pixels(tmp_path, oracle_backend_cls, w2i, k1, relationship):
     """tests/test_derived_cameras.py:251-313"""
+    be = oracle_backend_cls()
     fake = np.zeros((101, 101, 3), dtype=np.uint8)
     cameras = _metashape_set(tmp_path)
     camera = simplify_camera(cameras.cameras[0], fake)
     camera.distortion_params["k1"] = k1
     pixels = np.array([[20, 20], [20, 50], [20, 80], [50, 20], [50, 80], [80, 20], [80, 50], [80, 80]])
     center = np.mean([[0, 0], fake.shape[:2]], axis=0).astype(int)
-    dewarped = cameras.warp_dewarp_pixels(camera, pixels, warped_to_ideal=w2i, inversion_downsample=2)
+    dewarped = cameras.warp_dewarp_pixels(camera, pixels, warped_to_ideal=w2i, inversion_downsample=2, backend=be)
     assert isinstance(dewarped, np.ndarray) and dewarped.shape == pixels.shape and dewarped.dtype == float
     original = np.linalg.norm(pixels - center, axis=1)
     altered = np.linalg.norm(dewarped - center, axis=1)
@@ -268,9 +313,6 @@ def test_dewarp_pix2face(kind, request, tmp_path, render_img_scale):
     cameras.cameras[0].cam_to_world_transform = HT
     cameras.cameras[0].world_to_cam_transform = np.linalg.inv(HT)
     kwargs = {"cameras": cameras, "cache_folder": None, "distortion_set": cameras, "render_img_scale": render_img_scale}
-    # the camera set's warp uses the mesh's backend in this test (the product default is the shared HIP context)
-    orig = cameras.warp_dewarp_image
-    cameras.warp_dewarp_image = lambda *a, **k: orig(*a, backend=be, **k)
     ideal = textured_mesh.pix2face(**kwargs, apply_distortion=False)
     assert len(ideal) == 1
     ideal = ideal[0]
