@@ -727,12 +727,22 @@ class TexturedPhotogrammetryMesh:
         upsampling (nearest for discrete textures, bilinear otherwise) is the warp kernel with a resize map.
         Like the reference this renders with `distortion_set=camera_set` (a camera set without a distortion model
         needs `apply_distortion=False`).  `make_composites` (matplotlib visualisation) is outside the projection path.
+
+        Extra keywords (not forwarded to pix2face): `writer_threads` (default min(16, cores)) host threads that deflate
+        and write while the GPU renders the next views -- results travel through a ring of pinned buffers, one
+        asynchronous copy per view; `views_per_group` (default 8) views rasterized per device call.
         """
+        from concurrent.futures import ThreadPoolExecutor
+
         from PIL import Image
+
+        from geograypher_amd.utils.tiff import write_tiff_deflate
 
         if make_composites:
             raise NotImplementedError("composite visualisations are outside the projection path (utils/visualization.py)")
         torch = _torch()
+        writer_threads = int(render_kwargs.pop("writer_threads", min(16, __import__("os").cpu_count() or 1)))
+        views_per_group = int(render_kwargs.pop("views_per_group", 8))
         output_folder = Path(output_folder)
         output_folder.mkdir(parents=True, exist_ok=True)
         self.logger.info(f"Saving renders to {output_folder}")
@@ -747,35 +757,11 @@ class TexturedPhotogrammetryMesh:
         resize_maps = {}
         render_kwargs = dict(render_kwargs)
         render_kwargs.setdefault("distortion_set", camera_set)
+        on_gpu = self.backend.device.type == "cuda"
 
-        for i in tqdm(range(len(camera_set)), total=len(camera_set), desc="Computing and saving renders"):
-            camera = camera_set[i]
-            ids = self.pix2face(cameras=camera, mesh=mesh, render_img_scale=render_image_scale, return_tensor=True,
-                                **render_kwargs)
-            if isinstance(ids, np.ndarray):
-                ids = self.backend._dev(ids.astype(np.int32), torch.int32)
-            native = save_native_resolution and render_image_scale != 1
-            if native:
-                key = (tuple(ids.shape), tuple(camera.get_image_size()))
-                if key not in resize_maps:
-                    resize_maps[key] = self.backend.upload_map(self._resize_map(*key))
-            if cast_to_uint8 and (not native or discrete):
-                if native:  # nearest-neighbour upsampling commutes with the per-pixel gather: resize the ids
-                    ids = self.backend.warp_image(ids, resize_maps[key], order=0, fill_value=-1)
-                rendered = _to_host(self.backend.gather_texture_u8(ids, tex_dev, int(uint8_value_for_null_texture)))
-                rendered = np.squeeze(rendered)
-            else:
-                rendered = self.backend.gather_texture(ids, tex_dev)  # (h, w, C) float64, NaN without a face
-                if native:
-                    rendered = self.backend.warp_image(rendered, resize_maps[key], order=0 if discrete else 1,
-                                                       fill_value=float("nan"))
-                rendered = _to_host(rendered)
-                if cast_to_uint8:
-                    mask = np.logical_or.reduce([rendered < 0, rendered > 255, np.logical_not(np.isfinite(rendered))])
-                    rendered[mask] = uint8_value_for_null_texture
-                    rendered = np.squeeze(rendered.astype(np.uint8))
-            if rendered.ndim == 3:
-                rendered = rendered[..., :3]
+        # Output paths first: a camera outside the image folder fails before any rendering, as in the reference
+        output_files = []
+        for camera in camera_set.cameras:
             try:
                 camera_filename = Path(camera.get_image_filename()).relative_to(camera_set.image_folder)
             except (ValueError, TypeError):
@@ -786,19 +772,91 @@ class TexturedPhotogrammetryMesh:
                     " may have an 'original_image_folder' argument, which could be used to"
                     " delete the initial, mismatched portion of the camera path."
                 )
-            output_filename = Path(output_folder, camera_filename)
+            output_files.append(Path(output_folder, camera_filename))
+
+        def write_one(host, event, output_filename):
+            """Writer thread: wait for the view's copy to land in its pinned slot, finish the reference's post-processing
+            (meshes.py:2325-2349) where it was not fused into the gather kernel, compress and write."""
+            if event is not None:
+                event.synchronize()
+            rendered = host.numpy() if hasattr(host, "numpy") else host
+            if rendered.dtype != np.uint8 and cast_to_uint8:
+                rendered = rendered.copy()
+                mask = np.logical_or.reduce([rendered < 0, rendered > 255, np.logical_not(np.isfinite(rendered))])
+                rendered[mask] = uint8_value_for_null_texture
+                rendered = rendered.astype(np.uint8)
+            rendered = np.squeeze(rendered)
+            if rendered.ndim == 3:
+                rendered = rendered[..., :3]
             output_filename.parent.mkdir(parents=True, exist_ok=True)
             if save_as_npy is True:
                 np.save(str(output_filename.with_suffix(".npy")), rendered)
             else:
-                rendered = np.squeeze(rendered)
                 if cast_to_uint8 is False:
                     with np.errstate(invalid="ignore"):
                         if np.nanmax(rendered) <= np.iinfo(np.uint16).max:
                             rendered = rendered.astype(np.uint16)
                         else:
                             rendered = rendered.astype(np.uint32)
-                Image.fromarray(rendered).save(str(output_filename.with_suffix(".tif")), compression="tiff_deflate")
+                target = output_filename.with_suffix(".tif")
+                if rendered.dtype in (np.uint8, np.uint16, np.uint32) and (rendered.ndim == 2 or rendered.shape[2] == 3):
+                    write_tiff_deflate(target, rendered)  # zlib releases the interpreter lock: the writers run in parallel
+                else:
+                    Image.fromarray(rendered).save(str(target), compression="tiff_deflate")
+
+        # Pipeline (row f2): the GPU rasterizes / gathers a group of views and copies each result into a slot of a pinned
+        # ring while `writer_threads` host threads deflate and write the views before it.  A slot is reused only after
+        # the writer that read it last is done, so at most ring_slots results are in flight.
+        ring_slots = max(2 * writer_threads, 2)
+        ring = {}
+        slot_writer = {}
+        futures = []
+        n = len(camera_set)
+        with ThreadPoolExecutor(max_workers=max(writer_threads, 1)) as pool:
+            for g0 in tqdm(range(0, n, views_per_group), total=(n + views_per_group - 1) // views_per_group,
+                           desc="Computing and saving renders"):
+                group = list(range(g0, min(g0 + views_per_group, n)))
+                sub = camera_set.get_subset_cameras(group) if len(group) > 1 else camera_set[g0]
+                ids_group = self.pix2face(cameras=sub, mesh=mesh, render_img_scale=render_image_scale, return_tensor=True,
+                                          **render_kwargs)
+                if isinstance(ids_group, np.ndarray):
+                    ids_group = self.backend._dev(ids_group.astype(np.int32), torch.int32)
+                if ids_group.ndim == 2:
+                    ids_group = ids_group[None]
+                for k, i in enumerate(group):
+                    camera = camera_set.cameras[i]
+                    ids = ids_group[k]
+                    native = save_native_resolution and render_image_scale != 1
+                    if native:
+                        key = (tuple(ids.shape), tuple(camera.get_image_size()))
+                        if key not in resize_maps:
+                            resize_maps[key] = self.backend.upload_map(self._resize_map(*key))
+                    if cast_to_uint8 and (not native or discrete):
+                        if native:  # nearest-neighbour upsampling commutes with the per-pixel gather: resize the ids
+                            ids = self.backend.warp_image(ids, resize_maps[key], order=0, fill_value=-1)
+                        rendered = self.backend.gather_texture_u8(ids, tex_dev, int(uint8_value_for_null_texture))
+                    else:
+                        rendered = self.backend.gather_texture(ids, tex_dev)  # (h, w, C) float64, NaN without a face
+                        if native:
+                            rendered = self.backend.warp_image(rendered, resize_maps[key], order=0 if discrete else 1,
+                                                               fill_value=float("nan"))
+                    slot = i % ring_slots
+                    if slot in slot_writer:
+                        slot_writer[slot].result()  # the slot's previous view is on disk (a failed writer raises here)
+                    if on_gpu and rendered.is_cuda:
+                        skey = (slot, tuple(rendered.shape), rendered.dtype)
+                        if ring.get(slot, (None,))[0] != skey[1:]:
+                            ring[slot] = (skey[1:], torch.empty(rendered.shape, dtype=rendered.dtype, pin_memory=True))
+                        host = ring[slot][1]
+                        host.copy_(rendered, non_blocking=True)
+                        event = torch.cuda.Event()
+                        event.record(torch.cuda.current_stream(rendered.device))
+                    else:
+                        host, event = rendered, None
+                    slot_writer[slot] = pool.submit(write_one, host, event, output_files[i])
+                    futures.append(slot_writer[slot])
+            for f in futures:
+                f.result()
 
 
 _FUSED_KWARGS = ("near", "principal_point", "focal_scaling")
