@@ -33,7 +33,7 @@
 #define GR_TILE_LOG2 6
 #define GR_MAX_BATCH 64     // views per launch group (amortises kernel boundaries and per-launch tails)
 #define GR_ENT_Q 3          // int4 per compiled (face, tile) entry: 48 bytes, 12 words
-#define GR_CTRL_HDR 8       // ctrl words before the tile arrays: rec_count, total_entries, overflow, work_count, clip_count
+#define GR_CTRL_HDR 8       // ctrl words before the tile arrays: rec_count, total_entries, overflow, work_count, clip_count, big_count
 #define GR_MAX_DIM 16384    // h, w limit (guard band and 16-bit bbox packing)
 
 namespace {
@@ -48,7 +48,8 @@ struct BinArgs {
   const int32_t *orig;   // [F] soup position -> face id of the caller's mesh
   const float4 *blk;     // [ceil(F/64)] bounding sphere (centre, radius) of each block of GR_BLOCK faces, local frame
   uint32_t *work;        // [slot][work_stride] blocks of this view that passed the frustum test (ctrl[3] = count)
-  uint32_t *clip;        // [slot][F] soup faces that straddle the near plane / guard band (R7; ctrl[4] = count)
+  uint32_t *clip;        // [slot][F] from the front: soup faces that straddle the near plane / guard band (R7; ctrl[4] = count);
+                         //           from the back: faces over more than 2 x 2 tiles (single-pass binning; ctrl[5] = count)
   int64_t work_stride;
   int4 *comp;            // [slot][ent_cap][GR_ENT_Q]  compiled (face, tile) entries grouped by tile, 48 bytes each
   uint8_t *nrow8;        // [slot][ent_cap] rows of each entry inside its tile (the tile kernel's scan input: a compact stream)
@@ -272,8 +273,52 @@ __global__ __launch_bounds__(256) void k_cull_blocks(const float *__restrict__ c
   if (keep) a.work[(int64_t)slot * a.work_stride + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)b;
 }
 
-__device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, uint8_t *__restrict__ nr8, const int4 p0, const int4 p1,
+__device__ __forceinline__ bool compile_entry(int4 *__restrict__ dst, uint8_t *__restrict__ nr8, const int4 p0, const int4 p1,
                                               const int4 p2, int px0, int py0, int TW, int TH);
+
+// R1 / R2 / R4 for one face of the soup: the record (three int4) that compile_entry turns into per-tile entries, and the
+// range of tiles its pixel bounding box touches.  Returns false for faces that draw nothing in this view; clip_me: the face
+// straddles the near plane or the guard band (R7).  Used by K1 and, for faces over more than 2 x 2 tiles, by k_bin_big:
+// same code, same bits.
+__device__ __forceinline__ bool face_setup(const BinArgs &a, const float *__restrict__ cam, int64_t f, int4 &r0, int4 &r1,
+                                           int4 &r2, int &tx0, int &tx1, int &ty0, int &ty1, bool &clip_me) {
+  // the face's three vertices sit side by side in the soup: one coalesced 36-byte read per lane instead of an index
+  // load followed by three dependent 12-byte gathers (one dependent memory round trip less per wave)
+  const float *sp = a.soup + 9 * f;
+  Vtx v0 = project_vertex(sp, cam);
+  Vtx v1 = project_vertex(sp + 3, cam);
+  Vtx v2 = project_vertex(sp + 6, cam);
+  clip_me = !(v0.valid && v1.valid && v2.valid) && (v0.front || v1.front || v2.front) && v0.finite && v1.finite && v2.finite;
+  if (!(v0.valid && v1.valid && v2.valid)) return false;
+  long long area2 = (long long)(v1.X - v0.X) * (long long)(v2.Y - v0.Y) - (long long)(v2.X - v0.X) * (long long)(v1.Y - v0.Y);
+  if (area2 == 0) return false;
+  if (area2 < 0) {  // both windings are drawn: normalise to positive area
+    Vtx s = v1; v1 = v2; v2 = s;
+    area2 = -area2;
+  }
+  const int Xmin = imin3(v0.X, v1.X, v2.X), Xmax = imax3(v0.X, v1.X, v2.X);
+  const int Ymin = imin3(v0.Y, v1.Y, v2.Y), Ymax = imax3(v0.Y, v1.Y, v2.Y);
+  int jmin = (Xmin - 128 + 255) >> 8, jmax = (Xmax - 128) >> 8;  // R2: pixel centres inside the bbox
+  int imin = (Ymin - 128 + 255) >> 8, imax = (Ymax - 128) >> 8;
+  jmin = max(jmin, 0); imin = max(imin, 0);
+  jmax = min(jmax, a.w - 1); imax = min(imax, a.h - 1);
+  if (jmin > jmax || imin > imax) return false;
+  // R4: gradients of 1/z in double, rounded once to float
+  const double d1 = (double)v1.iz - (double)v0.iz;
+  const double d2 = (double)v2.iz - (double)v0.iz;
+  const double a2 = (double)area2;
+  double n1, n2;
+  n1 = d1 * (double)(v2.Y - v0.Y); n2 = d2 * (double)(v1.Y - v0.Y);
+  const float A = (float)((n1 - n2) / a2);
+  n1 = d2 * (double)(v1.X - v0.X); n2 = d1 * (double)(v2.X - v0.X);
+  const float B = (float)((n1 - n2) / a2);
+  r0 = make_int4(v0.X, v0.Y, v1.X, v1.Y);
+  r1 = make_int4(v2.X, v2.Y, __float_as_int(v0.iz), a.orig[f]);
+  r2 = make_int4(__float_as_int(A), __float_as_int(B), jmin | (jmax << 16), imin | (imax << 16));
+  tx0 = jmin >> a.twl; tx1 = jmax >> a.twl;
+  ty0 = imin >> a.thl; ty1 = imax >> a.thl;
+  return true;
+}
 
 // DIRECT = true: single-pass binning.  Every tile owns a fixed segment of a.cap_tile entries; the list position
 // returned by the (wave-aggregated) tile counter is final, so the compiled entry is written straight from here and
@@ -298,49 +343,7 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
   bool keep = false, clip_me = false;
   int4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0};
   int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
-  if (f < a.F) {
-    // the face's three vertices sit side by side in the soup: one coalesced 36-byte read per lane instead of an index
-    // load followed by three dependent 12-byte gathers (one dependent memory round trip less per wave)
-    const float *sp = a.soup + 9 * f;
-    Vtx v0 = project_vertex(sp, cam);
-    Vtx v1 = project_vertex(sp + 3, cam);
-    Vtx v2 = project_vertex(sp + 6, cam);
-    clip_me = !(v0.valid && v1.valid && v2.valid) && (v0.front || v1.front || v2.front) && v0.finite && v1.finite &&
-              v2.finite;
-    if (v0.valid && v1.valid && v2.valid) {
-      long long area2 = (long long)(v1.X - v0.X) * (long long)(v2.Y - v0.Y) -
-                        (long long)(v2.X - v0.X) * (long long)(v1.Y - v0.Y);
-      if (area2 != 0) {
-        if (area2 < 0) {  // both windings are drawn: normalise to positive area
-          Vtx s = v1; v1 = v2; v2 = s;
-          area2 = -area2;
-        }
-        const int Xmin = imin3(v0.X, v1.X, v2.X), Xmax = imax3(v0.X, v1.X, v2.X);
-        const int Ymin = imin3(v0.Y, v1.Y, v2.Y), Ymax = imax3(v0.Y, v1.Y, v2.Y);
-        int jmin = (Xmin - 128 + 255) >> 8, jmax = (Xmax - 128) >> 8;  // R2: pixel centres inside the bbox
-        int imin = (Ymin - 128 + 255) >> 8, imax = (Ymax - 128) >> 8;
-        jmin = max(jmin, 0); imin = max(imin, 0);
-        jmax = min(jmax, a.w - 1); imax = min(imax, a.h - 1);
-        if (jmin <= jmax && imin <= imax) {
-          keep = true;
-          // R4: gradients of 1/z in double, rounded once to float
-          const double d1 = (double)v1.iz - (double)v0.iz;
-          const double d2 = (double)v2.iz - (double)v0.iz;
-          const double a2 = (double)area2;
-          double n1, n2;
-          n1 = d1 * (double)(v2.Y - v0.Y); n2 = d2 * (double)(v1.Y - v0.Y);
-          const float A = (float)((n1 - n2) / a2);
-          n1 = d2 * (double)(v1.X - v0.X); n2 = d1 * (double)(v2.X - v0.X);
-          const float B = (float)((n1 - n2) / a2);
-          r0 = make_int4(v0.X, v0.Y, v1.X, v1.Y);
-          r1 = make_int4(v2.X, v2.Y, __float_as_int(v0.iz), a.orig[f]);
-          r2 = make_int4(__float_as_int(A), __float_as_int(B), jmin | (jmax << 16), imin | (imax << 16));
-          tx0 = jmin >> a.twl; tx1 = jmax >> a.twl;
-          ty0 = imin >> a.thl; ty1 = imax >> a.thl;
-        }
-      }
-    }
-  }
+  if (f < a.F) keep = face_setup(a, cam, f, r0, r1, r2, tx0, tx1, ty0, ty1, clip_me);
   // R7: faces that straddle the near plane or the guard band go to the view's clip list (k_clip_faces)
   const unsigned long long mc = __ballot(clip_me);
   if (mc) {
@@ -400,19 +403,19 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
           compile_entry(comp + idx * GR_ENT_Q, nr8 + idx, r0, r1, r2, tx << a.twl, ty << a.thl, TW, TH);
         } else ctrl[2] = 1u;
       }
-    } else {  // faces over more than 2x2 tiles (rare): one plain atomic per tile
-#pragma unroll 1
-      for (int ty = ty0; ty <= ty1; ++ty) {
-#pragma unroll 1
-        for (int tx = tx0; tx <= tx1; ++tx) {
-          const int t = ty * a.TX + tx;
-          const uint32_t pos = atomicAdd(&cntS[t], 1u);
-          if (pos < (uint32_t)a.cap_tile) {
-            const int64_t idx = (int64_t)t * a.cap_tile + pos;
-            compile_entry(comp + idx * GR_ENT_Q, nr8 + idx, r0, r1, r2, tx << a.twl, ty << a.thl, TW, TH);
-          } else ctrl[2] = 1u;
-        }
-      }
+    }
+  }
+  if (DIRECT) {
+    // faces over more than 2 x 2 tiles go to the view's big list (the back of the clip buffer, ctrl[5] = count): k_bin_big
+    // gives each of them a whole wave, one lane per tile of the bounding box
+    const bool big_fp = keep && !small_fp;
+    const unsigned long long mb = __ballot(big_fp);
+    if (mb) {
+      const int lead = __ffsll((long long)mb) - 1;
+      uint32_t bb = 0;
+      if (lane == lead) bb = atomicAdd(&ctrl[5], (uint32_t)__popcll(mb));
+      bb = __shfl(bb, lead);
+      if (big_fp) a.clip[(int64_t)slot * a.F + (a.F - 1 - (int64_t)(bb + __popcll(mb & ((1ull << lane) - 1ull))))] = (uint32_t)f;
     }
   }
   if (keep && !DIRECT) {
@@ -523,8 +526,8 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(BinArgs a) {
 // Larger faces take the general form below (identical coverage: both forms are exact).
 #define GR_FAST_EXT 24000
 __device__ __forceinline__ int pack16(int lo, int hi) { return (lo & 0xFFFF) | (hi << 16); }
-__device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, uint8_t *__restrict__ nr8, const int4 p0, const int4 p1,
-                                              const int4 p2, int px0, int py0, int TW, int TH) {
+__device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const int4 p2, int px0, int py0, int TW, int TH,
+                                            int4 &e0, int4 &e1, int4 &e2, int &rows) {
   const int X0 = p0.x, Y0 = p0.y, X1 = p0.z, Y1 = p0.w, X2 = p1.x, Y2 = p1.y;
   const int Pxo = px0 * 256 + 128, Pyo = py0 * 256 + 128;  // centre of the tile's first pixel
   const int jlo = max((p2.z & 0xFFFF) - px0, 0), jhi = min((int)((uint32_t)p2.z >> 16) - px0, TW - 1);
@@ -535,54 +538,77 @@ __device__ __forceinline__ void compile_entry(int4 *__restrict__ dst, uint8_t *_
   const int t2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
   const int ext = max(imax3(X0, X1, X2) - imin3(X0, X1, X2), imax3(Y0, Y1, Y2) - imin3(Y0, Y1, Y2));
   const int yw = ((Pyo - Y0) & 0xFFFFFF) | (ilo << 24);  // |Pyo - Y0| < 2^23 inside the guard band
-  const int nr = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;   // rows of the entry in this tile (<= 64)
-  const int xw = ((Pxo - X0) & 0xFFFFFF) | (nr << 24);
-  *nr8 = (uint8_t)nr;
-  // Small forms (every face whose edge values stay inside int32 in this tile): the three edge functions in units of 256,
-  //   E'_k(x, y) = C'_k + a_k x + b_k y,  C'_k = floor(C_k / 256), a_k = -dy_k, b_k = dx_k  (|a|, |b| < 2^15),
-  // exact because A_k, B_k are multiples of 256: E_k >= 0 <=> floor(E_k / 256) >= 0 <=> E'_k >= 0.  The edges are stored
-  // in an order the tile kernel relies on: FIRST an edge with a > 0 (it bounds the span from the left), LAST one with
-  // a < 0 (from the right; its magnitude is stored), the remaining one in the middle -- a triangle of non-zero area has
-  // both kinds (the a_k sum to zero).  The plane of 1/z refers to vertex 0 whatever the edge order.
+  int nr = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;         // rows of the entry in this tile (<= 64)
+  // ONE form for every face, however large: the three edge functions in units of 256 around the tile CENTRE,
+  //   E'_k(x_c, y_c) = C'_k + a_k x_c + b_k y_c,   x_c = x - TW/2, y_c = y - TH/2,   a_k = -dy_k, b_k = dx_k (|.| < 2^23),
+  //   C'_k = floor(C_k / 256) with C_k the exact edge value (fill-rule bias included) at the centre pixel.
+  // Exact because A_k = 256 a_k and B_k = 256 b_k are multiples of 256: E_k >= 0 <=> floor(E_k / 256) >= 0 <=> E'_k >= 0.
+  // C'_k can be as large as 2^39 for a face that spans the guard band, but inside the tile (|x_c| <= TW/2 + 2 with the
+  // solver's reach, |y_c| <= TH/2) the sum a x_c + b y_c stays within M_k = (TW/2 + 2)|a_k| + (TH/2)|b_k|: a C'_k beyond
+  // +-M_k cannot change sign in the tile, so it is CLAMPED to +-(M_k + 1) -- same coverage, and every value the tile
+  // kernel forms fits int32 (M_k < 2^29.1).  The edges are stored in an order the tile kernel relies on: FIRST an edge
+  // with a > 0 (it bounds the span from the left), LAST one with a < 0 (from the right), the remaining one in between
+  // -- a triangle of non-zero area has both kinds (the a_k sum to zero; so do the b_k: the last edge's slopes are not
+  // stored).  The plane of 1/z refers to vertex 0 whatever the edge order.
+  const int Pxc = Pxo + (TW / 2) * 256, Pyc = Pyo + (TH / 2) * 256;  // centre of the tile's centre pixel
   int c0, c1, c2;
-  bool small = true;
-  if (ext < GR_FAST_EXT) {
-    c0 = __mul24(dx0, Pyo - Y0) - __mul24(dy0, Pxo - X0) + t0;
-    c1 = __mul24(dx1, Pyo - Y1) - __mul24(dy1, Pxo - X1) + t1;
-    c2 = __mul24(dx2, Pyo - Y2) - __mul24(dy2, Pxo - X2) + t2;
+  if (ext < GR_FAST_EXT) {  // every product has 24-bit factors and every value fits int32: no 64-bit arithmetic, no clamp
+    c0 = (__mul24(dx0, Pyc - Y0) - __mul24(dy0, Pxc - X0) + t0) >> 8;
+    c1 = (__mul24(dx1, Pyc - Y1) - __mul24(dy1, Pxc - X1) + t1) >> 8;
+    c2 = (__mul24(dx2, Pyc - Y2) - __mul24(dy2, Pxc - X2) + t2) >> 8;
   } else {
-    const long long b0 = t0, b1 = t1, b2 = t2;
-    const long long C0 = (long long)dx0 * (Pyo - Y0) - (long long)dy0 * (Pxo - X0) + b0;
-    const long long C1 = (long long)dx1 * (Pyo - Y1) - (long long)dy1 * (Pxo - X1) + b1;
-    const long long C2 = (long long)dx2 * (Pyo - Y2) - (long long)dy2 * (Pxo - X2) + b2;
-    const long long A0 = -(long long)dy0 * 256, A1 = -(long long)dy1 * 256, A2 = -(long long)dy2 * 256;
-    const long long B0 = (long long)dx0 * 256, B1 = (long long)dx1 * 256, B2 = (long long)dx2 * 256;
-    const long long lim = 0x7FFFFFFFll;
-    const long long m24 = (1ll << 23) - 1;  // |a|, |b| <= 32767 once divided by 256
-    // int32-safe inside this tile, with room for the +-2 pixel reach of the span solver
-    small = (llabs(C0) + (TW + 2) * llabs(A0) + TH * llabs(B0) < lim) &&
-            (llabs(C1) + (TW + 2) * llabs(A1) + TH * llabs(B1) < lim) &&
-            (llabs(C2) + (TW + 2) * llabs(A2) + TH * llabs(B2) < lim) &&
-            llabs(A0) <= m24 && llabs(A1) <= m24 && llabs(A2) <= m24 &&
-            llabs(B0) <= m24 && llabs(B1) <= m24 && llabs(B2) <= m24;
-    c0 = (int)C0; c1 = (int)C1; c2 = (int)C2;
+    const long long C0 = ((long long)dx0 * (Pyc - Y0) - (long long)dy0 * (Pxc - X0) + (long long)t0) >> 8;
+    const long long C1 = ((long long)dx1 * (Pyc - Y1) - (long long)dy1 * (Pxc - X1) + (long long)t1) >> 8;
+    const long long C2 = ((long long)dx2 * (Pyc - Y2) - (long long)dy2 * (Pxc - X2) + (long long)t2) >> 8;
+    const long long hx = TW / 2 + 2, hy = TH / 2;
+    const long long M0 = hx * abs(dy0) + hy * abs(dx0) + 1, M1 = hx * abs(dy1) + hy * abs(dx1) + 1,
+                    M2 = hx * abs(dy2) + hy * abs(dx2) + 1;
+    c0 = (int)min(max(C0, -M0), M0);
+    c1 = (int)min(max(C1, -M1), M1);
+    c2 = (int)min(max(C2, -M2), M2);
   }
-  if (small) {
-    const int a0 = -dy0, a1 = -dy1, a2 = -dy2;
-    const int kf = a0 > 0 ? 0 : (a1 > 0 ? 1 : 2);   // first: a > 0
-    const int kl = a0 < 0 ? 0 : (a1 < 0 ? 1 : 2);   // last: a < 0
-    const int km = 3 - kf - kl;
-    auto pick = [](int k, int v0, int v1, int v2) { return k == 0 ? v0 : (k == 1 ? v1 : v2); };
-    const int cf = pick(kf, c0, c1, c2) >> 8, cm = pick(km, c0, c1, c2) >> 8, cl = pick(kl, c0, c1, c2) >> 8;
-    const int af = pick(kf, a0, a1, a2), am = pick(km, a0, a1, a2), al = pick(kl, a0, a1, a2);
-    const int bf = pick(kf, dx0, dx1, dx2), bm = pick(km, dx0, dx1, dx2), bl = pick(kl, dx0, dx1, dx2);
-    dst[0] = make_int4(cf, cm, cl, pack16(af, am));
-    dst[1] = make_int4(pack16(-al, bf), pack16(bm, bl), p1.z, p2.x);
+  const int a0 = -dy0, a1 = -dy1, a2 = -dy2;
+  // The bounding box reaches this tile; the triangle itself may not (the far corner of a diagonal face).  An edge whose
+  // value is negative even at the tile corner most in its favour, C' + (TW/2)|a| + (TH/2)|b| < 0, excludes every pixel of
+  // the tile: the entry is DEAD (0 rows: the tile kernel never looks at it); k_bin_big asks before it takes a list slot.
+  const bool touches = nr > 0 && c0 + (TW / 2) * abs(a0) + (TH / 2) * abs(dx0) >= 0 &&
+                       c1 + (TW / 2) * abs(a1) + (TH / 2) * abs(dx1) >= 0 && c2 + (TW / 2) * abs(a2) + (TH / 2) * abs(dx2) >= 0;
+  if (!touches) nr = 0;
+  rows = nr;
+  // float(P_x - X0) of the pixel with CENTRED column x_c = x - TW/2 is float(256 x_c + Xw)
+  const int xw = ((Pxo - X0 + (TW / 2) * 256) & 0xFFFFFF) | (nr << 24);
+  const int kf = a0 > 0 ? 0 : (a1 > 0 ? 1 : 2);   // first: a > 0
+  const int kl = a0 < 0 ? 0 : (a1 < 0 ? 1 : 2);   // last: a < 0
+  const int km = 3 - kf - kl;
+  auto pick = [](int k, int v0, int v1, int v2) { return k == 0 ? v0 : (k == 1 ? v1 : v2); };
+  const int cf = pick(kf, c0, c1, c2), cm = pick(km, c0, c1, c2), cl = pick(kl, c0, c1, c2);
+  const int af = pick(kf, a0, a1, a2), am = pick(km, a0, a1, a2);
+  const int bf = pick(kf, dx0, dx1, dx2), bm = pick(km, dx0, dx1, dx2);
+  // slopes: four values (the last edge's are -(first + middle)).  Two packings: 16 bits each when every slope of the face
+  // fits (faces below 128 pixels: nearly all of them), else 24 bits each, flagged in bit 31 of the Yw word
+  const bool narrow = max(max(abs(a0), abs(a1)), max(abs(a2), max(abs(dx0), max(abs(dx1), abs(dx2))))) <= 32767;
+  int w3, w4, w5;
+  if (narrow) {
+    w3 = pack16(af, am); w4 = pack16(bf, bm); w5 = 0;
   } else {
-    dst[0] = make_int4(X0, Y0, X1, Y1);
-    dst[1] = make_int4(X2, Y2, p1.z, p2.x);
+    w3 = (af & 0xFFFFFF) | (am << 24);
+    w4 = ((am >> 8) & 0xFFFF) | (bf << 16);
+    w5 = ((bf >> 16) & 0xFF) | (bm << 8);
   }
-  dst[2] = make_int4(p2.y, xw, yw | (small ? 0 : (int)0x80000000), (int)~(uint32_t)p1.w);
+  e0 = make_int4(cf, cm, cl, w3);
+  e1 = make_int4(w4, w5, p1.z, p2.x);
+  e2 = make_int4(p2.y, xw, yw | (narrow ? 0 : (int)0x80000000), (int)~(uint32_t)p1.w);
+  return touches;
+}
+
+__device__ __forceinline__ bool compile_entry(int4 *__restrict__ dst, uint8_t *__restrict__ nr8, const int4 p0, const int4 p1,
+                                              const int4 p2, int px0, int py0, int TW, int TH) {
+  int4 e0, e1, e2;
+  int rows;
+  const bool touches = build_entry(p0, p1, p2, px0, py0, TW, TH, e0, e1, e2, rows);
+  dst[0] = e0; dst[1] = e1; dst[2] = e2;
+  *nr8 = (uint8_t)rows;
+  return touches;
 }
 
 __global__ __launch_bounds__(256) void k_fill_compile(BinArgs a) {
@@ -855,7 +881,7 @@ __device__ __forceinline__ int lds_idx(int row, int col) {
 template <bool CORR>
 __device__ __forceinline__ int edge_floor(int E, int m, float mf) {
   float g = ((float)E + 0.5f) * __builtin_amdgcn_rcpf(mf);
-  g = __builtin_amdgcn_fmed3f(g, -66.0f, 65.0f);
+  g = __builtin_amdgcn_fmed3f(g, -34.0f, 33.0f);  // centred columns -32 .. 31, plus the solver's reach
   int fl = (int)floorf(g);
   if (CORR) {
     const int rem = E - __mul24(fl, m);
@@ -864,18 +890,25 @@ __device__ __forceinline__ int edge_floor(int E, int m, float mf) {
   return fl;
 }
 
-// exact covered span [xs, xe] of scanline y: the first edge (a > 0) bounds it from the left, x >= ceil(-E'/a) =
-// -floor(E'/a); the last (a < 0) from the right, x <= floor(E'/|a|); the middle one does either (a == 0 works as either)
-template <int TW, bool CORR>
-__device__ __forceinline__ void span_solve(int C0, int C1, int C2, int w3, int w4, int w5, int y, int &xs, int &xe) {
-  const int a0 = w3 & 0xFFFF, a1 = w3 >> 16, m2 = w4 & 0xFFFF;
-  const int b0 = w4 >> 16, b1 = (w5 << 16) >> 16, b2 = w5 >> 16;
+// exact covered span [xs, xe] of one scanline in CENTRED tile coordinates (x_c = x - TW/2 in [-TW/2, TW/2 - 1],
+// y_c = y - TH/2): the first edge (a > 0) bounds it from the left, x_c >= ceil(-E'/a) = -floor(E'/a); the last (a < 0)
+// from the right, x_c <= floor(E'/|a|); the middle one does either (a == 0 works as either).  WIDE = false: every lane's
+// slopes are packed in 16 bits and at most GR_FLOOR_NOCORR_MAX; WIDE = true: any packing, exact correction.
+template <int TW, bool WIDE>
+__device__ __forceinline__ void span_solve(int C0, int C1, int C2, int w3, int w4, int w5, bool wide24, int yc, int &xs, int &xe) {
+  int a0 = (int)((uint32_t)w3 << 16) >> 16, a1 = w3 >> 16, b0 = (int)((uint32_t)w4 << 16) >> 16, b1 = w4 >> 16;
+  if (WIDE) {
+    const int A0 = (int)((uint32_t)w3 << 8) >> 8, A1 = (int)((((uint32_t)w3 >> 24) | ((uint32_t)w4 << 8)) << 8) >> 8;
+    const int B0 = (int)((((uint32_t)w4 >> 16) | ((uint32_t)w5 << 16)) << 8) >> 8, B1 = w5 >> 8;
+    a0 = wide24 ? A0 : a0; a1 = wide24 ? A1 : a1; b0 = wide24 ? B0 : b0; b1 = wide24 ? B1 : b1;
+  }
+  const int m2 = a0 + a1, b2 = -(b0 + b1);   // the last edge: a2 = -(a0 + a1) < 0, stored nowhere
   const int m1 = a1 < 0 ? -a1 : a1;
-  const int f0 = edge_floor<CORR>(C0 + __mul24(b0, y), a0, (float)a0);
-  const int f1 = edge_floor<CORR>(C1 + __mul24(b1, y), m1, (float)m1);
-  const int f2 = edge_floor<CORR>(C2 + __mul24(b2, y), m2, (float)m2);
-  xs = max(0, -f0);
-  xe = min(TW - 1, f2);
+  const int f0 = edge_floor<WIDE>(C0 + __mul24(b0, yc), a0, (float)a0);
+  const int f1 = edge_floor<WIDE>(C1 + __mul24(b1, yc), m1, (float)m1);
+  const int f2 = edge_floor<WIDE>(C2 + __mul24(b2, yc), m2, (float)m2);
+  xs = max(-(TW / 2), -f0);
+  xe = min(TW / 2 - 1, f2);
   const int lo = max(xs, -f1), hi = min(xe, f1);
   xs = a1 > 0 ? lo : xs;
   xe = a1 > 0 ? xe : hi;
@@ -908,73 +941,43 @@ __device__ __forceinline__ int wave_incl_max(int x) {
 }
 
 // Phase 3 for ONE work item: scanline `q - et` of the entry whose 12 words the lane holds (however they got there).
-template <int TWL>
+template <int TWL, int TH>
 __device__ __forceinline__ void raster_item(unsigned long long *keys, const int C0, const int C1, const int C2, const int w3,
                                             const int w4, const int w5, const float iz0, const float zA, const float zB,
                                             const int xw, const int yw, const uint32_t key_lo, const int q, const int et,
-                                            const bool live, const int px0, const int py0) {
+                                            const bool live) {
   constexpr int TW = 1 << TWL;
-  const int X0rel = (xw << 8) >> 8;
+  const int X0rel = (xw << 8) >> 8;  // biased by TW/2 columns: float(P_x - X0) = float(256 x_c + X0rel)
   const int Y0rel = (yw << 8) >> 8, ilo = (yw >> 24) & 0x3F;
   const int y = ilo + (q - et);
   const float m1 = zB * (float)(y * 256 + Y0rel);
-  const bool big = live && (yw < 0);
-  const bool small_item = live && !big;
-  // slopes beyond GR_FLOOR_NOCORR_MAX (edges taller than 62 pixels) take the span solver with the exact correction; the
-  // choice is made per wave so that the usual case carries no extra instructions
-  const bool wide = small_item && (max(max(w3 & 0xFFFF, w4 & 0xFFFF), abs(w3 >> 16)) > GR_FLOOR_NOCORR_MAX);
+  // faces with a slope beyond GR_FLOOR_NOCORR_MAX (edges longer than 62 pixels) or 24-bit slopes take the span solver
+  // with the exact correction; the choice is made per wave so that the usual case carries no extra instructions
+  const bool wide24 = yw < 0;
+  const bool wide = live && (wide24 || max(max(abs((w3 << 16) >> 16), abs(w3 >> 16)), abs(((w3 << 16) >> 16) + (w3 >> 16))) >
+                                           GR_FLOOR_NOCORR_MAX);
   int xs = 0, xe = -1;
   if (__ballot(wide) != 0ull) {
-    if (small_item) span_solve<TW, true>(C0, C1, C2, w3, w4, w5, y, xs, xe);
+    if (live) span_solve<TW, true>(C0, C1, C2, w3, w4, w5, wide24, y - TH / 2, xs, xe);
   } else {
-    if (small_item) span_solve<TW, false>(C0, C1, C2, w3, w4, w5, y, xs, xe);
+    if (live) span_solve<TW, false>(C0, C1, C2, w3, w4, w5, false, y - TH / 2, xs, xe);
   }
-  if (small_item) {
-    // two pixels per step with packed fp32 math (v_pk_mul_f32 / v_pk_add_f32: same IEEE results as the scalar
-    // forms, R4 op for op).  float(P_x - X0) advances by exact float adds (integers below 2^24).  An odd span's
-    // spare slot is steered to the row's padding key (column TW), which nobody reads.
-    if (xs <= xe) {
-      const f32x2 zA2 = {zA, zA}, m12 = {m1, m1}, iz2 = {iz0, iz0}, step = {512.0f, 512.0f};
-      const float fx0 = (float)(xs * 256 + X0rel);
-      f32x2 fx = {fx0, fx0 + 256.0f};
-      unsigned long long *kp = keys + lds_idx<TWL>(y, xs);
-      unsigned long long *const pad = keys + lds_idx<TWL>(y, TW);
-      unsigned long long *const kend = keys + lds_idx<TWL>(y, xe);
-      for (; kp <= kend; kp += 2, fx += step) {
-        const f32x2 z = iz2 + (zA2 * fx + m12);
-        const int zb0 = max(__float_as_int(z.x), 1), zb1 = max(__float_as_int(z.y), 1);
-        atomicMax(kp, ((unsigned long long)(uint32_t)zb0 << 32) | key_lo);
-        atomicMax(kp < kend ? kp + 1 : pad, ((unsigned long long)(uint32_t)zb1 << 32) | key_lo);
-      }
-    }
-  }
-  if (__ballot(big) != 0ull) {
-    if (big) {  // 64-bit form: words 0..5 hold the snapped vertices
-      const int X0 = C0, Y0 = C1, X1 = C2, Y1 = w3, X2 = w4, Y2 = w5;
-      // column range: pixel centres inside the face's bounding box, clipped to the tile (R2)
-      const int jlo = max(((imin3(X0, X1, X2) - 128 + 255) >> 8) - px0, 0);
-      const int jhi = min(((imax3(X0, X1, X2) - 128) >> 8) - px0, TW - 1);
-      const int dx0 = X1 - X0, dy0 = Y1 - Y0, dx1 = X2 - X1, dy1 = Y2 - Y1, dx2 = X0 - X2, dy2 = Y0 - Y2;
-      const long long b0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;
-      const long long b1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
-      const long long b2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
-      const long long Py = (long long)(py0 + y) * 256 + 128;
-      const long long Px = (long long)(px0 + jlo) * 256 + 128;
-      long long e0 = (long long)dx0 * (Py - Y0) - (long long)dy0 * (Px - X0) + b0;
-      long long e1 = (long long)dx1 * (Py - Y1) - (long long)dy1 * (Px - X1) + b1;
-      long long e2 = (long long)dx2 * (Py - Y2) - (long long)dy2 * (Px - X2) + b2;
-      const long long a0 = -(long long)dy0 * 256, a1 = -(long long)dy1 * 256, a2 = -(long long)dy2 * 256;
-      int fxi = jlo * 256 + X0rel;
-      for (int x = jlo; x <= jhi; ++x, e0 += a0, e1 += a1, e2 += a2, fxi += 256) {
-        if ((e0 | e1 | e2) >= 0) {
-          const float m0 = zA * (float)fxi;
-          const float s = m0 + m1;
-          const float z = iz0 + s;
-          const int zb = max(__float_as_int(z), 1);
-          const unsigned long long key = ((unsigned long long)(uint32_t)zb << 32) | key_lo;
-          atomicMax(&keys[lds_idx<TWL>(y, x)], key);
-        }
-      }
+  // two pixels per step with packed fp32 math (v_pk_mul_f32 / v_pk_add_f32: same IEEE results as the scalar forms,
+  // R4 op for op).  float(P_x - X0) advances by exact float adds (integers below 2^24).  An odd span's spare slot is
+  // steered to the row's padding key (column TW), which nobody reads.
+  if (live && xs <= xe) {
+    const f32x2 zA2 = {zA, zA}, m12 = {m1, m1}, iz2 = {iz0, iz0}, step = {512.0f, 512.0f};
+    const float fx0 = (float)(xs * 256 + X0rel);
+    f32x2 fx = {fx0, fx0 + 256.0f};
+    unsigned long long *const row = keys + lds_idx<TWL>(y, TW / 2);  // centred column 0
+    unsigned long long *kp = row + xs;
+    unsigned long long *const pad = row + TW / 2;
+    unsigned long long *const kend = row + xe;
+    for (; kp <= kend; kp += 2, fx += step) {
+      const f32x2 z = iz2 + (zA2 * fx + m12);
+      const int zb0 = max(__float_as_int(z.x), 1), zb1 = max(__float_as_int(z.y), 1);
+      atomicMax(kp, ((unsigned long long)(uint32_t)zb0 << 32) | key_lo);
+      atomicMax(kp < kend ? kp + 1 : pad, ((unsigned long long)(uint32_t)zb1 << 32) | key_lo);
     }
   }
 }
@@ -982,10 +985,10 @@ __device__ __forceinline__ void raster_item(unsigned long long *keys, const int 
 // Phases 2-3 for one CHUNK of up to 64 entries staged in LDS (`ent`, 48 bytes each).  Every wave of the workgroup scans
 // the same 64 row counts; batch b of the chunk belongs to wave (b + rot) % NW.  tab: the wave's 64 mailbox words in LDS,
 // gen: the wave's batch counter (mailbox generation).  Returns the number of batches of the chunk.
-template <int TWL, int NW, typename EntPtr>
+template <int TWL, int TH, int NW, typename EntPtr>
 __device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, uint32_t *tab, uint32_t &gen,
                                                    EntPtr ent, const int nrows, const int lane,
-                                                   const int first_b, const int px0, const int py0, const int dbg) {
+                                                   const int first_b, const int dbg) {
   const int incl = wave_incl_scan(nrows);
   int total = __builtin_amdgcn_readlane(incl, 63);
   const int excl = incl - nrows;
@@ -1003,8 +1006,8 @@ __device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, uin
     const int et = m ? k0 + (m & 63) : carry_e;
     const bool live = q < total;
     const int4 e0 = ent[(t & 63) * 3], e1 = ent[(t & 63) * 3 + 1], e2 = ent[(t & 63) * 3 + 2];
-    raster_item<TWL>(keys, e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, __int_as_float(e1.z), __int_as_float(e1.w),
-                     __int_as_float(e2.x), e2.y, e2.z, (uint32_t)e2.w, q, et, live, px0, py0);
+    raster_item<TWL, TH>(keys, e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, __int_as_float(e1.z), __int_as_float(e1.w),
+                         __int_as_float(e2.x), e2.y, e2.z, (uint32_t)e2.w, q, et, live);
   }
   return (total + 63) >> 6;
 }
@@ -1195,7 +1198,7 @@ __global__ __launch_bounds__(NT) void k_raster_tile(BinArgs a, RasterOut out) {
     const uint32_t e = c0 + (uint32_t)lane;
     int nrows = 0;
     if (e < cnt) nrows = (spec && c0 == 0) ? (int)nr_first : (int)nr8[e];
-    const int nb = raster_chunk_gather<TWL, NW, const int4 *>(keys, tab, gen, ent_lds, nrows, lane, rot, px0, py0, a.dbg);
+    const int nb = raster_chunk_gather<TWL, TH, NW, const int4 *>(keys, tab, gen, ent_lds, nrows, lane, rot, a.dbg);
     rot = (rot - nb) & (NW - 1);
     if (c0 + 64 < cnt) __syncthreads();  // every wave is done with this chunk before it is overwritten
   }
@@ -1228,6 +1231,64 @@ __global__ __launch_bounds__(NT) void k_raster_tile(BinArgs a, RasterOut out) {
         if (out.ids) out.ids[p] = (int32_t)~(uint32_t)key;  // low dword = ~face, 0 when empty: ~0 = -1
         if (out.depth) out.depth[p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
       }
+  }
+}
+
+// K1b  single-pass binning of the faces that reach over more than 2 x 2 tiles (the view's big list, filled by K1).  K1 used
+//      to walk those tiles in a per-lane loop while the other lanes waited -- 112 us per view on a scene with 20 000 trees
+//      seen obliquely (canopy and trunk faces of 300 x 40 pixels), where the terrain alone takes 7.  Here a wave takes 64
+//      big faces, one per lane (records recomputed from the soup: same code as K1, same bits, no record buffer), prefix-sums
+//      their tile counts and EXPANDS: the wave's (face, tile) pairs are taken 64 at a time, a pair finds its face by a
+//      6-step search over the prefix sums and pulls the record out of the owning lane's registers (ds_bpermute).  A tile
+//      the triangle does not touch takes no list slot; all 64 counter atomics of a step are in flight together.
+__global__ __launch_bounds__(256) void k_bin_big(const float *__restrict__ cams, BinArgs a) {
+  const int slot = blockIdx.y;
+  const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
+  uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  const int64_t n_big = min((int64_t)ctrl[5], a.F);
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), wstep = (int64_t)gridDim.x * 4;
+  if (wave0 * 64 >= n_big) return;  // the usual case for terrain: nothing to do
+  uint32_t *cntS = ctrl + GR_CTRL_HDR;
+  int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
+  uint8_t *nr8 = a.nrow8 + slot * a.ent_cap;
+  const int TW = 1 << a.twl, TH = 1 << a.thl;
+  for (int64_t i0 = wave0 * 64; i0 < n_big; i0 += wstep * 64) {
+    int4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0};
+    int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+    bool clip_me, keep = false;
+    if (i0 + lane < n_big) keep = face_setup(a, cam, a.clip[(int64_t)slot * a.F + (a.F - 1 - (i0 + lane))], r0, r1, r2, tx0, tx1, ty0, ty1, clip_me);
+    const int ntx = tx1 - tx0 + 1;
+    const int nt = keep ? ntx * (ty1 - ty0 + 1) : 0;
+    const int incl = wave_incl_scan(nt);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    const int geo = tx0 | (ty0 << 12) | ((ntx - 1) << 24);  // at most 256 x 512 tiles per image (GR_MAX_DIM)
+    for (int k0 = 0; k0 < total; k0 += 64) {
+      const int q = k0 + lane;
+      int t = 0;  // the face of pair q: the first lane whose inclusive sum exceeds q
+#pragma unroll
+      for (int step = 32; step >= 1; step >>= 1) t += (__shfl(incl, t + step - 1) <= q) ? step : 0;
+      t = min(t, 63);
+      const int ex = __shfl(incl, t) - __shfl(nt, t);
+      const int g = __shfl(geo, t);
+      const int4 p0 = make_int4(__shfl(r0.x, t), __shfl(r0.y, t), __shfl(r0.z, t), __shfl(r0.w, t));
+      const int4 p1 = make_int4(__shfl(r1.x, t), __shfl(r1.y, t), __shfl(r1.z, t), __shfl(r1.w, t));
+      const int4 p2 = make_int4(__shfl(r2.x, t), __shfl(r2.y, t), __shfl(r2.z, t), __shfl(r2.w, t));
+      if (q >= total) continue;
+      const int k = q - ex, gtx = g & 0xFFF, gty = (g >> 12) & 0xFFF, gn = (int)((uint32_t)g >> 24) + 1;
+      const int tx = gtx + k % gn, ty = gty + k / gn;
+      int4 e0, e1, e2;
+      int rows;
+      if (!build_entry(p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH, e0, e1, e2, rows)) continue;
+      const int tile = ty * a.TX + tx;
+      const uint32_t pos = atomicAdd(&cntS[tile], 1u);
+      if (pos < (uint32_t)a.cap_tile) {
+        const int64_t idx = (int64_t)tile * a.cap_tile + pos;
+        int4 *dst = comp + idx * GR_ENT_Q;
+        dst[0] = e0; dst[1] = e1; dst[2] = e2;
+        nr8[idx] = (uint8_t)rows;
+      } else ctrl[2] = 1u;
+    }
   }
 }
 
@@ -1780,6 +1841,7 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int
     if (a.cap_tile > 0) {
       hipLaunchKernelGGL(k_setup_cull<true>, dim3((unsigned)std::min((nblk + 3) / 4, 1024), nb), dim3(256), 0, s, c->verts,
                          c->faces, cams, a);
+      hipLaunchKernelGGL(k_bin_big, dim3(256, nb), dim3(256), 0, s, cams, a);
       hipLaunchKernelGGL(k_clip_faces<true>, dim3(8, nb), dim3(64), 0, s, cams, a);
     } else {
       hipLaunchKernelGGL(k_setup_cull<false>, dim3((unsigned)std::min((nblk + 3) / 4, 1024), nb), dim3(256), 0, s, c->verts,
