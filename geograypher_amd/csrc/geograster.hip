@@ -525,6 +525,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(BinArgs a) {
 // every product has 24-bit factors and every value fits int32 -- no 64-bit arithmetic, no per-tile range test.
 // Larger faces take the general form below (identical coverage: both forms are exact).
 #define GR_FAST_EXT 24000
+#define GR_FLOOR_NOCORR_MAX 16000  // largest slope magnitude for which edge_floor<false> is exact (see there)
 __device__ __forceinline__ int pack16(int lo, int hi) { return (lo & 0xFFFF) | (hi << 16); }
 __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const int4 p2, int px0, int py0, int TW, int TH,
                                             int4 &e0, int4 &e1, int4 &e2, int &rows) {
@@ -597,7 +598,9 @@ __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const 
   }
   e0 = make_int4(cf, cm, cl, w3);
   e1 = make_int4(w4, w5, p1.z, p2.x);
-  e2 = make_int4(p2.y, xw, yw | (narrow ? 0 : (int)0x80000000), (int)~(uint32_t)p1.w);
+  // bit 31: 24-bit slopes; bit 30: some slope magnitude beyond GR_FLOOR_NOCORR_MAX (the span solver must correct its floor)
+  const bool corr = !narrow || max(abs(a0), max(abs(a1), abs(a2))) > GR_FLOOR_NOCORR_MAX;
+  e2 = make_int4(p2.y, xw, yw | (narrow ? 0 : (int)0x80000000) | (corr ? 0x40000000 : 0), (int)~(uint32_t)p1.w);
   return touches;
 }
 
@@ -877,7 +880,6 @@ __device__ __forceinline__ int lds_idx(int row, int col) {
 //   reciprocal perturbed by up to 3.5 ulp (tests/test_span_floor.py) -- so no probe of the edge function is needed.
 //   CORR (m up to 32767): one exact remainder puts a proposal that is off by one right.
 //   m == 0 (an edge parallel to the scanline): g = +-inf, clamped to "no constraint" / "empty" by the sign of E.
-#define GR_FLOOR_NOCORR_MAX 16000
 template <bool CORR>
 __device__ __forceinline__ int edge_floor(int E, int m, float mf) {
   float g = ((float)E + 0.5f) * __builtin_amdgcn_rcpf(mf);
@@ -954,8 +956,7 @@ __device__ __forceinline__ void raster_item(unsigned long long *keys, const int 
   // faces with a slope beyond GR_FLOOR_NOCORR_MAX (edges longer than 62 pixels) or 24-bit slopes take the span solver
   // with the exact correction; the choice is made per wave so that the usual case carries no extra instructions
   const bool wide24 = yw < 0;
-  const bool wide = live && (wide24 || max(max(abs((w3 << 16) >> 16), abs(w3 >> 16)), abs(((w3 << 16) >> 16) + (w3 >> 16))) >
-                                           GR_FLOOR_NOCORR_MAX);
+  const bool wide = live && ((uint32_t)yw >= 0x40000000u);  // compile_entry's flags: 24-bit slopes or a slope beyond 16000
   int xs = 0, xe = -1;
   if (__ballot(wide) != 0ull) {
     if (live) span_solve<TW, true>(C0, C1, C2, w3, w4, w5, wide24, y - TH / 2, xs, xe);
@@ -1045,66 +1046,68 @@ __device__ __forceinline__ void store_ids(const unsigned long long *keys, const 
 // the tile shows goes to winner[face] with a global atomicMax of pixel + 1 -- meshes.py:1987-2001, where numpy's fancy
 // assignment lets the last pixel of a face win.  A pixel can only be that last pixel if none of right / below-left /
 // below / below-right shows the same face (a face's consecutive scanlines touch at least diagonally unless it is a steep
-// sliver; extra candidates are harmless): 1.7 candidates per visible face on C2.  What makes this epilogue cheap is
-// its LATENCY (a workgroup's lifetime is the kernel's currency): a lane owns 4 consecutive pixels of two rows, ALL its
-// LDS reads -- the rows and the rows below them -- are issued up front, the neighbours across lanes come from DPP row
-// shifts (a 16-lane DPP row is exactly one 64-pixel tile row: lanes outside keep the `old` operand, "differs"), and
-// nothing waits on global memory: the label of the winning pixel is looked up by the vote kernel.  Background needs no
-// mapping here: the tile was filled with the id that background aliases (F - 1 with GR_FLAG_NEG1_IS_LAST_FACE, else
-// -1, which no candidate test accepts).  Unknown neighbours count as "differs": -3 across a tile edge, -2 outside the
-// image (EDGE tiles only).
+// sliver; extra candidates are harmless): 1.7 candidates per visible face on C2.  The fused kernel has almost no memory
+// traffic, so this epilogue is priced in INSTRUCTIONS: a lane owns 4 consecutive pixels of TWO consecutive rows (three
+// row reads serve both), all LDS reads are issued up front, the neighbours across lanes come from DPP row shifts (a
+// 16-lane DPP row is exactly one 64-pixel tile row: lanes outside keep the `old` operand), every comparison is made on
+// the RAW low dword of the key (~face: negative for a face, 0 for plain background; "differs" sentinels 1 and 2 can never
+// equal one), the candidate conditions are plain mask arithmetic, and nothing waits on global memory: the label of the
+// winning pixel is looked up by the vote kernel.  Background needs no mapping: the tile was filled with the id that
+// background aliases (F - 1 with GR_FLAG_NEG1_IS_LAST_FACE, else -1 = raw 0, which no candidate test accepts).
+// Unknown neighbours count as "differs": 1 across a tile edge, 2 outside the image (EDGE tiles only).
 template <int TWL, int TH, int NT, bool EDGE>
 __device__ __forceinline__ void fused_winners(const unsigned long long *keys, const BinArgs &a, uint32_t *__restrict__ win,
                                               int te, int px0, int py0, int dbg) {
-  static_assert(TWL == 6 && NT == 256, "16 lanes x 4 pixels per tile row");
+  static_assert(TWL == 6 && NT == 256 && TH % 32 == 0, "16 lanes x 4 pixels per tile row, 16 row pairs per pass");
   const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
-  const int c4 = (te & 15) * 4, rr = te >> 4;
-  constexpr int NPASS = TH / 16;
+  const int c4 = (te & 15) * 4, rp = te >> 4;  // row pair 0 .. 15 of a pass
 #pragma unroll
-  for (int g = 0; g < NPASS; g += 2) {
-    int cur[2][4], bel[2][4];
+  for (int pass = 0; pass < TH / 32; ++pass) {
+    const int r0 = 2 * rp + 32 * pass;          // rows r0, r0 + 1; the row below them is r0 + 2
+    int c[3][6];                                // c[k][j + 1]: raw key of row r0 + k, column c4 + j, j = -1 .. 4
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int r = rr + (g + u) * 16;
-      const uint32_t *kr = klo + 2 * lds_idx<TWL>(r, c4);
+    for (int k = 0; k < 3; ++k) {
+      if (k < 2 || r0 + 2 < TH) {
+        const uint32_t *kr = klo + 2 * lds_idx<TWL>(r0 + k, c4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) cur[u][j] = (int)~kr[2 * j];
-      if (r + 1 < TH) {
-        const uint32_t *kb = klo + 2 * lds_idx<TWL>(r + 1, c4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bel[u][j] = (int)~kb[2 * j];
+        for (int j = 0; j < 4; ++j) c[k][j + 1] = (int)kr[2 * j];
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bel[u][j] = -3;
+        for (int j = 0; j < 4; ++j) c[k][j + 1] = 1;  // the tile below: unknown
+      }
+    }
+    const int gy = py0 + r0;
+    if (EDGE) {
+      if (gy >= a.h) continue;
+      if (gy + 1 >= a.h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[1][j + 1] = 2;
+      }
+      if (gy + 2 >= a.h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[2][j + 1] = 2;
       }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int r = rr + (g + u) * 16;
-      const int gy = py0 + r;
-      if (EDGE && gy >= a.h) continue;
-      int c[5], b[6];  // c[j]: this row, b[j + 1]: the row below, j = -1 .. 4
+    for (int k = 0; k < 3; ++k) {
+      c[k][5] = __builtin_amdgcn_update_dpp(1, c[k][1], 0x101 /* row_shl:1: lane + 1 */, 0xf, 0xf, false);
+      if (k > 0) c[k][0] = __builtin_amdgcn_update_dpp(1, c[k][4], 0x111 /* row_shr:1: lane - 1 */, 0xf, 0xf, false);
+    }
+    const uint32_t p1 = (uint32_t)(gy * a.w + px0 + c4 + 1);  // linear pixel index + 1 of the lane's first pixel (h, w <= 16384)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { c[j] = cur[u][j]; b[j + 1] = bel[u][j]; }
-      if (EDGE && gy + 1 >= a.h) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b[j + 1] = -2;
-      }
-      c[4] = __builtin_amdgcn_update_dpp(-3, c[0], 0x101 /* row_shl:1: lane + 1 */, 0xf, 0xf, false);
-      b[5] = __builtin_amdgcn_update_dpp(-3, b[1], 0x101 /* row_shl:1 */, 0xf, 0xf, false);
-      b[0] = __builtin_amdgcn_update_dpp(-3, b[4], 0x111 /* row_shr:1: lane - 1 */, 0xf, 0xf, false);
-      const int p1 = gy * a.w + px0 + c4 + 1;  // linear pixel index + 1 of the lane's first pixel (h, w <= 16384)
+    for (int k = 0; k < 2; ++k) {
+      if (EDGE && gy + k >= a.h) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int f = c[j];
-        bool cand = f >= 0 && b[j] != f && b[j + 1] != f;
+        const int f = c[k][j + 1];
+        bool cand = (f < 0) & (c[k + 1][j + 1] != f) & (c[k + 1][j] != f);
         if (EDGE) {
           const int gx = px0 + c4 + j;
-          cand = cand && gx < a.w && (gx + 1 >= a.w || (c[j + 1] != f && b[j + 2] != f));
+          cand = cand & (gx < a.w) & ((gx + 1 >= a.w) | ((c[k][j + 2] != f) & (c[k + 1][j + 2] != f)));
         } else {
-          cand = cand && c[j + 1] != f && b[j + 2] != f;
+          cand = cand & (c[k][j + 2] != f) & (c[k + 1][j + 2] != f);
         }
-        if (cand && !(dbg & 8)) atomicMax(win + f, (uint32_t)(p1 + j));
+        if (cand && !(dbg & 8)) atomicMax(win + ~f, p1 + (uint32_t)(k * a.w + j));
       }
     }
   }
@@ -1341,7 +1344,7 @@ __global__ __launch_bounds__(256) void k_winner(const int32_t *__restrict__ ids,
 //     a face belongs to exactly one thread).  The label of the winning pixel is looked up here (one byte per visible
 //     face and view; neighbouring faces win neighbouring pixels): votes[f][label] += 1, counts[f] += 1; a label >= C
 //     (255 = ignore) is an all-zero one-hot row that still counts (predictors/segmentor.py:37-69).  Winners are
-//     cleared for reuse.
+//     cleared for reuse (only the faces a view shows were written: a tenth of the array).
 __global__ __launch_bounds__(256) void k_vote_labels(uint32_t *__restrict__ winner, const uint8_t *__restrict__ labels,
                                                      int n_views, int64_t F, int64_t P, int C,
                                                      uint32_t *__restrict__ votes, uint32_t *__restrict__ counts,
