@@ -15,8 +15,8 @@ warm-up steps, R windows of EXACTLY K steps each are timed, every window bracket
 sides and reduced with MAX over ranks; `value` / `ms_per_step` are the median window, the spread is reported beside it.
 The per-kernel HIP-event durations of the roofline object are collected over the timed windows themselves.
 
-Outside the headline region the same run times: (a) "aggregate": the fused raster + last-writer-wins projection + per-face
-votes on 50 views per GPU (one RCCL all-reduce of the votes at N > 1), checked against the CPU oracle on one view;
+Outside the headline region the same run times: (a) "aggregate": BASELINE config 3 -- the 500-view grid with 4-class labels through the fused raster +
+last-writer-wins projection + per-face votes (one RCCL all-reduce of the votes at N > 1), checked against the CPU oracle on one view;
 (b) "c4": BASELINE config 4's per-GPU shard (250 views of the 2000-view set, view i -> GPU i mod N) with the single
 all-reduce of the packed [F x (C+1)] int32 votes timed separately; (c) at N == 1, "workload_2": a hostile scene (terrain +
 20 000 trees, cameras tilted 30-45 degrees) at full and at quarter resolution, with sampled oracle parity; (d) at
@@ -41,6 +41,7 @@ H, W = 3000, 4000
 VIEWS_PER_RANK = 50
 N_CLASSES = 4
 C4_VIEWS_PER_RANK = 250
+C3_VIEWS = 500
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -238,27 +239,36 @@ def run(args) -> int:
         "pipeline_frac": round(br_bytes / (pipeline_ms_per_view * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
     }
 
-    # ---- aggregation pipeline (config 3 shape): fused raster + winners + votes, one all-reduce of the votes at N > 1 ----
+    # ---- aggregation pipeline = BASELINE config 3: the 500-view camera grid, 4-class labels, aggregate_viewpoints on one GPU:
+    #      fused raster + winners + votes in ONE call per step (8 launch groups), one all-reduce of the votes at N > 1 ----------
     aggregate = None
     labels = None
     if not args.no_aggregate:
-        labels = torch.empty((nv, H, W), dtype=torch.uint8, device=dev)
-        for v in range(nv):
-            labels[v] = device_labels(ids[v], rank * nv + v)
+        cams3 = synthetic.config3_cameras(C3_VIEWS)
+        n3 = len(cams3)
+        recs3_np = cams3.get_raster_records(1.0, near=1.0)
+        recs3 = torch.from_numpy(recs3_np).to(dev)
+        labels = torch.empty((n3, H, W), dtype=torch.uint8, device=dev)
+        for c0 in range(0, n3, nv):  # labels are generated on the device from the ids, chunk by chunk
+            c1 = min(c0 + nv, n3)
+            hip.raster_face_ids(recs3[c0:c1], H, W, out=ids[: c1 - c0], check=(c0 == 0))
+            for k in range(c1 - c0):
+                labels[c0 + k] = device_labels(ids[k], c0 + k)
         votes, counts = hip.new_vote_buffers(N_CLASSES)
 
         def agg_step():
             votes.zero_()
             counts.zero_()
-            hip.raster_project_labels(recs, labels, N_CLASSES, votes, counts, ids_out=None, check=False)
+            hip.raster_project_labels(recs3, labels, N_CLASSES, votes, counts, ids_out=None, check=False)
             if distributed:
                 all_reduce_votes(votes, counts)
             return hip.finalize_votes(votes, counts)
 
+        hip.raster_project_labels(recs3, labels, N_CLASSES, votes, counts, check=True)  # sizing / warm-up pass
         agg_step()
         barrier()
         t0 = time.perf_counter()
-        agg_steps = max(1, args.steps // 2)
+        agg_steps = 5
         for _ in range(agg_steps):
             avg, summed, cnt = agg_step()
         barrier()
@@ -267,12 +277,14 @@ def run(args) -> int:
         agg_step()
         ast = hip.stage_times()
         hip.set_profiling(False)
-        agg_views = world * nv * agg_steps
+        agg_views = world * n3 * agg_steps
         aggregate = {
-            "workload": f"C3-shaped: fused raster + last-writer-wins projection (ids stay in LDS) + uint32 votes, "
-                        f"{N_CLASSES} classes, {nv} views/GPU, one RCCL all-reduce of [F x {N_CLASSES + 1}] int32 per step at N>1",
+            "workload": f"BASELINE config 3: {n3} views (25 x 20 grid) of the C2 mesh per GPU, {N_CLASSES}-class labels, fused raster + "
+                        f"last-writer-wins projection (ids stay in LDS) + uint32 votes in one call per step, one RCCL all-reduce of "
+                        f"[F x {N_CLASSES + 1}] int32 per step at N>1",
             "views_per_s": round(agg_views / agg_elapsed, 2),
             "mpix_per_s": round(agg_views / agg_elapsed * P / 1e6, 1),
+            "ms_per_step": round(agg_elapsed / agg_steps * 1e3, 3),
             "faces_observed": int((cnt > 0).sum().item()),
             "setup_ms_per_view": round(ast["setup_ms"] / max(ast["views"], 1), 5),
             "raster_fused_ms_per_view": round(ast["raster_ms"] / max(ast["views"], 1), 5),
@@ -382,10 +394,11 @@ def run(args) -> int:
         if aggregate is not None:
             # the aggregate leg against the oracle: votes of view 0 alone, fused on the GPU vs rasterized + projected on the CPU
             v1, c1 = hip.new_vote_buffers(N_CLASSES)
-            hip.raster_project_labels(recs[:1], labels[:1], N_CLASSES, v1, c1, check=True)
+            hip.raster_project_labels(recs3[:1], labels[:1], N_CLASSES, v1, c1, check=True)
             want_v = np.zeros((F, N_CLASSES), dtype=np.uint32)
             want_c = np.zeros(F, dtype=np.uint32)
-            oracle_c.project_labels(one[0], labels[0].cpu().numpy(), F, N_CLASSES, want_v, want_c)
+            one3 = oracle_c.raster(points, faces, recs3_np[0], H, W)
+            oracle_c.project_labels(one3, labels[0].cpu().numpy(), F, N_CLASSES, want_v, want_c)
             ok = bool(np.array_equal(v1.cpu().numpy().view(np.uint32), want_v) and
                       np.array_equal(c1.cpu().numpy().view(np.uint32), want_c))
             aggregate["oracle_check"] = f"votes and counts of view 0 (fused call) equal the CPU oracle's: {ok}"
