@@ -2084,7 +2084,8 @@ int gr_mesh_upload(gr_ctx *c, const float *verts, const int32_t *faces, int64_t 
   uint32_t *up = reinterpret_cast<uint32_t *>(c->flag);
   GR_HIP(c, hipMemcpyAsync(up, init, sizeof(init), hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_validate_faces, dim3((unsigned)ceil_div(3 * F, 256)), dim3(256), 0, s, faces, 3 * F, V, c->flag);
-  hipLaunchKernelGGL(k_mesh_bounds, dim3((unsigned)std::min<int64_t>(ceil_div(V, 256), 2048)), dim3(256), 0, s, verts, V,
+  // few blocks: every wave ends with six atomics on the same six words (2048 blocks spent 0.56 ms queueing on them)
+  hipLaunchKernelGGL(k_mesh_bounds, dim3((unsigned)std::min<int64_t>(ceil_div(V, 256), 128)), dim3(256), 0, s, verts, V,
                      up + 1);
   uint32_t got[8];
   GR_HIP(c, hipMemcpyAsync(got, up, sizeof(got), hipMemcpyDeviceToHost, s));

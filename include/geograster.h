@@ -59,7 +59,7 @@ typedef struct gr_stage_times {
   float setup_ms;   /* k_setup_cull : transform + cull + record + tile counts      */
   float scan_ms;    /* k_scan_tiles                                                */
   float fill_ms;    /* k_fill_compile                                              */
-  float raster_ms;  /* k_raster_rows (the dominant kernel)                         */
+  float raster_ms;  /* k_raster_tile (the dominant kernel)                         */
   float project_ms; /* k_winner_* : last-writer-wins pixel -> face                 */
   float vote_ms;    /* k_vote_*   : per-face accumulate                            */
   float gather_ms;  /* k_gather_texture                                            */

@@ -55,7 +55,7 @@ def main():
     out_txt = os.path.join(raw, f"summary_{tag}.txt")
     lines = []
     path, rows = kernel_stats(raw)
-    lines.append(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline   [{tag}]")
+    lines.append(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 2 --windows 2 --no-cpu-baseline --no-workload2 --no-c4   [{tag}]")
     lines.append(f"# source: {path}")
     # median from the per-launch trace of the same run (the first launches after a mesh upload run cold and pull the mean up)
     trace = kernel_trace_durations(raw, "trace")
@@ -70,7 +70,7 @@ def main():
     write = pmc(raw, "pmc_write", "WRITE_SIZE")
     dur = kernel_trace_durations(raw, "pmc_fetch")
     lines.append("")
-    lines.append("# PMC passes (separate runs): python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-aggregate")
+    lines.append("# PMC passes (separate runs): python3 bench.py --steps 2 --warmup 1 --windows 1 --no-cpu-baseline --no-aggregate --no-workload2 --no-c4")
     lines.append("# FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; on gfx950 FETCH_SIZE counts 64 B per 128-B request")
     lines.append("# for wide streaming reads (MI355X_MICROARCH.md, HBM): the 'fetch_x2' column doubles it as the guide prescribes.")
     lines.append(f"{'kernel':40s} {'launches':>8s} {'fetch_MB':>10s} {'fetch_x2_MB':>12s} {'write_MB':>10s} {'avg_us':>9s}")
@@ -94,6 +94,7 @@ def main():
         if fm == fm and wm == wm:
             traffic[name] = {"hbm_bytes_per_launch": (fm + wm) * 1e6, "fetch_x2_MB": fm, "write_MB": wm,
                              "launches": v["launches"], "source": f"profiles/summary_{tag}.txt"}
+    traffic["_source"] = f"tools/profile.sh {tag}: summary_{tag}.txt"
     with open(os.path.join(raw, "traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
     print("\n".join(lines))
