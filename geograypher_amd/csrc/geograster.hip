@@ -63,7 +63,7 @@ struct BinArgs {
   int h, w;
   int twl, thl;          // log2 of the tile width / height in pixels
   int cap_tile;          // > 0: single-pass binning, every tile owns cap_tile entry slots (list base = tile * cap_tile)
-  int var;               // kernel variant bits (GR_OPT_VARIANT): 64 = XCD-aware tile order
+  int var;               // variant bits (GR_OPT_VARIANT): 1 = one tile per workgroup instead of two, 4 = votes on the caller's stream
   int dbg;               // timing-only ablation mask (GR_OPT_DEBUG): 1 skip scanline loop, 2 skip id stores, 4 skip triangles,
                          // fused epilogue: 8 skip winner atomics, 16 skip label loads
 };
@@ -538,7 +538,9 @@ __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const 
   const int t1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
   const int t2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
   const int ext = max(imax3(X0, X1, X2) - imin3(X0, X1, X2), imax3(Y0, Y1, Y2) - imin3(Y0, Y1, Y2));
-  const int yw = ((Pyo - Y0) & 0xFFFFFF) | (ilo << 24);  // |Pyo - Y0| < 2^23 inside the guard band
+  // row word, CENTRED like everything else the tile kernel reads: float(P_y - Y0) of centred row y_c = y - TH/2 is
+  // float(256 y_c + Yw); the entry's first row as y_c (6 bits, signed).  |Pyo - Y0| + 8192 < 2^23 inside the guard band
+  const int yw = ((Pyo - Y0 + (TH / 2) * 256) & 0xFFFFFF) | (((ilo - TH / 2) & 0x3F) << 24);
   int nr = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;         // rows of the entry in this tile (<= 64)
   // ONE form for every face, however large: the three edge functions in units of 256 around the tile CENTRE,
   //   E'_k(x_c, y_c) = C'_k + a_k x_c + b_k y_c,   x_c = x - TW/2, y_c = y - TH/2,   a_k = -dy_k, b_k = dx_k (|.| < 2^23),
@@ -600,7 +602,9 @@ __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const 
   e1 = make_int4(w4, w5, p1.z, p2.x);
   // bit 31: 24-bit slopes; bit 30: some slope magnitude beyond GR_FLOOR_NOCORR_MAX (the span solver must correct its floor)
   const bool corr = !narrow || max(abs(a0), max(abs(a1), abs(a2))) > GR_FLOOR_NOCORR_MAX;
-  e2 = make_int4(p2.y, xw, yw | (narrow ? 0 : (int)0x80000000) | (corr ? 0x40000000 : 0), (int)~(uint32_t)p1.w);
+  // ~face sits in an EVEN word: the tile kernel forms the 64-bit key (depth << 32 | ~face) in the register pair the entry
+  // was read into, without a move
+  e2 = make_int4(p2.y, xw, (int)~(uint32_t)p1.w, yw | (narrow ? 0 : (int)0x80000000) | (corr ? 0x40000000 : 0));
   return touches;
 }
 
@@ -867,9 +871,9 @@ struct RasterOut {
 // 5 px per row (a pad of 1 piled up every 45-degree edge: 530 of 1820 LDS cycles per tile were bank conflicts), and a
 // pixel's address advances by a plain +8 bytes along the scanline (no wrap arithmetic in the inner loop).
 #define GR_LDS_PAD 5
-template <int TWL>
+template <int TWL, int PAD>
 __device__ __forceinline__ int lds_idx(int row, int col) {
-  return __mul24(row, (1 << TWL) + GR_LDS_PAD) + col;
+  return __mul24(row, (1 << TWL) + PAD) + col;
 }
 
 // floor(E / m) for an integer edge value E (|E| < 2^23 wherever the result matters) and an edge slope magnitude
@@ -884,7 +888,8 @@ template <bool CORR>
 __device__ __forceinline__ int edge_floor(int E, int m, float mf) {
   float g = ((float)E + 0.5f) * __builtin_amdgcn_rcpf(mf);
   g = __builtin_amdgcn_fmed3f(g, -34.0f, 33.0f);  // centred columns -32 .. 31, plus the solver's reach
-  int fl = (int)floorf(g);
+  int fl;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(fl) : "v"(g));  // (int)floorf(g) in one instruction
   if (CORR) {
     const int rem = E - __mul24(fl, m);
     fl += (rem >= m ? 1 : 0) - (rem < 0 ? 1 : 0);
@@ -931,84 +936,110 @@ __device__ __forceinline__ int wave_incl_scan(int x) {
   return x;
 }
 
-// Inclusive prefix maximum of non-negative values, same DPP pattern.
-__device__ __forceinline__ int wave_incl_max(int x) {
-  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111 /* row_shr:1 */, 0xf, 0xf, false));
-  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112 /* row_shr:2 */, 0xf, 0xf, false));
-  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114 /* row_shr:4 */, 0xf, 0xf, false));
-  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118 /* row_shr:8 */, 0xf, 0xf, false));
-  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false));
-  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
+// Inclusive prefix maximum (unsigned), same DPP pattern.
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t x) {
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112 /* row_shr:2 */, 0xf, 0xf, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114 /* row_shr:4 */, 0xf, 0xf, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118 /* row_shr:8 */, 0xf, 0xf, false));
+  // the two row-broadcast steps as single instructions (the compiler makes three of each): rows 1, 3 take the maximum
+  // with lane 15 of the row before, then rows 2, 3 with lane 31; masked-out rows keep their value
+  asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(x));
   return x;
 }
 
-// Phase 3 for ONE work item: scanline `q - et` of the entry whose 12 words the lane holds (however they got there).
-template <int TWL, int TH>
-__device__ __forceinline__ void raster_item(unsigned long long *keys, const int C0, const int C1, const int C2, const int w3,
-                                            const int w4, const int w5, const float iz0, const float zA, const float zB,
-                                            const int xw, const int yw, const uint32_t key_lo, const int q, const int et,
+// Phase 3 for ONE work item: scanline `q - et` of the entry whose 12 words (e0, e1, e2) the lane holds.
+// The tile kernel is VALU-issue bound (SQ_ACTIVE_INST_VALU: 85 % of the SIMD cycles), so this function is written for
+// instruction count: packed fp32 operands are broadcast by op_sel instead of being copied into register pairs, the
+// 64-bit key is formed in the pair the entry word ~face was read into, an odd span is extended to the LEFT (only the
+// first step has a spare slot, steered to the row's padding key), and the row addresses come from one multiply-add.
+template <int TWL, int TH, int PAD>
+__device__ __forceinline__ void raster_item(unsigned long long *keys, const int4 e0, const int4 e1, const int4 e2, const int r,
                                             const bool live) {
   constexpr int TW = 1 << TWL;
+  const int xw = e2.y, yw = e2.w;
   const int X0rel = (xw << 8) >> 8;  // biased by TW/2 columns: float(P_x - X0) = float(256 x_c + X0rel)
-  const int Y0rel = (yw << 8) >> 8, ilo = (yw >> 24) & 0x3F;
-  const int y = ilo + (q - et);
-  const float m1 = zB * (float)(y * 256 + Y0rel);
+  const int Y0rel = (yw << 8) >> 8;  // biased by TH/2 rows
+  const int yc = ((yw << 2) >> 26) + r;  // centred row of the item: the entry's first row + the item's row within the entry
   // faces with a slope beyond GR_FLOOR_NOCORR_MAX (edges longer than 62 pixels) or 24-bit slopes take the span solver
   // with the exact correction; the choice is made per wave so that the usual case carries no extra instructions
   const bool wide24 = yw < 0;
   const bool wide = live && ((uint32_t)yw >= 0x40000000u);  // compile_entry's flags: 24-bit slopes or a slope beyond 16000
   int xs = 0, xe = -1;
   if (__ballot(wide) != 0ull) {
-    if (live) span_solve<TW, true>(C0, C1, C2, w3, w4, w5, wide24, y - TH / 2, xs, xe);
+    if (live) span_solve<TW, true>(e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, wide24, yc, xs, xe);
   } else {
-    if (live) span_solve<TW, false>(C0, C1, C2, w3, w4, w5, false, y - TH / 2, xs, xe);
+    if (live) span_solve<TW, false>(e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, false, yc, xs, xe);
   }
   // two pixels per step with packed fp32 math (v_pk_mul_f32 / v_pk_add_f32: same IEEE results as the scalar forms,
-  // R4 op for op).  float(P_x - X0) advances by exact float adds (integers below 2^24).  An odd span's spare slot is
-  // steered to the row's padding key (column TW), which nobody reads.
+  // R4 op for op: z = iz0 + (A * float(P_x - X0) + B * float(P_y - Y0))).  float(P_x - X0) advances by exact float adds
+  // (integers below 2^24).
   if (live && xs <= xe) {
-    const f32x2 zA2 = {zA, zA}, m12 = {m1, m1}, iz2 = {iz0, iz0}, step = {512.0f, 512.0f};
-    const float fx0 = (float)(xs * 256 + X0rel);
+    const float m1 = __int_as_float(e2.x) * (float)(yc * 256 + Y0rel);
+    const bool even = ((xe - xs) & 1) != 0;       // an even number of pixels xs .. xe
+    const int x0 = even ? xs : xs - 1;            // x0 .. xe is always an even number; pixel xs - 1 is computed, not stored
+    const float fx0 = (float)(x0 * 256 + X0rel);
     f32x2 fx = {fx0, fx0 + 256.0f};
-    unsigned long long *const row = keys + lds_idx<TWL>(y, TW / 2);  // centred column 0
-    unsigned long long *kp = row + xs;
-    unsigned long long *const pad = row + TW / 2;
-    unsigned long long *const kend = row + xe;
-    for (; kp <= kend; kp += 2, fx += step) {
-      const f32x2 z = iz2 + (zA2 * fx + m12);
+    const f32x2 step = {512.0f, 512.0f};
+    f32x2 izA;                                    // {iz0, A}: the two words as the entry holds them
+    izA.x = __int_as_float(e1.z); izA.y = __int_as_float(e1.w);
+    f32x2 mp;
+    mp.x = m1;                                    // the high half is never selected (op_sel_hi)
+    // byte offset of the row's centred column 0: the key rows are (TW + PAD) * 8 bytes apart
+    const int row = __mul24(yc, (TW + PAD) * 8) + ((TH / 2) * (TW + PAD) + TW / 2) * 8;
+    int kp = row + x0 * 8;
+    const int kend = row + xe * 8;
+    const uint32_t key_a = (uint32_t)e2.z;
+    uint32_t key_b = key_a;                       // a second copy: each pixel of a step forms its key in its own pair
+    asm("v_mov_b32 %0, %1" : "=v"(key_b) : "v"(key_a));
+    auto pixel_pair = [&](bool first_too) {
+      f32x2 t, z;
+      asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t) : "v"(izA), "v"(fx));   // A * fx
+      asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(mp), "v"(t));                   // + m1
+      asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(z) : "v"(izA), "v"(t));                  // iz0 +
       const int zb0 = max(__float_as_int(z.x), 1), zb1 = max(__float_as_int(z.y), 1);
-      atomicMax(kp, ((unsigned long long)(uint32_t)zb0 << 32) | key_lo);
-      atomicMax(kp < kend ? kp + 1 : pad, ((unsigned long long)(uint32_t)zb1 << 32) | key_lo);
-    }
+      unsigned long long *const k = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(keys) + kp);
+      if (first_too) atomicMax(k, ((unsigned long long)(uint32_t)zb0 << 32) | key_a);
+      atomicMax(k + 1, ((unsigned long long)(uint32_t)zb1 << 32) | key_b);
+      kp += 16;
+      fx += step;
+    };
+    pixel_pair(even);
+    while (kp < kend) pixel_pair(true);
   }
 }
 
 // Phases 2-3 for one CHUNK of up to 64 entries staged in LDS (`ent`, 48 bytes each).  Every wave of the workgroup scans
 // the same 64 row counts; batch b of the chunk belongs to wave (b + rot) % NW.  tab: the wave's 64 mailbox words in LDS,
 // gen: the wave's batch counter (mailbox generation).  Returns the number of batches of the chunk.
-template <int TWL, int TH, int NW, typename EntPtr>
-__device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, uint32_t *tab, uint32_t &gen,
+// item -> entry: an entry that starts inside the batch posts gen | lane | slot into the mailbox of its start slot; the
+// words of the current batch are larger than any stale one (gen grows), and among them the latest start is the largest,
+// so an unsigned prefix maximum over the RAW words carries the right entry to every item lane.
+template <int TWL, int TH, int NW, int PAD, typename EntPtr>
+__device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, const int tab_base, const int tab_self, uint32_t &gen,
                                                    EntPtr ent, const int nrows, const int lane,
                                                    const int first_b, const int dbg) {
+  char *const lds = reinterpret_cast<char *>(keys);
   const int incl = wave_incl_scan(nrows);
   int total = __builtin_amdgcn_readlane(incl, 63);
   const int excl = incl - nrows;
   if (dbg & 1) total = 0;
   for (int k0 = first_b * 64; k0 < total; k0 += 64 * NW) {
     const int q = k0 + lane;
-    ++gen;
+    gen += 1u << 12;
     const int slot = excl - k0;
-    if (nrows > 0 && slot >= 0 && slot < 64) tab[slot] = (gen << 13) | (uint32_t)((lane + 1) << 6) | (uint32_t)slot;
-    const int carry_t = __popcll(__ballot(incl <= k0));  // the entry that holds item k0: it exists (k0 < total)
-    const int carry_e = __builtin_amdgcn_readlane(excl, carry_t & 63);
-    const uint32_t mail = tab[lane];
-    const int m = wave_incl_max((mail >> 13) == gen ? (int)(mail & 0x1FFFu) : 0);
-    const int t = m ? (m >> 6) - 1 : carry_t;  // always an entry of this chunk, also for lanes beyond the last item
-    const int et = m ? k0 + (m & 63) : carry_e;
+    if (nrows > 0 && slot >= 0 && slot < 64)
+      *reinterpret_cast<uint32_t *>(lds + tab_base + slot * 4) = gen | (uint32_t)(lane << 6) | (uint32_t)slot;
+    const int carry_t = __popcll(__ballot(incl <= k0));  // the entry that holds item k0: it exists (k0 < total), <= 63
+    const int carry_r = k0 - __builtin_amdgcn_readlane(excl, carry_t);  // row of item k0 within that entry
+    const uint32_t m = wave_incl_max(*reinterpret_cast<const uint32_t *>(lds + tab_self));
+    const bool started = m >= gen;                       // some entry starts at or before this lane's item in the batch
+    const int t = started ? (int)((m >> 6) & 63u) : carry_t;  // always an entry of this chunk, also beyond the last item
+    const int r = lane - (started ? (int)(m & 63u) : -carry_r);  // the item's row within its entry
     const bool live = q < total;
-    const int4 e0 = ent[(t & 63) * 3], e1 = ent[(t & 63) * 3 + 1], e2 = ent[(t & 63) * 3 + 2];
-    raster_item<TWL, TH>(keys, e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, __int_as_float(e1.z), __int_as_float(e1.w),
-                         __int_as_float(e2.x), e2.y, e2.z, (uint32_t)e2.w, q, et, live);
+    const int4 e0 = ent[t * 3], e1 = ent[t * 3 + 1], e2 = ent[t * 3 + 2];
+    raster_item<TWL, TH, PAD>(keys, e0, e1, e2, r, live);
   }
   return (total + 63) >> 6;
 }
@@ -1016,7 +1047,7 @@ __device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, uin
 // ids-only epilogue.  16-byte stores where the rows allow it: a lane owns 4 consecutive pixels of a row (16 lanes per
 // 64-pixel row, 16 rows per pass); the four low dwords sit 8 bytes apart in LDS (two ds_read2_b32), id = ~low (0 for an
 // empty pixel -> -1).  Images whose width is not a multiple of 4 take one pixel per lane.
-template <int TWL, int TH, int NT>
+template <int TWL, int TH, int NT, int PAD>
 __device__ __forceinline__ void store_ids(const unsigned long long *keys, const BinArgs &a, int32_t *ids_plane, int te,
                                           int px0, int py0) {
   const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
@@ -1029,7 +1060,7 @@ __device__ __forceinline__ void store_ids(const unsigned long long *keys, const 
     int32_t *dst = ids_plane + (int64_t)(py0 + rr) * a.w + gx4;
     const int64_t dstep = (int64_t)(NT / 16) * a.w;
     for (int row = rr; row < rows_here; row += NT / 16, dst += dstep) {
-      const uint32_t *kr = klo + 2 * lds_idx<TWL>(row, c4);
+      const uint32_t *kr = klo + 2 * lds_idx<TWL, PAD>(row, c4);
       *reinterpret_cast<int4 *>(dst) = make_int4((int)~kr[0], (int)~kr[2], (int)~kr[4], (int)~kr[6]);
     }
   } else {
@@ -1038,7 +1069,7 @@ __device__ __forceinline__ void store_ids(const unsigned long long *keys, const 
     if (gx >= a.w) return;
     int32_t *dst = ids_plane + (int64_t)(py0 + (te >> TWL)) * a.w + gx;
     const int64_t dstep = (int64_t)(NT / TW) * a.w;
-    for (int row = te >> TWL; row < rows_here; row += NT / TW, dst += dstep) *dst = (int32_t)~klo[2 * lds_idx<TWL>(row, col)];
+    for (int row = te >> TWL; row < rows_here; row += NT / TW, dst += dstep) *dst = (int32_t)~klo[2 * lds_idx<TWL, PAD>(row, col)];
   }
 }
 
@@ -1055,7 +1086,7 @@ __device__ __forceinline__ void store_ids(const unsigned long long *keys, const 
 // winning pixel is looked up by the vote kernel.  Background needs no mapping: the tile was filled with the id that
 // background aliases (F - 1 with GR_FLAG_NEG1_IS_LAST_FACE, else -1 = raw 0, which no candidate test accepts).
 // Unknown neighbours count as "differs": 1 across a tile edge, 2 outside the image (EDGE tiles only).
-template <int TWL, int TH, int NT, bool EDGE>
+template <int TWL, int TH, int NT, int PAD, bool EDGE>
 __device__ __forceinline__ void fused_winners(const unsigned long long *keys, const BinArgs &a, uint32_t *__restrict__ win,
                                               int te, int px0, int py0, int dbg) {
   static_assert(TWL == 6 && NT == 256 && TH % 32 == 0, "16 lanes x 4 pixels per tile row, 16 row pairs per pass");
@@ -1068,7 +1099,7 @@ __device__ __forceinline__ void fused_winners(const unsigned long long *keys, co
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       if (k < 2 || r0 + 2 < TH) {
-        const uint32_t *kr = klo + 2 * lds_idx<TWL>(r0 + k, c4);
+        const uint32_t *kr = klo + 2 * lds_idx<TWL, PAD>(r0 + k, c4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) c[k][j + 1] = (int)kr[2 * j];
       } else {
@@ -1113,50 +1144,9 @@ __device__ __forceinline__ void fused_winners(const unsigned long long *keys, co
   }
 }
 
-template <int TWL, int THL, int NT, bool FUSE>
-__global__ __launch_bounds__(NT) void k_raster_tile(BinArgs a, RasterOut out) {
-  constexpr int TW = 1 << TWL, TH = 1 << THL;
-  constexpr int NKEYS = (TW + GR_LDS_PAD) * TH;
-  constexpr int NW = NT / 64;
-  constexpr int NMAIL = NW * 32;  // u64 units: 64 mailbox words per wave
-  // the kernel's only LDS: keys (17.25 KiB for 64x32) + mailboxes (1 KiB) + one chunk of entries (3 KiB) -> 7 workgroups/CU
-  __shared__ __attribute__((aligned(16))) unsigned long long keys[NKEYS + NMAIL + 64 * 6];
-  int4 *ent_lds = reinterpret_cast<int4 *>(keys + NKEYS + NMAIL);
-  static_assert(NT == 256, "the entry copy deals 48 int4 to each of 4 waves");
-  static_assert(NKEYS % 2 == 0 && TH % 32 == 0, "key pairs; two 16-row passes per fused group");
-
-  const int slot = blockIdx.y;
-  // XCD-aware tile order (GR_OPT_VARIANT bit 64): workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8,
-  // observed, speed only), so XCD x takes the contiguous tiles [x * per, (x + 1) * per)
-  int tile = blockIdx.x;
-  if (a.var & 64) {
-    const int per = (a.T + 7) >> 3;
-    tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (tile >= a.T) return;
-  }
-  const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int ROWS_PER_PASS = NT / TW;
-  const int64_t P = (int64_t)a.h * a.w;
-  const int64_t plane = (int64_t)slot * P;
-  const bool direct = a.cap_tile > 0;
-
-  // single-pass binning: the segment address is static, so the first chunk (entries and row counts) is requested before
-  // the tile's count is known; slots beyond the count hold stale data that nobody reads
-  const bool spec = a.cap_tile >= 64;
-  uint32_t nr_first = 0;
-  int4 ex;
-  if (spec) {
-    const int64_t seg = slot * a.ent_cap + (int64_t)tile * a.cap_tile;
-    nr_first = a.nrow8[seg + lane];
-    if (lane < 48) ex = a.comp[seg * GR_ENT_Q + wv * 48 + lane];
-  }
-  const int tx = tile % a.TX, ty = tile / a.TX;
-  const int px0 = tx << TWL, py0 = ty << THL;
-  uint32_t cnt;
-  int64_t beg;
-  if (direct) {
+// the tile's entry list: count and first slot (single-pass binning: the tile's fixed segment; exact binning: the scan's offset)
+__device__ __forceinline__ void tile_list(const BinArgs &a, const uint32_t *__restrict__ ctrl, int tile, uint32_t &cnt, int64_t &beg) {
+  if (a.cap_tile > 0) {
     cnt = min(ctrl[GR_CTRL_HDR + tile], (uint32_t)a.cap_tile);
     beg = (int64_t)tile * a.cap_tile;
   } else {
@@ -1165,11 +1155,37 @@ __global__ __launch_bounds__(NT) void k_raster_tile(BinArgs a, RasterOut out) {
     if (beg >= a.ent_cap) cnt = 0;
     else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
   }
-  if (a.dbg & 4) cnt = 0;
+}
+
+// One tile: keys in LDS -> chunks of entries -> scanline items -> epilogue.  nr_first / ex: the tile's first chunk (row
+// counts and this lane's 16 bytes of the 3 KiB of entries), requested by the caller.  ex_next: the first chunk of the
+// workgroup's next tile (requested last); it is waited for together with this tile's (GR_WAIT_CHUNKS) on every path, so that the compiler
+// finds no path on which a request is still open when the next tile starts -- it would wait for this tile's stores there
+// (loads and stores share one in-order counter).
+template <int TWL, int THL, int NT, bool FUSE, int PAD>
+__device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOut &out, unsigned long long *keys, const int slot,
+                                                const int tile, uint32_t cnt, const int64_t beg, const uint8_t nr_first, int4 ex,
+                                                int4 ex_next) {
+  constexpr int TW = 1 << TWL, TH = 1 << THL;
+  constexpr int NKEYS = (TW + PAD) * TH;
+  constexpr int NW = NT / 64;
+  constexpr int NMAIL = NW * 32;  // u64 units: 64 mailbox words per wave
+  int4 *ent_lds = reinterpret_cast<int4 *>(keys + NKEYS + NMAIL);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int ROWS_PER_PASS = NT / TW;
+  const int64_t P = (int64_t)a.h * a.w;
+  const int64_t plane = (int64_t)slot * P;
+  const int tx = tile % a.TX, ty = tile / a.TX;
+  const int px0 = tx << TWL, py0 = ty << THL;
   const int4 *comp = a.comp + (slot * a.ent_cap + beg) * GR_ENT_Q;
   const uint8_t *nr8 = a.nrow8 + slot * a.ent_cap + beg;
 
+#define GR_WAIT_CHUNKS()                                                                                                  \
+  asm volatile("" : "+v"(ex.x), "+v"(ex.y), "+v"(ex.z), "+v"(ex.w), "+v"(ex_next.x), "+v"(ex_next.y), "+v"(ex_next.z),  \
+               "+v"(ex_next.w))
   if (!FUSE && cnt == 0) {  // empty tile (a view that overhangs the mesh): background, without the LDS round trip
+    GR_WAIT_CHUNKS();
     const int col = tid & (TW - 1), gx = px0 + col;
     if (gx < a.w && !(a.dbg & 2)) {
       for (int row = tid >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
@@ -1180,30 +1196,42 @@ __global__ __launch_bounds__(NT) void k_raster_tile(BinArgs a, RasterOut out) {
     }
     return;
   }
+  const int tab_base = NKEYS * 8 + wv * 256;  // byte offset of the wave's 64 mailbox words, behind the keys
+  const int tab_self = tab_base + lane * 4;
   {  // fill the tile (16-byte LDS stores): depth 0 | the id background stands for; mailboxes zero
     const int bg = (FUSE && out.compat) ? (int)out.F - 1 : -1;
     const unsigned long long fill = (unsigned long long)(uint32_t)~bg;
     ulonglong2 *k2 = reinterpret_cast<ulonglong2 *>(keys);
-    for (int i = tid; i < NKEYS / 2; i += NT) k2[i] = make_ulonglong2(fill, fill);
+#pragma unroll
+    for (int i = 0; i < (NKEYS / 2 + NT - 1) / NT; ++i)
+      if (i * NT + tid < NKEYS / 2) k2[i * NT + tid] = make_ulonglong2(fill, fill);
     for (int i = tid; i < NMAIL / 2; i += NT) k2[NKEYS / 2 + i] = make_ulonglong2(0ull, 0ull);
   }
-  uint32_t *tab = reinterpret_cast<uint32_t *>(keys + NKEYS) + wv * 64;
   uint32_t gen = 0;
   int rot = wv;  // this wave's first batch of the current chunk
+  {  // first chunk: in registers already (no wait on the memory counter here: a second tile of the workgroup would wait
+     // for the first one's stores)
+    GR_WAIT_CHUNKS();
+#undef GR_WAIT_CHUNKS
+    if (lane < 48) ent_lds[wv * 48 + lane] = ex;
+    __syncthreads();  // keys filled, chunk visible
+    const int nrows = (uint32_t)lane < cnt ? (int)nr_first : 0;
+    const int nb = raster_chunk_gather<TWL, TH, NW, PAD, const int4 *>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot, a.dbg);
+    rot = (rot - nb) & (NW - 1);
+  }
 #pragma unroll 1
-  for (uint32_t c0 = 0; c0 < cnt || c0 == 0; c0 += 64) {
+  for (uint32_t c0 = 64; c0 < cnt; c0 += 64) {
+    __syncthreads();  // every wave is done with the previous chunk before it is overwritten
     if (lane < 48) {
       const uint32_t q = c0 * GR_ENT_Q + wv * 48 + lane;
-      if (!(spec && c0 == 0) && q < cnt * GR_ENT_Q) ex = comp[q];
+      if (q < cnt * GR_ENT_Q) ex = comp[q];
       ent_lds[wv * 48 + lane] = ex;
     }
-    __syncthreads();  // keys filled, chunk visible
+    __syncthreads();
     const uint32_t e = c0 + (uint32_t)lane;
-    int nrows = 0;
-    if (e < cnt) nrows = (spec && c0 == 0) ? (int)nr_first : (int)nr8[e];
-    const int nb = raster_chunk_gather<TWL, TH, NW, const int4 *>(keys, tab, gen, ent_lds, nrows, lane, rot, a.dbg);
+    const int nrows = e < cnt ? (int)nr8[e] : 0;
+    const int nb = raster_chunk_gather<TWL, TH, NW, PAD, const int4 *>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot, a.dbg);
     rot = (rot - nb) & (NW - 1);
-    if (c0 + 64 < cnt) __syncthreads();  // every wave is done with this chunk before it is overwritten
   }
 
   int te = tid;
@@ -1213,27 +1241,86 @@ __global__ __launch_bounds__(NT) void k_raster_tile(BinArgs a, RasterOut out) {
   if (FUSE) {
     uint32_t *win = out.winner + slot * out.F;
     const bool edge = px0 + TW > a.w || py0 + TH + 1 > a.h;
-    if (edge) fused_winners<TWL, TH, NT, true>(keys, a, win, te, px0, py0, a.dbg);
-    else fused_winners<TWL, TH, NT, false>(keys, a, win, te, px0, py0, a.dbg);
+    if (edge) fused_winners<TWL, TH, NT, PAD, true>(keys, a, win, te, px0, py0, a.dbg);
+    else fused_winners<TWL, TH, NT, PAD, false>(keys, a, win, te, px0, py0, a.dbg);
     if (out.ids) {  // the id image as well (rare): background is where no fragment landed (depth bits 0)
       const int col = te & (TW - 1), gx = px0 + col;
       if (gx < a.w)
         for (int row = te >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
-          const unsigned long long key = keys[lds_idx<TWL>(row, col)];
+          const unsigned long long key = keys[lds_idx<TWL, PAD>(row, col)];
           out.ids[plane + (int64_t)(py0 + row) * a.w + gx] = (key >> 32) ? (int32_t)~(uint32_t)key : -1;
         }
     }
   } else if (out.ids && !out.depth) {
-    store_ids<TWL, TH, NT>(keys, a, out.ids + plane, te, px0, py0);
+    store_ids<TWL, TH, NT, PAD>(keys, a, out.ids + plane, te, px0, py0);
   } else {
     const int col = te & (TW - 1), gx = px0 + col;
     if (gx < a.w)
       for (int row = te >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
-        const unsigned long long key = keys[lds_idx<TWL>(row, col)];
+        const unsigned long long key = keys[lds_idx<TWL, PAD>(row, col)];
         const int64_t p = plane + (int64_t)(py0 + row) * a.w + gx;
         if (out.ids) out.ids[p] = (int32_t)~(uint32_t)key;  // low dword = ~face, 0 when empty: ~0 = -1
         if (out.depth) out.depth[p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
       }
+  }
+}
+
+// K3  the tile kernel.  TWIN: a workgroup takes two neighbouring tiles one after the other and requests the first chunk
+//     of BOTH before anything else -- the second tile's entries arrive while the first one is rasterized, so one of the
+//     two waits for memory (the longest single piece of a workgroup's life) disappears.
+template <int TWL, int THL, int NT, bool FUSE, bool TWIN, int PAD>
+__global__ __launch_bounds__(NT) void k_raster_tile(BinArgs a, RasterOut out) {
+  constexpr int TW = 1 << TWL, TH = 1 << THL;
+  constexpr int NKEYS = (TW + PAD) * TH;
+  constexpr int NW = NT / 64;
+  constexpr int NMAIL = NW * 32;
+  // the kernel's only LDS: keys (17.25 KiB for 64x32) + mailboxes (1 KiB) + one chunk of entries (3 KiB) -> 7 workgroups/CU
+  // (20 KiB -- 4 padding keys per row with the mailboxes inside the padding -- gives 8, and loses more to LDS bank
+  // conflicts than it gains: plain 16.6 vs 16.3 us per C2 view, fused 19.8 vs 17.9)
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[NKEYS + NMAIL + 64 * 6];
+  static_assert(NT == 256, "the entry copy deals 48 int4 to each of 4 waves");
+  static_assert(NKEYS % 2 == 0 && TH % 32 == 0, "key pairs; two 16-row passes per fused group");
+  const int slot = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  // single-pass binning: the segment address is static, so the first chunk (entries and row counts) is requested before
+  // the tile's count is known; slots beyond the count hold stale data that nobody reads
+  const bool spec = a.cap_tile >= 64;
+  const int tile0 = TWIN ? 2 * (int)blockIdx.x : (int)blockIdx.x;
+  const bool two = TWIN && tile0 + 1 < a.T;
+  uint8_t nr0 = 0, nr1 = 0;
+  int4 ex0, ex1;
+  if (spec) {
+    const int64_t seg = slot * a.ent_cap + (int64_t)tile0 * a.cap_tile;
+    nr0 = a.nrow8[seg + lane];
+    if (lane < 48) ex0 = a.comp[seg * GR_ENT_Q + wv * 48 + lane];
+    if (two) {
+      nr1 = a.nrow8[seg + a.cap_tile + lane];
+      if (lane < 48) ex1 = a.comp[(seg + a.cap_tile) * GR_ENT_Q + wv * 48 + lane];
+    }
+  }
+  // both counts before any store: they are scalar loads here, and a vector load behind the first tile's stores would wait
+  // for those stores (one in-order counter)
+  const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  uint32_t cnt0, cnt1 = 0;
+  int64_t beg0, beg1 = 0;
+  tile_list(a, ctrl, tile0, cnt0, beg0);
+  if (two) tile_list(a, ctrl, tile0 + 1, cnt1, beg1);
+  if (!spec) {  // exact binning (or segments under 64 slots): the first chunks can only be requested now
+    const int64_t s0 = slot * a.ent_cap + beg0, s1 = slot * a.ent_cap + beg1;
+    const uint32_t q = wv * 48 + lane;
+    if ((uint32_t)lane < cnt0) nr0 = a.nrow8[s0 + lane];
+    if (lane < 48 && q < cnt0 * GR_ENT_Q) ex0 = a.comp[s0 * GR_ENT_Q + q];
+    if (two) {
+      if ((uint32_t)lane < cnt1) nr1 = a.nrow8[s1 + lane];
+      if (lane < 48 && q < cnt1 * GR_ENT_Q) ex1 = a.comp[s1 * GR_ENT_Q + q];
+    }
+  }
+  if (a.dbg & 4) cnt0 = cnt1 = 0;
+  raster_one_tile<TWL, THL, NT, FUSE, PAD>(a, out, keys, slot, tile0, cnt0, beg0, nr0, ex0, two ? ex1 : ex0);
+  if (two) {
+    __syncthreads();  // every wave has read the first tile's keys
+    raster_one_tile<TWL, THL, NT, FUSE, PAD>(a, out, keys, slot, tile0 + 1, cnt1, beg1, nr1, ex1, ex1);
   }
 }
 
@@ -1708,6 +1795,9 @@ struct gr_ctx {
   // winner scratch
   void *winner = nullptr;
   size_t winner_bytes = 0;
+  // fused aggregation: the vote kernel of launch group g runs on a side stream beside the binning of group g + 1
+  hipStream_t side = nullptr;
+  hipEvent_t ev_raster[2] = {nullptr, nullptr}, ev_vote[2] = {nullptr, nullptr};
   void *sort_tmp = nullptr;
   size_t sort_bytes = 0;
   hipStream_t last_stream = nullptr;
@@ -1876,13 +1966,20 @@ int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStr
   BinArgs a = make_args(c, h, w, slot0);
   {
     Timed t(c, s, ST_RASTER);
-    const dim3 grid((a.var & 64) ? (unsigned)(((a.T + 7) >> 3) << 3) : (unsigned)a.T, nb), block(256);
+    const bool twin = (a.var & 1) == 0;  // two neighbouring tiles per workgroup (default)
+    const dim3 grid(twin ? (unsigned)((a.T + 1) >> 1) : (unsigned)a.T, nb), block(256);
     const size_t pad = (size_t)c->opt_lds_pad;
+#define GR_LAUNCH_TILE(THL_, FUSE_)                                                                                   \
+  do {                                                                                                                \
+    if (twin) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, true, GR_LDS_PAD>), grid, block, pad, s, a, out); \
+    else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, false, GR_LDS_PAD>), grid, block, pad, s, a, out);    \
+  } while (0)
     if (out.winner) {
-      if (a.thl == 6) hipLaunchKernelGGL((k_raster_tile<6, 6, 256, true>), grid, block, pad, s, a, out);
-      else hipLaunchKernelGGL((k_raster_tile<6, 5, 256, true>), grid, block, pad, s, a, out);
-    } else if (a.thl == 6) hipLaunchKernelGGL((k_raster_tile<6, 6, 256, false>), grid, block, pad, s, a, out);
-    else hipLaunchKernelGGL((k_raster_tile<6, 5, 256, false>), grid, block, pad, s, a, out);
+      if (a.thl == 6) GR_LAUNCH_TILE(6, true);
+      else GR_LAUNCH_TILE(5, true);
+    } else if (a.thl == 6) GR_LAUNCH_TILE(6, false);
+    else GR_LAUNCH_TILE(5, false);
+#undef GR_LAUNCH_TILE
     c->prof_raster_launches += 1;
   }
   c->prof_views += nb;
@@ -1943,32 +2040,60 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   if (rc) return rc;
   c->last_T = T; c->last_B = B;
   const int64_t P = (int64_t)h * w, F = c->F;
+  // Fused aggregation over several launch groups: the vote kernel of group g (a light, latency-bound pass over F winners)
+  // runs on a side stream beside the binning of group g + 1 (also light); the tile kernels in between fill the machine on
+  // their own.  Two winner buffers alternate; votes are still added group by group, in order (one side stream).
+  const bool overlap = labels && n_views > B && !(c->opt_var & 4);
   if (labels) {
-    rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F * B);
+    rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F * B * (overlap ? 2 : 1));
     if (rc) return rc;
+    if (overlap && !c->side) {
+      GR_HIP(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+      for (int i = 0; i < 2; ++i) {
+        GR_HIP(c, hipEventCreateWithFlags(&c->ev_raster[i], hipEventDisableTiming));
+        GR_HIP(c, hipEventCreateWithFlags(&c->ev_vote[i], hipEventDisableTiming));
+      }
+    }
   }
   c->last_stream = s;
   GR_HIP(c, hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 4, s));
   GR_HIP(c, hipMemsetAsync(c->stats + 4, 0xFF, sizeof(unsigned long long), s));  // first overflowed group: none
   c->last_n_views = n_views;
-  for (int v0 = 0; v0 < n_views; v0 += B) {
+  int g = 0;
+  for (int v0 = 0; v0 < n_views; v0 += B, ++g) {
     const int nb = (n_views - v0) < B ? (n_views - v0) : B;
     rc = bin_batch(c, cams + (int64_t)v0 * GR_CAM_FLOATS, nb, h, w, 0, v0 / B, s);
     if (rc) return rc;
+    const int buf = overlap ? (g & 1) : 0;
+    uint32_t *win = labels ? (uint32_t *)c->winner + (int64_t)buf * F * B : nullptr;
     RasterOut out;
     out.ids = ids ? ids + v0 * P : nullptr;
     out.depth = depth ? depth + v0 * P : nullptr;
-    out.winner = labels ? (uint32_t *)c->winner : nullptr;
+    out.winner = win;
     out.F = F;
     out.compat = (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0;
+    if (overlap && g >= 2) GR_HIP(c, hipStreamWaitEvent(s, c->ev_vote[buf], 0));  // the votes of group g - 2 have read this buffer
     rc = tile_batch(c, nb, h, w, 0, out, s);
     if (rc) return rc;
     if (labels) {
-      Timed t(c, s, ST_VOTE);
-      hipLaunchKernelGGL(k_vote_labels, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s, (uint32_t *)c->winner,
-                         labels + v0 * P, nb, F, P, C, votes, counts, (const unsigned long long *)c->stats, v0 / B);
+      hipStream_t vs = s;
+      if (overlap) {
+        GR_HIP(c, hipEventRecord(c->ev_raster[buf], s));
+        GR_HIP(c, hipStreamWaitEvent(c->side, c->ev_raster[buf], 0));
+        vs = c->side;
+      }
+      {
+        Timed t(c, vs, ST_VOTE);
+        hipLaunchKernelGGL(k_vote_labels, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, vs, win, labels + v0 * P, nb, F, P, C,
+                           votes, counts, (const unsigned long long *)c->stats, v0 / B);
+      }
       GR_HIP(c, hipGetLastError());
+      if (overlap) GR_HIP(c, hipEventRecord(c->ev_vote[buf], c->side));
     }
+  }
+  if (overlap) {  // the caller's stream continues after the last votes
+    GR_HIP(c, hipStreamWaitEvent(s, c->ev_vote[(g - 1) & 1], 0));
+    if (g >= 2) GR_HIP(c, hipStreamWaitEvent(s, c->ev_vote[g & 1], 0));
   }
   return GR_OK;
 }
@@ -2011,6 +2136,11 @@ int gr_ctx_destroy(gr_ctx *c) {
   if (c->work) (void)hipFree(c->work);
   if (c->clip) (void)hipFree(c->clip);
   if (c->winner) (void)hipFree(c->winner);
+  for (int i = 0; i < 2; ++i) {
+    if (c->ev_raster[i]) (void)hipEventDestroy(c->ev_raster[i]);
+    if (c->ev_vote[i]) (void)hipEventDestroy(c->ev_vote[i]);
+  }
+  if (c->side) (void)hipStreamDestroy(c->side);
   if (c->sort_tmp) (void)hipFree(c->sort_tmp);
   if (c->blk) (void)hipFree(c->blk);
   if (c->soup) (void)hipFree(c->soup);

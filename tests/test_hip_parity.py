@@ -16,7 +16,10 @@ pytestmark = pytest.mark.gpu
 # every raster test runs against each setting of the tuning knobs (include/geograster.h GR_OPT_*): tile height log2,
 # single-pass slots per tile (0 = exact two-pass binning), tile order (GR_OPT_VARIANT 64 = XCD-aware) -- results must
 # not depend on them
-VARIANTS = {"tile32_direct": (5, 512, 0), "tile64_direct": (6, 512, 64), "tile32_exact": (5, 0, 64), "tile64_exact": (6, 0, 0)}
+# (tile height log2, slots per tile [0 = exact two-pass binning], GR_OPT_VARIANT bits: 1 = one tile per workgroup, 4 = votes on
+# the caller's stream) -- every combination must give identical results
+VARIANTS = {"tile32_direct": (5, 512, 0), "tile64_direct": (6, 512, 1), "tile32_exact": (5, 0, 5), "tile64_exact": (6, 0, 0),
+            "tile32_direct_single": (5, 512, 5)}
 
 
 @pytest.fixture(params=list(VARIANTS), autouse=True)

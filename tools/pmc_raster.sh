@@ -1,6 +1,6 @@
 #!/bin/bash
-# tools/pmc_raster.sh <tag> [kernel] [thl] -- SQ / LDS counter passes over tools/prof_raster.py (GPU box only)
-TAG=${1:-pmc}; K=${2:-1}; THL=${3:-5}
+# tools/pmc_raster.sh <tag> [variant_bits] [thl] -- SQ / LDS counter passes over tools/prof_raster.py (GPU box only)
+TAG=${1:-pmc}; K=${2:-0}; THL=${3:-5}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/prof_raster.py [unused] [tile_h_log2] [views] [reps] -- run only the pix2face pipeline on the C2 workload
+"""tools/prof_raster.py [variant_bits] [tile_h_log2] [views] [reps] -- run only the pix2face pipeline on the C2 workload
 (for rocprofv3 --pmc passes: no torch kernels, no CPU baseline)."""
 import sys
 from pathlib import Path
@@ -20,6 +20,7 @@ cams = synthetic.config2_cameras(50)
 recs = torch.from_numpy(cams.get_raster_records(1.0, near=1.0)[:nv]).cuda()
 hip = HipRaster(0)
 hip.set_option(2, thl)
+hip.set_option(7, kernel)  # GR_OPT_VARIANT
 hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
 ids = torch.empty((nv, 3000, 4000), dtype=torch.int32, device="cuda")
 for _ in range(reps):
