@@ -63,7 +63,7 @@ struct BinArgs {
   int h, w;
   int twl, thl;          // log2 of the tile width / height in pixels
   int cap_tile;          // > 0: single-pass binning, every tile owns cap_tile entry slots (list base = tile * cap_tile)
-  int var;               // variant bits (GR_OPT_VARIANT): 1 = one tile per workgroup instead of two, 4 = votes on the caller's stream
+  int var;               // variant bits (GR_OPT_VARIANT): 1 = one tile per workgroup instead of four, 4 = votes on the caller's stream, 8 = no speculative first chunk
   int dbg;               // timing-only ablation mask (GR_OPT_DEBUG): 1 skip scanline loop, 2 skip id stores, 4 skip triangles,
                          // fused epilogue: 8 skip winner atomics, 16 skip label loads
 };
@@ -1050,6 +1050,8 @@ __device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, con
 template <int TWL, int TH, int NT, int PAD>
 __device__ __forceinline__ void store_ids(const unsigned long long *keys, const BinArgs &a, int32_t *ids_plane, int te,
                                           int px0, int py0) {
+  // (exchanging every key with the empty one here -- ds_wrxchg_rtn_b64, so that the workgroup's next tile needs no fill --
+  // was measured: returning LDS atomics are slow, 17.0 vs 15.6 us per C2 view)
   const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
   const int rows_here = min(TH, a.h - py0);
   const bool vec = ((a.w & 3) == 0) && ((reinterpret_cast<uintptr_t>(ids_plane) & 15) == 0);
@@ -1158,14 +1160,14 @@ __device__ __forceinline__ void tile_list(const BinArgs &a, const uint32_t *__re
 }
 
 // One tile: keys in LDS -> chunks of entries -> scanline items -> epilogue.  nr_first / ex: the tile's first chunk (row
-// counts and this lane's 16 bytes of the 3 KiB of entries), requested by the caller.  ex_next: the first chunk of the
-// workgroup's next tile (requested last); it is waited for together with this tile's (GR_WAIT_CHUNKS) on every path, so that the compiler
+// counts and this lane's 16 bytes of the 3 KiB of entries), requested by the caller.  ex_b .. ex_d: the first chunks of
+// the workgroup's next tiles; they are waited for together with this tile's (GR_WAIT_CHUNKS) on every path, so that the compiler
 // finds no path on which a request is still open when the next tile starts -- it would wait for this tile's stores there
 // (loads and stores share one in-order counter).
 template <int TWL, int THL, int NT, bool FUSE, int PAD>
 __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOut &out, unsigned long long *keys, const int slot,
                                                 const int tile, uint32_t cnt, const int64_t beg, const uint8_t nr_first, int4 ex,
-                                                int4 ex_next) {
+                                                int4 ex_b, int4 ex_c, int4 ex_d) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   constexpr int NKEYS = (TW + PAD) * TH;
   constexpr int NW = NT / 64;
@@ -1182,8 +1184,7 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
   const uint8_t *nr8 = a.nrow8 + slot * a.ent_cap + beg;
 
 #define GR_WAIT_CHUNKS()                                                                                                  \
-  asm volatile("" : "+v"(ex.x), "+v"(ex.y), "+v"(ex.z), "+v"(ex.w), "+v"(ex_next.x), "+v"(ex_next.y), "+v"(ex_next.z),  \
-               "+v"(ex_next.w))
+  asm volatile("" : "+v"(ex.x), "+v"(ex.y), "+v"(ex.z), "+v"(ex.w), "+v"(ex_b.x), "+v"(ex_c.x), "+v"(ex_d.x))
   if (!FUSE && cnt == 0) {  // empty tile (a view that overhangs the mesh): background, without the LDS round trip
     GR_WAIT_CHUNKS();
     const int col = tid & (TW - 1), gx = px0 + col;
@@ -1265,10 +1266,13 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
   }
 }
 
-// K3  the tile kernel.  TWIN: a workgroup takes two neighbouring tiles one after the other and requests the first chunk
-//     of BOTH before anything else -- the second tile's entries arrive while the first one is rasterized, so one of the
-//     two waits for memory (the longest single piece of a workgroup's life) disappears.
-template <int TWL, int THL, int NT, bool FUSE, bool TWIN, int PAD>
+// K3  the tile kernel.  KT = 4: a workgroup takes four consecutive tiles one after the other.  The first tile's first chunk
+//     is requested before its count is known (the segment address is static; slots beyond the count hold stale data that
+//     nobody reads), the other three EXACTLY, as soon as the four counts are there -- they arrive while the first tile is
+//     rasterized: three of four waits for memory disappear, and so do three quarters of the stale requests (9 MB of the
+//     67 MB a C2 view moves).  All counts are read before any store: they are scalar loads there, and a vector load behind
+//     a tile's stores would wait for those stores (one in-order counter).
+template <int TWL, int THL, int NT, bool FUSE, int KT, int PAD>
 __global__ __launch_bounds__(NT) void k_raster_tile(BinArgs a, RasterOut out) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   constexpr int NKEYS = (TW + PAD) * TH;
@@ -1280,47 +1284,53 @@ __global__ __launch_bounds__(NT) void k_raster_tile(BinArgs a, RasterOut out) {
   __shared__ __attribute__((aligned(16))) unsigned long long keys[NKEYS + NMAIL + 64 * 6];
   static_assert(NT == 256, "the entry copy deals 48 int4 to each of 4 waves");
   static_assert(NKEYS % 2 == 0 && TH % 32 == 0, "key pairs; two 16-row passes per fused group");
+  static_assert(KT == 1 || KT == 4, "one tile per workgroup, or a chain of four");
   const int slot = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  // single-pass binning: the segment address is static, so the first chunk (entries and row counts) is requested before
-  // the tile's count is known; slots beyond the count hold stale data that nobody reads
-  const bool spec = a.cap_tile >= 64;
-  const int tile0 = TWIN ? 2 * (int)blockIdx.x : (int)blockIdx.x;
-  const bool two = TWIN && tile0 + 1 < a.T;
-  uint8_t nr0 = 0, nr1 = 0;
-  int4 ex0, ex1;
+  const bool spec = a.cap_tile >= 64 && !(a.var & 8);
+  const int tile0 = KT * (int)blockIdx.x;
+  const int n_tiles = min(KT, a.T - tile0);
+  const uint32_t q = wv * 48 + lane;  // this thread's 16-byte piece of a 3 KiB chunk (lanes 0 .. 47 of every wave)
+  uint8_t nr0 = 0, nr1 = 0, nr2 = 0, nr3 = 0;
+  int4 ex0, ex1, ex2, ex3;
   if (spec) {
     const int64_t seg = slot * a.ent_cap + (int64_t)tile0 * a.cap_tile;
     nr0 = a.nrow8[seg + lane];
-    if (lane < 48) ex0 = a.comp[seg * GR_ENT_Q + wv * 48 + lane];
-    if (two) {
-      nr1 = a.nrow8[seg + a.cap_tile + lane];
-      if (lane < 48) ex1 = a.comp[(seg + a.cap_tile) * GR_ENT_Q + wv * 48 + lane];
-    }
+    if (lane < 48) ex0 = a.comp[seg * GR_ENT_Q + q];
   }
-  // both counts before any store: they are scalar loads here, and a vector load behind the first tile's stores would wait
-  // for those stores (one in-order counter)
   const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
-  uint32_t cnt0, cnt1 = 0;
-  int64_t beg0, beg1 = 0;
+  uint32_t cnt0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
+  int64_t beg0, beg1 = 0, beg2 = 0, beg3 = 0;
   tile_list(a, ctrl, tile0, cnt0, beg0);
-  if (two) tile_list(a, ctrl, tile0 + 1, cnt1, beg1);
-  if (!spec) {  // exact binning (or segments under 64 slots): the first chunks can only be requested now
-    const int64_t s0 = slot * a.ent_cap + beg0, s1 = slot * a.ent_cap + beg1;
-    const uint32_t q = wv * 48 + lane;
-    if ((uint32_t)lane < cnt0) nr0 = a.nrow8[s0 + lane];
-    if (lane < 48 && q < cnt0 * GR_ENT_Q) ex0 = a.comp[s0 * GR_ENT_Q + q];
-    if (two) {
-      if ((uint32_t)lane < cnt1) nr1 = a.nrow8[s1 + lane];
-      if (lane < 48 && q < cnt1 * GR_ENT_Q) ex1 = a.comp[s1 * GR_ENT_Q + q];
-    }
+  if (KT > 1) {
+    if (n_tiles > 1) tile_list(a, ctrl, tile0 + 1, cnt1, beg1);
+    if (n_tiles > 2) tile_list(a, ctrl, tile0 + 2, cnt2, beg2);
+    if (n_tiles > 3) tile_list(a, ctrl, tile0 + 3, cnt3, beg3);
   }
-  if (a.dbg & 4) cnt0 = cnt1 = 0;
-  raster_one_tile<TWL, THL, NT, FUSE, PAD>(a, out, keys, slot, tile0, cnt0, beg0, nr0, ex0, two ? ex1 : ex0);
-  if (two) {
-    __syncthreads();  // every wave has read the first tile's keys
-    raster_one_tile<TWL, THL, NT, FUSE, PAD>(a, out, keys, slot, tile0 + 1, cnt1, beg1, nr1, ex1, ex1);
+  if (a.dbg & 4) cnt0 = cnt1 = cnt2 = cnt3 = 0;
+  const int64_t sbase = slot * a.ent_cap;
+  if (!spec) {  // exact binning (or segments under 64 slots): the first chunk can only be requested now
+    if ((uint32_t)lane < cnt0) nr0 = a.nrow8[sbase + beg0 + lane];
+    if (lane < 48 && q < cnt0 * GR_ENT_Q) ex0 = a.comp[(sbase + beg0) * GR_ENT_Q + q];
+  }
+  if (KT > 1) {
+    if ((uint32_t)lane < cnt1) nr1 = a.nrow8[sbase + beg1 + lane];
+    if (lane < 48 && q < cnt1 * GR_ENT_Q) ex1 = a.comp[(sbase + beg1) * GR_ENT_Q + q];
+    if ((uint32_t)lane < cnt2) nr2 = a.nrow8[sbase + beg2 + lane];
+    if (lane < 48 && q < cnt2 * GR_ENT_Q) ex2 = a.comp[(sbase + beg2) * GR_ENT_Q + q];
+    if ((uint32_t)lane < cnt3) nr3 = a.nrow8[sbase + beg3 + lane];
+    if (lane < 48 && q < cnt3 * GR_ENT_Q) ex3 = a.comp[(sbase + beg3) * GR_ENT_Q + q];
+  }
+  raster_one_tile<TWL, THL, NT, FUSE, PAD>(a, out, keys, slot, tile0, cnt0, beg0, nr0, ex0, ex1, ex2, ex3);
+  if (KT > 1) {
+#pragma unroll 1
+    for (int k = 1; k < n_tiles; ++k) {  // ONE copy of the tile code for tiles 1 .. 3: the chunks rotate through ex1
+      __syncthreads();                   // every wave has read the previous tile's keys
+      raster_one_tile<TWL, THL, NT, FUSE, PAD>(a, out, keys, slot, tile0 + k, cnt1, beg1, nr1, ex1, ex1, ex1, ex1);
+      cnt1 = cnt2; cnt2 = cnt3; beg1 = beg2; beg2 = beg3;
+      nr1 = nr2; nr2 = nr3; ex1 = ex2; ex2 = ex3;
+    }
   }
 }
 
@@ -1966,13 +1976,13 @@ int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStr
   BinArgs a = make_args(c, h, w, slot0);
   {
     Timed t(c, s, ST_RASTER);
-    const bool twin = (a.var & 1) == 0;  // two neighbouring tiles per workgroup (default)
-    const dim3 grid(twin ? (unsigned)((a.T + 1) >> 1) : (unsigned)a.T, nb), block(256);
+    const bool chain = (a.var & 1) == 0;  // four consecutive tiles per workgroup (default)
+    const dim3 grid(chain ? (unsigned)((a.T + 3) >> 2) : (unsigned)a.T, nb), block(256);
     const size_t pad = (size_t)c->opt_lds_pad;
 #define GR_LAUNCH_TILE(THL_, FUSE_)                                                                                   \
   do {                                                                                                                \
-    if (twin) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, true, GR_LDS_PAD>), grid, block, pad, s, a, out); \
-    else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, false, GR_LDS_PAD>), grid, block, pad, s, a, out);    \
+    if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD>), grid, block, pad, s, a, out);  \
+    else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD>), grid, block, pad, s, a, out);        \
   } while (0)
     if (out.winner) {
       if (a.thl == 6) GR_LAUNCH_TILE(6, true);
