@@ -96,7 +96,7 @@ enum {
                                gr_raster_status (GR_EOVERFLOW); the retry uses segments of the size that image needs
                                (remembered for images of the same tile count) or, beyond 16384 slots / 24 GB of
                                entry memory per launch group, bins exactly                                     */
-  GR_OPT_VARIANT = 7,       /* variant bits for A/B runs (results identical): 1 = one tile per workgroup instead of a chain of four, 4 = fused votes on the caller's stream instead of a side stream, 8 = no speculative first chunk */
+  GR_OPT_VARIANT = 7,       /* variant bits for A/B runs (results identical): 1 = one tile per workgroup instead of a chain of four, 4 = fused votes on the caller's stream instead of a side stream, 8 = no speculative first chunk, 16 = chains of four tiles whatever the size of the launch (default: large launches of light tiles only) */
   GR_OPT_DEBUG_LDS = 98,    /* extra dynamic LDS bytes per tile workgroup: lowers occupancy (timing experiments)     */
   GR_OPT_DEBUG = 99         /* timing-only ablation mask for tools/ab_raster.py: OUTPUTS BECOME WRONG         */
 };

@@ -17,9 +17,10 @@ pytestmark = pytest.mark.gpu
 # single-pass slots per tile (0 = exact two-pass binning), tile order (GR_OPT_VARIANT 64 = XCD-aware) -- results must
 # not depend on them
 # (tile height log2, slots per tile [0 = exact two-pass binning], GR_OPT_VARIANT bits: 1 = one tile per workgroup, 4 = votes on
-# the caller's stream) -- every combination must give identical results
-VARIANTS = {"tile32_direct": (5, 512, 0), "tile64_direct": (6, 512, 1), "tile32_exact": (5, 0, 5), "tile64_exact": (6, 0, 0),
-            "tile32_direct_single": (5, 512, 5)}
+# the caller's stream, 8 = no speculative first chunk, 16 = chains of four tiles even in small launches) -- every combination
+# must give identical results
+VARIANTS = {"tile32_chain": (5, 512, 16), "tile64_single": (6, 512, 1), "tile32_exact_single": (5, 0, 5),
+            "tile64_exact_chain": (6, 0, 16), "tile32_single_nospec": (5, 512, 13), "tile32_chain_nospec": (5, 512, 24)}
 
 
 @pytest.fixture(params=list(VARIANTS), autouse=True)
