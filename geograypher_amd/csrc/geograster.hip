@@ -375,12 +375,15 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ve
   if (__ballot(t10 >= 0)) wave_group(t10, lane, l2, k2, n2);
   if (__ballot(t11 >= 0)) wave_group(t11, lane, l3, k3, n3);
   uint32_t base = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-  if (lane == leader) base = atomicAdd(&ctrl[0], (uint32_t)n);
+  if (lane == leader) {  // record count: a list position for the exact path, a statistic (nobody waits for it) otherwise
+    if (DIRECT) atomicAdd(&ctrl[0], (uint32_t)n);
+    else base = atomicAdd(&ctrl[0], (uint32_t)n);
+  }
   if (t00 >= 0 && lane == l0) b0 = atomicAdd(&cntS[t00], (uint32_t)n0);
   if (t01 >= 0 && lane == l1) b1 = atomicAdd(&cntS[t01], (uint32_t)n1);
   if (t10 >= 0 && lane == l2) b2 = atomicAdd(&cntS[t10], (uint32_t)n2);
   if (t11 >= 0 && lane == l3) b3 = atomicAdd(&cntS[t11], (uint32_t)n3);
-  base = __shfl(base, leader);
+  if (!DIRECT) base = __shfl(base, leader);
   int4 r3;
   r3.x = (int)(__shfl(b0, l0) + (uint32_t)k0);
   r3.y = (int)(__shfl(b1, l1) + (uint32_t)k1);
