@@ -1,12 +1,16 @@
 // geograypher_amd/csrc/geograster.hip -- hand-written CDNA4 (gfx950, wave64) kernels + the C ABI of include/geograster.h.
 //
 // Hot path of geograypher re-designed for MI355X (reference lines in include/geograster.h and DESIGN.md):
-//   pix2face            k_setup_cull -> k_scan_tiles -> k_fill_compile -> k_raster_tile  (meshes.py:1776-1836)
-//   project/aggregate   k_winner_*   -> k_vote_*                                          (meshes.py:1987-2002, 2057-2067)
+//   pix2face            k_cull_blocks -> k_setup_cull (+ k_bin_big, k_clip_faces) -> k_bin_stats -> k_raster_tile
+//                       (single-pass binning; exact fallback: k_setup_cull<false> -> k_scan_tiles -> k_fill_compile)
+//                                                                                          (meshes.py:1776-1836)
+//   project/aggregate   k_raster_tile<FUSE> | k_winner  ->  k_vote_labels / k_vote_values (meshes.py:1987-2002, 2057-2067)
 //   render_flat gather  k_gather_texture                                                  (meshes.py:1921-1937)
+//   distortion (row f1) k_invert_distortion (once per lens), k_warp_nearest_i32 / k_warp_f64 (cameras.py:995-1156)
 // No MFMA anywhere: there is no dense contraction on this path.  The work is integer edge functions, an
 // LDS-resident depth|id tile per workgroup, wave ballot/popcount compaction of surviving faces and global
-// atomicMax/atomicAdd for bins and per-face winners.
+// atomicMax/atomicAdd for bins and per-face winners.  The tile kernel is bound by VALU issue, then by the LDS pipe
+// (DESIGN.md section 5): its inner pieces are written for instruction count.
 //
 // Rule-set R0-R7 is implemented here independently of oracle/oracle_raster.c; tests demand equality.
 // Compile with -ffp-contract=off: every floating-point operation below is individually rounded on purpose.
@@ -29,7 +33,7 @@
 // ------------------------------------------------------------------------------------------------------------------
 // constants
 // ------------------------------------------------------------------------------------------------------------------
-#define GR_TILE 64          // tile edge in pixels (one workgroup rasterizes one 64x64 tile out of LDS)
+#define GR_TILE 64          // tile width in pixels (a workgroup rasterizes 64x32 or 64x64 tiles out of LDS)
 #define GR_TILE_LOG2 6
 #define GR_MAX_BATCH 64     // views per launch group (amortises kernel boundaries and per-launch tails)
 #define GR_ENT_Q 3          // int4 per compiled (face, tile) entry: 48 bytes, 12 words
