@@ -1279,8 +1279,13 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
 //     rasterized: three of four waits for memory disappear, and so do three quarters of the stale requests (9 MB of the
 //     67 MB a C2 view moves).  All counts are read before any store: they are scalar loads there, and a vector load behind
 //     a tile's stores would wait for those stores (one in-order counter).
+// The ids-only kernel asks the compiler for 7 waves per SIMD -- what its LDS allows anyway: the schedule the compiler picks
+// under that hint is 3-4 % faster (15.8 -> 15.2 us per C2 view, builds alternated on one box with tools/ab_builds.sh); the
+// fused kernel is not (left at the default).  Work items of two consecutive rows (look-up, unpack and the reciprocals paid
+// once per two rows: -16 % VALU instructions) were measured as well: 74 VGPRs and half as many batches per tile for four
+// waves -- 15.6 vs 16.0 without the hint, 16.3 vs 15.3 with it, fused 18.3 vs 17.2 -- dropped.
 template <int TWL, int THL, int NT, bool FUSE, int KT, int PAD>
-__global__ __launch_bounds__(NT) void k_raster_tile(BinArgs a, RasterOut out) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : 7, 8))) void k_raster_tile(BinArgs a, RasterOut out) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   constexpr int NKEYS = (TW + PAD) * TH;
   constexpr int NW = NT / 64;
