@@ -11,7 +11,7 @@ P3="SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_
 i=0
 for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/p$i -o p$i -- python3 $REPO/tools/prof_raster.py $K $THL 32 2 > $OUT/p$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/p$i -o p$i -- python3 $REPO/tools/prof_raster.py $K $THL 32 2 > $OUT/p$i.log 2>&1
   echo "pass $i rc=$?" >> $OUT/p$i.log
 done
 cd $REPO && python3 - <<PY
