@@ -399,12 +399,11 @@ class TexturedPhotogrammetryMesh:
             out = torch.stack([w.to(torch.int32) for w in warped], dim=0)
             if return_tensor:
                 return out[0] if single else out
-            out = _to_host(out.to(torch.int64))
+            out = _ids_to_host_int64(out)
             return out[0] if single else out
         if return_tensor:
             return ids[0] if single else ids
-        # int64 like the reference (meshes.py:1804): widened on the device, one copy to the host
-        out = _to_host(ids.to(_torch().int64))
+        out = _ids_to_host_int64(ids)  # int64 like the reference (meshes.py:1804)
         return out[0] if single else out
 
     # -- render_flat ---------------------------------------------------------------------------------------------
@@ -599,7 +598,9 @@ class TexturedPhotogrammetryMesh:
                 for ci in tqdm(range(len(chunks)), total=len(chunks), desc="Aggregating projected viewpoints"):
                     lab = pending.result()
                     pending = pool.submit(load_chunk, chunks[ci + 1], img_pool) if ci + 1 < len(chunks) else None
-                    sub = cameras.get_subset_cameras(chunks[ci])
+                    # the chunk's cameras only: a subset of the segmentor wrapper would deep-copy the segmentor with it
+                    # (segmentor.py:49-55) -- every in-memory label image of an ArrayLabelSegmentor, per chunk
+                    sub = getattr(cameras, "base_camera_set", cameras).get_subset_cameras(chunks[ci])
                     if lab.device.type != self.backend.device.type:
                         lab = lab.to(self.backend.device, non_blocking=True)
                     if fused_ok:
@@ -870,6 +871,64 @@ def _raster_kwargs(kwargs: dict) -> dict:
 # device -> host through pinned memory.  A pageable destination moves at ~10 GB/s on the MI355X host link, a pinned one
 # at the link rate; torch's caching host allocator hands the same pinned blocks back once earlier results are dropped.
 _PINNED_LIMIT_BYTES = 8 << 30
+
+
+def _ids_to_host_int64(ids, views_per_step: int = 4, threads: typing.Optional[int] = None) -> np.ndarray:
+    """(n, h, w) int32 ids on the device -> int64 numpy, as the reference returns them (meshes.py:1804).  The PCIe link is the
+    bottleneck of this call, so the ids cross it as int32 (half the bytes of a device-side widening) into a pinned ring,
+    and host threads widen slot k into the result while slot k+1 is on the wire."""
+    torch = _torch()
+    if not ids.is_cuda or ids.dim() != 3 or ids.numel() < (1 << 21):
+        return _to_host(ids.to(torch.int64))
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    n, h, w = ids.shape
+    ids = ids.contiguous()
+    if threads is None:
+        threads = max(1, min(16, os.cpu_count() or 1))
+    step = max(1, min(int(views_per_step), n))
+    try:
+        ring = [torch.empty((step, h, w), dtype=torch.int32, pin_memory=True) for _ in range(2)]
+    except RuntimeError:  # pinned memory exhausted
+        return _to_host(ids.to(torch.int64))
+    out = np.empty((n, h, w), dtype=np.int64)
+    stream = torch.cuda.current_stream(ids.device)
+    events = [torch.cuda.Event() for _ in range(2)]
+    rows = max(1, (step * h + threads - 1) // threads)
+
+    def widen(dst2d, src2d, r0, r1):
+        np.copyto(dst2d[r0:r1], src2d[r0:r1], casting="safe")  # numpy releases the interpreter lock for this loop
+
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        jobs = [[], []]
+        starts = list(range(0, n, step))
+        for k, v0 in enumerate(starts):
+            slot = k & 1
+            for j in jobs[slot]:  # the slot's previous contents have been widened
+                j.result()
+            m = min(step, n - v0)
+            ring[slot][:m].copy_(ids[v0 : v0 + m], non_blocking=True)
+            events[slot].record(stream)
+            if k >= 1:  # widen the previous slot while this one is on the wire
+                ps = (k - 1) & 1
+                pv0 = starts[k - 1]
+                pm = min(step, n - pv0)
+                events[ps].synchronize()
+                src = ring[ps][:pm].numpy().reshape(pm * h, w)
+                dst = out[pv0 : pv0 + pm].reshape(pm * h, w)
+                jobs[ps] = [pool.submit(widen, dst, src, r0, min(r0 + rows, pm * h)) for r0 in range(0, pm * h, rows)]
+        ls = (len(starts) - 1) & 1
+        lv0 = starts[-1]
+        lm = min(step, n - lv0)
+        events[ls].synchronize()
+        src = ring[ls][:lm].numpy().reshape(lm * h, w)
+        dst = out[lv0 : lv0 + lm].reshape(lm * h, w)
+        jobs[ls] = [pool.submit(widen, dst, src, r0, min(r0 + rows, lm * h)) for r0 in range(0, lm * h, rows)]
+        for js in jobs:
+            for j in js:
+                j.result()
+    return out
 
 
 def _to_host(t) -> np.ndarray:
