@@ -96,9 +96,12 @@ enum {
                                gr_raster_status (GR_EOVERFLOW); the retry uses segments of the size that image needs
                                (remembered for images of the same tile count) or, beyond 16384 slots / 24 GB of
                                entry memory per launch group, bins exactly                                     */
-  GR_OPT_VARIANT = 7,       /* variant bits for A/B runs (results identical): 1 = one tile per workgroup instead of a chain of four, 4 = fused votes on the caller's stream instead of a side stream, 8 = no speculative first chunk, 16 = chains of four tiles whatever the size of the launch (default: large launches of light tiles only) */
+  GR_OPT_VARIANT = 7,       /* variant bits for A/B runs (results identical): 1 = one tile per workgroup instead of a
+                               chain of four; 4 = fused votes on the caller's stream instead of a side stream; 8 = no
+                               first chunk requested ahead of the tile's count; 16 = chains of four tiles whatever the
+                               size of the launch (default: large launches of light tiles only)                */
   GR_OPT_DEBUG_LDS = 98,    /* extra dynamic LDS bytes per tile workgroup: lowers occupancy (timing experiments)     */
-  GR_OPT_DEBUG = 99         /* timing-only ablation mask for tools/ab_raster.py: OUTPUTS BECOME WRONG         */
+  GR_OPT_DEBUG = 99         /* timing-only ablation mask for tools/ab_kernel.py: OUTPUTS BECOME WRONG          */
 };
 int gr_set_option(gr_ctx *ctx, int key, int value);
 int gr_get_stage_times(gr_ctx *ctx, gr_stage_times *out_h);
