@@ -403,27 +403,38 @@ def run(args) -> int:
                       np.array_equal(c1.cpu().numpy().view(np.uint32), want_c))
             aggregate["oracle_check"] = f"votes and counts of view 0 (fused call) equal the CPU oracle's: {ok}"
             assert ok, "fused aggregation differs from the CPU oracle on view 0"
-        # bounded sample on all host cores: passes over the rank's views until ~cpu_seconds of wall time are used
-        n_done, tc, used = 0, 0.0, 1
-        per_pass = int(min(max(cores, nv), 64))  # one view per thread (more threads only contend for host memory bandwidth)
-        recs_pass = np.concatenate([recs_np] * (per_pass // nv + 1), axis=0)[:per_pass]
-        while tc < args.cpu_seconds and n_done < 4000:
-            t0 = time.perf_counter()
-            _, used = oracle_c.raster_views(points, faces, recs_pass, H, W, n_threads=min(cores, per_pass))
-            tc += time.perf_counter() - t0
-            n_done += per_pass
-        cpu_baseline = {
-            "value": round(n_done * P / tc / 1e6, 2),
-            "unit": "Mpix/s",
-            "cores": int(used),
-            "kind": "port",
-            "sample": f"{n_done} C2 views at 4000x3000 ({n_done // per_pass} passes of {per_pass}, one view per thread) on "
-                      f"{used} threads of {cores} cores ({_cpu_model()}) in {tc:.1f} s",
-            "views_per_s": round(n_done / tc, 3),
-            "single_thread": {"value": round(P / t1 / 1e6, 2), "unit": "Mpix/s", "cores": 1,
-                              "sample": f"1 C2 view at 4000x3000 in {t1:.2f} s"},
-            "host_cores": cores,
-        }
+        # bounded samples, one view per thread: (a) 64 threads -- where the un-culled oracle stops scaling on a 2 x 64-core host
+        # (it is bound by host memory bandwidth: every thread streams the whole mesh and its own 150 MB of image buffers) --
+        # and (b) ALL logical cores, as SURVEY section 8d asks; `value` is the better of the two, both are in the line
+        try:
+            with open("/proc/meminfo") as fh:
+                avail = next(int(l.split()[1]) * 1024 for l in fh if l.startswith("MemAvailable"))
+        except (OSError, StopIteration):
+            avail = 16 << 30
+        fit = int(max(1, (avail // 2) // (200 << 20)))
+
+        def sample(n_thr, seconds):
+            n_done, tc, used = 0, 0.0, 1
+            recs_pass = np.concatenate([recs_np] * (n_thr // nv + 1), axis=0)[:n_thr]
+            while tc < seconds and n_done < 4000:
+                t0 = time.perf_counter()
+                _, used = oracle_c.raster_views(points, faces, recs_pass, H, W, n_threads=n_thr)
+                tc += time.perf_counter() - t0
+                n_done += n_thr
+            return {"value": round(n_done * P / tc / 1e6, 2), "unit": "Mpix/s", "cores": int(used),
+                    "sample": f"{n_done} C2 views at 4000x3000 ({n_done // n_thr} passes of {n_thr}, one view per thread) on "
+                              f"{used} threads of {cores} cores ({_cpu_model()}) in {tc:.1f} s",
+                    "views_per_s": round(n_done / tc, 3)}
+
+        s64 = sample(int(min(cores, 64, fit)), args.cpu_seconds / 2)
+        sall = sample(int(min(cores, fit, 512)), args.cpu_seconds / 2) if cores > 64 and fit > 64 else s64
+        best = s64 if s64["value"] >= sall["value"] else sall
+        cpu_baseline = dict(best)
+        cpu_baseline["kind"] = "port"
+        cpu_baseline["all_cores"] = sall
+        cpu_baseline["single_thread"] = {"value": round(P / t1 / 1e6, 2), "unit": "Mpix/s", "cores": 1,
+                                         "sample": f"1 C2 view at 4000x3000 in {t1:.2f} s"}
+        cpu_baseline["host_cores"] = cores
 
     if rank == 0:
         line = {
