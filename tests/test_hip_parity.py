@@ -120,6 +120,27 @@ def test_ragged_sizes_and_scales(hip, scale):
     _check_views(hip, points, faces, _records(cams, scale), h, w)
 
 
+@pytest.mark.parametrize("pitch", [0.9, 1.5, 2.6])
+def test_tile_sized_faces_many_tiles_per_wave(hip, pitch):
+    """Faces about as large as a tile: the 64 faces of one wave of the set-up kernel touch more distinct tiles than the wave
+    has lanes (the joint tile grouping hands one tile to each lane and takes the rest one by one), and small faces (at
+    most 2x2 tiles, binned by k_setup_cull) mix with big ones (k_bin_big) in the same blocks."""
+    nx, ny = 24, 24
+    xs, ys = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1))
+    rng = np.random.default_rng(int(pitch * 10))
+    z = rng.uniform(0.0, 0.4, xs.shape)
+    f = 300.0
+    height = 30.0
+    step = pitch * 64.0 * height / f  # world size of a cell that projects to `pitch` tile widths
+    points = np.stack([(xs - nx / 2) * step + 0.013, (ys - ny / 2) * step * 0.5 + 0.007, z], axis=-1).reshape(-1, 3)
+    idx = lambda i, j: j * (nx + 1) + i
+    faces = np.array([[idx(i, j), idx(i + 1, j), idx(i + 1, j + 1)] for j in range(ny) for i in range(nx)] +
+                     [[idx(i, j), idx(i + 1, j + 1), idx(i, j + 1)] for j in range(ny) for i in range(nx)])
+    poses = [synthetic.nadir_pose(0.0, 0.0, height), synthetic.nadir_pose(3.0, -2.0, height, yaw_deg=23.0)]
+    cams = synthetic.camera_set_from_poses(poses, f=f, width=1600, height=900)
+    _check_views(hip, points, faces, _records(cams), 900, 1600)
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_triangle_soup_occlusion_degenerates_behind_camera(hip, seed):
     """Random overlapping triangles of every size: sub-pixel slivers, triangles larger than a tile (64-bit edge path),
