@@ -206,3 +206,26 @@ def test_many_classes_and_largest_image_winner_keys(hip):
         last = int(ids[-1, -1, -1])
         assert int(want_c[last if last >= 0 else F - 1]) >= 1
         del ids, labels
+
+
+def test_pix2face_host_copy_pipeline_matches_the_device_ids(hip):
+    """pix2face -> int64 numpy crosses PCIe as int32 through a pinned ring while host threads widen (meshes._ids_to_host_int64):
+    the numpy result must equal the device tensor of the same call, for view counts that do and do not fill the ring's
+    steps, and for the short path taken by small outputs."""
+    from geograypher_amd.meshes import TexturedPhotogrammetryMesh
+    from geograypher_amd.meshes.meshes import _ids_to_host_int64
+
+    (points, faces), cams = synthetic.config1_scene()
+    for c in cams.cameras:
+        c.image_width, c.image_height, c.image_size, c.f = 2000, 1500, (1500, 2000), 1500.0
+    mesh = TexturedPhotogrammetryMesh((points, faces), log_level="ERROR")
+    for n in (1, 3, 7):
+        want = mesh.pix2face(cams[0:n], apply_distortion=False, return_tensor=True)
+        got = mesh.pix2face(cams[0:n], apply_distortion=False)
+        assert got.dtype == np.int64 and got.shape == tuple(want.shape)
+        np.testing.assert_array_equal(got, want.cpu().numpy().astype(np.int64))
+    t = torch.randint(-1, 1 << 30, (5, 1024, 1024), dtype=torch.int32, device="cuda")
+    for step, threads in ((1, 1), (2, 3), (4, 16), (8, 5)):
+        np.testing.assert_array_equal(_ids_to_host_int64(t, step, threads), t.cpu().numpy().astype(np.int64))
+    small = torch.arange(-5, 95, dtype=torch.int32, device="cuda").reshape(1, 10, 10)
+    np.testing.assert_array_equal(_ids_to_host_int64(small), small.cpu().numpy().astype(np.int64))
