@@ -329,8 +329,7 @@ __device__ __forceinline__ bool face_setup(const BinArgs &a, const float *__rest
 // the record planes, k_scan_tiles and k_fill_compile are skipped.  A tile that receives more than cap_tile entries
 // raises the view's overflow word; the caller then repeats the call with the exact two-pass path (DIRECT = false).
 template <bool DIRECT>
-__global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ verts, const int32_t *__restrict__ faces,
-                                                    const float *__restrict__ cams, BinArgs a) {
+__global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ cams, BinArgs a) {
   const int slot = blockIdx.y;
   const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
   uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
@@ -1285,7 +1284,7 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
 // once per two rows: -16 % VALU instructions) were measured as well: 74 VGPRs and half as many batches per tile for four
 // waves -- 15.6 vs 16.0 without the hint, 16.3 vs 15.3 with it, fused 18.3 vs 17.2 -- dropped.
 template <int TWL, int THL, int NT, bool FUSE, int KT, int PAD>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : 7, 8))) void k_raster_tile(BinArgs a, RasterOut out) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (THL == 5 ? 7 : 4), 8))) void k_raster_tile(BinArgs a, RasterOut out) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   constexpr int NKEYS = (TW + PAD) * TH;
   constexpr int NW = NT / 64;
@@ -1960,13 +1959,11 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int
     const int gmax = std::min((nblk + 3) / 4, 1024);
     const unsigned gsetup = (unsigned)std::max(1, std::min(gmax, std::max(nblk / 128, 4096 / std::max(nb, 1))));
     if (a.cap_tile > 0) {
-      hipLaunchKernelGGL(k_setup_cull<true>, dim3(gsetup, nb), dim3(256), 0, s, c->verts,
-                         c->faces, cams, a);
+      hipLaunchKernelGGL(k_setup_cull<true>, dim3(gsetup, nb), dim3(256), 0, s, cams, a);
       hipLaunchKernelGGL(k_bin_big, dim3(256, nb), dim3(256), 0, s, cams, a);
       hipLaunchKernelGGL(k_clip_faces<true>, dim3(8, nb), dim3(64), 0, s, cams, a);
     } else {
-      hipLaunchKernelGGL(k_setup_cull<false>, dim3(gsetup, nb), dim3(256), 0, s, c->verts,
-                         c->faces, cams, a);
+      hipLaunchKernelGGL(k_setup_cull<false>, dim3(gsetup, nb), dim3(256), 0, s, cams, a);
       hipLaunchKernelGGL(k_clip_faces<false>, dim3(8, nb), dim3(64), 0, s, cams, a);
     }
   }
@@ -2409,7 +2406,7 @@ int gr_project_view_f64(gr_ctx *c, const int32_t *ids, const double *img, int h,
   if (!ids || !img || !tex || C <= 0) return fail(c, GR_EINVAL, "bad project args");
   hipStream_t s = (hipStream_t)stream;
   GR_HIP(c, hipSetDevice(c->device));
-  const int64_t P = (int64_t)h * w, F = c->F;
+  const int64_t F = c->F;
   rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F);
   if (rc) return rc;
   uint32_t *win = (uint32_t *)c->winner;
