@@ -51,6 +51,9 @@ struct BinArgs {
   const float *soup;     // [F][9] the three vertex positions of every face, in Morton order (built once per upload)
   const int32_t *orig;   // [F] soup position -> face id of the caller's mesh
   const float4 *blk;     // [ceil(F/64)] bounding sphere (centre, radius) of each block of GR_BLOCK faces, local frame
+  const uint32_t *blk_chunks;  // [ceil(F/64)][17] count (or ~0: more than 16) + the 256-face chunks of CALLER ids the block's faces lie in
+  uint32_t *touched;     // [slot][tw] bit per 256-face chunk of caller ids that a surviving block reaches (+ last word: all), or null
+  int tw;                // words per slot of `touched`
   uint32_t *work;        // [slot][work_stride] blocks of this view that passed the frustum test (ctrl[3] = count)
   uint32_t *clip;        // [slot][F] from the front: soup faces that straddle the near plane / guard band (R7; ctrl[4] = count);
                          //           from the back: faces over more than 2 x 2 tiles (single-pass binning; ctrl[5] = count)
@@ -67,7 +70,7 @@ struct BinArgs {
   int h, w;
   int twl, thl;          // log2 of the tile width / height in pixels
   int cap_tile;          // > 0: single-pass binning, every tile owns cap_tile entry slots (list base = tile * cap_tile)
-  int var;               // variant bits (GR_OPT_VARIANT): 1 = one tile per workgroup instead of four, 4 = votes on the caller's stream, 8 = no speculative first chunk, 16 = chains of four whatever the launch looks like
+  int var;               // variant bits (GR_OPT_VARIANT): 1 = one tile per workgroup instead of four, 4 = votes on the caller's stream, 8 = no speculative first chunk, 16 = chains of four whatever the launch looks like, 32 = votes without chunk bitmaps
   int dbg;               // timing-only ablation mask (GR_OPT_DEBUG): 1 skip scanline loop, 2 skip id stores, 4 skip triangles,
                          // fused epilogue: 8 skip winner atomics, 16 skip label loads
 };
@@ -242,6 +245,28 @@ __device__ __forceinline__ void wave_group(int t, int lane, int &leader, int &ra
   }
 }
 
+// K0a  (once per upload) for every block of 64 soup faces: the 256-face chunks of the CALLER's face ids its faces lie in
+//      (at most 16 listed; a block whose faces are scattered over more says so).  The fused aggregation marks, per view,
+//      the chunks that surviving blocks reach, and its vote kernel -- one workgroup per chunk -- reads the winners of the
+//      views that can have any.  One wave per block.
+#define GR_CHUNK_LIST 16
+__global__ __launch_bounds__(256) void k_block_chunks(const int32_t *__restrict__ orig, int64_t F, uint32_t *__restrict__ out) {
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int64_t f = b * GR_BLOCK + lane;
+  if (b * GR_BLOCK >= F) return;
+  const int ch = f < F ? (orig[f] >> 8) : -1;
+  unsigned long long rem = __ballot(ch >= 0);
+  int n = 0;
+  while (rem && n < GR_CHUNK_LIST) {
+    const int cl = __builtin_amdgcn_readlane(ch, __ffsll((long long)rem) - 1);
+    if (lane == 0) out[b * (GR_CHUNK_LIST + 1) + 1 + n] = (uint32_t)cl;
+    rem &= ~__ballot(ch == cl);
+    ++n;
+  }
+  if (lane == 0) out[b * (GR_CHUNK_LIST + 1)] = rem ? 0xFFFFFFFFu : (uint32_t)n;
+}
+
 // K0b  per view: sphere-vs-frustum test of every 64-face block (one thread per block); survivors are appended to the
 //      view's work list with one wave-aggregated atomic.  grid (ceil(nblk/256), views)
 __global__ __launch_bounds__(256) void k_cull_blocks(const float *__restrict__ cams, BinArgs a, int nblk) {
@@ -268,13 +293,36 @@ __global__ __launch_bounds__(256) void k_cull_blocks(const float *__restrict__ c
     keep = !out;
   }
   const unsigned long long m = __ballot(keep);
-  if (m == 0ull) return;
-  const int lane = threadIdx.x & 63;
-  const int leader = __ffsll((long long)m) - 1;
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(&ctrl[3], (uint32_t)__popcll(m));
-  base = __shfl(base, leader);
-  if (keep) a.work[(int64_t)slot * a.work_stride + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)b;
+  if (m != 0ull) {
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&ctrl[3], (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    if (keep) a.work[(int64_t)slot * a.work_stride + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)b;
+  }
+  // fused aggregation: which 256-face chunks of caller ids can receive winners in this view.  The workgroup's 256 blocks
+  // are neighbours on the Morton curve and share most of their chunks: the bits are collected in LDS and every non-zero
+  // word leaves the workgroup as one atomicOr.
+  if (a.touched) {
+    extern __shared__ uint32_t bits[];
+    for (int i = threadIdx.x; i < a.tw; i += 256) bits[i] = 0u;
+    __syncthreads();
+    if (keep) {
+      const uint32_t *cl = a.blk_chunks + (int64_t)b * (GR_CHUNK_LIST + 1);
+      const uint32_t n = cl[0];
+      if (n == 0xFFFFFFFFu) atomicOr(&bits[a.tw - 1], 1u);
+      else
+        for (uint32_t i = 0; i < n; ++i) {
+          const uint32_t ch = cl[1 + i];
+          atomicOr(&bits[ch >> 5], 1u << (ch & 31u));
+        }
+    }
+    __syncthreads();
+    uint32_t *dst = a.touched + (int64_t)slot * a.tw;
+    for (int i = threadIdx.x; i < a.tw; i += 256)
+      if (bits[i]) atomicOr(&dst[i], bits[i]);
+  }
 }
 
 __device__ __forceinline__ bool compile_entry(int4 *__restrict__ dst, uint8_t *__restrict__ nr8, const int4 p0, const int4 p1,
@@ -1456,8 +1504,23 @@ __global__ __launch_bounds__(256) void k_winner(const int32_t *__restrict__ ids,
 __global__ __launch_bounds__(256) void k_vote_labels(uint32_t *__restrict__ winner, const uint8_t *__restrict__ labels,
                                                      int n_views, int64_t F, int64_t P, int C,
                                                      uint32_t *__restrict__ votes, uint32_t *__restrict__ counts,
-                                                     const unsigned long long *__restrict__ stats, int group) {
+                                                     const unsigned long long *__restrict__ stats, int group,
+                                                     const uint32_t *__restrict__ touched, int tw, int last_face_aliases_bg) {
   const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // which views of the group can hold a winner for this workgroup's 256 faces (chunk = blockIdx.x): the bit the cull pass
+  // set for the chunk, or the view's "all" word; without the bitmap (ids given by the caller) every view can.  Lane v of
+  // every wave looks at view v: the ballot is the same in all four waves.
+  unsigned long long dirty = ~0ull;
+  if (touched) {
+    const int v = threadIdx.x & 63;
+    bool d = false;
+    if (v < n_views) {
+      const uint32_t *tv = touched + (int64_t)v * tw;
+      d = (((tv[blockIdx.x >> 5] >> (blockIdx.x & 31u)) | tv[tw - 1]) & 1u) != 0u;
+    }
+    dirty = __ballot(d);
+    if (last_face_aliases_bg && (int64_t)blockIdx.x == ((F - 1) >> 8)) dirty = ~0ull;  // background pixels vote for face F - 1
+  }
   if (f >= F) return;
   // a launch group whose binning overflowed (and every group after it) must not vote: its winners are incomplete.  The
   // caller learns how many views were folded in (gr_raster_status: views_done) and repeats the call for the rest.
@@ -1466,9 +1529,11 @@ __global__ __launch_bounds__(256) void k_vote_labels(uint32_t *__restrict__ winn
   // eight views' winners are requested together (the kernel is a stream over winner[views][F]: memory-level
   // parallelism, not arithmetic, sets its speed), then their labels, then the votes in view order
   for (int v0 = 0; v0 < n_views; v0 += 8) {
+    const uint32_t d8 = (uint32_t)(dirty >> v0) & 0xFFu;
+    if (d8 == 0u) continue;
     uint32_t key[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) key[k] = (v0 + k < n_views) ? winner[(int64_t)(v0 + k) * F + f] : 0u;
+    for (int k = 0; k < 8; ++k) key[k] = (v0 + k < n_views && ((d8 >> k) & 1u)) ? winner[(int64_t)(v0 + k) * F + f] : 0u;
     uint32_t lab[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) lab[k] = (key[k] && !skip) ? (uint32_t)labels[(int64_t)(v0 + k) * P + (key[k] - 1)] : 0u;
@@ -1791,6 +1856,11 @@ struct gr_ctx {
   uint32_t *clip = nullptr;   // [slot][F] clip lists (R7)
   int64_t clip_have = 0;
   float4 *blk = nullptr;
+  uint32_t *blk_chunks = nullptr;  // [blk_cap][GR_CHUNK_LIST + 1]
+  uint32_t *touched = nullptr;     // fused aggregation: [2][slots][tw] chunk bitmaps of the launch groups in flight
+  int64_t touched_have = 0;
+  uint32_t *cur_touched = nullptr; // the bitmap the next bin_batch fills (null: none)
+  int cur_tw = 0;
   int64_t blk_cap = 0;
   float *soup = nullptr;
   int32_t *orig = nullptr;   // soup position -> caller's face id (Morton order)
@@ -1934,6 +2004,7 @@ BinArgs make_args(gr_ctx *c, int h, int w, int slot0) {
   a.comp = c->comp + slot0 * a.ent_cap * GR_ENT_Q; a.work = c->work + slot0 * a.work_stride;
   a.nrow8 = c->nrow8 + slot0 * a.ent_cap;
   a.stats = c->stats; a.blk = c->blk; a.soup = c->soup; a.orig = c->orig;
+  a.blk_chunks = c->blk_chunks; a.touched = c->cur_touched; a.tw = c->cur_tw;
   a.clip = c->clip + slot0 * c->F;
   a.twl = GR_TILE_LOG2; a.thl = c->opt_thl;
   a.TX = (w + (1 << a.twl) - 1) >> a.twl; a.TY = (h + (1 << a.thl) - 1) >> a.thl; a.T = a.TX * a.TY; a.Tcap = c->Tcap;
@@ -1951,7 +2022,8 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int
   {
     Timed t(c, s, ST_SETUP);
     const int nblk = (int)ceil_div(c->F, GR_BLOCK);
-    hipLaunchKernelGGL(k_cull_blocks, dim3((unsigned)ceil_div(nblk, 256), nb), dim3(256), 0, s, cams, a, nblk);
+    hipLaunchKernelGGL(k_cull_blocks, dim3((unsigned)ceil_div(nblk, 256), nb), dim3(256), a.touched ? sizeof(uint32_t) * a.tw : 0, s,
+                       cams, a, nblk);
     // k_setup_cull: a wave per surviving 64-face block would mostly pay for starting waves (a survey view keeps a tenth of
     // the blocks: C2 7.5 -> 6.1 us per view with an eighth of the workgroups): about nblk / 32 waves per view take a few
     // blocks each -- but never fewer than 16 k waves per launch, so that a call with a few views still fills the machine.
@@ -2040,7 +2112,7 @@ int project_labels(gr_ctx *c, const int32_t *ids, const uint8_t *labels, int n_v
     {
       Timed t(c, s, ST_VOTE);
       hipLaunchKernelGGL(k_vote_labels, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s, win, labels + v0 * P, nb, F, P, C,
-                         votes, counts, (const unsigned long long *)nullptr, 0);
+                         votes, counts, (const unsigned long long *)nullptr, 0, (const uint32_t *)nullptr, 0, 0);
     }
   }
   GR_HIP(c, hipGetLastError());
@@ -2072,9 +2144,17 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   // runs on a side stream beside the binning of group g + 1 (also light); the tile kernels in between fill the machine on
   // their own.  Two winner buffers alternate; votes are still added group by group, in order (one side stream).
   const bool overlap = labels && n_views > B && !(c->opt_var & 4);
+  // chunk bitmaps for the vote kernel (k_block_chunks / k_cull_blocks): one per launch group in flight; meshes beyond
+  // 33 M faces do without (the bitmap of a view would not fit the cull kernel's LDS)
+  const int tw = (int)(ceil_div(ceil_div(F, 256), 32) + 1);
+  const bool use_touched = labels && tw <= 4096 && !(c->opt_var & 32);
   if (labels) {
     rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F * B * (overlap ? 2 : 1));
     if (rc) return rc;
+    if (use_touched) {
+      rc = grow(c, c->touched, c->touched_have, (int64_t)2 * B * tw, "chunk bitmaps");
+      if (rc) return rc;
+    }
     if (overlap && !c->side) {
       GR_HIP(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
       for (int i = 0; i < 2; ++i) {
@@ -2090,9 +2170,18 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   int g = 0;
   for (int v0 = 0; v0 < n_views; v0 += B, ++g) {
     const int nb = (n_views - v0) < B ? (n_views - v0) : B;
-    rc = bin_batch(c, cams + (int64_t)v0 * GR_CAM_FLOATS, nb, h, w, 0, v0 / B, s);
-    if (rc) return rc;
     const int buf = overlap ? (g & 1) : 0;
+    uint32_t *tch = use_touched ? c->touched + (int64_t)buf * B * tw : nullptr;
+    if (tch) {
+      // (the votes of group g - 2, which read this bitmap, are waited for below, before the tile kernel -- but the bitmap
+      // is rewritten here already: wait now)
+      if (overlap && g >= 2) GR_HIP(c, hipStreamWaitEvent(s, c->ev_vote[buf], 0));
+      GR_HIP(c, hipMemsetAsync(tch, 0, sizeof(uint32_t) * (size_t)nb * tw, s));
+    }
+    c->cur_touched = tch; c->cur_tw = tw;
+    rc = bin_batch(c, cams + (int64_t)v0 * GR_CAM_FLOATS, nb, h, w, 0, v0 / B, s);
+    c->cur_touched = nullptr;
+    if (rc) return rc;
     uint32_t *win = labels ? (uint32_t *)c->winner + (int64_t)buf * F * B : nullptr;
     RasterOut out;
     out.ids = ids ? ids + v0 * P : nullptr;
@@ -2113,7 +2202,8 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
       {
         Timed t(c, vs, ST_VOTE);
         hipLaunchKernelGGL(k_vote_labels, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, vs, win, labels + v0 * P, nb, F, P, C,
-                           votes, counts, (const unsigned long long *)c->stats, v0 / B);
+                           votes, counts, (const unsigned long long *)c->stats, v0 / B, (const uint32_t *)tch, tw,
+                           (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0);
       }
       GR_HIP(c, hipGetLastError());
       if (overlap) GR_HIP(c, hipEventRecord(c->ev_vote[buf], c->side));
@@ -2171,6 +2261,8 @@ int gr_ctx_destroy(gr_ctx *c) {
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->sort_tmp) (void)hipFree(c->sort_tmp);
   if (c->blk) (void)hipFree(c->blk);
+  if (c->blk_chunks) (void)hipFree(c->blk_chunks);
+  if (c->touched) (void)hipFree(c->touched);
   if (c->soup) (void)hipFree(c->soup);
   if (c->orig) (void)hipFree(c->orig);
   if (c->stats) (void)hipFree(c->stats);
@@ -2267,6 +2359,10 @@ int gr_mesh_upload(gr_ctx *c, const float *verts, const int32_t *faces, int64_t 
     if (c->blk) (void)hipFree(c->blk);
     c->blk = nullptr; c->blk_cap = 0;
     if (hipMalloc(&c->blk, sizeof(float4) * nblk) != hipSuccess) return fail(c, GR_ENOMEM, "block bounds allocation failed");
+    if (c->blk_chunks) (void)hipFree(c->blk_chunks);
+    c->blk_chunks = nullptr;
+    if (hipMalloc(&c->blk_chunks, sizeof(uint32_t) * (GR_CHUNK_LIST + 1) * nblk) != hipSuccess)
+      return fail(c, GR_ENOMEM, "block chunk list allocation failed");
     c->blk_cap = nblk;
   }
   if (c->soup_cap < F) {
@@ -2300,6 +2396,7 @@ int gr_mesh_upload(gr_ctx *c, const float *verts, const int32_t *faces, int64_t 
   GR_HIP(c, hipcub::DeviceRadixSort::SortPairs(tmp, tb, code_in, code_out, idx_in, c->orig, (int)F, 0, 32, s));
   hipLaunchKernelGGL(k_build_soup, dim3((unsigned)ceil_div(3 * F, 256)), dim3(256), 0, s, verts, faces, c->orig, F, c->soup);
   hipLaunchKernelGGL(k_block_bounds, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s, c->soup, F, c->blk);
+  hipLaunchKernelGGL(k_block_chunks, dim3((unsigned)ceil_div(nblk, 4)), dim3(256), 0, s, c->orig, F, c->blk_chunks);
   GR_HIP(c, hipGetLastError());
   c->verts = verts; c->faces = faces; c->V = V; c->F = F;
   return GR_OK;

@@ -17,10 +17,10 @@ pytestmark = pytest.mark.gpu
 # single-pass slots per tile (0 = exact two-pass binning), tile order (GR_OPT_VARIANT 64 = XCD-aware) -- results must
 # not depend on them
 # (tile height log2, slots per tile [0 = exact two-pass binning], GR_OPT_VARIANT bits: 1 = one tile per workgroup, 4 = votes on
-# the caller's stream, 8 = no speculative first chunk, 16 = chains of four tiles even in small launches) -- every combination
+# the caller's stream, 8 = no speculative first chunk, 16 = chains of four tiles even in small launches, 32 = fused votes without the chunk bitmaps) -- every combination
 # must give identical results
 VARIANTS = {"tile32_chain": (5, 512, 16), "tile64_single": (6, 512, 1), "tile32_exact_single": (5, 0, 5),
-            "tile64_exact_chain": (6, 0, 16), "tile32_single_nospec": (5, 512, 13), "tile32_chain_nospec": (5, 512, 24)}
+            "tile64_exact_chain": (6, 0, 16), "tile32_single_nospec": (5, 512, 13), "tile32_chain_nospec_nobitmap": (5, 512, 56)}
 
 
 @pytest.fixture(params=list(VARIANTS), autouse=True)
@@ -345,6 +345,43 @@ def test_label_votes_bit_exact_vs_oracle(hip, compat):
     v2, c2 = hip.new_vote_buffers(C)
     hip.raster_project_labels(recs, labels, C, v2, c2, neg1_is_last_face=compat)
     assert torch.equal(v2, votes) and torch.equal(c2, counts)
+
+
+@pytest.mark.parametrize("compat", [True, False])
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_fused_votes_with_partial_views_and_scattered_face_order(hip, compat, shuffle):
+    """The fused vote kernel reads the winners only of views whose cull pass reached the workgroup's 256-face chunk of caller
+    ids.  Views that see a corner of the mesh (most chunks untouched, background around it: with the compatibility flag
+    background pixels vote for face F - 1, whose chunk no block may have reached), a caller face order that is shuffled (the
+    faces of a 64-face block lie in more chunks than its list holds: the view's "all" word), several launch groups."""
+    (points, faces), _ = synthetic.config1_scene()
+    if shuffle:
+        faces = faces[np.random.default_rng(5).permutation(faces.shape[0])]
+    F, C = faces.shape[0], 3
+    lo, hi = points.min(axis=0), points.max(axis=0)
+    mid, half = 0.5 * (lo + hi), 0.5 * (hi - lo)
+    poses = [synthetic.nadir_pose(mid[0] + half[0] * np.cos(0.7 * k), mid[1] + half[1] * np.sin(0.7 * k), hi[2] + 14.0 + k,
+                                  yaw_deg=31.0 * k) for k in range(9)]  # above the rim of the mesh: half of every view is background
+    cams = synthetic.camera_set_from_poses(poses, f=300.0, width=320, height=200)
+    recs = _records(cams)
+    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+    hip.set_option(3, 4)  # three launch groups
+    try:
+        ids = hip.raster_face_ids(recs, 200, 320)
+        ids_np = ids.cpu().numpy()
+        assert (ids_np == -1).mean() > 0.1 and (ids_np >= 0).mean() > 0.1
+        labels = np.stack([synthetic.synthetic_labels(ids_np[v], v, C) for v in range(len(cams))])
+        want_v = np.zeros((F, C), dtype=np.uint32)
+        want_c = np.zeros(F, dtype=np.uint32)
+        for v in range(len(cams)):
+            oracle_c.project_labels(ids_np[v], labels[v], F, C, want_v, want_c, neg1_is_last_face=compat)
+        for _ in range(2):  # twice: the winner buffers must be left clean
+            v2, c2 = hip.new_vote_buffers(C)
+            hip.raster_project_labels(recs, labels, C, v2, c2, neg1_is_last_face=compat)
+            np.testing.assert_array_equal(v2.cpu().numpy().view(np.uint32), want_v)
+            np.testing.assert_array_equal(c2.cpu().numpy().view(np.uint32), want_c)
+    finally:
+        hip.set_option(3, 64)
 
 
 def test_end_to_end_api_matches_oracle_pipeline(hip, oracle_backend_cls):
