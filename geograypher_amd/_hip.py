@@ -158,6 +158,34 @@ def _torch():
     return torch
 
 
+class _StatsAccumulator:
+    """Statistics of a checked raster call over its attempts: an attempt that overflowed contributes the views it
+    completed (records and entries are summed over the views a call processed, so they are scaled by the completed share);
+    `max_entries` is the largest per-tile (single-pass) or per-view (exact binning) count any attempt saw."""
+
+    def __init__(self):
+        self.records = 0.0
+        self.entries = 0.0
+        self.max_entries = 0
+        self.views = 0
+        self.last = None
+
+    def add(self, st: "RasterStats", n_views: int, partial: bool):
+        done = int(st.views_done) if partial else n_views
+        share = done / max(n_views, 1)
+        self.records += st.records * share
+        self.entries += st.entries * share
+        self.max_entries = max(self.max_entries, int(st.max_entries))
+        self.views += done
+        self.last = st
+
+    def result(self) -> dict:
+        d = self.last.as_dict()
+        d.update(records=int(round(self.records)), entries=int(round(self.entries)), max_entries=self.max_entries,
+                 views_done=self.views)
+        return d
+
+
 class _nullcontext:
     def __enter__(self):
         return None
@@ -253,7 +281,7 @@ class HipRaster:
 
     def set_option(self, key: int, value: int):
         """Tuning knobs of include/geograster.h (GR_OPT_*): 2 tile height log2, 3 views per launch group, 6 single-pass
-        slots per tile (0 = exact binning), 7 tile-kernel variant bits (64 = XCD-aware tile order)."""
+        slots per tile (0 = exact binning), 7 variant bits (see GR_OPT_VARIANT in the header)."""
         self._check(self.lib.gr_set_option(self._ctx, int(key), int(value)), "gr_set_option")
 
     def stage_times(self) -> dict:
@@ -277,7 +305,13 @@ class HipRaster:
 
     # -- pix2face ------------------------------------------------------------------------------------------------
     def raster_face_ids(self, cams, h: int, w: int, out=None, want_depth: bool = False, check: bool = True):
-        """cams (N,16) camera records -> ids (N,h,w) int32 tensor [, depth (N,h,w) float32]."""
+        """cams (N,16) camera records -> ids (N,h,w) int32 tensor [, depth (N,h,w) float32].
+
+        `check=True` (default) reads the call's status back and repeats the unfinished views when a tile overflowed its
+        bin segment (`last_retries`; the statistics of all attempts are summed in `last_stats`).  `check=False` only
+        enqueues the work: nothing is known about its outcome -- `last_stats` says `{"unchecked": True}` -- and a view whose
+        bins overflowed is INCOMPLETE until the caller asks `raster_status()`, which raises on overflow.  Use it only for
+        repeats of a call that was sized with `check=True` on the same inputs."""
         torch = _torch()
         cams_t = self._dev(cams, torch.float32)
         if cams_t.ndim != 2 or cams_t.shape[1] != GR_CAM_FLOATS:
@@ -290,6 +324,7 @@ class HipRaster:
         depth = torch.empty((n, h, w), dtype=torch.float32, device=self.device) if want_depth else None
         v0 = 0
         self.last_retries = 0
+        acc = _StatsAccumulator()
         for attempt in range(4):
             with torch.cuda.device(self.device):
                 rc = self.lib.gr_raster_face_ids(
@@ -298,15 +333,18 @@ class HipRaster:
                 )
             self._check(rc, "gr_raster_face_ids")
             if not check:
+                self.last_stats = {"unchecked": True}
                 break
             st = RasterStats()
             rc = self.lib.gr_raster_status(self._ctx, ctypes.byref(st))
             if rc == GR_EOVERFLOW and attempt < 3:
+                acc.add(st, n - v0, partial=True)
                 v0 += int(st.views_done)  # the library has recorded the need; only the unfinished views are repeated
                 self.last_retries += 1
                 continue
             self._check(rc, "gr_raster_status")
-            self.last_stats = st.as_dict()
+            acc.add(st, n - v0, partial=False)
+            self.last_stats = acc.result()
             break
         return (out, depth) if want_depth else out
 
@@ -447,7 +485,9 @@ class HipRaster:
     def raster_project_labels(self, cams, labels, C: int, votes, counts, ids_out=None, neg1_is_last_face: bool = True,
                               check: bool = True):
         """Fused pix2face + label projection for N views (aggregate_projected_images fast path): the face ids stay in
-        the rasterizer's LDS tiles unless `ids_out` (N,h,w int32) is given.  Accumulates into votes / counts."""
+        the rasterizer's LDS tiles unless `ids_out` (N,h,w int32) is given.  Accumulates into votes / counts.
+        `check` as in `raster_face_ids`: with `check=False` a launch group whose bins overflowed (and every later one) adds
+        NO votes and nobody is told until `raster_status()` is asked."""
         torch = _torch()
         cams_t = self._dev(cams, torch.float32)
         lab_t = self._dev(labels, torch.uint8)
@@ -457,6 +497,7 @@ class HipRaster:
         flags = GR_FLAG_NEG1_IS_LAST_FACE if neg1_is_last_face else 0
         v0 = 0
         self.last_retries = 0
+        acc = _StatsAccumulator()
         for attempt in range(4):
             with torch.cuda.device(self.device):
                 rc = self.lib.gr_raster_project_labels_u8(
@@ -465,16 +506,19 @@ class HipRaster:
                 )
             self._check(rc, "gr_raster_project_labels_u8")
             if not check:
+                self.last_stats = {"unchecked": True}
                 break
             st = RasterStats()
             rc = self.lib.gr_raster_status(self._ctx, ctypes.byref(st))
             if rc == GR_EOVERFLOW and attempt < 3:
                 # the votes of the first views_done views are in; the library skipped the rest on the device
+                acc.add(st, n - v0, partial=True)
                 v0 += int(st.views_done)
                 self.last_retries += 1
                 continue
             self._check(rc, "gr_raster_status")
-            self.last_stats = st.as_dict()
+            acc.add(st, n - v0, partial=False)
+            self.last_stats = acc.result()
             break
         return ids_out
 

@@ -398,7 +398,7 @@ class PhotogrammetryCameraSet:
         return "|".join(strings)
 
     def make_distortion_map(self, camera: PhotogrammetryCamera, inversion_downsample: int = 8, image_scale: float = 1.0,
-                            backend=None) -> None:
+                            backend=None, reference_inverse: bool = False) -> None:
         """Build and cache the two sampling maps of a distortion key (reference: cameras.py:995-1062).
 
         `_maps_ideal_to_warped[key]` (2, H, W): for every pixel of the IDEAL image, where it lands in the warped image
@@ -407,9 +407,14 @@ class PhotogrammetryCameraSet:
         `_maps_warped_to_ideal[key]`: its inverse.  The reference inverts by scattered-data interpolation
         (scipy griddata) on every `inversion_downsample`-th pixel, minutes of host time at full resolution; here every
         pixel solves the lens model with Newton's method on the device (`gr_invert_distortion_f64`, float64, residual
-        below 1e-9 px).  `inversion_downsample` is accepted for API compatibility and has no effect: the result is the
-        DENSE inverse, from which the reference's down-sampled one differs by its own interpolation error (0.022 px at
-        downsample 8, 0.003 px at 2 on the reference's test lens; tests/test_warp.py).  One-time work per key.
+        below 1e-9 px): the DENSE inverse, from which the reference's down-sampled one differs by its own interpolation
+        error (0.022 px at downsample 8, 0.003 px at 2 on the reference's test lens; tests/test_warp.py) -- enough to move
+        about 0.01 % of the nearest-neighbour samples of an id image.  One-time work per key.
+
+        reference_inverse=True inverts the way the reference does instead -- `utils.indexing.inverse_map_interpolation` over
+        every `inversion_downsample`-th pixel, on the host, bit-equal to the reference's map -- for parity runs.  The same
+        host inversion is what a machine without a GPU gets (and only then is `inversion_downsample` used by default):
+        building the maps and `warp_dewarp_pixels` need no device; the image warps themselves do.
         """
         im_h, im_w = camera.image_size
         if np.isclose(image_scale, 1.0):
@@ -426,13 +431,22 @@ class PhotogrammetryCameraSet:
             warp_rows = warp_rows * image_scale
         dkey = self.distortion_key(camera.distortion_params, image_scale)
         self._maps_ideal_to_warped[dkey] = np.stack([warp_rows, warp_cols], axis=0)
-        if backend is None:
-            from geograypher_amd._hip import default_backend
-
-            backend = default_backend()
-        inv = backend.invert_distortion(self.distortion_model(camera), len(h_range), len(w_range), image_scale)
         self._maps_device = getattr(self, "_maps_device", {})
         self._maps_device.pop((dkey, True), None)
+        self._maps_device.pop((dkey, False), None)
+        if backend is None and not reference_inverse:
+            import torch
+
+            if torch.cuda.is_available():
+                from geograypher_amd._hip import default_backend
+
+                backend = default_backend()
+        if reference_inverse or backend is None:
+            from geograypher_amd.utils.indexing import inverse_map_interpolation
+
+            self._maps_warped_to_ideal[dkey] = inverse_map_interpolation(self._maps_ideal_to_warped[dkey], inversion_downsample)
+            return
+        inv = backend.invert_distortion(self.distortion_model(camera), len(h_range), len(w_range), image_scale)
         self._maps_device[(dkey, False)] = (backend, inv)  # already where the warp kernels want it
         self._maps_warped_to_ideal[dkey] = inv.cpu().numpy()
 

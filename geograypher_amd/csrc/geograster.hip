@@ -1,7 +1,7 @@
 // geograypher_amd/csrc/geograster.hip -- hand-written CDNA4 (gfx950, wave64) kernels + the C ABI of include/geograster.h.
 //
 // Hot path of geograypher re-designed for MI355X (reference lines in include/geograster.h and DESIGN.md):
-//   pix2face            k_cull_blocks -> k_setup_cull (+ k_bin_big, k_clip_faces) -> k_bin_stats -> k_raster_tile
+//   pix2face            k_cull_blocks -> k_setup_cull (+ k_clip_faces) -> k_bin_stats -> k_raster_tile
 //                       (single-pass binning; exact fallback: k_setup_cull<false> -> k_scan_tiles -> k_fill_compile)
 //                                                                                          (meshes.py:1776-1836)
 //   project/aggregate   k_raster_tile<FUSE> | k_winner  ->  k_vote_labels / k_vote_values (meshes.py:1987-2002, 2057-2067)
@@ -25,6 +25,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -245,6 +246,24 @@ __device__ __forceinline__ void wave_group(int t, int lane, int &leader, int &ra
   }
 }
 
+// The same with at most `max_groups` groups looked for: lanes that are left over stand alone (leader = itself, size 1).
+// For the (face, tile) pairs of big faces, where a step of 64 pairs can name 64 different tiles.
+__device__ __forceinline__ void wave_group_capped(int t, int lane, int &leader, int &rank, int &size, int max_groups) {
+  leader = lane; rank = 0; size = 1;
+  unsigned long long rem = __ballot(t >= 0);
+  for (int g = 0; rem && g < max_groups; ++g) {
+    const int l = __ffsll((long long)rem) - 1;
+    const int tl = __builtin_amdgcn_readlane(t, l);
+    const unsigned long long m = __ballot(t == tl);
+    if (t == tl) {
+      leader = l;
+      rank = __popcll(m & ((1ull << lane) - 1ull));
+      size = __popcll(m);
+    }
+    rem &= ~m;
+  }
+}
+
 // K0a  (once per upload) for every block of 64 soup faces: the 256-face chunks of the CALLER's face ids its faces lie in
 //      (at most 16 listed; a block whose faces are scattered over more says so).  The fused aggregation marks, per view,
 //      the chunks that surviving blocks reach, and its vote kernel -- one workgroup per chunk -- reads the winners of the
@@ -327,6 +346,9 @@ __global__ __launch_bounds__(256) void k_cull_blocks(const float *__restrict__ c
 
 __device__ __forceinline__ bool compile_entry(int4 *__restrict__ dst, uint8_t *__restrict__ nr8, const int4 p0, const int4 p1,
                                               const int4 p2, int px0, int py0, int TW, int TH);
+__device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const int4 p2, int px0, int py0, int TW, int TH,
+                                            int4 &e0, int4 &e1, int4 &e2, int &rows);
+__device__ __forceinline__ int wave_incl_scan(int x);
 
 // R1 / R2 / R4 for one face of the soup: the record (three int4) that compile_entry turns into per-tile entries, and the
 // range of tiles its pixel bounding box touches.  Returns false for faces that draw nothing in this view; clip_me: the face
@@ -372,6 +394,60 @@ __device__ __forceinline__ bool face_setup(const BinArgs &a, const float *__rest
   return true;
 }
 
+// Single-pass binning of the wave's faces that reach over more than 2 x 2 tiles (`big`: this lane holds one, records r0 .. r2,
+// tile rectangle tx0 .. ty1).  A per-lane walk over the tiles would leave 63 lanes waiting for the largest face -- 112 us per
+// view on a scene with 20 000 trees seen obliquely (canopy and trunk faces of 300 x 40 pixels), where the terrain alone
+// takes 7.  Instead the wave prefix-sums the tile counts of its faces and EXPANDS: the (face, tile) pairs are taken 64 at a
+// time, a pair finds its face by a 6-step search over the prefix sums and pulls the record out of the owning lane's
+// registers (ds_bpermute).  A tile the triangle does not touch takes no list slot.  The pairs of a step that name the same
+// tile (neighbouring faces of one tree do) share ONE returning counter atomic (wave_group_capped: at most 16 groups are
+// looked for, left-over pairs stand alone); all atomics of a step are in flight together.
+__device__ __forceinline__ void bin_big_pairs(const BinArgs &a, uint32_t *__restrict__ ctrl, const int slot, const int lane,
+                                              const bool big, const int4 r0, const int4 r1, const int4 r2, const int tx0,
+                                              const int tx1, const int ty0, const int ty1) {
+  uint32_t *cntS = ctrl + GR_CTRL_HDR;
+  int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
+  uint8_t *nr8 = a.nrow8 + slot * a.ent_cap;
+  const int TW = 1 << a.twl, TH = 1 << a.thl;
+  const int ntx = tx1 - tx0 + 1;
+  const int nt = big ? ntx * (ty1 - ty0 + 1) : 0;
+  const int incl = wave_incl_scan(nt);
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  const int geo = tx0 | (ty0 << 12) | ((ntx - 1) << 24);  // at most 256 x 512 tiles per image (GR_MAX_DIM)
+  for (int k0 = 0; k0 < total; k0 += 64) {
+    const int q = k0 + lane;
+    int t = 0;  // the face of pair q: the first lane whose inclusive sum exceeds q
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1) t += (__shfl(incl, t + step - 1) <= q) ? step : 0;
+    t = min(t, 63);
+    const int ex = __shfl(incl, t) - __shfl(nt, t);
+    const int g = __shfl(geo, t);
+    const int4 p0 = make_int4(__shfl(r0.x, t), __shfl(r0.y, t), __shfl(r0.z, t), __shfl(r0.w, t));
+    const int4 p1 = make_int4(__shfl(r1.x, t), __shfl(r1.y, t), __shfl(r1.z, t), __shfl(r1.w, t));
+    const int4 p2 = make_int4(__shfl(r2.x, t), __shfl(r2.y, t), __shfl(r2.z, t), __shfl(r2.w, t));
+    int tile = -1, rows = 0;
+    int4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0}, e2 = {0, 0, 0, 0};
+    if (q < total) {
+      const int k = q - ex, gtx = g & 0xFFF, gty = (g >> 12) & 0xFFF, gn = (int)((uint32_t)g >> 24) + 1;
+      const int tx = gtx + k % gn, ty = gty + k / gn;
+      if (build_entry(p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH, e0, e1, e2, rows)) tile = ty * a.TX + tx;
+    }
+    int ld, rk, sz;
+    wave_group_capped(tile, lane, ld, rk, sz, 16);
+    uint32_t base = 0;
+    if (tile >= 0 && lane == ld) base = atomicAdd(&cntS[tile], (uint32_t)sz);
+    const uint32_t pos = __shfl(base, ld) + (uint32_t)rk;
+    if (tile >= 0) {
+      if (pos < (uint32_t)a.cap_tile) {
+        const int64_t idx = (int64_t)tile * a.cap_tile + pos;
+        int4 *dst = comp + idx * GR_ENT_Q;
+        dst[0] = e0; dst[1] = e1; dst[2] = e2;
+        nr8[idx] = (uint8_t)rows;
+      } else ctrl[2] = 1u;
+    }
+  }
+}
+
 // DIRECT = true: single-pass binning.  Every tile owns a fixed segment of a.cap_tile entries; the list position
 // returned by the (wave-aggregated) tile counter is final, so the compiled entry is written straight from here and
 // the record planes, k_scan_tiles and k_fill_compile are skipped.  A tile that receives more than cap_tile entries
@@ -387,6 +463,7 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ca
   const uint32_t wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), wstep = gridDim.x * 4;
   uint32_t blk_next = work[wave0];       // read alongside the count (any slot of the list is valid memory)
   const uint32_t n_work = ctrl[3];       // (a) blocks that passed k_cull_blocks for this view
+  uint32_t n_rec = 0;                    // single-pass binning: the wave's record count (a statistic), added once at the end
   for (uint32_t wi = wave0; wi < n_work; wi += wstep) {
   const int64_t f = (int64_t)blk_next * GR_BLOCK + lane;
   if (wi + wstep < n_work) blk_next = work[wi + wstep];
@@ -426,10 +503,11 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ca
   if (__ballot(t10 >= 0)) wave_group(t10, lane, l2, k2, n2);
   if (__ballot(t11 >= 0)) wave_group(t11, lane, l3, k3, n3);
   uint32_t base = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-  if (lane == leader) {  // record count: a list position for the exact path, a statistic (nobody waits for it) otherwise
-    if (DIRECT) atomicAdd(&ctrl[0], (uint32_t)n);
-    else base = atomicAdd(&ctrl[0], (uint32_t)n);
-  }
+  // record count: a list position for the exact path; a statistic otherwise, kept in a register until the wave is done (one
+  // atomic per block on the view's one address made every wave of the view queue there: same-address atomics are served
+  // one after the other, tools/ubench/atomic_rate.hip)
+  if (DIRECT) n_rec += (uint32_t)n;
+  else if (lane == leader) base = atomicAdd(&ctrl[0], (uint32_t)n);
   if (t00 >= 0 && lane == l0) b0 = atomicAdd(&cntS[t00], (uint32_t)n0);
   if (t01 >= 0 && lane == l1) b1 = atomicAdd(&cntS[t01], (uint32_t)n1);
   if (t10 >= 0 && lane == l2) b2 = atomicAdd(&cntS[t10], (uint32_t)n2);
@@ -460,16 +538,21 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ca
     }
   }
   if (DIRECT) {
-    // faces over more than 2 x 2 tiles go to the view's big list (the back of the clip buffer, ctrl[5] = count): k_bin_big
-    // gives each of them a whole wave, one lane per tile of the bounding box
+    // faces over more than 2 x 2 tiles: the wave expands their (face, tile) pairs right here, from the records it holds
+    // (bin_big_pairs).  Variant bit 64: they go to the view's big list instead (the back of the clip buffer, ctrl[5] = count)
+    // and k_bin_big sets them up again, 64 per wave -- one returning atomic per block on ONE address per view.
     const bool big_fp = keep && !small_fp;
     const unsigned long long mb = __ballot(big_fp);
     if (mb) {
-      const int lead = __ffsll((long long)mb) - 1;
-      uint32_t bb = 0;
-      if (lane == lead) bb = atomicAdd(&ctrl[5], (uint32_t)__popcll(mb));
-      bb = __shfl(bb, lead);
-      if (big_fp) a.clip[(int64_t)slot * a.F + (a.F - 1 - (int64_t)(bb + __popcll(mb & ((1ull << lane) - 1ull))))] = (uint32_t)f;
+      if (!(a.var & 64)) {
+        bin_big_pairs(a, ctrl, slot, lane, big_fp, r0, r1, r2, tx0, tx1, ty0, ty1);
+      } else {
+        const int lead = __ffsll((long long)mb) - 1;
+        uint32_t bb = 0;
+        if (lane == lead) bb = atomicAdd(&ctrl[5], (uint32_t)__popcll(mb));
+        bb = __shfl(bb, lead);
+        if (big_fp) a.clip[(int64_t)slot * a.F + (a.F - 1 - (int64_t)(bb + __popcll(mb & ((1ull << lane) - 1ull))))] = (uint32_t)f;
+      }
     }
   }
   if (keep && !DIRECT) {
@@ -484,6 +567,7 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ca
         for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&cntB[ty * a.TX + tx], 1u);
   }
   }  // work list loop
+  if (DIRECT && lane == 0 && n_rec) atomicAdd(&ctrl[0], n_rec);
 }
 
 // K2d  (single-pass binning) per view: totals of the per-tile counters for gr_raster_status.  grid (views), 1024 threads
@@ -557,20 +641,16 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(BinArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K3  per (face, tile) entry: re-base the face's edge functions to the tile origin and store the 48-byte "compiled"
-//     entry at its place in the tile's list.  grid (G, views), grid-stride over the surviving records.
-//       E_k(x, y) = C_k + A_k x + B_k y,  x, y = tile-local pixel;  covered <=> all E_k >= 0 (fill rule folded in C_k)
-//     All 64-bit set-up arithmetic happens here, once per entry, at full occupancy; the tile rasterizer then only
-//     streams entries (no index indirection, no 64-bit multiplies).  Entries whose edge values could leave int32
-//     inside the tile keep their vertices instead and are walked with 64-bit adds (flag bit 31 of the Yw word).
-//     List positions of <= 2x2-tile faces come from K1 (plain stores); larger faces take one cursor atomic per tile.
-//     An entry is 12 words (48 bytes): all of them travel to the lanes that walk its scanlines (one ds_bpermute each per
-//     64 items, and the LDS pipe is the tile kernel's bottleneck), so A_k / 256 and B_k / 256 (|.| < 2^15) are packed in
-//     pairs and the small fields ride in the spare top bytes of the two 24-bit offsets:
-//       word  0..3   C0 C1 C2 a0|a1<<16          | X0 Y0 X1 Y1      (64-bit form)
-//       word  4..7   a2|b0<<16 b1|b2<<16 iz0 zA  | X2 Y2 iz0 zA
-//       word  8..11  zB Xw Yw ~face              (Px - X0 = 256 x + X0rel;  Xw = X0rel (24 bit) | rows in tile << 24;
-//                                                 Yw = Y0rel (24 bit) | first row ilo << 24 | 64-bit flag << 31)
+// K3  per (face, tile) entry: the face's edge functions re-based to the CENTRE of the tile and stored as a 48-byte
+//     "compiled" entry at its place in the tile's list (build_entry; layout in DESIGN.md section 5):
+//       E'_k(x_c, y_c) = C'_k + a_k x_c + b_k y_c   in units of one pixel, covered <=> all E'_k >= 0 (fill rule folded into C'_k)
+//     One int32 form for every face: all 64-bit set-up arithmetic happens here, once per entry; the tile rasterizer only
+//     streams entries (no index indirection, no 64-bit arithmetic).  12 words:
+//       word  0..3   C'_first C'_middle C'_last | slopes (a_first, a_middle: 16 + 16 bits, or the start of 4 x 24 bits)
+//       word  4..7   slopes (b_first, b_middle) | slopes (24-bit form only) | iz0 | A
+//       word  8..11  B | Xw = X0rel (24 bit) + rows in tile << 24 | ~face | Yw = Y0rel (24 bit) + first row << 24 + flags
+//     Single-pass binning calls it from K1 (compile_entry at the position the tile counter returned); the exact path from
+//     k_fill_compile below (positions of <= 2x2-tile faces come from K1, larger faces take one cursor atomic per tile).
 // ------------------------------------------------------------------------------------------------------------------
 // Faces whose snapped bounding box is smaller than GR_FAST_EXT sub-pixels (93 px) take a short form of the set-up: the
 // face overlaps the tile, so every pixel the tile rasterizer can probe (x in [-2, TW+2], y in [0, TH]) lies within
@@ -889,12 +969,10 @@ __global__ __launch_bounds__(64) void k_clip_faces(const float *__restrict__ cam
 //                maximum carries the latest start forward) and reads the entry's 12 words with three ds_read_b128
 //                (12 LDS cycles per batch; the register-resident entries of round 1 cost twelve ds_bpermute = 48);
 //       phase 3  ONE SCANLINE OF ONE TRIANGLE PER LANE: the exact covered span [xs, xe] comes from the three edge
-//                inequalities (float reciprocal proposal + exact int32 correction), then the lane walks the span
-//                and issues one ds_max_u64 per covered pixel.  Entries flagged 64-bit take a bounding-box walk
-//                with 64-bit edge adds (same results, exact).
-//     What bounds it: the lifetime of a workgroup.  7 workgroups fit a CU (21.25 KiB of LDS each);
-//     a C2 view is 23 tiles per CU, so every microsecond of a workgroup's life costs 3.3 us per view.  The
-//     id stores plus the entry reads alone keep the memory system busy for 12.7 of the 17.5 us.
+//                inequalities (span_solve: probe-free float floor division, exact by construction -- edge_floor), then
+//                the lane walks the span two pixels at a time and issues one ds_max_u64 per covered pixel.
+//     What bounds it: VALU issue (74-80 % of the SIMD cycles), then the LDS pipe (62-66 %); 7 workgroups
+//     fit a CU (21.25 KiB of LDS each).
 //     Epilogues: ids -> 16-byte stores (4 pixels per lane); fused projection -> per-face winners (see fused_winners).
 // ------------------------------------------------------------------------------------------------------------------
 // last-writer-wins candidate of the unfused pass (K5): issue the global atomicMax only when neither the right nor the
@@ -1393,13 +1471,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (
   }
 }
 
-// K1b  single-pass binning of the faces that reach over more than 2 x 2 tiles (the view's big list, filled by K1).  K1 used
-//      to walk those tiles in a per-lane loop while the other lanes waited -- 112 us per view on a scene with 20 000 trees
-//      seen obliquely (canopy and trunk faces of 300 x 40 pixels), where the terrain alone takes 7.  Here a wave takes 64
-//      big faces, one per lane (records recomputed from the soup: same code as K1, same bits, no record buffer), prefix-sums
-//      their tile counts and EXPANDS: the wave's (face, tile) pairs are taken 64 at a time, a pair finds its face by a
-//      6-step search over the prefix sums and pulls the record out of the owning lane's registers (ds_bpermute).  A tile
-//      the triangle does not touch takes no list slot; all 64 counter atomics of a step are in flight together.
+// K1b  (variant bit 64 only: the default expands big faces inside K1) single-pass binning of the view's big list: a wave takes
+//      64 big faces, one per lane (records recomputed from the soup: same code as K1, same bits) and expands their
+//      (face, tile) pairs with bin_big_pairs.
 __global__ __launch_bounds__(256) void k_bin_big(const float *__restrict__ cams, BinArgs a) {
   const int slot = blockIdx.y;
   const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
@@ -1408,46 +1482,12 @@ __global__ __launch_bounds__(256) void k_bin_big(const float *__restrict__ cams,
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), wstep = (int64_t)gridDim.x * 4;
   if (wave0 * 64 >= n_big) return;  // the usual case for terrain: nothing to do
-  uint32_t *cntS = ctrl + GR_CTRL_HDR;
-  int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
-  uint8_t *nr8 = a.nrow8 + slot * a.ent_cap;
-  const int TW = 1 << a.twl, TH = 1 << a.thl;
   for (int64_t i0 = wave0 * 64; i0 < n_big; i0 += wstep * 64) {
     int4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0};
     int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
     bool clip_me, keep = false;
     if (i0 + lane < n_big) keep = face_setup(a, cam, a.clip[(int64_t)slot * a.F + (a.F - 1 - (i0 + lane))], r0, r1, r2, tx0, tx1, ty0, ty1, clip_me);
-    const int ntx = tx1 - tx0 + 1;
-    const int nt = keep ? ntx * (ty1 - ty0 + 1) : 0;
-    const int incl = wave_incl_scan(nt);
-    const int total = __builtin_amdgcn_readlane(incl, 63);
-    const int geo = tx0 | (ty0 << 12) | ((ntx - 1) << 24);  // at most 256 x 512 tiles per image (GR_MAX_DIM)
-    for (int k0 = 0; k0 < total; k0 += 64) {
-      const int q = k0 + lane;
-      int t = 0;  // the face of pair q: the first lane whose inclusive sum exceeds q
-#pragma unroll
-      for (int step = 32; step >= 1; step >>= 1) t += (__shfl(incl, t + step - 1) <= q) ? step : 0;
-      t = min(t, 63);
-      const int ex = __shfl(incl, t) - __shfl(nt, t);
-      const int g = __shfl(geo, t);
-      const int4 p0 = make_int4(__shfl(r0.x, t), __shfl(r0.y, t), __shfl(r0.z, t), __shfl(r0.w, t));
-      const int4 p1 = make_int4(__shfl(r1.x, t), __shfl(r1.y, t), __shfl(r1.z, t), __shfl(r1.w, t));
-      const int4 p2 = make_int4(__shfl(r2.x, t), __shfl(r2.y, t), __shfl(r2.z, t), __shfl(r2.w, t));
-      if (q >= total) continue;
-      const int k = q - ex, gtx = g & 0xFFF, gty = (g >> 12) & 0xFFF, gn = (int)((uint32_t)g >> 24) + 1;
-      const int tx = gtx + k % gn, ty = gty + k / gn;
-      int4 e0, e1, e2;
-      int rows;
-      if (!build_entry(p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH, e0, e1, e2, rows)) continue;
-      const int tile = ty * a.TX + tx;
-      const uint32_t pos = atomicAdd(&cntS[tile], 1u);
-      if (pos < (uint32_t)a.cap_tile) {
-        const int64_t idx = (int64_t)tile * a.cap_tile + pos;
-        int4 *dst = comp + idx * GR_ENT_Q;
-        dst[0] = e0; dst[1] = e1; dst[2] = e2;
-        nr8[idx] = (uint8_t)rows;
-      } else ctrl[2] = 1u;
-    }
+    bin_big_pairs(a, ctrl, slot, lane, keep, r0, r1, r2, tx0, tx1, ty0, ty1);
   }
 }
 
@@ -1878,7 +1918,10 @@ struct gr_ctx {
   int opt_var = 0;
   int opt_lds_pad = 0;   // extra dynamic LDS bytes per tile workgroup (occupancy experiments, GR_OPT_DEBUG_LDS)
   int opt_direct_cap = 512;  // single-pass binning: entry slots per tile (0 = always use the exact two-pass path)
-  int learned_cap = 0, learned_T = 0;  // slots per tile learned from an overflow, valid for images with learned_T tiles
+  struct Learned { int64_t F; int T, cap; };
+  Learned learned[8] = {};             // slots per tile learned from overflows, per (mesh size, tile count); [n_learned % 8] is replaced next
+  int n_learned = 0;
+  bool share_learned = true;           // consult / feed the process-wide table (off once GR_OPT_DIRECT_CAP was set by hand)
   int last_T = 0, last_B = 0;          // tile count and launch-group size of the last raster call
   int last_n_views = 0;
   bool direct_ok = true;     // cleared when a tile overflowed its slots: later calls take the exact path
@@ -1907,9 +1950,38 @@ namespace {
 // overflowed the configured slots teaches the context the size that image needs (gr_raster_status), as long as the
 // entry memory of a launch group stays within GR_DIRECT_BUDGET; other image sizes keep the configured value.
 #define GR_DIRECT_BUDGET (24ll << 30)
+// What one context has learned is kept process-wide as well, keyed by (face count, tile count): a second context for the
+// same mesh and image size -- another camera set, another thread -- starts with segments that fit, without an overflowed
+// first call.
+std::mutex g_learned_mu;
+gr_ctx::Learned g_learned[32];
+int g_n_learned = 0;
+
 int direct_cap(const gr_ctx *c, int T) {
   if (c->opt_direct_cap <= 0 || !c->direct_ok) return 0;
-  return (c->learned_cap > 0 && c->learned_T == T) ? c->learned_cap : c->opt_direct_cap;
+  for (int i = 0; i < std::min(c->n_learned, 8); ++i)
+    if (c->learned[i].F == c->F && c->learned[i].T == T) return c->learned[i].cap;
+  if (c->share_learned) {
+    std::lock_guard<std::mutex> lk(g_learned_mu);
+    for (int i = 0; i < std::min(g_n_learned, 32); ++i)
+      if (g_learned[i].F == c->F && g_learned[i].T == T) return std::max(g_learned[i].cap, c->opt_direct_cap);
+  }
+  return c->opt_direct_cap;
+}
+
+void learn_cap(gr_ctx *c, int T, int cap) {
+  int i = 0;
+  for (; i < std::min(c->n_learned, 8); ++i)
+    if (c->learned[i].F == c->F && c->learned[i].T == T) break;
+  if (i == std::min(c->n_learned, 8)) { i = c->n_learned % 8; c->n_learned += 1; }
+  c->learned[i] = {c->F, T, cap};
+  if (!c->share_learned) return;
+  std::lock_guard<std::mutex> lk(g_learned_mu);
+  int j = 0;
+  for (; j < std::min(g_n_learned, 32); ++j)
+    if (g_learned[j].F == c->F && g_learned[j].T == T) break;
+  if (j == std::min(g_n_learned, 32)) { j = g_n_learned % 32; g_n_learned += 1; }
+  g_learned[j] = {c->F, T, cap};
 }
 
 int fail(gr_ctx *c, int code, const char *fmt, ...) {
@@ -2032,7 +2104,7 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int
     const unsigned gsetup = (unsigned)std::max(1, std::min(gmax, std::max(nblk / 128, 4096 / std::max(nb, 1))));
     if (a.cap_tile > 0) {
       hipLaunchKernelGGL(k_setup_cull<true>, dim3(gsetup, nb), dim3(256), 0, s, cams, a);
-      hipLaunchKernelGGL(k_bin_big, dim3(256, nb), dim3(256), 0, s, cams, a);
+      if (a.var & 64) hipLaunchKernelGGL(k_bin_big, dim3(256, nb), dim3(256), 0, s, cams, a);
       hipLaunchKernelGGL(k_clip_faces<true>, dim3(8, nb), dim3(64), 0, s, cams, a);
     } else {
       hipLaunchKernelGGL(k_setup_cull<false>, dim3(gsetup, nb), dim3(256), 0, s, cams, a);
@@ -2300,7 +2372,7 @@ int gr_set_option(gr_ctx *c, int key, int value) {
       c->opt_lds_pad = value; return GR_OK;
     case GR_OPT_DIRECT_CAP:
       if (value < 0 || value > 65536) return fail(c, GR_EINVAL, "slots per tile must be in [0, 65536]");
-      c->opt_direct_cap = value; c->direct_ok = true; c->learned_cap = 0; c->learned_T = 0; return GR_OK;
+      c->opt_direct_cap = value; c->direct_ok = true; c->n_learned = 0; c->share_learned = false; return GR_OK;
     default: return fail(c, GR_EINVAL, "unknown option %d", key);
   }
 }
@@ -2425,7 +2497,7 @@ int gr_raster_status(gr_ctx *c, gr_raster_stats *o) {
     const int used = direct_cap(c, c->last_T);
     const int64_t need = ((int64_t)st[2] + (int64_t)st[2] / 8 + 16 + 63) / 64 * 64;
     const int64_t bytes = need * (16 * GR_ENT_Q) * (int64_t)c->last_T * (int64_t)std::max(c->last_B, 1);
-    if (need <= 16384 && bytes <= GR_DIRECT_BUDGET) { c->learned_cap = (int)need; c->learned_T = c->last_T; }
+    if (need <= 16384 && bytes <= GR_DIRECT_BUDGET) learn_cap(c, c->last_T, (int)need);
     else c->direct_ok = false;
     return fail(c, GR_EOVERFLOW, "single-pass binning overflow: a tile received %llu entries (slots per tile %d); "
                 "retry the call", st[2], used);

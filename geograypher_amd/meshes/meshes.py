@@ -809,6 +809,7 @@ class TexturedPhotogrammetryMesh:
         # ring while `writer_threads` host threads deflate and write the views before it.  A slot is reused only after
         # the writer that read it last is done, so at most ring_slots results are in flight.
         ring_slots = max(2 * writer_threads, 2)
+        ring_budget = _PINNED_LIMIT_BYTES  # pinned bytes the ring may hold: float64 (h, w, C) frames are 8 C bytes per pixel
         ring = {}
         slot_writer = {}
         futures = []
@@ -841,17 +842,27 @@ class TexturedPhotogrammetryMesh:
                         if native:
                             rendered = self.backend.warp_image(rendered, resize_maps[key], order=0 if discrete else 1,
                                                                fill_value=float("nan"))
-                    slot = i % ring_slots
+                    frame_bytes = rendered.numel() * rendered.element_size() if hasattr(rendered, "numel") else rendered.nbytes
+                    slots_now = max(2, min(ring_slots, ring_budget // max(frame_bytes, 1)))
+                    slot = i % slots_now
                     if slot in slot_writer:
                         slot_writer[slot].result()  # the slot's previous view is on disk (a failed writer raises here)
                     if on_gpu and rendered.is_cuda:
                         skey = (slot, tuple(rendered.shape), rendered.dtype)
                         if ring.get(slot, (None,))[0] != skey[1:]:
-                            ring[slot] = (skey[1:], torch.empty(rendered.shape, dtype=rendered.dtype, pin_memory=True))
-                        host = ring[slot][1]
-                        host.copy_(rendered, non_blocking=True)
-                        event = torch.cuda.Event()
-                        event.record(torch.cuda.current_stream(rendered.device))
+                            ring.pop(slot, None)
+                            try:
+                                ring[slot] = (skey[1:], torch.empty(rendered.shape, dtype=rendered.dtype, pin_memory=True))
+                            except RuntimeError:  # the host refuses more pinned memory: this view takes a blocking pageable copy
+                                ring[slot] = None
+                        if ring[slot] is not None:
+                            host = ring[slot][1]
+                            host.copy_(rendered, non_blocking=True)
+                            event = torch.cuda.Event()
+                            event.record(torch.cuda.current_stream(rendered.device))
+                        else:
+                            del ring[slot]
+                            host, event = rendered.cpu(), None
                     else:
                         host, event = rendered, None
                     slot_writer[slot] = pool.submit(write_one, host, event, output_files[i])

@@ -100,7 +100,9 @@ enum {
                                chain of four; 4 = fused votes on the caller's stream instead of a side stream; 8 = no
                                first chunk requested ahead of the tile's count; 16 = chains of four tiles whatever the
                                size of the launch (default: large launches of light tiles only); 32 = fused votes scan
-                               every view's winners (default: only views whose cull pass reached the 256-face chunk) */
+                               every view's winners (default: only views whose cull pass reached the 256-face chunk);
+                               64 = faces over more than 2 x 2 tiles go through a per-view list and a second kernel
+                               (default: expanded inside the set-up kernel)                                        */
   GR_OPT_DEBUG_LDS = 98,    /* extra dynamic LDS bytes per tile workgroup: lowers occupancy (timing experiments)     */
   GR_OPT_DEBUG = 99         /* timing-only ablation mask for tools/ab_kernel.py: OUTPUTS BECOME WRONG          */
 };

@@ -12,6 +12,12 @@ REAL scikit-image (0.18.3, the version this container has under /opt/conda/bin/p
             such ties by the rounding noise of a least-squares-estimated affine map (not reproducible even between
             its own runs on different shapes), 0.19+ by scipy.ndimage.zoom's round-half-up -- which is what the
             product's `floor((j + 0.5) * n_in / n_out)` does.
+  labelf_*  the same call WITHOUT preserve_range -- what the reference really hands to `inds_to_one_hot`
+            (derived_segmentors.py:44-50): float64 in [0, 1] (index / 255), so that only index 0 (-> class 0) and index 255
+            (1.0 -> class 1) match any class.  `reference_float_rescale=True` of the product reproduces this bit for bit.
+  zoom_*    the TIE scales 0.25 and 0.5 (the reference's own example scales): scikit-image >= 0.19 (the pinned 0.21.0) resizes
+            order 0 without anti-aliasing through `scipy.ndimage.zoom(image, out/in, order=0, mode="mirror", grid_mode=True)`
+            (skimage/transform/_warps.py, resize); recorded with the scipy of this interpreter.
   up0_* / up1_*   meshes.py:2312-2323: `resize(rendered, native_size, order=0 | 1)` of a float render (NaN = no face)
             from a down-scaled render to the native image size: nearest for discrete textures, bilinear otherwise
             (default mode "reflect").
@@ -20,6 +26,8 @@ Output: tests/golden/reference_resize.npz (inputs and outputs)."""
 from pathlib import Path
 
 import numpy as np
+import scipy
+import scipy.ndimage as ndi
 import skimage
 from skimage.transform import resize
 
@@ -35,6 +43,13 @@ def main():
     for tag, s in (("s30", 0.3), ("s37", 0.37), ("s45", 0.45), ("s90", 0.9)):
         shape = (int(label.shape[0] * s), int(label.shape[1] * s))
         out[f"label_{tag}"] = resize(label, shape, order=0, anti_aliasing=False, preserve_range=True).astype(np.uint8)
+        out[f"labelf_{tag}"] = resize(label, shape, order=0, anti_aliasing=False)
+    out["scipy_version"] = np.array(scipy.__version__)
+    for tag, s in (("s25", 0.25), ("s50", 0.5)):
+        shape = (int(label.shape[0] * s), int(label.shape[1] * s))
+        out[f"zoom_{tag}"] = ndi.zoom(label, (shape[0] / label.shape[0], shape[1] / label.shape[1]), order=0, mode="mirror",
+                                      grid_mode=True)
+        assert out[f"zoom_{tag}"].shape == shape
     small = rng.random((23, 31))
     small[rng.random(small.shape) < 0.1] = np.nan
     ids_like = rng.integers(0, 5, size=(23, 31)).astype(np.float64)

@@ -132,6 +132,17 @@ def test_lookup_segmentor_png_files_through_the_threaded_loader(golden, oracle_b
     half = seg.segment_image_indices(None, filename=cs.cameras[1].image_filename, image_scale=0.5)
     h, w = labels[1].shape
     assert half.shape == (int(h * 0.5), int(w * 0.5)) and set(np.unique(half)) <= set(np.unique(labels[1]))
+    # reference_float_rescale: what the reference's resize-without-preserve_range makes of a scaled look-up (index / 255 as
+    # float: only 0 and 255 select a class); the one-hot image and its index form agree, scale 1 is untouched
+    ref = LookUpSegmentor(base, lookup, num_classes=golden["onehot"].shape[-1], reference_float_rescale=True)
+    onehot = ref.segment_image(None, filename=cs.cameras[1].image_filename, image_scale=0.5)
+    np.testing.assert_array_equal(onehot[..., 0], half == 0)
+    np.testing.assert_array_equal(onehot[..., 1], half == 255)
+    assert not onehot[..., 2:].any()
+    np.testing.assert_array_equal(ref.inds_to_one_hot(ref.segment_image_indices(None, filename=cs.cameras[1].image_filename, image_scale=0.5),
+                                                      golden["onehot"].shape[-1]), onehot)
+    np.testing.assert_array_equal(ref.segment_image(None, filename=cs.cameras[1].image_filename, image_scale=1),
+                                  seg.segment_image(None, filename=cs.cameras[1].image_filename, image_scale=1))
 
 
 def test_camera_helpers_match_reference(golden):

@@ -42,8 +42,18 @@ def test_integration_stub_runs_as_written(hip):
     assert ids.shape == (8, 240, 320) and ids.dtype == np.int64
     one = mesh.pix2face(cams[3], render_img_scale=0.5)
     np.testing.assert_array_equal(one, ids[3])
-    near = np.float32(1e-3 * np.linalg.norm(np.ptp(points, axis=0)))
-    recs = cams.get_raster_records(0.5, near=float(near))
+    # the stub's near plane is the product's (VTK's clipping-range rule): the same mesh + cameras through the two bindings
+    # clip the same faces
+    from geograypher_amd.cameras.cameras import vtk_like_near_planes
+
+    lo, hi = points.min(axis=0), points.max(axis=0)
+    nears = vtk_like_near_planes(np.stack([np.asarray(c.cam_to_world_transform, dtype=np.float64) for c in cams.cameras]),
+                                 np.array([lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]]))
+    recs = cams.get_raster_records(0.5, near=list(nears))
     for v in (0, 3, 7):
         want = oracle_c.raster(points, faces, recs[v], 240, 320)
         np.testing.assert_array_equal(ids[v], want)
+    from geograypher_amd.meshes import TexturedPhotogrammetryMesh as ProductMesh
+
+    product = ProductMesh((points, faces), log_level="ERROR", backend=hip)
+    np.testing.assert_array_equal(product.pix2face(cams, render_img_scale=0.5, apply_distortion=False), ids)

@@ -41,6 +41,49 @@ def test_label_nearest_resize_matches_skimage(golden_resize, tag, scale):
     np.testing.assert_array_equal(got[keep], want[keep])
 
 
+@pytest.mark.parametrize("tag,scale", [("s25", 0.25), ("s50", 0.5)])
+def test_label_resize_tie_scales_match_scipy_zoom(golden_resize, tag, scale):
+    """The reference's own example scales put EVERY sample exactly between two source pixels.  scikit-image >= 0.19 (the
+    reference pins 0.21.0) resolves them through scipy.ndimage.zoom(order=0, grid_mode=True); the golden holds that call's
+    output (tests/golden/make_golden_resize.py) and the product must take the same source pixel everywhere."""
+    label = golden_resize["label_in"]
+    want = golden_resize[f"zoom_{tag}"]
+    got = _nearest_resize(label, (int(label.shape[0] * scale), int(label.shape[1] * scale)))
+    np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("tag,scale", [("s30", 0.3), ("s37", 0.37), ("s45", 0.45), ("s90", 0.9)])
+def test_reference_float_rescale_reproduces_the_reference_one_hot(golden_resize, tag, scale):
+    """derived_segmentors.py:44-50 calls resize(..., order=0) WITHOUT preserve_range: `inds_to_one_hot` then sees index / 255
+    as float64, so only index 0 (class 0) and index 255 (1.0: class 1) select a class.  `reference_float_rescale=True`
+    reproduces that one-hot image bit for bit (golden: the real scikit-image call), and its uint8 index form -- what the
+    aggregation fast path votes with -- selects the same classes; the default keeps the indices."""
+    from geograypher_amd.predictors import ArrayLabelSegmentor
+    from geograypher_amd.predictors.derived_segmentors import _float_rescaled
+
+    label = golden_resize["label_in"]
+    want_float = golden_resize[f"labelf_{tag}"]
+    C = 7
+    want_onehot = want_float[..., None] == np.arange(C)  # segmentor.py:58-67 on the float image
+    assert want_onehot[..., 1].sum() == (golden_resize[f"label_{tag}"] == 255).sum() > 0 and not want_onehot[..., 2:].any()
+    np.testing.assert_array_equal(_float_rescaled(golden_resize[f"label_{tag}"]), want_float)
+    seg = ArrayLabelSegmentor([label], C, filenames=["a.png"], reference_float_rescale=True)
+    got = seg.segment_image(None, filename="a.png", image_scale=scale)
+    assert got.dtype == bool
+    tie = np.zeros(want_float.shape, bool)  # scikit-image 0.18's own rounding noise on exact ties: see the test above
+    pos_r = (np.arange(want_float.shape[0]) + 0.5) * (label.shape[0] / want_float.shape[0])
+    pos_c = (np.arange(want_float.shape[1]) + 0.5) * (label.shape[1] / want_float.shape[1])
+    tie |= (np.abs(pos_r - np.round(pos_r)) <= 1e-9)[:, None] | (np.abs(pos_c - np.round(pos_c)) <= 1e-9)[None, :]
+    assert tie.mean() < 0.5
+    np.testing.assert_array_equal(got[~tie], want_onehot[~tie])
+    inds = seg.segment_image_indices(None, filename="a.png", image_scale=scale)
+    np.testing.assert_array_equal(seg.inds_to_one_hot(inds, C)[~tie], want_onehot[~tie])
+    # scale 1: the reference does not resize, indices pass through unchanged
+    np.testing.assert_array_equal(seg.segment_image_indices(None, filename="a.png", image_scale=1), label)
+    plain = ArrayLabelSegmentor([label], C, filenames=["a.png"])
+    assert plain.segment_image(None, filename="a.png", image_scale=scale)[..., 2:].any()
+
+
 @pytest.mark.parametrize("kind", BACKENDS)
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_native_resolution_upsampling_matches_skimage(kind, request, golden_resize, tag):

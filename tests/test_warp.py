@@ -109,6 +109,34 @@ def test_distortion_maps_match_reference(kind, request, tmp_path, golden_warp, s
     assert 0.1 * tol < max(np.abs(rr - ti)[ref_valid].max(), np.abs(rc - tj)[ref_valid].max()) < tol
 
 
+@pytest.mark.parametrize("scale,ds", [(1.0, 8), (0.5, 2)])
+def test_reference_inverse_flag_and_host_fallback_are_bit_equal_to_the_reference(tmp_path, golden_warp, scale, ds):
+    """`make_distortion_map(reference_inverse=True)` -- and, on a machine without a GPU, the default -- inverts by
+    `utils.indexing.inverse_map_interpolation` over every `ds`-th pixel like cameras.py:1045-1062: the map equals the
+    REAL reference's bit for bit, and `warp_dewarp_pixels` (host look-ups only) works without a device."""
+    import torch
+
+    from geograypher_amd.utils.indexing import inverse_map_interpolation
+
+    tag = f"s{int(scale * 100)}_d{ds}"
+    np.testing.assert_array_equal(inverse_map_interpolation(golden_warp[f"i2w_{tag}"], ds), golden_warp[f"w2i_{tag}"])
+    cams = _metashape_set(tmp_path)
+    n = int(golden_warp["sensor"])
+    cam = simplify_camera(cams.cameras[0], np.ones((n, n, 3)))
+    cam.distortion_params["k1"] = float(golden_warp["k1"])
+    key = cams.distortion_key(cam.distortion_params, scale)
+    cams.make_distortion_map(cam, ds, scale, reference_inverse=True)
+    np.testing.assert_array_equal(cams._maps_warped_to_ideal[key], golden_warp[f"w2i_{tag}"])
+    if not torch.cuda.is_available():  # host fallback: no backend given, no GPU
+        cams._maps_warped_to_ideal.clear()
+        cams.make_distortion_map(cam, ds, scale)
+        np.testing.assert_array_equal(cams._maps_warped_to_ideal[key], golden_warp[f"w2i_{tag}"])
+        if scale == 1.0:
+            pix = np.array([[10, 12], [40, 41], [80, 7]])
+            got = cams.warp_dewarp_pixels(cam, pix, inversion_downsample=ds)
+            np.testing.assert_array_equal(got, golden_warp[f"w2i_{tag}"][:, pix[:, 0], pix[:, 1]].T)
+
+
 @pytest.mark.parametrize("kind", BACKENDS)
 def test_full_model_maps_match_reference(kind, request, tmp_path, golden_warp):
     """All eight parameters of the XML's lens (k1..k4, p1, p2, b1, b2; cx, cy != 0) at scale 0.02: forward map bit-equal
