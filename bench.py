@@ -6,22 +6,31 @@
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment makes this process a LAUNCHER: it starts N fresh ranks
 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`, one rank per GPU over
 RCCL) and relays rank 0's JSON line; the launcher itself never touches the GPU.  Started by torchrun (WORLD_SIZE set) it
-is a rank.
+is a rank.  A line that claims N GPUs is only printed when N ranks answered (exit code 3 otherwise).
 
 One "step" = one pass of the hot path (pix2face: cull -> set-up/bin -> tile raster) over this rank's batch of 50
 synthetic views, inputs (mesh, camera records) resident in HBM, ids written to HBM.  Weak scaling: every rank rasterizes
 its own 50 views of the same replicated mesh, no data-path collective (pix2face has no exchange step).  After W
-warm-up steps, R windows of EXACTLY K steps each are timed, every window bracketed by barrier + synchronize on both
+warm-up steps, windows of EXACTLY K steps each are timed -- at least --windows of them, and as many more as it takes to
+put --min-timed-s (1 s) of GPU time inside timed regions --, every window bracketed by barrier + synchronize on both
 sides and reduced with MAX over ranks; `value` / `ms_per_step` are the median window, the spread is reported beside it.
-The per-kernel HIP-event durations of the roofline object are collected over the timed windows themselves.
+The per-kernel HIP-event durations of the roofline objects are collected over the timed windows themselves.
 
-Outside the headline region the same run times: (a) "aggregate": BASELINE config 3 -- the 500-view grid with 4-class labels through the fused raster +
-last-writer-wins projection + per-face votes (one RCCL all-reduce of the votes at N > 1), checked against the CPU oracle on one view;
-(b) "c4": BASELINE config 4's per-GPU shard (250 views of the 2000-view set, view i -> GPU i mod N) with the single
-all-reduce of the packed [F x (C+1)] int32 votes timed separately; (c) at N == 1, "workload_2": a hostile scene (terrain +
-20 000 trees, cameras tilted 30-45 degrees) at full and at quarter resolution, with sampled oracle parity; (d) at
-N == 1, the CPU oracle on a bounded sample ("cpu_baseline", one thread and all cores).
+Outside the headline region the same run times
+  (a) "aggregate": BASELINE config 3 -- the 500-view grid with 4-class labels through the fused raster + last-writer-wins
+      projection + per-face votes (one RCCL all-reduce of the votes at N > 1), checked against the CPU oracle on one view;
+  (b) "c4": BASELINE config 4's per-GPU shard (250 views of the 2000-view set, view i -> GPU i mod N) with the single
+      all-reduce of the packed [F x (C+1)] int32 votes timed separately, its bytes and its algorithmic xGMI time;
+  (c) "c5": BASELINE config 5's per-GPU shard (5 M faces, 6000x4000, 10 classes, view i -> GPU i mod N), ids-only and
+      fused aggregation, one view checked against the oracle (N == 1);
+  (d) at N == 1, "workload_2": a hostile scene (terrain + 20 000 trees, cameras tilted 30-45 degrees) at full and at quarter
+      resolution, with sampled oracle parity, and "api": the PCIe-inclusive rates of the reference-shaped numpy API;
+  (e) at N == 1, the CPU oracle on a bounded sample ("cpu_baseline", one thread and all cores).
 Rank 0 prints ONE JSON line.
+
+`run(args, rig)` takes the platform glue as an object: the default `GpuRig` is the MI355X box (RCCL, HipRaster, the
+BASELINE sizes); tests/test_bench_distributed.py drives the same control flow -- every collective, every MAX reduction,
+the rank-0-only line -- at world size 2 on gloo with a CPU stand-in and a toy workload.
 """
 import argparse
 import json
@@ -30,6 +39,7 @@ import statistics
 import subprocess
 import sys
 import time
+from dataclasses import dataclass
 from pathlib import Path
 
 import numpy as np
@@ -37,12 +47,76 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-H, W = 3000, 4000
-VIEWS_PER_RANK = 50
-N_CLASSES = 4
-C4_VIEWS_PER_RANK = 250
-C3_VIEWS = 500
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+N_SIMD = 1024           # 256 CUs x 4 SIMDs
+SHADER_GHZ = 2.4        # nominal shader clock the VALU-issue fraction is priced at
+XGMI_LINK_GBS = 153.0   # one xGMI link, per direction; 7 links per GPU
+
+
+@dataclass
+class Workload:
+    """Sizes of every leg.  The defaults are the BASELINE.json configs; the distributed control-flow test shrinks them."""
+    n_side: int = 776            # C2 / C3 / C4 heightfield: 776 x 776 vertices -> 1 201 250 faces
+    extent: float = 400.0
+    H: int = 3000
+    W: int = 4000
+    f: float = 3000.0
+    views_per_rank: int = 50     # C2
+    c3_views: int = 500
+    c4_views_per_rank: int = 250
+    n_classes: int = 4
+    c5_n_side: int = 1582        # C5: 4 999 122 faces over 800 m, 6000 x 4000, f = 4500 px, 150 m AGL, 10 classes
+    c5_extent: float = 800.0
+    c5_H: int = 4000
+    c5_W: int = 6000
+    c5_f: float = 4500.0
+    c5_views_total: int = 2000
+    c5_views_per_rank: int = 250
+    c5_classes: int = 10
+    c5_raster_views: int = 20    # ids-only sample of the shard (96 MB of ids per view)
+
+    def cam_kw(self):
+        return dict(f=self.f, width=self.W, height=self.H)
+
+
+class GpuRig:
+    """Everything that ties bench.run to the MI355X box."""
+    dist_backend = "nccl"
+
+    def __init__(self):
+        self.workload = Workload()
+
+    def device(self, local_rank):
+        import torch
+
+        torch.cuda.set_device(local_rank)
+        return torch.device("cuda", local_rank)
+
+    def init_process_group(self, dev):
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(self.dist_backend, device_id=dev)
+
+    def synchronize(self, dev):
+        import torch
+
+        torch.cuda.synchronize(dev)
+
+    def make_raster(self, local_rank):
+        from geograypher_amd._hip import HipRaster
+
+        return HipRaster(local_rank)
+
+    def checker(self):
+        """The CPU oracle: the checker of the oracle-checked legs and the thing timed as `cpu_baseline` -- never on the
+        measured GPU path."""
+        from oracle import oracle_c
+
+        return oracle_c
+
+    def side_legs(self):  # workload_2 / api need the real library and the real sizes
+        return True
 
 
 def parse_args(argv=None):
@@ -50,13 +124,17 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each")
-    ap.add_argument("--views", type=int, default=VIEWS_PER_RANK, help="views per rank per step")
+    ap.add_argument("--windows", type=int, default=5, help="least number of timed windows of --steps steps each")
+    ap.add_argument("--min-timed-s", type=float, default=1.0,
+                    help="keep adding timed windows until this much GPU time lies inside timed regions")
+    ap.add_argument("--views", type=int, default=0, help="views per rank per step (default: the workload's 50)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the all-core CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aggregate", action="store_true")
     ap.add_argument("--no-c4", action="store_true")
+    ap.add_argument("--no-c5", action="store_true")
     ap.add_argument("--no-workload2", action="store_true")
+    ap.add_argument("--no-api", action="store_true")
     ap.add_argument("--master-port", type=int, default=0)
     return ap.parse_args(argv)
 
@@ -100,7 +178,7 @@ def torch_hash32(x):
     return x
 
 
-def device_labels(ids, view, n_classes=N_CLASSES, seed_face=4, seed_pix=5):
+def device_labels(ids, view, n_classes=4, seed_face=4, seed_pix=5):
     """Device twin of geograypher_amd.utils.synthetic.synthetic_labels (same hash, same output)."""
     import torch
 
@@ -122,28 +200,75 @@ def main(argv=None):
     return run(args)
 
 
-def run(args) -> int:
+def _profile_json(name):
+    path = ROOT / "profiles" / name
+    if path.is_file():
+        try:
+            return json.loads(path.read_text())
+        except Exception:
+            return None
+    return None
+
+
+def valu_bound(kernel_key, kernel_ms_per_launch, views_per_launch):
+    """Second roofline of a VALU-bound kernel: wave-level VALU instructions (SQ_INSTS_VALU of the committed PMC pass,
+    profiles/valu.json, per view) x 4 issue cycles / (SIMDs x kernel duration x shader clock)."""
+    vj = _profile_json("valu.json") or {}
+    entry = vj.get(kernel_key)
+    if not entry or not kernel_ms_per_launch:
+        return None
+    insts = entry["valu_insts_per_view"] * views_per_launch
+    frac = insts * 4.0 / (N_SIMD * kernel_ms_per_launch * 1e-3 * SHADER_GHZ * 1e9)
+    return {"bound": "valu", "achieved": round(insts * 4.0 / (kernel_ms_per_launch * 1e-3) / 1e9, 1), "peak": N_SIMD * SHADER_GHZ,
+            "unit": "G SIMD-cycles/s", "frac": round(frac, 4), "valu_insts_per_view": entry["valu_insts_per_view"],
+            "source": f"profiles/valu.json ({vj.get('_source', 'committed PMC pass')}: SQ_INSTS_VALU per launch / views per "
+                      f"launch, not measured in this run), 4 issue cycles per wave64 instruction, {N_SIMD} SIMDs at {SHADER_GHZ} GHz"}
+
+
+def hbm_roofline(kernel, bytes_per_launch, kernel_ms_per_launch, views_per_launch, traffic_key=None, note=None):
+    achieved = bytes_per_launch / (kernel_ms_per_launch * 1e-3) / 1e9 if kernel_ms_per_launch else 0.0
+    traffic, source = None, None
+    tj = _profile_json("traffic.json")
+    if tj and traffic_key:
+        entry = tj.get(traffic_key) or {}
+        if entry.get("hbm_bytes_per_view") is not None:
+            traffic = entry["hbm_bytes_per_view"] * views_per_launch
+        elif entry.get("hbm_bytes_per_launch") is not None and traffic_key == "k_raster_tile":
+            traffic = entry["hbm_bytes_per_launch"]
+        if traffic is not None:
+            source = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes recorded by tools/profile.sh "
+                      f"({tj.get('_source', 'committed profile')}); not measured in this run")
+    out = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": source,
+           "kernel_ms_per_launch": round(kernel_ms_per_launch, 4), "views_per_launch": round(views_per_launch, 2),
+           "algorithmic_bytes_per_launch": bytes_per_launch}
+    if note:
+        out["algorithmic_bytes"] = note
+    return out
+
+
+def run(args, rig=None) -> int:
     import torch
     import torch.distributed as dist
 
-    from geograypher_amd._hip import HipRaster
     from geograypher_amd.distributed import all_reduce_votes
     from geograypher_amd.utils import synthetic
 
+    rig = rig or GpuRig()
+    wl = rig.workload
+    H, W, N_CLASSES = wl.H, wl.W, wl.n_classes
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = "WORLD_SIZE" in os.environ and "RANK" in os.environ  # launched by torch.distributed.run
-    torch.cuda.set_device(local_rank)
+    dev = rig.device(local_rank)
     if distributed:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        rig.init_process_group(dev)
 
     def barrier():
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        rig.synchronize(dev)
 
     def max_over_ranks(seconds: float) -> float:
         if not distributed:
@@ -157,14 +282,20 @@ def run(args) -> int:
         one = torch.ones(1, dtype=torch.int32, device=dev)
         dist.all_reduce(one)
         ranks_seen = int(one.item())
+    if ranks_seen != args.gpus or world != args.gpus:
+        # a line that claims N GPUs must come from N ranks: refuse to print one otherwise
+        print(f"bench.py: --gpus {args.gpus} but {ranks_seen} rank(s) answered (WORLD_SIZE={world})", file=sys.stderr, flush=True)
+        if distributed:
+            dist.destroy_process_group()
+        return 3
 
     # ---- workload: C2 mesh replicated, this rank's own 50 views (lawn-mower grid, per-rank tilt seed) -----------------
-    points, faces = synthetic.terrain_mesh()
+    points, faces = synthetic.terrain_mesh(wl.n_side, wl.extent)
     V, F = points.shape[0], faces.shape[0]
-    cams = synthetic.survey_cameras(10, 5, 40.0, 60.0, seed=3 + rank)
-    nv = min(args.views, len(cams))
+    cams = synthetic.survey_cameras(10, 5, 40.0, 60.0, seed=3 + rank, **wl.cam_kw())
+    nv = min(args.views or wl.views_per_rank, len(cams))
     recs_np = cams.get_raster_records(1.0, near=1.0)[:nv]
-    hip = HipRaster(local_rank)
+    hip = rig.make_raster(local_rank)
     hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
     recs = torch.from_numpy(recs_np).to(dev)
     ids = torch.empty((nv, H, W), dtype=torch.int32, device=dev)
@@ -183,8 +314,10 @@ def run(args) -> int:
     # the library's HIP events (one pair per kernel group, recorded on the stream the kernels run on) stay ON through the
     # timed windows: the per-kernel durations of the roofline object are those of exactly the timed steps
     hip.set_profiling(True)
+    # windows of EXACTLY --steps steps; at least --windows of them, and as many more as it takes to put --min-timed-s of GPU
+    # time inside timed regions (every rank takes the same decision: it is made on the MAX-reduced times)
     window_s = []
-    for _ in range(max(args.windows, 1)):
+    while len(window_s) < max(args.windows, 1) or (sum(window_s) < args.min_timed_s and len(window_s) < 400):
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -202,49 +335,34 @@ def run(args) -> int:
     ms_windows = [round(s / args.steps * 1e3, 4) for s in window_s]
 
     # ---- per-kernel HIP-event times: st, collected over the timed windows above -----------------------------------------
-    raster_ms_per_launch = st["raster_ms"] / max(st["raster_launches"], 1)
-    views_per_launch = st["views"] / max(st["raster_launches"], 1)
+    launches = max(st["raster_launches"], 1)
+    raster_ms_per_launch = st["raster_ms"] / launches
+    setup_ms_per_launch = st["setup_ms"] / launches
+    views_per_launch = st["views"] / launches
     # algorithmic bytes of the dominant kernel (k_raster_tile): the int32 id image it writes, 4*P per view.
     # (k_setup_cull owns the other part of B_r = 12V + 12F + 4P: the mesh read.)  DESIGN.md section "Kernels".
-    raster_bytes_per_launch = 4.0 * P * views_per_launch
-    achieved = raster_bytes_per_launch / (raster_ms_per_launch * 1e-3) / 1e9
     stage_ms_per_view = {k: st[k] / max(st["views"], 1) for k in ("setup_ms", "scan_ms", "fill_ms", "raster_ms")}
     pipeline_ms_per_view = sum(stage_ms_per_view.values())
     br_bytes = 12.0 * V + 12.0 * F + 4.0 * P
-    traffic, traffic_source = None, None
-    tfile = ROOT / "profiles" / "traffic.json"
-    if tfile.is_file():
-        try:
-            tj = json.loads(tfile.read_text())
-            entry = tj.get("k_raster_tile") or tj.get("k_raster_rows") or {}
-            traffic = entry.get("hbm_bytes_per_launch")
-            traffic_source = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes recorded by "
-                              f"tools/profile.sh ({tj.get('_source', 'committed profile')}); not measured in this run")
-        except Exception:
-            traffic = None
-    roofline = {
-        "bound": "hbm",
-        "kernel": "k_raster_tile",
-        "achieved": round(achieved, 2),
-        "peak": HBM_PEAK_GBS,
-        "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5),
-        "traffic": traffic,
-        "traffic_source": traffic_source,
-        "kernel_ms_per_launch": round(raster_ms_per_launch, 4),
-        "views_per_launch": round(views_per_launch, 2),
-        "algorithmic_bytes_per_launch": raster_bytes_per_launch,
-        "stage_ms_per_view": {k: round(v, 5) for k, v in stage_ms_per_view.items()},
-        "pipeline_GBs": round(br_bytes / (pipeline_ms_per_view * 1e-3) / 1e9, 2),
-        "pipeline_frac": round(br_bytes / (pipeline_ms_per_view * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+    roofline = hbm_roofline("k_raster_tile", 4.0 * P * views_per_launch, raster_ms_per_launch, views_per_launch, "k_raster_tile")
+    roofline["stage_ms_per_view"] = {k: round(v, 5) for k, v in stage_ms_per_view.items()}
+    roofline["pipeline_GBs"] = round(br_bytes / max(pipeline_ms_per_view * 1e-3, 1e-12) / 1e9, 2)
+    roofline["pipeline_frac"] = round(br_bytes / max(pipeline_ms_per_view * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 5)
+    roofline["valu"] = valu_bound("k_raster_tile", raster_ms_per_launch, views_per_launch)
+    rooflines = {
+        "k_setup_cull": hbm_roofline(
+            "set-up stage of pix2face: k_cull_blocks + k_setup_cull + k_clip_faces (one HIP-event pair around the three)",
+            (12.0 * V + 12.0 * F) * views_per_launch, setup_ms_per_launch, views_per_launch, "k_setup_cull",
+            note="12 V + 12 F per view: the mesh read of B_r (SURVEY 8d)"),
     }
+    rooflines["k_setup_cull"]["valu"] = valu_bound("k_setup_cull", setup_ms_per_launch, views_per_launch)
 
     # ---- aggregation pipeline = BASELINE config 3: the 500-view camera grid, 4-class labels, aggregate_viewpoints on one GPU:
     #      fused raster + winners + votes in ONE call per step (8 launch groups), one all-reduce of the votes at N > 1 ----------
     aggregate = None
-    labels = None
+    labels = recs3 = recs3_np = None
     if not args.no_aggregate:
-        cams3 = synthetic.config3_cameras(C3_VIEWS)
+        cams3 = synthetic.config3_cameras(wl.c3_views, **wl.cam_kw())
         n3 = len(cams3)
         recs3_np = cams3.get_raster_records(1.0, near=1.0)
         recs3 = torch.from_numpy(recs3_np).to(dev)
@@ -253,14 +371,16 @@ def run(args) -> int:
             c1 = min(c0 + nv, n3)
             hip.raster_face_ids(recs3[c0:c1], H, W, out=ids[: c1 - c0], check=(c0 == 0))
             for k in range(c1 - c0):
-                labels[c0 + k] = device_labels(ids[k], c0 + k)
+                labels[c0 + k] = device_labels(ids[k], c0 + k, N_CLASSES)
         votes, counts = hip.new_vote_buffers(N_CLASSES)
+        local_obs = [0.0]
 
         def agg_step():
             votes.zero_()
             counts.zero_()
             hip.raster_project_labels(recs3, labels, N_CLASSES, votes, counts, ids_out=None, check=False)
             if distributed:
+                local_obs[0] = float(counts.to(torch.int64).sum().item())  # this rank's own face observations
                 all_reduce_votes(votes, counts)
             return hip.finalize_votes(votes, counts)
 
@@ -278,6 +398,9 @@ def run(args) -> int:
         ast = hip.stage_times()
         hip.set_profiling(False)
         agg_views = world * n3 * agg_steps
+        f_vis = (local_obs[0] if distributed else float(cnt.sum().item())) / max(n3, 1)  # faces a view shows, on average
+        a_launches = max(ast["raster_launches"], 1)
+        a_vpl = ast["views"] / a_launches
         aggregate = {
             "workload": f"BASELINE config 3: {n3} views (25 x 20 grid) of the C2 mesh per GPU, {N_CLASSES}-class labels, fused raster + "
                         f"last-writer-wins projection (ids stay in LDS) + uint32 votes in one call per step, one RCCL all-reduce of "
@@ -285,18 +408,36 @@ def run(args) -> int:
             "views_per_s": round(agg_views / agg_elapsed, 2),
             "mpix_per_s": round(agg_views / agg_elapsed * P / 1e6, 1),
             "ms_per_step": round(agg_elapsed / agg_steps * 1e3, 3),
+            "timed_s": round(agg_elapsed, 4),
             "faces_observed": int((cnt > 0).sum().item()),
+            "faces_seen_per_view": round(f_vis, 1),
             "setup_ms_per_view": round(ast["setup_ms"] / max(ast["views"], 1), 5),
             "raster_fused_ms_per_view": round(ast["raster_ms"] / max(ast["views"], 1), 5),
             "vote_ms_per_view": round(ast["vote_ms"] / max(ast["views"], 1), 5),
             "oracle_check": None,
         }
+        # the fused tile kernel moves almost nothing through HBM by design (the ids stay in LDS; what leaves is one 4-byte
+        # winner per candidate pixel): its HBM line is reported for completeness, its VALU line is the one that binds
+        rooflines["k_raster_tile_fused"] = hbm_roofline(
+            "k_raster_tile<FUSE> (fused aggregation)", 4.0 * f_vis * a_vpl, ast["raster_ms"] / a_launches, a_vpl,
+            "k_raster_tile_fused", note="4 F_vis per view: the winners it writes (ids are never written); the entries it reads "
+                                        "are a binning tax, not algorithmic bytes")
+        rooflines["k_raster_tile_fused"]["valu"] = valu_bound("k_raster_tile_fused", ast["raster_ms"] / a_launches, a_vpl)
+        rooflines["k_vote_labels"] = hbm_roofline(
+            "k_vote_labels", (8.0 * F + 9.0 * f_vis) * a_vpl, ast["vote_ms"] / a_launches, a_vpl, "k_vote_labels",
+            note="8 F (winner read + reset; an upper bound: the chunk bitmaps skip untouched chunks) + 9 F_vis (label byte, vote "
+                 "and count read-modify-write) per view (SURVEY 8d: B_f without the mesh read)")
+        rooflines["k_vote_labels"]["valu"] = valu_bound("k_vote_labels", ast["vote_ms"] / a_launches, a_vpl)
+        # whole fused pipeline against B_f = 12V + 12F + 1P + 8F + 8F_vis
+        bf_bytes = 12.0 * V + 12.0 * F + 1.0 * P + 8.0 * F + 8.0 * f_vis
+        aggregate["pipeline_GBs"] = round(bf_bytes * n3 * agg_steps / agg_elapsed / 1e9, 2)
+        aggregate["pipeline_frac"] = round(bf_bytes * n3 * agg_steps / agg_elapsed / 1e9 / HBM_PEAK_GBS, 5)
 
     # ---- BASELINE config 4: this GPU's shard of the 2000-view set + the single all-reduce, timed separately --------------
     c4 = None
     if not args.no_c4:
-        cams4 = synthetic.config4_cameras()
-        mine = list(range(rank, len(cams4), world))[:C4_VIEWS_PER_RANK]
+        cams4 = synthetic.config4_cameras(**wl.cam_kw())
+        mine = list(range(rank, len(cams4), world))[:wl.c4_views_per_rank]
         recs4_np = cams4.get_subset_cameras(mine).get_raster_records(1.0, near=1.0)
         recs4 = torch.from_numpy(recs4_np).to(dev)
         n4 = len(mine)
@@ -305,7 +446,7 @@ def run(args) -> int:
             c1 = min(c0 + nv, n4)
             hip.raster_face_ids(recs4[c0:c1], H, W, out=ids[: c1 - c0], check=(c0 == 0))
             for k in range(c1 - c0):
-                labels4[c0 + k] = device_labels(ids[k], mine[c0 + k])
+                labels4[c0 + k] = device_labels(ids[k], mine[c0 + k], N_CLASSES)
         votes4, counts4 = hip.new_vote_buffers(N_CLASSES)
         hip.raster_project_labels(recs4, labels4, N_CLASSES, votes4, counts4, check=True)  # sizing / warm-up pass
         reps = 3
@@ -316,7 +457,7 @@ def run(args) -> int:
             barrier()
             t0 = time.perf_counter()
             hip.raster_project_labels(recs4, labels4, N_CLASSES, votes4, counts4, check=False)
-            torch.cuda.synchronize(dev)
+            rig.synchronize(dev)
             t1 = time.perf_counter()
             if distributed:
                 all_reduce_votes(votes4, counts4)
@@ -326,71 +467,52 @@ def run(args) -> int:
             t_reduce.append(max_over_ranks(t2 - t1))
         tl, tr = statistics.median(t_local), statistics.median(t_reduce)
         total_counts = int(counts4.to(torch.int64).sum().item())
+        reduce_bytes = F * (N_CLASSES + 1) * 4
+        ring = 2.0 * (world - 1) / world * reduce_bytes
         c4 = {
             "workload": f"BASELINE config 4: {len(cams4)}-view set (C3 grid x 4 altitudes), view i -> GPU i mod {world}, "
                         f"{n4} views on this GPU, {N_CLASSES} classes, fused aggregation + ONE all-reduce of "
-                        f"[{F} x {N_CLASSES + 1}] int32 ({F * (N_CLASSES + 1) * 4 / 1e6:.1f} MB)",
+                        f"[{F} x {N_CLASSES + 1}] int32 ({reduce_bytes / 1e6:.1f} MB)",
             "views_per_gpu": n4,
             "aggregate_ms": round(tl * 1e3, 3),
             "all_reduce_ms": round(tr * 1e3, 3),
+            "all_reduce_bytes": reduce_bytes,
+            # ring all-reduce: every GPU sends and receives 2 (N-1)/N x S; over ONE xGMI link per direction, and over all
+            # seven (the fully connected node lets RCCL run several rings side by side)
+            "all_reduce_algorithmic_ms": {"bytes_on_the_wire_per_gpu": ring,
+                                          "one_link": round(ring / (XGMI_LINK_GBS * 1e9) * 1e3, 4),
+                                          "seven_links": round(ring / (7 * XGMI_LINK_GBS * 1e9) * 1e3, 4),
+                                          "link_GBs": XGMI_LINK_GBS},
             "views_per_s": round(world * n4 / (tl + tr), 2),
             "face_observations_after_reduce": total_counts,
         }
         del labels4, votes4, counts4
 
+    # ---- BASELINE config 5: this GPU's shard of the 5 M-face / 6000x4000 / 10-class stress config ------------------------
+    c5 = None
+    if not args.no_c5:
+        c5 = leg_c5(rig, wl, rank, world, local_rank, dev, distributed, barrier, max_over_ranks)
+
     # ---- hostile workload (N == 1): terrain + 20 000 trees, cameras tilted 30-45 degrees; full and quarter resolution -------
     workload_2 = None
-    if rank == 0 and world == 1 and not args.no_workload2:
-        from oracle import oracle_c
+    if rank == 0 and world == 1 and not args.no_workload2 and rig.side_legs():
+        workload_2 = leg_workload2(rig, local_rank, dev)
 
-        fpts, ffaces = synthetic.forest_scene()
-        fcams = synthetic.oblique_cameras(20)
-        hip2 = HipRaster(local_rank)
-        hip2.upload_mesh(fpts.astype(np.float32), ffaces.astype(np.int32))
-        workload_2 = {"workload": f"C2 terrain + 20 000 trees ({ffaces.shape[0]} faces, cone canopies on cylinder trunks: "
-                                  "geograypher/utils/example_data.py:30-112 restated), 20 cameras tilted 30-45 degrees"}
-        for scale in (1.0, 0.25):
-            h2, w2 = fcams[0].get_image_size(scale)
-            r2_np = fcams.get_raster_records(scale, near=1.0)
-            r2 = torch.from_numpy(r2_np).to(dev)
-            out2 = torch.empty((len(fcams), h2, w2), dtype=torch.int32, device=dev)
-            hip2.raster_face_ids(r2, h2, w2, out=out2, check=True)
-            retries = hip2.last_retries
-            st2 = dict(hip2.last_stats)
-            for _ in range(3):
-                hip2.raster_face_ids(r2, h2, w2, out=out2, check=False)
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            n_rep = 10
-            for _ in range(n_rep):
-                hip2.raster_face_ids(r2, h2, w2, out=out2, check=False)
-            torch.cuda.synchronize(dev)
-            dt = time.perf_counter() - t0
-            want = oracle_c.raster(fpts, ffaces, r2_np[3], h2, w2)
-            same = bool(np.array_equal(out2[3].cpu().numpy(), want))
-            workload_2[f"scale_{scale:g}"] = {
-                "image": f"{w2}x{h2}",
-                "mpix_per_s": round(n_rep * len(fcams) * h2 * w2 / dt / 1e6, 1),
-                "views_per_s": round(n_rep * len(fcams) / dt, 1),
-                "entries_per_view": round(st2["entries"] / len(fcams), 1),
-                "max_entries_per_tile": int(st2["max_entries"]),
-                "overflow_retries_first_call": int(retries),
-                "oracle_parity_view_3": same,
-                "covered_fraction": round(float((want >= 0).mean()), 4),
-            }
-            assert same, f"workload_2 scale {scale}: GPU ids differ from the CPU oracle"
-        del hip2
+    # ---- PCIe-inclusive rates of the reference-shaped numpy API (N == 1) -------------------------------------------------------
+    api = None
+    if rank == 0 and world == 1 and not args.no_api and rig.side_legs():
+        api = leg_api(points, faces, wl)
 
     # ---- CPU baseline: the C oracle (a port of the rule-set; the reference's VTK path cannot run here) ------------------
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle_c
-
+        oracle_c = rig.checker()
         cores = os.cpu_count() or 1
         t0 = time.perf_counter()
         one, _ = oracle_c.raster_views(points, faces, recs_np[:1], H, W, n_threads=1)
         t1 = time.perf_counter() - t0
-        assert np.array_equal(one[0], ids_first_view(hip, recs, ids)), "GPU ids differ from the CPU oracle on view 0"
+        hip.raster_face_ids(recs[:1], H, W, out=ids[:1], check=True)  # view 0 again (the other legs reuse the id buffer)
+        assert np.array_equal(one[0], ids[0].cpu().numpy()), "GPU ids differ from the CPU oracle on view 0"
         if aggregate is not None:
             # the aggregate leg against the oracle: votes of view 0 alone, fused on the GPU vs rasterized + projected on the CPU
             v1, c1 = hip.new_vote_buffers(N_CLASSES)
@@ -422,7 +544,7 @@ def run(args) -> int:
                 tc += time.perf_counter() - t0
                 n_done += n_thr
             return {"value": round(n_done * P / tc / 1e6, 2), "unit": "Mpix/s", "cores": int(used),
-                    "sample": f"{n_done} C2 views at 4000x3000 ({n_done // n_thr} passes of {n_thr}, one view per thread) on "
+                    "sample": f"{n_done} C2 views at {W}x{H} ({n_done // n_thr} passes of {n_thr}, one view per thread) on "
                               f"{used} threads of {cores} cores ({_cpu_model()}) in {tc:.1f} s",
                     "views_per_s": round(n_done / tc, 3)}
 
@@ -433,7 +555,7 @@ def run(args) -> int:
         cpu_baseline["kind"] = "port"
         cpu_baseline["all_cores"] = sall
         cpu_baseline["single_thread"] = {"value": round(P / t1 / 1e6, 2), "unit": "Mpix/s", "cores": 1,
-                                         "sample": f"1 C2 view at 4000x3000 in {t1:.2f} s"}
+                                         "sample": f"1 C2 view at {W}x{H} in {t1:.2f} s"}
         cpu_baseline["host_cores"] = cores
 
     if rank == 0:
@@ -447,7 +569,8 @@ def run(args) -> int:
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "ms_per_step_windows": {"n": len(ms_windows), "median": statistics.median(ms_windows), "min": min(ms_windows),
-                                    "max": max(ms_windows), "all": ms_windows},
+                                    "max": max(ms_windows), "first": ms_windows[:5], "last": ms_windows[-5:]},
+            "timed_gpu_s": round(sum(window_s), 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -455,7 +578,7 @@ def run(args) -> int:
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE config 2: {F}-face heightfield (V={V}), {nv} pinhole views/GPU @ {W}x{H}, "
-                            "f=3000 px, 120 m AGL lawn-mower grid, face-ID raster to int32 in HBM",
+                            f"f={wl.f:g} px, 120 m AGL lawn-mower grid, face-ID raster to int32 in HBM",
                 "views_per_gpu_per_step": nv,
                 "faces": F,
                 "vertices": V,
@@ -466,10 +589,13 @@ def run(args) -> int:
             "records_per_view": round(stats["records"] / max(nv, 1), 1),
             "bin_entries_per_view": round(stats["entries"] / max(nv, 1), 1),
             "roofline": roofline,
+            "rooflines": rooflines,
             "cpu_baseline": cpu_baseline,
             "aggregate": aggregate,
             "c4": c4,
+            "c5": c5,
             "workload_2": workload_2,
+            "api": api,
         }
         print(json.dumps(line), flush=True)
     if distributed:
@@ -477,10 +603,272 @@ def run(args) -> int:
     return 0
 
 
-def ids_first_view(hip, recs, ids):
-    """View 0 of the headline workload, rasterized again (the c4 / workload legs reuse the id buffer)."""
-    hip.raster_face_ids(recs[:1], H, W, out=ids[:1], check=True)
-    return ids[0].cpu().numpy()
+def leg_c5(rig, wl, rank, world, local_rank, dev, distributed, barrier, max_over_ranks):
+    """BASELINE config 5 on this GPU's share of the views (view i -> GPU i mod N): ids-only on a sample of the shard, fused
+    10-class aggregation on all of it, the vote all-reduce timed apart; one view against the oracle at N == 1."""
+    import torch
+
+    from geograypher_amd.distributed import all_reduce_votes
+    from geograypher_amd.utils import synthetic
+
+    H5, W5, C5 = wl.c5_H, wl.c5_W, wl.c5_classes
+    P5 = H5 * W5
+    pts5, faces5 = synthetic.terrain_mesh(wl.c5_n_side, wl.c5_extent)
+    V5, F5 = pts5.shape[0], faces5.shape[0]
+    cams5 = synthetic.survey_cameras(50, 40, 15.0, 18.0, agl=150.0, f=wl.c5_f, width=W5, height=H5, seed=6)
+    total = min(wl.c5_views_total, len(cams5))
+    mine = list(range(rank, total, world))[:wl.c5_views_per_rank]
+    recs_np = cams5.get_subset_cameras(mine).get_raster_records(1.0, near=1.0)
+    n5 = len(mine)
+    hip5 = rig.make_raster(local_rank)
+    hip5.upload_mesh(pts5.astype(np.float32), faces5.astype(np.int32))
+    recs = torch.from_numpy(recs_np).to(dev)
+    nr = min(wl.c5_raster_views, n5)
+    ids5 = torch.empty((nr, H5, W5), dtype=torch.int32, device=dev)
+    hip5.raster_face_ids(recs[:nr], H5, W5, out=ids5, check=True)
+    retries = hip5.last_retries
+    st0 = dict(hip5.last_stats)
+    for _ in range(2):
+        hip5.raster_face_ids(recs[:nr], H5, W5, out=ids5, check=False)
+    hip5.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        hip5.raster_face_ids(recs[:nr], H5, W5, out=ids5, check=False)
+    barrier()
+    t_raster = max_over_ranks(time.perf_counter() - t0)
+    st = hip5.stage_times()
+    hip5.set_profiling(False)
+    labels5 = torch.empty((n5, H5, W5), dtype=torch.uint8, device=dev)
+    check_view, check_ids = nr // 2, None
+    for c0 in range(0, n5, nr):  # labels are generated on the device from the ids, chunk by chunk
+        c1 = min(c0 + nr, n5)
+        hip5.raster_face_ids(recs[c0:c1], H5, W5, out=ids5[: c1 - c0], check=True)
+        for k in range(c1 - c0):
+            labels5[c0 + k] = device_labels(ids5[k], mine[c0 + k], C5)
+        if c0 == 0:
+            check_ids = ids5[check_view].cpu().numpy()
+    del ids5
+    votes5, counts5 = hip5.new_vote_buffers(C5)
+    hip5.raster_project_labels(recs, labels5, C5, votes5, counts5, check=True)  # sizing / warm-up pass
+    t_local, t_reduce = [], []
+    for _ in range(2):
+        votes5.zero_()
+        counts5.zero_()
+        barrier()
+        t0 = time.perf_counter()
+        hip5.raster_project_labels(recs, labels5, C5, votes5, counts5, check=False)
+        rig.synchronize(dev)
+        t1 = time.perf_counter()
+        if distributed:
+            all_reduce_votes(votes5, counts5)
+        barrier()
+        t2 = time.perf_counter()
+        t_local.append(max_over_ranks(t1 - t0))
+        t_reduce.append(max_over_ranks(t2 - t1))
+    tl, tr = min(t_local), min(t_reduce)
+    reduce_bytes = F5 * (C5 + 1) * 4
+    ring = 2.0 * (world - 1) / world * reduce_bytes
+    br5 = 12.0 * V5 + 12.0 * F5 + 4.0 * P5
+    launches = max(st["raster_launches"], 1)
+    out = {
+        "workload": f"BASELINE config 5: {F5}-face heightfield over {wl.c5_extent:g} m (V={V5}), {total}-view set {W5}x{H5} f={wl.c5_f:g} px "
+                    f"150 m AGL, view i -> GPU i mod {world}: {n5} views on this GPU, {C5} classes; ids-only on {nr} of them",
+        "views_per_gpu": n5,
+        "raster_views_per_s": round(world * nr * reps / t_raster, 2),
+        "raster_mpix_per_s": round(world * nr * reps / t_raster * P5 / 1e6, 1),
+        "raster_stage_ms_per_view": {k: round(st[k] / max(st["views"], 1), 5) for k in ("setup_ms", "scan_ms", "fill_ms", "raster_ms")},
+        "raster_kernel_frac_of_hbm_peak": round(4.0 * P5 * st["views"] / launches / max(st["raster_ms"] / launches * 1e-3, 1e-12) / 1e9
+                                                / HBM_PEAK_GBS, 5),
+        "pipeline_frac_of_hbm_peak": round(br5 * nr * reps / t_raster / 1e9 / HBM_PEAK_GBS, 5),
+        "entries_per_view": round(st0["entries"] / max(nr, 1), 1),
+        "max_entries_per_tile": int(st0["max_entries"]),
+        "overflow_retries_first_call": int(retries),
+        "aggregate_ms": round(tl * 1e3, 3),
+        "aggregate_views_per_s": round(world * n5 / (tl + tr), 2),
+        "all_reduce_ms": round(tr * 1e3, 3),
+        "all_reduce_bytes": reduce_bytes,
+        "all_reduce_algorithmic_ms": {"one_link": round(ring / (XGMI_LINK_GBS * 1e9) * 1e3, 4),
+                                      "seven_links": round(ring / (7 * XGMI_LINK_GBS * 1e9) * 1e3, 4)},
+        "face_observations_after_reduce": int(counts5.to(torch.int64).sum().item()),
+        "oracle_check": None,
+    }
+    if rank == 0 and world == 1 and rig.side_legs():
+        oracle_c = rig.checker()
+        want = oracle_c.raster(pts5, faces5, recs_np[check_view], H5, W5)
+        ok_ids = bool(np.array_equal(check_ids, want))
+        v1, c1 = hip5.new_vote_buffers(C5)
+        hip5.raster_project_labels(recs[check_view:check_view + 1], labels5[check_view:check_view + 1], C5, v1, c1, check=True)
+        want_v = np.zeros((F5, C5), dtype=np.uint32)
+        want_c = np.zeros(F5, dtype=np.uint32)
+        oracle_c.project_labels(want, labels5[check_view].cpu().numpy(), F5, C5, want_v, want_c)
+        ok_votes = bool(np.array_equal(v1.cpu().numpy().view(np.uint32), want_v) and
+                        np.array_equal(c1.cpu().numpy().view(np.uint32), want_c))
+        out["oracle_check"] = f"view {mine[check_view]}: ids equal the CPU oracle's: {ok_ids}; fused votes and counts equal: {ok_votes}"
+        assert ok_ids and ok_votes, "config 5 differs from the CPU oracle"
+    del labels5, votes5, counts5, hip5
+    return out
+
+
+def leg_workload2(rig, local_rank, dev):
+    """Terrain + 20 000 trees seen obliquely, full and quarter resolution.  The slots per tile such images need are learned
+    from the overflow of the very first call in this process (`overflow_retries_cold`); a second, fresh context -- the one
+    that is timed -- starts with what the process has learned (`overflow_retries_first_call`)."""
+    import torch
+
+    from geograypher_amd.utils import synthetic
+
+    oracle_c = rig.checker()
+    fpts, ffaces = synthetic.forest_scene()
+    fcams = synthetic.oblique_cameras(20)
+    out = {"workload": f"C2 terrain + 20 000 trees ({ffaces.shape[0]} faces, cone canopies on cylinder trunks: "
+                       "geograypher/utils/example_data.py:30-112 restated), 20 cameras tilted 30-45 degrees"}
+    cold = {}
+    hip_cold = rig.make_raster(local_rank)
+    hip_cold.upload_mesh(fpts.astype(np.float32), ffaces.astype(np.int32))
+    for scale in (1.0, 0.25):
+        h2, w2 = fcams[0].get_image_size(scale)
+        r2 = torch.from_numpy(fcams.get_raster_records(scale, near=1.0)).to(dev)
+        o2 = torch.empty((len(fcams), h2, w2), dtype=torch.int32, device=dev)
+        hip_cold.raster_face_ids(r2, h2, w2, out=o2, check=True)
+        cold[scale] = int(hip_cold.last_retries)
+        del o2
+    del hip_cold
+    hip2 = rig.make_raster(local_rank)
+    hip2.upload_mesh(fpts.astype(np.float32), ffaces.astype(np.int32))
+    for scale in (1.0, 0.25):
+        h2, w2 = fcams[0].get_image_size(scale)
+        r2_np = fcams.get_raster_records(scale, near=1.0)
+        r2 = torch.from_numpy(r2_np).to(dev)
+        out2 = torch.empty((len(fcams), h2, w2), dtype=torch.int32, device=dev)
+        hip2.raster_face_ids(r2, h2, w2, out=out2, check=True)
+        retries = hip2.last_retries
+        st2 = dict(hip2.last_stats)
+        for _ in range(3):
+            hip2.raster_face_ids(r2, h2, w2, out=out2, check=False)
+        hip2.set_profiling(True)
+        rig.synchronize(dev)
+        t0 = time.perf_counter()
+        n_rep = 10
+        for _ in range(n_rep):
+            hip2.raster_face_ids(r2, h2, w2, out=out2, check=False)
+        rig.synchronize(dev)
+        dt = time.perf_counter() - t0
+        stg = hip2.stage_times()
+        hip2.set_profiling(False)
+        want = oracle_c.raster(fpts, ffaces, r2_np[3], h2, w2)
+        same = bool(np.array_equal(out2[3].cpu().numpy(), want))
+        out[f"scale_{scale:g}"] = {
+            "image": f"{w2}x{h2}",
+            "mpix_per_s": round(n_rep * len(fcams) * h2 * w2 / dt / 1e6, 1),
+            "views_per_s": round(n_rep * len(fcams) / dt, 1),
+            "us_per_view": {"setup": round(stg["setup_ms"] / max(stg["views"], 1) * 1e3, 1),
+                            "raster": round(stg["raster_ms"] / max(stg["views"], 1) * 1e3, 1)},
+            "entries_per_view": round(st2["entries"] / len(fcams), 1),
+            "max_entries_per_tile": int(st2["max_entries"]),
+            "overflow_retries_first_call": int(retries),
+            "overflow_retries_cold": cold[scale],
+            "oracle_parity_view_3": same,
+            "covered_fraction": round(float((want >= 0).mean()), 4),
+        }
+        assert same, f"workload_2 scale {scale}: GPU ids differ from the CPU oracle"
+        del out2
+    del hip2
+    return out
+
+
+def host_image_set(base, images):
+    """A camera set that serves in-memory images (float images, class-index images) to the general aggregation paths."""
+    from geograypher_amd.cameras import PhotogrammetryCameraSet
+
+    class HostImageSet(PhotogrammetryCameraSet):
+        def __init__(self, base, images):
+            self.base_camera_set, self.images, self.cameras = base, images, base.cameras
+            self._local_to_epsg_4978_transform = base._local_to_epsg_4978_transform
+            self._maps_ideal_to_warped, self._maps_warped_to_ideal = {}, {}
+            self.image_folder = getattr(base, "image_folder", None)
+
+        def __len__(self):
+            return len(self.images)
+
+        def n_image_channels(self):
+            im = np.asarray(self.images[0])
+            return 1 if im.ndim == 2 else int(im.shape[-1])
+
+        def get_subset_cameras(self, inds):
+            return HostImageSet(self.base_camera_set.get_subset_cameras(inds), [self.images[i] for i in inds])
+
+        def get_image_by_index(self, i, image_scale=1.0):
+            return self.images[i]
+
+    return HostImageSet(base, images)
+
+
+def leg_api(points, faces, wl, n_views=16):
+    """What a drop-in caller of the reference-shaped API gets, host copies included (C2 views): numpy in, numpy out."""
+    import torch
+
+    from geograypher_amd.cameras import SegmentorPhotogrammetryCameraSet
+    from geograypher_amd.meshes import TexturedPhotogrammetryMesh
+    from geograypher_amd.meshes.derived_meshes import TexturedPhotogrammetryMeshIndexPredictions
+    from geograypher_amd.predictors import ArrayLabelSegmentor
+    from geograypher_amd.utils import synthetic
+
+    cams = synthetic.config2_cameras(n_views, **wl.cam_kw())
+    n = len(cams)
+    C = wl.n_classes
+    tex = (np.arange(faces.shape[0]) % C).astype(float)
+    mesh = TexturedPhotogrammetryMesh((points, faces), texture=tex, IDs_to_labels={i: str(i) for i in range(C)}, log_level="ERROR")
+    mesh.pix2face(cams[0:2], apply_distortion=False)  # warm up (upload, scratch)
+    out = {"workload": f"{n} C2 views {wl.W}x{wl.H} through geograypher_amd's numpy-in / numpy-out methods, host copies included"}
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return r, time.perf_counter() - t0
+
+    ids, dt = timed(lambda: mesh.pix2face(cams, apply_distortion=False))
+    del ids
+    ids, dt = timed(lambda: mesh.pix2face(cams, apply_distortion=False))  # the pinned block of the first call is reused
+    out["pix2face_int64_numpy_views_per_s"] = round(n / dt, 1)
+    _, dt = timed(lambda: mesh.pix2face(cams, apply_distortion=False, return_tensor=True))
+    out["pix2face_device_tensor_views_per_s"] = round(n / dt, 1)
+    cnt, dt = timed(lambda: sum(1 for _ in mesh.render_flat(cams, apply_distortion=False)))
+    out["render_flat_f64_numpy_views_per_s"] = round(cnt / dt, 1)
+    labels = [synthetic.synthetic_labels(ids[v], v, C) for v in range(n)]
+    names = [c.image_filename for c in cams.cameras]
+    seg = SegmentorPhotogrammetryCameraSet(cams, ArrayLabelSegmentor(labels, C, filenames=names))
+    mesh.aggregate_projected_images(seg)
+    _, dt = timed(lambda: mesh.aggregate_projected_images(seg))
+    out["aggregate_uint8_labels_from_host_views_per_s"] = round(n / dt, 1)
+    # float images (the general path of meshes.py:2057-2067): one (h, w, 3) float64 image per view from host memory
+    nf = min(n, 8)
+    rng = np.random.default_rng(0)
+    fset = host_image_set(cams[0:nf], [rng.random((wl.H, wl.W, 3)) for _ in range(nf)])
+    try:
+        mesh.aggregate_projected_images(fset)
+        _, dt = timed(lambda: mesh.aggregate_projected_images(fset))
+        out["aggregate_float64_images_from_host_views_per_s"] = round(nf / dt, 1)
+    except Exception as exc:  # the leg reports, it does not take the line down
+        out["aggregate_float64_images_from_host_views_per_s"] = f"failed: {exc!r}"
+    # sparse index aggregation (derived_meshes.py:414-550): one (h, w) class-index image per view
+    try:
+        sparse_mesh = TexturedPhotogrammetryMeshIndexPredictions((points, faces), log_level="ERROR", backend=mesh.backend)
+        idx_imgs = []
+        for v in range(nf):
+            im = labels[v].astype(np.float64)
+            im[im >= C] = np.nan
+            idx_imgs.append(im)
+        iset = host_image_set(cams[0:nf], idx_imgs)
+        sparse_mesh.aggregate_projected_images(iset, n_classes=C)
+        _, dt = timed(lambda: sparse_mesh.aggregate_projected_images(iset, n_classes=C))
+        out["aggregate_sparse_index_images_from_host_views_per_s"] = round(nf / dt, 1)
+    except Exception as exc:
+        out["aggregate_sparse_index_images_from_host_views_per_s"] = f"failed: {exc!r}"
+    return out
 
 
 if __name__ == "__main__":

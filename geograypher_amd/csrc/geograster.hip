@@ -518,21 +518,47 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ca
   r3.y = (int)(__shfl(b1, l1) + (uint32_t)k1);
   r3.z = (int)(__shfl(b2, l2) + (uint32_t)k2);
   r3.w = (int)(__shfl(b3, l3) + (uint32_t)k3);
-  if (DIRECT && keep) {
+  if (DIRECT) {
+    // faces over at most 2x2 tiles: positions came from the wave-aggregated counters; the lanes of a group hold
+    // consecutive positions of the same tile segment, so their 48-byte entries are written side by side.  Every such face has
+    // a FIRST tile: one dense round of entry compilation.  Second to fourth tiles are the exception (0.5 per face): instead of
+    // three more rounds in which most lanes wait (the set-up kernel of a forest scene is VALU-bound: SQ counters in
+    // profiles/), those (face, tile) pairs are dealt to the lanes -- prefix sum of the extra tiles per face, 6-step search for
+    // the owning lane, records pulled from its registers (ds_bpermute) -- and take one round together.
     int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
     uint8_t *nr8 = a.nrow8 + slot * a.ent_cap;
     const int TW = 1 << a.twl, TH = 1 << a.thl;
     if (small_fp) {
-      // faces over at most 2x2 tiles: positions came from the wave-aggregated counters; the lanes of a group hold
-      // consecutive positions of the same tile segment, so their 48-byte entries are written side by side
-#pragma unroll 1
-      for (int k = 0; k < 4; ++k) {
-        const int tx = tx0 + (k & 1), ty = ty0 + (k >> 1);
-        if (tx > tx1 || ty > ty1) continue;
-        const uint32_t pos = (uint32_t)(k == 0 ? r3.x : k == 1 ? r3.y : k == 2 ? r3.z : r3.w);
+      if ((uint32_t)r3.x < (uint32_t)a.cap_tile) {
+        const int64_t idx = (int64_t)t00 * a.cap_tile + (uint32_t)r3.x;
+        compile_entry(comp + idx * GR_ENT_Q, nr8 + idx, r0, r1, r2, tx0 << a.twl, ty0 << a.thl, TW, TH);
+      } else ctrl[2] = 1u;
+    }
+    const int shape = small_fp ? ((tx1 > tx0 ? 1 : 0) | (ty1 > ty0 ? 2 : 0)) : 0;  // which neighbours exist: 1 right, 2 below
+    const int ne = shape == 3 ? 3 : (shape ? 1 : 0);
+    const int incl_e = wave_incl_scan(ne);
+    const int total_e = __builtin_amdgcn_readlane(incl_e, 63);
+    const int geo = tx0 | (ty0 << 12) | (shape << 24);
+    for (int k0 = 0; k0 < total_e; k0 += 64) {
+      const int q = k0 + lane;
+      int t = 0;  // the face of pair q: the first lane whose inclusive sum exceeds q
+#pragma unroll
+      for (int step = 32; step >= 1; step >>= 1) t += (__shfl(incl_e, t + step - 1) <= q) ? step : 0;
+      t = min(t, 63);
+      const int g = __shfl(geo, t);
+      const int sh = (g >> 24) & 3;
+      const int which = q - (__shfl(incl_e, t) - (sh == 3 ? 3 : 1));  // 0 .. 2: the face's extra tile
+      const int k = sh == 3 ? which + 1 : sh;                          // tile slot 1 (right), 2 (below), 3 (below right)
+      const int4 p0 = make_int4(__shfl(r0.x, t), __shfl(r0.y, t), __shfl(r0.z, t), __shfl(r0.w, t));
+      const int4 p1 = make_int4(__shfl(r1.x, t), __shfl(r1.y, t), __shfl(r1.z, t), __shfl(r1.w, t));
+      const int4 p2 = make_int4(__shfl(r2.x, t), __shfl(r2.y, t), __shfl(r2.z, t), __shfl(r2.w, t));
+      const int py = __shfl(r3.y, t), pz = __shfl(r3.z, t), pw = __shfl(r3.w, t);
+      if (q < total_e) {
+        const uint32_t pos = (uint32_t)(k == 1 ? py : k == 2 ? pz : pw);
+        const int tx = (g & 0xFFF) + (k & 1), ty = ((g >> 12) & 0xFFF) + (k >> 1);
         if (pos < (uint32_t)a.cap_tile) {
           const int64_t idx = (int64_t)(ty * a.TX + tx) * a.cap_tile + pos;
-          compile_entry(comp + idx * GR_ENT_Q, nr8 + idx, r0, r1, r2, tx << a.twl, ty << a.thl, TW, TH);
+          compile_entry(comp + idx * GR_ENT_Q, nr8 + idx, p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH);
         } else ctrl[2] = 1u;
       }
     }

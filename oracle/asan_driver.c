@@ -18,7 +18,7 @@ int orc_raster_fast(const float *, const int32_t *, int64_t, int64_t, const floa
 int orc_raster_views(const float *, const int32_t *, int64_t, int64_t, const float *, int, int, int, int32_t *, int);
 int orc_project_labels(const int32_t *, const uint8_t *, int, int, int64_t, int, int, uint32_t *, uint32_t *, int64_t *);
 int orc_envelope(const float *, const int32_t *, int64_t, const float *, int, int, double, double, uint8_t *, int32_t *,
-                 double *, double *, int32_t *, uint8_t *);
+                 double *, double *, int32_t *, uint8_t *, double *, double *);
 int orc_raster_float(const float *, const int32_t *, int64_t, const float *, int, int, int32_t *, double *);
 
 static uint64_t state = 0x9E3779B97F4A7C15ull;
@@ -71,8 +71,8 @@ static int run_scene(int n, int h, int w, double size_lo, double size_hi, double
   /* envelope classifier and the second rasterizer */
   uint8_t *cls = malloc(np), *sure = malloc(np);
   int32_t *eid = malloc(4 * np), *fa = malloc(4 * np);
-  double *za = malloc(8 * np), *zbb = malloc(8 * np);
-  orc_envelope(verts, faces, n, cam, h, w, 1.0 / 256 + 2e-3, 1e-5, cls, eid, za, zbb, fa, sure);
+  double *za = malloc(8 * np), *zbb = malloc(8 * np), *zlo = malloc(8 * np), *zhi = malloc(8 * np);
+  orc_envelope(verts, faces, n, cam, h, w, 1.0 / 256 + 2e-3, 1e-5, cls, eid, za, zbb, fa, sure, zlo, zhi);
   orc_raster_float(verts, faces, n, cam, h, w, eid, za);
   /* two views through the threaded entry point */
   float cams2[32];
@@ -81,7 +81,7 @@ static int run_scene(int n, int h, int w, double size_lo, double size_hi, double
   orc_raster_views(verts, faces, 3 * n, n, cams2, 2, h, w, two, 1);
   bad |= memcmp(two, b, 4 * np) != 0 || memcmp(two + np, b, 4 * np) != 0;
   free(verts); free(faces); free(a); free(b); free(zb); free(da); free(db); free(lab); free(votes); free(counts);
-  free(winner); free(cls); free(sure); free(eid); free(fa); free(za); free(zbb); free(two);
+  free(winner); free(cls); free(sure); free(eid); free(fa); free(za); free(zbb); free(zlo); free(zhi); free(two);
   return bad;
 }
 

@@ -34,7 +34,7 @@ def lib():
         L.orc_project_labels.argtypes = [vp, vp, i32, i32, i64, i32, i32, vp, vp, vp]
         f64 = ctypes.c_double
         L.orc_envelope.restype = i32
-        L.orc_envelope.argtypes = [vp, vp, i64, vp, i32, i32, f64, f64, vp, vp, vp, vp, vp, vp]
+        L.orc_envelope.argtypes = [vp, vp, i64, vp, i32, i32, f64, f64, vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_raster_float.restype = i32
         L.orc_raster_float.argtypes = [vp, vp, i64, vp, i32, i32, vp, vp]
         _lib = L
@@ -97,8 +97,9 @@ def envelope(verts, faces, cam, h, w, delta=ENVELOPE_DELTA, gap_rel=ENVELOPE_GAP
     ids = np.empty((h, w), dtype=np.int32)
     zA, zB = np.empty((h, w), dtype=np.float64), np.empty((h, w), dtype=np.float64)
     fA, sure = np.empty((h, w), dtype=np.int32), np.empty((h, w), dtype=np.uint8)
+    zlo, zhi = np.empty((h, w), dtype=np.float64), np.empty((h, w), dtype=np.float64)
     n = lib().orc_envelope(_p(verts), _p(faces), faces.shape[0], _p(cam), h, w, float(delta), float(gap_rel), _p(cls),
-                           _p(ids), _p(zA), _p(zB), _p(fA), _p(sure))
+                           _p(ids), _p(zA), _p(zB), _p(fA), _p(sure), _p(zlo), _p(zhi))
     return cls, ids, n
 
 

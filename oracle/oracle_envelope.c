@@ -15,7 +15,15 @@
  *                     4000-pixel focal lengths) from every edge of every triangle that could reach it, OR the triangles
  *                     it is that close to lie clearly behind the winner; (2) the nearest surely-covering triangle is nearer
  *                     than any other triangle that could cover the pixel by a relative depth gap `gap_rel` (default 1e-5,
- *                     two orders above the fp32 error of 1/z).  All other pixels are IMPLEMENTATION-DEFINED: two
+ *                     two orders above the fp32 error of 1/z) BEYOND the depth uncertainty of both triangles at that
+ *                     pixel.  That uncertainty has two sources an implementation is free about: moving the vertices by
+ *                     up to `delta` (snapping) tilts the triangle's depth plane -- by up to (max 1/z - min 1/z) x
+ *                     4 delta / (smallest altitude), everything for a needle-shaped sliver --, and evaluating the plane
+ *                     as anchor + gradient . offset in 32-bit floats loses (|anchor| + |A dx| + |B dy|) x 2^-21, far more
+ *                     than the result's own rounding when the two gradient terms cancel (the same slivers).  Round 2
+ *                     ignored both and 1-4 pixels per view of a forest scene (20 000 cone-and-cylinder trees seen
+ *                     obliquely: thousands of slivers) were claimed that the rule-set oracle decides differently.
+ *                     All other pixels are IMPLEMENTATION-DEFINED: two
  *                     conforming rasterizers may disagree there, and a comparison with VTK cannot ask for equality.
  *   orc_raster_float  a SECOND, independently written rasterizer with a different conforming convention: no sub-pixel
  *                     snapping at all (float64 edge functions of the float64 projections), closed triangles (a sample on
@@ -64,9 +72,12 @@ static void env_pixel_range(double lo, double hi, int n, int *j0, int *j1) {
 /* Returns the number of faces that straddle the near plane (not classified).  cls: 0 independent background,
  * 1 independent face (ids holds it), 2 implementation-defined.  work: caller scratch, 4 doubles + 2 int32 per pixel. */
 int orc_envelope(const float *verts, const int32_t *faces, int64_t F, const float *cam, int h, int w, double delta,
-                 double gap_rel, uint8_t *cls, int32_t *ids, double *zA, double *zB, int32_t *fA, uint8_t *sureA) {
+                 double gap_rel, uint8_t *cls, int32_t *ids, double *zA, double *zB, int32_t *fA, uint8_t *sureA,
+                 double *zAlo, double *zAhi) {
+  /* zA: nominal depth of the nearest candidate, [zAlo, zAhi] its uncertainty interval; zB: the smallest LOWER bound of any
+   * other candidate's depth */
   const int64_t n = (int64_t)h * w;
-  for (int64_t p = 0; p < n; ++p) { zA[p] = INFINITY; zB[p] = INFINITY; fA[p] = -1; sureA[p] = 0; }
+  for (int64_t p = 0; p < n; ++p) { zA[p] = INFINITY; zB[p] = INFINITY; zAlo[p] = INFINITY; zAhi[p] = INFINITY; fA[p] = -1; sureA[p] = 0; }
   int straddle = 0;
   for (int64_t f = 0; f < F; ++f) {
     const env_vtx a = env_project(verts + 3 * (int64_t)faces[3 * f], cam);
@@ -84,12 +95,20 @@ int orc_envelope(const float *verts, const int32_t *faces, int64_t F, const floa
     env_pixel_range(ymin, ymax, h, &i0, &i1);
     if (j0 > j1 || i0 > i1) continue;
     const env_vtx *vs[3] = {&v0, &v1, &v2};
-    double ex[3], ey[3], len[3];
+    double ex[3], ey[3], len[3], maxlen = 0.0;
     for (int k = 0; k < 3; ++k) {
       const env_vtx *p0 = vs[k], *p1 = vs[(k + 1) % 3];
       ex[k] = p1->x - p0->x; ey[k] = p1->y - p0->y;
       len[k] = sqrt(ex[k] * ex[k] + ey[k] * ey[k]);
+      if (len[k] > maxlen) maxlen = len[k];
     }
+    /* depth uncertainty of this triangle: (a) vertices moved by delta tilt the plane */
+    const double izmin = fmin(v0.iz, fmin(v1.iz, v2.iz)), izmax = fmax(v0.iz, fmax(v1.iz, v2.iz));
+    const double hmin = maxlen > 0 ? area / maxlen : 0.0;                /* smallest altitude, pixels */
+    const double tilt = (izmax - izmin) * (hmin > 4.0 * delta ? 4.0 * delta / hmin : 1.0);
+    /* (b) plane form in fp32: gradients of 1/z per pixel */
+    const double gA = ((v1.iz - v0.iz) * (v2.y - v0.y) - (v2.iz - v0.iz) * (v1.y - v0.y)) / area;
+    const double gB = ((v2.iz - v0.iz) * (v1.x - v0.x) - (v1.iz - v0.iz) * (v2.x - v0.x)) / area;
     for (int i = i0; i <= i1; ++i) {
       for (int j = j0; j <= j1; ++j) {
         const double px = j + 0.5, py = i + 0.5;
@@ -105,15 +124,24 @@ int orc_envelope(const float *verts, const int32_t *faces, int64_t F, const floa
         const int sure = dmin > delta;
         const double iz = bary[0] * v0.iz + bary[1] * v1.iz + bary[2] * v2.iz; /* 1/z is affine in window space */
         const double z = iz > 0 ? 1.0 / iz : INFINITY;
+        double mag = 0.0;                                               /* largest anchor + |A dx| + |B dy| over the anchors */
+        for (int k = 0; k < 3; ++k) {
+          const double m = fabs(vs[k]->iz) + fabs(gA * (px - vs[k]->x)) + fabs(gB * (py - vs[k]->y));
+          if (m > mag) mag = m;
+        }
+        const double err = tilt + mag * 0x1p-21;
+        const double zlo = 1.0 / (iz + err), zhi = iz - err > 0 ? 1.0 / (iz - err) : INFINITY;
         const int64_t p = (int64_t)i * w + j;
-        if (z < zA[p]) { zB[p] = zA[p]; zA[p] = z; fA[p] = (int32_t)f; sureA[p] = (uint8_t)sure; }
-        else if (z < zB[p]) zB[p] = z;
+        if (z < zA[p]) {
+          if (zAlo[p] < zB[p]) zB[p] = zAlo[p];
+          zA[p] = z; zAlo[p] = zlo; zAhi[p] = zhi; fA[p] = (int32_t)f; sureA[p] = (uint8_t)sure;
+        } else if (zlo < zB[p]) zB[p] = zlo;
       }
     }
   }
   for (int64_t p = 0; p < n; ++p) {
     if (fA[p] < 0) { cls[p] = 0; ids[p] = -1; continue; }
-    const int clear = !(zB[p] < zA[p] * (1.0 + gap_rel));
+    const int clear = !(zB[p] < zAhi[p] * (1.0 + gap_rel));
     if (sureA[p] && clear) { cls[p] = 1; ids[p] = fA[p]; }
     else { cls[p] = 2; ids[p] = fA[p]; }
   }

@@ -16,11 +16,20 @@ from geograypher_amd.utils import synthetic
 from oracle import oracle_c
 
 
-def _split(points, faces, rec, h, w):
+def _split(points, faces, rec, h, w, allow_invisible_straddlers=False):
     cls, env_ids, straddle = oracle_c.envelope(points, faces, rec, h, w)
     rule = oracle_c.raster(points, faces, rec, h, w)
     flt, skipped = oracle_c.raster_float(points, faces, rec, h, w)
-    assert straddle == 0 and skipped == 0
+    if allow_invisible_straddlers and straddle:
+        # a tilted camera's near plane cuts the ground far outside the frustum: those faces are clipped (R7) to nothing
+        # visible -- the rule-set oracle, which does clip them, must show none of them
+        cam = np.asarray(rec, dtype=np.float64)
+        qz = (points.astype(np.float32).astype(np.float64) - cam[9:12]) @ cam[:9].reshape(3, 3)[:, 2]
+        front = (qz > cam[15])[faces]
+        cut = np.nonzero(front.any(axis=1) & ~front.all(axis=1))[0]
+        assert abs(len(cut) - straddle) <= 2 and straddle == skipped and not np.isin(rule, cut).any()
+    else:
+        assert straddle == 0 and skipped == 0
     return cls, env_ids, rule, flt
 
 
@@ -89,3 +98,32 @@ def test_hip_agrees_with_both_oracles_on_config1_and_config2(hip):
         assert np.array_equal(got[k], rule)
     assert max(fractions) < 0.01, fractions
     print(f"C2: implementation-defined pixels {[round(100 * f, 3) for f in fractions]} %")
+
+
+@pytest.mark.gpu
+def test_hip_agrees_with_both_oracles_on_the_forest_and_config5(hip):
+    """The scenes where silhouettes, slivers and depth ties are frequent: the hostile workload of bench.py (terrain + 20 000
+    trees seen obliquely, views 3 and 11, depth complexity 10) and one BASELINE config-5 view (5 M faces, 6000 x 4000).  The
+    implementation-defined share is larger there (about 1 % on the forest) -- and on every other pixel the two oracles and the
+    HIP kernels still agree."""
+    points, faces = synthetic.forest_scene()
+    cams = synthetic.oblique_cameras(20)
+    recs = cams.get_raster_records(1.0, near=1.0)
+    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+    pick = [3, 11]
+    got = hip.raster_face_ids(recs[pick], 3000, 4000).cpu().numpy()
+    fractions = []
+    for k, v in enumerate(pick):
+        cls, env_ids, rule, flt = _split(points, faces, recs[v], 3000, 4000, allow_invisible_straddlers=True)
+        fractions.append(_check(cls, env_ids, rule, flt, got[k]))
+        assert np.array_equal(got[k], rule)
+    assert max(fractions) < 0.03, fractions
+    print(f"forest: implementation-defined pixels {[round(100 * f, 3) for f in fractions]} %")
+    (points, faces), cams = synthetic.config5_scene(n_views=60)
+    recs = cams.get_raster_records(1.0, near=1.0)
+    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+    got = hip.raster_face_ids(recs[57:58], 4000, 6000).cpu().numpy()
+    cls, env_ids, rule, flt = _split(points, faces, recs[57], 4000, 6000)
+    frac = _check(cls, env_ids, rule, flt, got[0])
+    assert np.array_equal(got[0], rule) and frac < 0.01
+    print(f"C5: implementation-defined pixels {100 * frac:.3f} %")

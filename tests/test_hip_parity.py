@@ -90,25 +90,6 @@ def test_face_order_does_not_matter(hip):
     _check_views(hip, broken, np.vstack([shuffled, extra]), recs, 480, 640)
 
 
-def test_maximum_image_size(hip, raster_variant):
-    """16384 x 16384, the largest image the library accepts (guard band, GR_MAX_DIM): 131 072 tiles.  The fixed tile
-    segments of a full launch group would not fit the scratch budget; the group shrinks instead.  One size larger is
-    refused."""
-    if raster_variant != "tile32_chain":
-        pytest.skip("one variant is enough for a 268-megapixel view")
-    (points, faces), _ = synthetic.config1_scene()
-    cams = synthetic.camera_set_from_poses([synthetic.nadir_pose(3.0, -2.0, 40.0, yaw_deg=20.0)] * 2, f=8000.0,
-                                           width=16384, height=16384)
-    recs = _records(cams)
-    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
-    ids = hip.raster_face_ids(recs, 16384, 16384)
-    want = oracle_c.raster(points, faces, recs[0], 16384, 16384)
-    assert torch.equal(ids[0].cpu(), torch.from_numpy(want)) and torch.equal(ids[1], ids[0])
-    assert (want >= 0).mean() > 0.5
-    with pytest.raises((ValueError, RuntimeError)):
-        hip.raster_face_ids(recs, 16385, 16384)
-
-
 @pytest.mark.parametrize("scale", [0.25, 0.37, 1.0])
 def test_ragged_sizes_and_scales(hip, scale):
     """h, w not multiples of the 64-pixel tile, and the int(H*s) truncation of cameras.py:179-200."""
@@ -381,56 +362,6 @@ def test_fused_votes_with_partial_views_and_scattered_face_order(hip, compat, sh
             np.testing.assert_array_equal(c2.cpu().numpy().view(np.uint32), want_c)
     finally:
         hip.set_option(3, 64)
-
-
-def test_fused_call_resumes_after_a_later_launch_group_overflows(hip, raster_variant):
-    """A fused call of three launch groups whose LAST groups overflow their tile segments (far views put many faces in a
-    tile, near views few; the slots per tile are chosen between the two needs): the device must fold in exactly the groups
-    in front of the first overflowed one, `views_done` must say so, and the resumed call must add the rest -- votes and
-    counts equal to the unfused projection of the id images, no view twice, none dropped.  With check=False the same call
-    reports nothing by itself; `raster_status()` must raise."""
-    if "exact" in raster_variant:
-        pytest.skip("single-pass binning only: the exact path sizes its lists from the counts")
-    (points, faces), _ = synthetic.config1_scene()
-    F, C = faces.shape[0], 3
-    near = [synthetic.nadir_pose(3.0 * k - 9.0, 2.0 * k - 7.0, 22.0, yaw_deg=20.0 * k) for k in range(6)]
-    far = [synthetic.nadir_pose(2.0 * k - 3.0, 1.0 - k, 130.0 + 5.0 * k, yaw_deg=15.0 * k) for k in range(5)]
-    cams = synthetic.camera_set_from_poses(near + far, f=500.0, width=640, height=480)
-    recs = _records(cams)
-    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
-    thl, _, var = VARIANTS[raster_variant]
-    try:
-        hip.set_option(6, 4096)
-        need = []
-        for v in range(len(cams)):
-            hip.raster_face_ids(recs[v:v + 1], 480, 640)
-            need.append(hip.last_stats["max_entries"])
-        cap = (max(need[:6]) + 63) // 64 * 64
-        assert cap < min(need[6:]), (need, cap)
-        ids = hip.raster_face_ids(recs, 480, 640)
-        ids_np = ids.cpu().numpy()
-        labels = np.stack([synthetic.synthetic_labels(ids_np[v], v, C) for v in range(len(cams))])
-        want_v, want_c = hip.new_vote_buffers(C)
-        hip.project_labels(ids, labels, C, want_v, want_c)
-        hip.set_option(3, 4)      # groups: views 0-3 | 4-7 (overflows: views 6, 7) | 8-10
-        hip.set_option(6, cap)    # forgets what the context has learned
-        v2, c2 = hip.new_vote_buffers(C)
-        hip.raster_project_labels(recs, labels, C, v2, c2)
-        assert hip.last_retries > 0 and hip.last_stats["overflow"] == 0 and hip.last_stats["views_done"] == len(cams)
-        assert torch.equal(v2, want_v) and torch.equal(c2, want_c)
-        # unchecked: the first group's votes only, and the status call is the one that tells
-        hip.set_option(6, cap)
-        v3, c3 = hip.new_vote_buffers(C)
-        hip.raster_project_labels(recs, labels, C, v3, c3, check=False)
-        assert hip.last_stats == {"unchecked": True}
-        with pytest.raises(RuntimeError, match="overflow"):
-            hip.raster_status()
-        part_v, part_c = hip.new_vote_buffers(C)
-        hip.project_labels(ids[:4], labels[:4], C, part_v, part_c)
-        assert torch.equal(v3, part_v) and torch.equal(c3, part_c)
-    finally:
-        hip.set_option(3, 64)
-        hip.set_option(6, VARIANTS[raster_variant][1])
 
 
 def test_end_to_end_api_matches_oracle_pipeline(hip, oracle_backend_cls):

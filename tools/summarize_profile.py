@@ -50,12 +50,34 @@ def pmc(raw, sub, counter):
     return d
 
 
+def views_per_launch(raw, sub):
+    """Views of a launch = the grid's y extent (z for k_winner) of the per-view kernels, from the kernel trace of the pass."""
+    path = find(os.path.join(raw, sub, "**", "*kernel_trace.csv"))
+    d = defaultdict(list)
+    if path:
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                d[short(r["Kernel_Name"])].append(int(r["Grid_Size_Y"]) // max(int(r["Workgroup_Size_Y"]), 1))
+    return d
+
+
+def key_of(kernel):
+    """traffic.json / valu.json key: the kernel's name without template arguments; the fused tile kernel gets its own."""
+    name = kernel.replace("void ", "").strip()
+    base = name.split("<")[0].strip()
+    if base == "k_raster_tile" and "<" in name:
+        args = [a.strip() for a in name.split("<", 1)[1].rstrip(">").split(",")]
+        if len(args) > 3 and args[3] == "true":
+            return "k_raster_tile_fused"
+    return base
+
+
 def main():
     raw, tag = sys.argv[1], sys.argv[2]
     out_txt = os.path.join(raw, f"summary_{tag}.txt")
     lines = []
     path, rows = kernel_stats(raw)
-    lines.append(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 2 --windows 2 --no-cpu-baseline --no-workload2 --no-c4   [{tag}]")
+    lines.append(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 2 --windows 2 --min-timed-s 0 --no-cpu-baseline --no-workload2 --no-c4 --no-c5 --no-api   [{tag}]")
     lines.append(f"# source: {path}")
     # median from the per-launch trace of the same run (the first launches after a mesh upload run cold and pull the mean up)
     trace = kernel_trace_durations(raw, "trace")
@@ -70,7 +92,7 @@ def main():
     write = pmc(raw, "pmc_write", "WRITE_SIZE")
     dur = kernel_trace_durations(raw, "pmc_fetch")
     lines.append("")
-    lines.append("# PMC passes (separate runs): python3 bench.py --steps 2 --warmup 1 --windows 1 --no-cpu-baseline --no-aggregate --no-workload2 --no-c4")
+    lines.append("# PMC passes (separate runs): python3 bench.py --steps 2 --warmup 1 --windows 1 --min-timed-s 0 --no-cpu-baseline --no-workload2 --no-c4 --no-c5 --no-api")
     lines.append("# FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; on gfx950 FETCH_SIZE counts 64 B per 128-B request")
     lines.append("# for wide streaming reads (MI355X_MICROARCH.md, HBM): the 'fetch_x2' column doubles it as the guide prescribes.")
     lines.append(f"{'kernel':40s} {'launches':>8s} {'fetch_MB':>10s} {'fetch_x2_MB':>12s} {'write_MB':>10s} {'avg_us':>9s}")
@@ -86,17 +108,49 @@ def main():
         f.write("\n".join(lines) + "\n")
     with open(os.path.join(raw, f"summary_{tag}.json"), "w") as f:
         json.dump(summary, f, indent=1)
-    # traffic.json: HBM bytes per launch of each kernel = 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE
+    # traffic.json: HBM bytes per launch of each kernel = 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, and per view
+    # (the per-view kernels carry the views of a launch in their grid's y extent)
+    vpl = views_per_launch(raw, "pmc_fetch")
     traffic = {}
     for k, v in summary.items():
-        name = k.replace("void ", "").split("<")[0].strip()
+        name = key_of(k)
         fm, wm = v["fetch_x2_MB_per_launch"], v["write_MB_per_launch"]
         if fm == fm and wm == wm:
+            nv = sum(vpl.get(k, [1])) / max(len(vpl.get(k, [1])), 1)
             traffic[name] = {"hbm_bytes_per_launch": (fm + wm) * 1e6, "fetch_x2_MB": fm, "write_MB": wm,
-                             "launches": v["launches"], "source": f"profiles/summary_{tag}.txt"}
+                             "launches": v["launches"], "views_per_launch": nv, "hbm_bytes_per_view": (fm + wm) * 1e6 / max(nv, 1),
+                             "source": f"profiles/summary_{tag}.txt"}
     traffic["_source"] = f"tools/profile.sh {tag}: summary_{tag}.txt"
     with open(os.path.join(raw, "traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
+    # valu.json: wave-level VALU instructions per view of the kernels the bench prices against the VALU-issue roofline
+    sq = {c: pmc(raw, "pmc_sq", c) for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
+                                               "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT")}
+    vpl = views_per_launch(raw, "pmc_sq")
+    valu = {}
+    lines.append("")
+    lines.append("# SQ pass (separate run, same command as the PMC passes): per launch, averages")
+    lines.append(f"{'kernel':44s} {'launches':>8s} {'views':>6s} {'VALU_insts':>14s} {'VALU_busy':>10s} {'SALU_insts':>14s} {'LDS_insts':>12s} {'LDS_busy':>9s} {'bank_conf':>10s}")
+    for k in sorted(sq["SQ_INSTS_VALU"]):
+        n = len(sq["SQ_INSTS_VALU"][k])
+        avg = {c: sum(sq[c].get(k, [0.0])) / max(len(sq[c].get(k, [0.0])), 1) for c in sq}
+        nv = sum(vpl.get(k, [1])) / max(len(vpl.get(k, [1])), 1)
+        cycles = avg["SQ_BUSY_CYCLES"] / 32.0  # the counter sums over 32 shader engines
+        busy = avg["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cycles) if cycles else float("nan")
+        lds_busy = avg["SQ_LDS_IDX_ACTIVE"] / (256.0 * cycles) if cycles else float("nan")
+        conf = avg["SQ_LDS_BANK_CONFLICT"] / avg["SQ_LDS_IDX_ACTIVE"] if avg["SQ_LDS_IDX_ACTIVE"] else float("nan")
+        lines.append(f"{k[:44]:44s} {n:8d} {nv:6.1f} {avg['SQ_INSTS_VALU']:14.0f} {busy:10.3f} {avg['SQ_INSTS_SALU']:14.0f} "
+                     f"{avg['SQ_INSTS_LDS']:12.0f} {lds_busy:9.3f} {conf:10.3f}")
+        if k.replace("void ", "").startswith("k_"):
+            valu[key_of(k)] = {"valu_insts_per_launch": avg["SQ_INSTS_VALU"], "views_per_launch": nv,
+                               "valu_insts_per_view": avg["SQ_INSTS_VALU"] / max(nv, 1), "valu_busy_in_pmc_pass": busy,
+                               "lds_busy_in_pmc_pass": lds_busy, "lds_bank_conflict_share": conf, "launches": n,
+                               "source": f"profiles/summary_{tag}.txt"}
+    valu["_source"] = f"tools/profile.sh {tag}: summary_{tag}.txt"
+    with open(os.path.join(raw, "valu.json"), "w") as f:
+        json.dump(valu, f, indent=1)
+    with open(out_txt, "w") as f:
+        f.write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
 
