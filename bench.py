@@ -136,6 +136,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-workload2", action="store_true")
     ap.add_argument("--no-api", action="store_true")
     ap.add_argument("--master-port", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=0,
+                    help="GR_OPT_VARIANT bits for every context (results identical); tools/profile.sh passes 4 -- fused votes on "
+                         "the caller's stream -- in its counter passes, where rocprofv3 does not survive the side stream")
     return ap.parse_args(argv)
 
 
@@ -255,6 +258,15 @@ def run(args, rig=None) -> int:
     from geograypher_amd.utils import synthetic
 
     rig = rig or GpuRig()
+    if args.variant:
+        make_plain = rig.make_raster
+
+        def make_raster(local_rank):
+            r = make_plain(local_rank)
+            r.set_option(7, args.variant)
+            return r
+
+        rig.make_raster = make_raster
     wl = rig.workload
     H, W, N_CLASSES = wl.H, wl.W, wl.n_classes
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -844,16 +856,26 @@ def leg_api(points, faces, wl, n_views=16):
     mesh.aggregate_projected_images(seg)
     _, dt = timed(lambda: mesh.aggregate_projected_images(seg))
     out["aggregate_uint8_labels_from_host_views_per_s"] = round(n / dt, 1)
-    # float images (the general path of meshes.py:2057-2067): one (h, w, 3) float64 image per view from host memory
+    # the general path of meshes.py:2057-2067, images from host memory: (h, w, 3) uint8 photos (what `aggregate_images` feeds
+    # it), (h, w, C) bool one-hot masks (what a segmentor returns) and (h, w, 3) float64 images
     nf = min(n, 8)
     rng = np.random.default_rng(0)
-    fset = host_image_set(cams[0:nf], [rng.random((wl.H, wl.W, 3)) for _ in range(nf)])
-    try:
-        mesh.aggregate_projected_images(fset)
-        _, dt = timed(lambda: mesh.aggregate_projected_images(fset))
-        out["aggregate_float64_images_from_host_views_per_s"] = round(nf / dt, 1)
-    except Exception as exc:  # the leg reports, it does not take the line down
-        out["aggregate_float64_images_from_host_views_per_s"] = f"failed: {exc!r}"
+    sets = {
+        "uint8_rgb": [rng.integers(0, 255, size=(wl.H, wl.W, 3), dtype=np.uint8) for _ in range(nf)],
+        "bool_one_hot": [labels[v][..., None] == np.arange(C) for v in range(nf)],
+        "float64_rgb": [rng.random((wl.H, wl.W, 3)) for _ in range(nf)],
+    }
+    for tag, imgs in sets.items():
+        key = f"aggregate_{tag}_images_from_host_views_per_s"
+        try:
+            fset = host_image_set(cams[0:nf], imgs)
+            mesh.aggregate_projected_images(fset)
+            _, dt = timed(lambda: mesh.aggregate_projected_images(fset))
+            out[key] = round(nf / dt, 1)
+        except Exception as exc:  # the leg reports, it does not take the line down
+            out[key] = f"failed: {exc!r}"
+        del imgs
+    sets.clear()
     # sparse index aggregation (derived_meshes.py:414-550): one (h, w) class-index image per view
     try:
         sparse_mesh = TexturedPhotogrammetryMeshIndexPredictions((points, faces), log_level="ERROR", backend=mesh.backend)

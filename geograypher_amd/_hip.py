@@ -20,6 +20,7 @@ _lib = None
 GR_OK = 0
 GR_EOVERFLOW = -6
 GR_FLAG_NEG1_IS_LAST_FACE = 1
+GR_FLAG_DEFER_CHECK = 2
 GR_CAM_FLOATS = 16
 
 # every symbol include/geograster.h declares (tests check that the library exports each of them)
@@ -192,6 +193,86 @@ class _nullcontext:
 
     def __exit__(self, *exc):
         return False
+
+
+class PairAccumulator:
+    """Device-resident pair keys of the sparse index aggregation (derived_meshes.py:470-520).  Every `add` appends the
+    keys `face * n_classes + class` of its views to one device buffer through `gr_project_index_pairs` with
+    GR_FLAG_DEFER_CHECK (no synchronisation, no per-view sort, no host round trip); `finish` runs ONE radix sort +
+    run-length encode over everything (`gr_count_pairs`) and returns (pair_keys, multiplicities) as int64 numpy arrays.
+    A view emits at most one pair per face, so the host knows an upper bound of the fill level without asking the
+    device; when the buffer could overflow it is counted down to its distinct pairs (with their multiplicities, kept on
+    the host) and reused."""
+
+    def __init__(self, backend: "HipRaster", n_classes: int, counts, neg1_is_last_face: bool = True):
+        torch = _torch()
+        self.b = backend
+        self.n_classes = int(n_classes)
+        self.counts = counts
+        self.flags = (GR_FLAG_NEG1_IS_LAST_FACE if neg1_is_last_face else 0) | GR_FLAG_DEFER_CHECK
+        self.cap = max(8 * backend.n_faces, 1 << 20)
+        self.keys = torch.empty((self.cap,), dtype=torch.int64, device=backend.device)
+        self.key_count = torch.zeros((1,), dtype=torch.int64, device=backend.device)
+        self.bound = 0          # upper bound of the pairs in the buffer
+        self.parts = []         # (keys, multiplicities) of earlier compactions, host
+        self.compactions = 0
+
+    def add(self, ids, img):
+        torch = _torch()
+        b = self.b
+        ids_t = b._dev(ids, torch.int32)
+        img_t = b._dev(img, torch.float64)
+        if ids_t.ndim == 2:
+            ids_t, img_t = ids_t[None], img_t[None]
+        if img_t.ndim == 4 and img_t.shape[-1] == 1:
+            img_t = img_t[..., 0]
+        if ids_t.shape != img_t.shape:
+            raise ValueError(f"ids {tuple(ids_t.shape)} and index image {tuple(img_t.shape)} differ in shape")
+        n, h, w = (int(x) for x in ids_t.shape)
+        if n * b.n_faces > self.cap:
+            for k in range(n):
+                self.add(ids_t[k], img_t[k])
+            return
+        if self.bound + n * b.n_faces > self.cap:
+            self._compact()
+        with torch.cuda.device(b.device):
+            rc = b.lib.gr_project_index_pairs(
+                b._ctx, ids_t.data_ptr(), img_t.contiguous().data_ptr(), n, h, w, self.n_classes, self.counts.data_ptr(),
+                self.keys.data_ptr(), self.cap, self.key_count.data_ptr(), self.flags, b._stream(),
+            )
+        b._check(rc, "gr_project_index_pairs")
+        self.bound += n * b.n_faces
+
+    def _compact(self):
+        torch = _torch()
+        b = self.b
+        raw = int(self.key_count.item())
+        if raw >> 32:
+            raise IndexError(f"gr_project_index_pairs: an image value is not a class index in [0, {self.n_classes})")
+        if raw > 0:
+            uniq = torch.empty((raw,), dtype=torch.int64, device=b.device)
+            mult = torch.empty((raw,), dtype=torch.int32, device=b.device)
+            n_unique = ctypes.c_int64(0)
+            with torch.cuda.device(b.device):
+                rc = b.lib.gr_count_pairs(b._ctx, self.keys.data_ptr(), raw, uniq.data_ptr(), mult.data_ptr(),
+                                          ctypes.byref(n_unique), b._stream())
+            b._check(rc, "gr_count_pairs")
+            k = int(n_unique.value)
+            self.parts.append((uniq[:k].cpu().numpy(), mult[:k].cpu().numpy().astype(np.int64)))
+            self.compactions += 1
+        self.key_count.zero_()
+        self.bound = 0
+
+    def finish(self):
+        self._compact()
+        if not self.parts:
+            return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+        if len(self.parts) == 1:
+            return self.parts[0]
+        keys = np.concatenate([p[0] for p in self.parts])
+        mult = np.concatenate([p[1] for p in self.parts])
+        uniq, inv = np.unique(keys, return_inverse=True)
+        return uniq, np.bincount(inv, weights=mult, minlength=uniq.size).astype(np.int64)
 
 
 _default_backends = {}
@@ -419,6 +500,11 @@ class HipRaster:
         self._check(rc, "gr_count_pairs")
         k = int(n_unique.value)
         return uniq[:k].cpu().numpy(), mult[:k].cpu().numpy().astype(np.int64)
+
+    def new_pair_accumulator(self, n_classes: int, counts, neg1_is_last_face: bool = True):
+        """Sparse index aggregation over MANY views with the (face, class) pair keys kept on the device: `add(ids, img)` per
+        view (or group of views) only enqueues work, `finish()` sorts and counts the pairs ONCE -- see `PairAccumulator`."""
+        return PairAccumulator(self, n_classes, counts, neg1_is_last_face)
 
     # -- projection / aggregation --------------------------------------------------------------------------------
     def new_vote_buffers(self, C: int):

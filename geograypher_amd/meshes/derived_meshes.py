@@ -66,7 +66,8 @@ class TexturedPhotogrammetryMeshIndexPredictions(TexturedPhotogrammetryMesh):
         kwargs.pop("check_null_image", None)
         all_projections = [] if return_all else None
         counts = torch.zeros((n_faces,), dtype=torch.int32, device=self.backend.device)
-        keys_acc, mult_acc = [], []
+        # the (face, class) pair keys of all views stay on the device; ONE sort + run-length count at the end
+        acc = self.backend.new_pair_accumulator(n_classes, counts, neg1_is_last_face=self.neg1_is_last_face)
         gen = self._iter_view_inputs(cameras, batch_size, aggregate_img_scale, True, kwargs)
         for _, ids, img, n_channels in tqdm(gen, total=len(cameras), desc="Aggregating projected viewpoints"):
             if return_all:
@@ -80,19 +81,10 @@ class TexturedPhotogrammetryMeshIndexPredictions(TexturedPhotogrammetryMesh):
                 continue
             if img.shape[-1] != 1:
                 raise ValueError("index predictions must be single-channel images")
-            k, m = self.backend.project_index_pairs(ids, img[..., 0], n_classes, counts,
-                                                    neg1_is_last_face=self.neg1_is_last_face)
-            keys_acc.append(k)
-            mult_acc.append(m)
-        if keys_acc:
-            keys = np.concatenate(keys_acc)
-            mult = np.concatenate(mult_acc)
-            uniq, inv = np.unique(keys, return_inverse=True)
-            summed_vals = np.bincount(inv, weights=mult, minlength=uniq.size).astype(int)
-            rows, cols = uniq // n_classes, uniq % n_classes
-        else:
-            rows = cols = np.zeros(0, dtype=np.int64)
-            summed_vals = np.zeros(0, dtype=int)
+            acc.add(ids, img[..., 0])
+        uniq, mult = acc.finish()
+        summed_vals = mult.astype(int)
+        rows, cols = uniq // n_classes, uniq % n_classes
         summed_projections = csr_array((summed_vals, (rows, cols)), shape=(n_faces, n_classes), dtype=int)
         cnt = counts.cpu().numpy().astype(int)
         seen = np.nonzero(cnt)[0]

@@ -41,7 +41,9 @@ enum {
 
 /* flags for the projection / aggregation entry points */
 enum {
-  GR_FLAG_NEG1_IS_LAST_FACE = 1 /* reproduce meshes.py:1998-2001: pix2face == -1 writes the LAST face */
+  GR_FLAG_NEG1_IS_LAST_FACE = 1, /* reproduce meshes.py:1998-2001: pix2face == -1 writes the LAST face */
+  GR_FLAG_DEFER_CHECK = 2        /* gr_project_index_pairs: do not synchronise; a value outside [0, n_classes) sets bit 32 of
+                                    *key_count instead of failing the call (the caller reads the counter once, at the end) */
 };
 
 /* camera record: 16 floats per view, see DESIGN.md R0.
@@ -165,8 +167,10 @@ int gr_gather_texture_u8(gr_ctx *ctx, const int32_t *ids, int64_t n_pix, const d
  * .aggregate_projected_images (derived_meshes.py:470-520) for single-channel images whose finite values are class
  * indices: per view the last pixel of each face wins (as project_images); a finite value v adds one observation:
  * counts[f] += 1 and the pair key f * n_classes + int(v) is appended to keys[*key_count ...] (device counter, capacity
- * key_cap; pairs beyond it are dropped but still counted in *key_count).  Synchronises `stream`; GR_EINDEX when a
- * value is outside [0, n_classes). */
+ * key_cap; pairs beyond it are dropped but still counted in *key_count).  Calls APPEND: the caller zeroes *key_count and may
+ * collect the pairs of many calls in one buffer before counting them once (gr_count_pairs).  Synchronises `stream` and
+ * returns GR_EINDEX when a value is outside [0, n_classes) -- unless GR_FLAG_DEFER_CHECK is set: then the call only enqueues
+ * work and such a value sets bit 32 of *key_count (the count itself stays below 2^31). */
 int gr_project_index_pairs(gr_ctx *ctx, const int32_t *ids, const double *img, int n_views, int h, int w,
                            int64_t n_classes, uint32_t *counts, uint64_t *keys, int64_t key_cap, uint64_t *key_count,
                            int flags, void *stream);

@@ -68,6 +68,27 @@ class OracleBackend:
         uniq, mult = np.unique(keys, return_counts=True)
         return uniq, mult.astype(np.int64)
 
+    def new_pair_accumulator(self, n_classes, counts, neg1_is_last_face=True):
+        backend = self
+
+        class _Acc:
+            def __init__(self):
+                self.parts = []
+
+            def add(self, ids, img):
+                self.parts.append(backend.project_index_pairs(ids, np.asarray(img, dtype=np.float64), n_classes, counts,
+                                                              neg1_is_last_face=neg1_is_last_face))
+
+            def finish(self):
+                if not self.parts:
+                    return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+                keys = np.concatenate([p[0] for p in self.parts])
+                mult = np.concatenate([p[1] for p in self.parts])
+                uniq, inv = np.unique(keys, return_inverse=True)
+                return uniq, np.bincount(inv, weights=mult, minlength=uniq.size).astype(np.int64)
+
+        return _Acc()
+
     def new_vote_buffers(self, C):
         return torch.zeros((self.n_faces, C), dtype=torch.int32), torch.zeros((self.n_faces,), dtype=torch.int32)
 

@@ -11,8 +11,10 @@ SKIP="--no-cpu-baseline --no-workload2 --no-c4 --no-c5 --no-api"
 BENCH="python3 $REPO/bench.py --steps 20 --warmup 2 --windows 2 --min-timed-s 0 $SKIP"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.log 2>&1
 echo "trace rc=$?" >> $OUT/trace_bench.log
-# the PMC passes keep the aggregate leg (fused tile kernel, vote kernel) in: one step per window is enough for counters
-SHORT="python3 $REPO/bench.py --steps 2 --warmup 1 --windows 1 --min-timed-s 0 $SKIP"
+# the counter passes run tools/prof_pipeline.py: the same kernels on the same workloads (50 C2 views per pix2face launch, 64 C3
+# views per fused launch) without torch's elementwise kernels and without the library's side stream -- rocprofv3's counter
+# collection segfaults on either
+SHORT="python3 $REPO/tools/prof_pipeline.py 50 3 64"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- $SHORT > $OUT/pmc_fetch.log 2>&1
 echo "fetch rc=$?" >> $OUT/pmc_fetch.log
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- $SHORT > $OUT/pmc_write.log 2>&1

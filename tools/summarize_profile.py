@@ -58,6 +58,12 @@ def views_per_launch(raw, sub):
         with open(path) as f:
             for r in csv.DictReader(f):
                 d[short(r["Kernel_Name"])].append(int(r["Grid_Size_Y"]) // max(int(r["Workgroup_Size_Y"]), 1))
+    # the vote kernel's grid is one thread per face: its views are those of the fused tile launch it follows
+    fused = [k for k in d if key_of(k) == "k_raster_tile_fused"]
+    if fused:
+        for k in list(d):
+            if key_of(k) == "k_vote_labels":
+                d[k] = list(d[fused[0]])
     return d
 
 
@@ -92,7 +98,7 @@ def main():
     write = pmc(raw, "pmc_write", "WRITE_SIZE")
     dur = kernel_trace_durations(raw, "pmc_fetch")
     lines.append("")
-    lines.append("# PMC passes (separate runs): python3 bench.py --steps 2 --warmup 1 --windows 1 --min-timed-s 0 --no-cpu-baseline --no-workload2 --no-c4 --no-c5 --no-api")
+    lines.append("# PMC passes (separate runs): python3 tools/prof_pipeline.py 50 3 64  (50 C2 views per pix2face launch, 64 C3 views per fused launch)")
     lines.append("# FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; on gfx950 FETCH_SIZE counts 64 B per 128-B request")
     lines.append("# for wide streaming reads (MI355X_MICROARCH.md, HBM): the 'fetch_x2' column doubles it as the guide prescribes.")
     lines.append(f"{'kernel':40s} {'launches':>8s} {'fetch_MB':>10s} {'fetch_x2_MB':>12s} {'write_MB':>10s} {'avg_us':>9s}")
