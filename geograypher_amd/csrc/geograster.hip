@@ -73,7 +73,8 @@ struct BinArgs {
   int cap_tile;          // > 0: single-pass binning, every tile owns cap_tile entry slots (list base = tile * cap_tile)
   int var;               // variant bits (GR_OPT_VARIANT): 1 = one tile per workgroup instead of four, 4 = votes on the caller's stream, 8 = no speculative first chunk, 16 = chains of four whatever the launch looks like, 32 = votes without chunk bitmaps
   int dbg;               // timing-only ablation mask (GR_OPT_DEBUG): 1 skip scanline loop, 2 skip id stores, 4 skip triangles,
-                         // fused epilogue: 8 skip winner atomics, 16 skip label loads
+                         // fused epilogue: 8 skip winner atomics, 16 skip label loads; set-up: 32 no entry compilation, 64 no
+                         // second-to-fourth tiles of small faces, 256 no depth gradients
 };
 
 __device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b, c)); }
@@ -378,14 +379,17 @@ __device__ __forceinline__ bool face_setup(const BinArgs &a, const float *__rest
   jmax = min(jmax, a.w - 1); imax = min(imax, a.h - 1);
   if (jmin > jmax || imin > imax) return false;
   // R4: gradients of 1/z in double, rounded once to float
-  const double d1 = (double)v1.iz - (double)v0.iz;
-  const double d2 = (double)v2.iz - (double)v0.iz;
-  const double a2 = (double)area2;
-  double n1, n2;
-  n1 = d1 * (double)(v2.Y - v0.Y); n2 = d2 * (double)(v1.Y - v0.Y);
-  const float A = (float)((n1 - n2) / a2);
-  n1 = d2 * (double)(v1.X - v0.X); n2 = d1 * (double)(v2.X - v0.X);
-  const float B = (float)((n1 - n2) / a2);
+  float A = 0.f, B = 0.f;
+  if (!(a.dbg & 256)) {
+    const double d1 = (double)v1.iz - (double)v0.iz;
+    const double d2 = (double)v2.iz - (double)v0.iz;
+    const double a2 = (double)area2;
+    double n1, n2;
+    n1 = d1 * (double)(v2.Y - v0.Y); n2 = d2 * (double)(v1.Y - v0.Y);
+    A = (float)((n1 - n2) / a2);
+    n1 = d2 * (double)(v1.X - v0.X); n2 = d1 * (double)(v2.X - v0.X);
+    B = (float)((n1 - n2) / a2);
+  }
   r0 = make_int4(v0.X, v0.Y, v1.X, v1.Y);
   r1 = make_int4(v2.X, v2.Y, __float_as_int(v0.iz), a.orig[f]);
   r2 = make_int4(__float_as_int(A), __float_as_int(B), jmin | (jmax << 16), imin | (imax << 16));
@@ -528,7 +532,7 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ca
     int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
     uint8_t *nr8 = a.nrow8 + slot * a.ent_cap;
     const int TW = 1 << a.twl, TH = 1 << a.thl;
-    if (small_fp) {
+    if (small_fp && !(a.dbg & 32)) {
       if ((uint32_t)r3.x < (uint32_t)a.cap_tile) {
         const int64_t idx = (int64_t)t00 * a.cap_tile + (uint32_t)r3.x;
         compile_entry(comp + idx * GR_ENT_Q, nr8 + idx, r0, r1, r2, tx0 << a.twl, ty0 << a.thl, TW, TH);
@@ -537,7 +541,7 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ca
     const int shape = small_fp ? ((tx1 > tx0 ? 1 : 0) | (ty1 > ty0 ? 2 : 0)) : 0;  // which neighbours exist: 1 right, 2 below
     const int ne = shape == 3 ? 3 : (shape ? 1 : 0);
     const int incl_e = wave_incl_scan(ne);
-    const int total_e = __builtin_amdgcn_readlane(incl_e, 63);
+    const int total_e = (a.dbg & (32 | 64)) ? 0 : __builtin_amdgcn_readlane(incl_e, 63);
     const int geo = tx0 | (ty0 << 12) | (shape << 24);
     for (int k0 = 0; k0 < total_e; k0 += 64) {
       const int q = k0 + lane;
