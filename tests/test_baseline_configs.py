@@ -229,3 +229,35 @@ def test_pix2face_host_copy_pipeline_matches_the_device_ids(hip):
         np.testing.assert_array_equal(_ids_to_host_int64(t, step, threads), t.cpu().numpy().astype(np.int64))
     small = torch.arange(-5, 95, dtype=torch.int32, device="cuda").reshape(1, 10, 10)
     np.testing.assert_array_equal(_ids_to_host_int64(small), small.cpu().numpy().astype(np.int64))
+
+
+def test_cameras_inside_the_canopy_bit_exact(hip):
+    """The hostile scene seen from INSIDE (the case the near plane and the guard band decide): cameras 3 m and 12 m above the
+    ground between the trees, looking horizontally and 20 degrees down, near plane 5 cm.  Trunks and canopies a metre away are
+    thousands of pixels wide, cross the near plane (R7: clipped, not dropped) and the +-16384 px guard band; hundreds of
+    thousands of faces lie behind the camera.  Ids and depth bits must equal the oracle's at 1000 x 750, and the view must not
+    be empty."""
+    points, faces = synthetic.forest_scene()
+    height_fn = synthetic._spectrum(1)
+    poses = []
+    # two cameras 2 m above the ground between the trunks (1.6-2 m from the nearest), one 30 m up just above the tree tops
+    # looking across them, one 0.4 m from a trunk (the trunk fills the picture: a handful of faces, each thousands of pixels)
+    for k, (x, y, agl, tilt) in enumerate([(12.0, -7.0, 3.0, 90.0), (14.9, -141.7, 2.0, 88.0), (-109.8, -29.1, 2.0, 100.0),
+                                           (76.1, 11.4, 30.0, 75.0)]):
+        ground = float(height_fn(np.array(x), np.array(y)))
+        poses.append(synthetic.nadir_pose(x, y, ground + agl, yaw_deg=40.0 * k, tilt_x_deg=tilt, tilt_y_deg=2.0 * k))
+    cams = synthetic.camera_set_from_poses(poses, f=3000.0, width=4000, height=3000)
+    h, w = cams[0].get_image_size(0.25)
+    recs = cams.get_raster_records(0.25, near=0.05)
+    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+    ids, depth = hip.raster_face_ids(recs, h, w, want_depth=True)
+    ids, depth = ids.cpu().numpy(), depth.cpu().numpy()
+    assert hip.last_stats["overflow"] == 0
+    for v in range(len(cams)):
+        want, wdep = oracle_c.raster(points, faces, recs[v], h, w, want_depth=True)
+        bad = np.argwhere(ids[v] != want)
+        assert bad.size == 0, f"view {v}: {bad.shape[0]} pixels differ, first {bad[:5].tolist()}"
+        np.testing.assert_array_equal(depth[v].view(np.int32), wdep.view(np.int32))
+        assert (want >= 0).mean() > 0.5 and len(np.unique(want)) > (100 if v > 0 else 2)
+        if v == 0:  # the trunk 8 cm in front of the lens: faces that cross the near plane are in the picture
+            assert wdep[np.isfinite(wdep)].min() < 0.2
