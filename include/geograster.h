@@ -96,8 +96,10 @@ enum {
   GR_OPT_DIRECT_CAP = 6,    /* single-pass binning: entry slots per tile (default 512); 0 = always bin exactly
                                (count, scan, fill).  A tile that outgrows its slots is reported by
                                gr_raster_status (GR_EOVERFLOW); the retry uses segments of the size that image needs
-                               (remembered for images of the same tile count) or, beyond 16384 slots / 24 GB of
-                               entry memory per launch group, bins exactly                                     */
+                               (remembered per mesh size and tile count, in the context and -- unless this option was
+                               set by hand -- process-wide, so that another context for the same mesh and image size
+                               starts with segments that fit) or, beyond 16384 slots / 24 GB of entry memory per
+                               launch group, bins exactly.  Setting the option forgets what the context learned     */
   GR_OPT_VARIANT = 7,       /* variant bits for A/B runs (results identical): 1 = one tile per workgroup instead of a
                                chain of four; 4 = fused votes on the caller's stream instead of a side stream; 8 = no
                                first chunk requested ahead of the tile's count; 16 = chains of four tiles whatever the
