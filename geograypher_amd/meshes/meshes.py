@@ -599,7 +599,9 @@ class TexturedPhotogrammetryMesh:
             C = int(cameras.n_image_channels())
             self._ensure_uploaded(mesh)
             votes, counts = self.backend.new_vote_buffers(C)
-            chunk = max(int(batch_size), 32)
+            # launch groups of up to 32 views; a short run is still cut into at least four chunks, so that the loader stages
+            # chunk i + 1 while chunk i crosses the link (16 views in ONE chunk ran staging, copy and kernels back to back)
+            chunk = max(int(batch_size), min(32, max(1, -(-len(my_inds) // 4))))
             chunks = [my_inds[c0 : c0 + chunk] for c0 in range(0, len(my_inds), chunk)]
 
             # Input pipeline (row f4).  The label images of a chunk are decoded straight into ONE pinned (n,h,w) uint8
