@@ -479,13 +479,13 @@ class TexturedPhotogrammetryMesh:
                 flat, tdtype = flat.astype(np.float64), torch.float64
             if not on_gpu:
                 return torch.from_numpy(np.ascontiguousarray(flat)), n_channels
+            if slot_free[k] is not None:
+                slot_free[k].synchronize()  # the copy that read this slot two views ago is done
             if slots[k] is None or slots[k].shape != flat.shape or slots[k].dtype != tdtype:
                 try:
                     slots[k] = torch.empty(flat.shape, dtype=tdtype, pin_memory=True)
                 except RuntimeError:  # no pinned memory left: pageable upload
                     return torch.from_numpy(np.ascontiguousarray(flat)), n_channels
-            if slot_free[k] is not None:
-                slot_free[k].synchronize()  # the copy that read this slot two views ago is done
             dst = slots[k].numpy()
             rows = flat.shape[0]
             if flat.nbytes >= (32 << 20) and rows >= 8:  # numpy releases the interpreter lock inside large copies
