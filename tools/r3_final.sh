@@ -1,0 +1,17 @@
+#!/bin/bash
+# final evidence of the round: profile (trace + PMC), bench line, GPU tests
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $REPO
+OUT=$REPO/gpurun_out/r3_final
+mkdir -p $OUT
+bash tools/profile.sh r03 > $OUT/profile.log 2>&1
+( time timeout 900 python bench.py ) > $OUT/bench.json 2> $OUT/bench.err
+tail -3 $OUT/bench.err
+timeout 2400 python -m pytest tests -m gpu -q > $OUT/gpu_tests.log 2>&1
+tail -3 $OUT/gpu_tests.log
+grep -E "k_raster_tile|k_setup_cull|k_vote" gpurun_out/prof_r03/summary_r03.txt | cut -c1-150
+python -c "
+import json
+d=json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1])
+print(d['value'], d['roofline']['frac'], d['roofline']['kernel_ms_per_launch'], d['aggregate']['views_per_s'], d['c5']['raster_mpix_per_s'], d['workload_2']['scale_1']['mpix_per_s'], d['workload_2']['scale_0.25']['mpix_per_s'])
+"
