@@ -1032,7 +1032,9 @@ struct RasterOut {
 // walk their spans in step; with a row offset of 5 key-banks a pile-up on one bank needs a left edge that recedes
 // 5 px per row (a pad of 1 piled up every 45-degree edge: 530 of 1820 LDS cycles per tile were bank conflicts), and a
 // pixel's address advances by a plain +8 bytes along the scanline (no wrap arithmetic in the inner loop).
+#ifndef GR_LDS_PAD
 #define GR_LDS_PAD 5
+#endif
 template <int TWL, int PAD>
 __device__ __forceinline__ int lds_idx(int row, int col) {
   return __mul24(row, (1 << TWL) + PAD) + col;
