@@ -612,7 +612,7 @@ class TexturedPhotogrammetryMesh:
             from concurrent.futures import ThreadPoolExecutor
 
             thread_safe = bool(getattr(getattr(cameras, "segmentor", None), "thread_safe_lookup", False))
-            n_workers = int(loader_threads if loader_threads is not None else (min(8, os.cpu_count() or 1) if thread_safe else 1))
+            n_workers = int(loader_threads if loader_threads is not None else (min(16, os.cpu_count() or 1) if thread_safe else 1))
             # the label images must have the size the camera records are built for (the reference fails with a shape
             # error in `textured_faces[flat_pix2face] = flat_img` otherwise, meshes.py:1998-2001)
             h0, w0 = cameras.cameras[view_inds[0]].get_image_size(aggregate_img_scale)
