@@ -170,6 +170,24 @@ def _cpu_model() -> str:
     return "unknown CPU"
 
 
+def _cpu_quota_cores():
+    """CPU time the container may use, in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown: the
+    hosts of the GPU pool show 256 logical cores but zlib and the oracle stop scaling at about 16 threads."""
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt[0] != "max":
+            return round(int(txt[0]) / int(txt[1]), 2)
+        return None
+    except (OSError, ValueError, IndexError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return round(q / p, 2) if q > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
 def torch_hash32(x):
     m = 0xFFFFFFFF
     x = x & m
@@ -569,6 +587,11 @@ def run(args, rig=None) -> int:
         cpu_baseline["single_thread"] = {"value": round(P / t1 / 1e6, 2), "unit": "Mpix/s", "cores": 1,
                                          "sample": f"1 C2 view at {W}x{H} in {t1:.2f} s"}
         cpu_baseline["host_cores"] = cores
+        cpu_baseline["cgroup_cpu_quota_cores"] = _cpu_quota_cores()
+        try:
+            cpu_baseline["affinity_cores"] = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            cpu_baseline["affinity_cores"] = None
 
     if rank == 0:
         line = {
