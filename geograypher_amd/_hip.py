@@ -8,9 +8,8 @@ only `tensor.data_ptr()` and the raw `hipStream_t` of the current torch stream.
 from __future__ import annotations
 
 import ctypes
-import os
 from pathlib import Path
-from typing import Optional, Tuple
+from typing import Optional
 
 import numpy as np
 

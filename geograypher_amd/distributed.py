@@ -8,7 +8,7 @@ tests).  uint32 votes travel as int32: sums stay below 2^31 for any realistic nu
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import List, Tuple
 
 
 def rank_world() -> Tuple[int, int]:

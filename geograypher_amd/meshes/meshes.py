@@ -25,7 +25,6 @@ import numpy as np
 from geograypher_amd.cameras.cameras import (
     PhotogrammetryCamera,
     PhotogrammetryCameraSet,
-    vtk_like_near_plane,
     vtk_like_near_planes,
 )
 from geograypher_amd.constants import (

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 from itertools import product
 from pathlib import Path
-from typing import List, Tuple
+from typing import List
 
 import numpy as np
 
