@@ -412,10 +412,12 @@ class TexturedPhotogrammetryMesh:
         batch_size: int = 1,
         render_img_scale: float = 1,
         return_camera: bool = False,
+        return_tensor: bool = False,
         **pix2face_kwargs,
     ):
         """Generator: the face texture seen from each camera, (h, w, C) float64 with NaN where no face is visible
-        (reference: meshes.py:1858-1942, including its batch arithmetic)."""
+        (reference: meshes.py:1858-1942, including its batch arithmetic).  `return_tensor=True` yields the renders as
+        device tensors instead (no 96 MB host copy per 4000 x 3000 channel: the numpy path is bound by the link)."""
         mesh = self.get_mesh_in_cameras_coords(cameras)
         if isinstance(cameras, PhotogrammetryCamera):
             cameras = PhotogrammetryCameraSet([cameras], local_to_epsg_4978_transform=cameras._local_to_epsg_4978_transform)
@@ -436,7 +438,9 @@ class TexturedPhotogrammetryMesh:
                 batch_pix2face = self.backend._dev(batch_pix2face.astype(np.int32), _torch().int32)
             if tex_dev is None:
                 tex_dev = self.backend._dev(face_texture, _torch().float64)
-            rendered = _to_host(self.backend.gather_texture(batch_pix2face, tex_dev))
+            rendered = self.backend.gather_texture(batch_pix2face, tex_dev)
+            if not return_tensor:
+                rendered = _to_host(rendered)
             for i in range(rendered.shape[0]):
                 if return_camera:
                     yield (rendered[i], batch_cameras[i])

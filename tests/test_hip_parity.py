@@ -379,6 +379,10 @@ def test_end_to_end_api_matches_oracle_pipeline(hip, oracle_backend_cls):
     for ra, rb in zip(m_hip.render_flat(sub, render_img_scale=0.5, apply_distortion=False),
                       m_orc.render_flat(sub, render_img_scale=0.5, apply_distortion=False)):
         _same(ra, rb)
+    for rt, rb in zip(m_hip.render_flat(sub, render_img_scale=0.5, apply_distortion=False, return_tensor=True),
+                      m_orc.render_flat(sub, render_img_scale=0.5, apply_distortion=False)):
+        assert isinstance(rt, torch.Tensor) and rt.is_cuda
+        _same(rt.cpu().numpy(), rb)
     full = m_orc.pix2face(sub, apply_distortion=False)
     labels = [synthetic.synthetic_labels(full[v], v, 4) for v in range(3)]  # full-size label images, NN-resized by 0.5
     seg = ArrayLabelSegmentor(labels, 4, filenames=[c.image_filename for c in sub.cameras])
