@@ -59,9 +59,11 @@ struct BinArgs {
   uint32_t *clip;        // [slot][F] from the front: soup faces that straddle the near plane / guard band (R7; ctrl[4] = count);
                          //           from the back: faces over more than 2 x 2 tiles (single-pass binning; ctrl[5] = count)
   int64_t work_stride;
-  int4 *comp;            // [slot][ent_cap][GR_ENT_Q]  compiled (face, tile) entries grouped by tile, 48 bytes each
+  int4 *comp;            // [slot][ent_cap][GR_ENT_Q]  compiled (face, tile) entries grouped by tile, 48 bytes each (ent40: 40 bytes
+                         //                            each at the front of the same slot memory)
   uint8_t *nrow8;        // [slot][ent_cap] rows of each entry inside its tile (the tile kernel's scan input: a compact stream)
-  unsigned long long *stats;  // [5] records, entries, max_entries, overflow, first overflowed launch group (over the call)
+  unsigned long long *stats;  // [6] records, entries, max_entries, overflow, first overflowed launch group (over the call),
+                              //     short-form miss (a face the 40-byte entry cannot hold: the caller repeats with 48 bytes)
   int group;             // index of this launch group inside the call
   int64_t ctrl_stride;   // words per slot
   int64_t rec_stride;    // int4 per slot (= 3*F)
@@ -71,6 +73,7 @@ struct BinArgs {
   int h, w;
   int twl, thl;          // log2 of the tile width / height in pixels
   int cap_tile;          // > 0: single-pass binning, every tile owns cap_tile entry slots (list base = tile * cap_tile)
+  int ent40;             // 1: entries are written in the SHORT form (40 bytes, store_entry below); single-pass binning only
   int var;               // variant bits (GR_OPT_VARIANT): 1 = one tile per workgroup instead of four, 4 = votes on the caller's stream, 8 = no speculative first chunk, 16 = chains of four whatever the launch looks like, 32 = votes without chunk bitmaps
   int dbg;               // timing-only ablation mask (GR_OPT_DEBUG): 1 skip scanline loop, 2 skip id stores, 4 skip triangles,
                          // fused epilogue: 8 skip winner atomics, 16 skip label loads; set-up: 32 no entry compilation, 64 no
@@ -345,10 +348,14 @@ __global__ __launch_bounds__(256) void k_cull_blocks(const float *__restrict__ c
   }
 }
 
-__device__ __forceinline__ bool compile_entry(int4 *__restrict__ dst, uint8_t *__restrict__ nr8, const int4 p0, const int4 p1,
+__device__ __forceinline__ bool compile_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
+                                              uint8_t *__restrict__ nr8, int64_t idx, const int4 p0, const int4 p1,
                                               const int4 p2, int px0, int py0, int TW, int TH);
 __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const int4 p2, int px0, int py0, int TW, int TH,
                                             int4 &e0, int4 &e1, int4 &e2, int &rows);
+__device__ __forceinline__ void store_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
+                                            uint8_t *__restrict__ nr8, int64_t idx, const int4 e0, const int4 e1, const int4 e2,
+                                            int rows);
 __device__ __forceinline__ int wave_incl_scan(int x);
 
 // R1 / R2 / R4 for one face of the soup: the record (three int4) that compile_entry turns into per-tile entries, and the
@@ -443,11 +450,8 @@ __device__ __forceinline__ void bin_big_pairs(const BinArgs &a, uint32_t *__rest
     const uint32_t pos = __shfl(base, ld) + (uint32_t)rk;
     if (tile >= 0) {
       if (pos < (uint32_t)a.cap_tile) {
-        const int64_t idx = (int64_t)tile * a.cap_tile + pos;
-        int4 *dst = comp + idx * GR_ENT_Q;
-        dst[0] = e0; dst[1] = e1; dst[2] = e2;
-        nr8[idx] = (uint8_t)rows;
-      } else ctrl[2] = 1u;
+        store_entry(a, ctrl, comp, nr8, (int64_t)tile * a.cap_tile + pos, e0, e1, e2, rows);
+      } else atomicOr(&ctrl[2], 1u);
     }
   }
 }
@@ -535,8 +539,8 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ca
     if (small_fp && !(a.dbg & 32)) {
       if ((uint32_t)r3.x < (uint32_t)a.cap_tile) {
         const int64_t idx = (int64_t)t00 * a.cap_tile + (uint32_t)r3.x;
-        compile_entry(comp + idx * GR_ENT_Q, nr8 + idx, r0, r1, r2, tx0 << a.twl, ty0 << a.thl, TW, TH);
-      } else ctrl[2] = 1u;
+        compile_entry(a, ctrl, comp, nr8, idx, r0, r1, r2, tx0 << a.twl, ty0 << a.thl, TW, TH);
+      } else atomicOr(&ctrl[2], 1u);
     }
     const int shape = small_fp ? ((tx1 > tx0 ? 1 : 0) | (ty1 > ty0 ? 2 : 0)) : 0;  // which neighbours exist: 1 right, 2 below
     const int ne = shape == 3 ? 3 : (shape ? 1 : 0);
@@ -562,8 +566,8 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ca
         const int tx = (g & 0xFFF) + (k & 1), ty = ((g >> 12) & 0xFFF) + (k >> 1);
         if (pos < (uint32_t)a.cap_tile) {
           const int64_t idx = (int64_t)(ty * a.TX + tx) * a.cap_tile + pos;
-          compile_entry(comp + idx * GR_ENT_Q, nr8 + idx, p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH);
-        } else ctrl[2] = 1u;
+          compile_entry(a, ctrl, comp, nr8, idx, p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH);
+        } else atomicOr(&ctrl[2], 1u);
       }
     }
   }
@@ -622,6 +626,7 @@ __global__ __launch_bounds__(1024) void k_bin_stats(BinArgs a) {
     atomicAdd(&a.stats[1], total);
     atomicMax(&a.stats[2], (unsigned long long)m);  // direct mode: the largest per-tile count
     if (ovf) { atomicMax(&a.stats[3], 1ull); atomicMin(&a.stats[4], (unsigned long long)a.group); }
+    if (ctrl[2] & 2u) atomicMax(&a.stats[5], 1ull);  // a face the 40-byte entry form cannot hold
   }
 }
 
@@ -756,7 +761,8 @@ __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const 
   const bool narrow = max(max(abs(a0), abs(a1)), max(abs(a2), max(abs(dx0), max(abs(dx1), abs(dx2))))) <= 32767;
   int w3, w4, w5;
   if (narrow) {
-    w3 = pack16(af, am); w4 = pack16(bf, bm); w5 = 0;
+    w3 = pack16(af, am); w4 = pack16(bf, bm);
+    w5 = ext < GR_FAST_EXT ? 0 : 1;  // never read for 16-bit slopes; non-zero tells store_entry that the short form does not fit
   } else {
     w3 = (af & 0xFFFFFF) | (am << 24);
     w4 = ((am >> 8) & 0xFFFF) | (bf << 16);
@@ -772,13 +778,46 @@ __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const 
   return touches;
 }
 
-__device__ __forceinline__ bool compile_entry(int4 *__restrict__ dst, uint8_t *__restrict__ nr8, const int4 p0, const int4 p1,
+// The SHORT form of an entry, 40 bytes (single-pass binning, a.ent40): what a face whose snapped bounding box stays below
+// GR_FAST_EXT sub-pixels (93 px: every face of a survey mesh) needs -- the three edge constants are below 2^23 in magnitude
+// there (|E| < 24000 * 64640 before the shift by 8: build_entry), the offsets of vertex 0 from the tile's centre pixel below
+// 2^15 (half a tile + the face's extent), the slopes fit 16 bits:
+//   s0 = c_first      s1 = c_mid      s2 = c_last[0:24] | first row (6 bits, centred) << 24 | corr << 31
+//   s3 = X0rel (16) | Y0rel << 16               s4, s5 = the slope words w3, w4        s6, s7 = iz0, A
+//   s8 = ~face (an EVEN word: the key pair)     s9 = B
+// (the tile kernel unpacks it with as many instructions as the 48-byte form: the kernel's time follows its VALU count)
+// 17 % fewer bytes written here and read by the tile kernel than the 48-byte form (the binning tax of DESIGN.md section 10).
+// A face the short form cannot hold raises bit 1 of the view's overflow word: gr_raster_status reports GR_EOVERFLOW like
+// for a tile that outgrew its segment, remembers that this (mesh, image) needs 48-byte entries, and the caller repeats.
+__device__ __forceinline__ void store_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
+                                            uint8_t *__restrict__ nr8, int64_t idx, const int4 e0, const int4 e1, const int4 e2,
+                                            int rows) {
+  if (a.ent40) {
+    // e1.y (the third slope word) is zero for 16-bit slopes; bit 0 of it is build_entry's "too large for the short form"
+    if (e1.y != 0 || e2.w < 0) { atomicOr(&ctrl[2], 2u); return; }
+    // a chunk of 64 entries (2560 bytes) holds the 64 x {s0 .. s7} first, then the 64 x {s8, s9}: the tile kernel copies the
+    // chunk to LDS as it is and reads an entry with two 16-byte reads and one 8-byte read, all aligned
+    char *chunk = reinterpret_cast<char *>(comp) + (idx >> 6) * 2560;
+    const int t = (int)(idx & 63);
+    int4 *d4 = reinterpret_cast<int4 *>(chunk) + t * 2;
+    d4[0] = make_int4(e0.x, e0.y, (int)(((uint32_t)e0.z & 0xFFFFFFu) | ((uint32_t)e2.w & 0x3F000000u) | (((uint32_t)e2.w << 1) & 0x80000000u)),
+                      (int)(((uint32_t)e2.y & 0xFFFFu) | ((uint32_t)e2.w << 16)));
+    d4[1] = make_int4(e0.w, e1.x, e1.z, e1.w);
+    reinterpret_cast<uint2 *>(chunk + 2048)[t] = make_uint2((uint32_t)e2.z, (uint32_t)e2.x);
+  } else {
+    int4 *dst = comp + idx * GR_ENT_Q;
+    dst[0] = e0; dst[1] = e1; dst[2] = e2;
+  }
+  nr8[idx] = (uint8_t)rows;
+}
+
+__device__ __forceinline__ bool compile_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
+                                              uint8_t *__restrict__ nr8, int64_t idx, const int4 p0, const int4 p1,
                                               const int4 p2, int px0, int py0, int TW, int TH) {
   int4 e0, e1, e2;
   int rows;
   const bool touches = build_entry(p0, p1, p2, px0, py0, TW, TH, e0, e1, e2, rows);
-  dst[0] = e0; dst[1] = e1; dst[2] = e2;
-  *nr8 = (uint8_t)rows;
+  store_entry(a, ctrl, comp, nr8, idx, e0, e1, e2, rows);
   return touches;
 }
 
@@ -808,7 +847,7 @@ __global__ __launch_bounds__(256) void k_fill_compile(BinArgs a) {
         const int k = ((ty - ty0) << 1) | (tx - tx0);
         const uint32_t pk = (uint32_t)(k == 0 ? pos.x : k == 1 ? pos.y : k == 2 ? pos.z : pos.w);
         const int64_t idx = small_fp ? (int64_t)off[t] + pk : (int64_t)off[t] + cntS[t] + atomicAdd(&cur[t], 1u);
-        if (idx < a.ent_cap) compile_entry(comp + idx * GR_ENT_Q, nr8 + idx, p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH);
+        if (idx < a.ent_cap) compile_entry(a, ctrl, comp, nr8, idx, p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH);
       }
     }
   }
@@ -874,8 +913,8 @@ __device__ void emit_triangle(const BinArgs &a, int slot, uint32_t *ctrl, Vtx v0
         const uint32_t pos = atomicAdd(&cntS[t], 1u);
         if (pos < (uint32_t)a.cap_tile) {
           const int64_t idx = (int64_t)t * a.cap_tile + pos;
-          compile_entry(comp + idx * GR_ENT_Q, nr8 + idx, r0, r1, r2, tx << a.twl, ty << a.thl, 1 << a.twl, 1 << a.thl);
-        } else ctrl[2] = 1u;
+          compile_entry(a, ctrl, comp, nr8, idx, r0, r1, r2, tx << a.twl, ty << a.thl, 1 << a.twl, 1 << a.thl);
+        } else atomicOr(&ctrl[2], 1u);
       }
   } else {
     const uint32_t s = atomicAdd(&ctrl[0], 1u);
@@ -1118,43 +1157,81 @@ __device__ __forceinline__ uint32_t wave_incl_max(uint32_t x) {
 // instruction count: packed fp32 operands are broadcast by op_sel instead of being copied into register pairs, the
 // 64-bit key is formed in the pair the entry word ~face was read into, an odd span is extended to the LEFT (only the
 // first step has a spare slot, steered to the row's padding key), and the row addresses come from one multiply-add.
-template <int TWL, int TH, int PAD>
-__device__ __forceinline__ void raster_item(unsigned long long *keys, const int4 e0, const int4 e1, const int4 e2, const int r,
-                                            const bool live) {
-  constexpr int TW = 1 << TWL;
+// The fields of an entry the scanline code works with, from either form (store_entry).
+struct EntryView {
+  int c0, c1, c2, w3, w4, w5;   // edge constants, slope words
+  int X0rel, Y0rel, y_first;    // float(P - vertex 0) offsets of the centred pixel (0, 0); the entry's first row, centred
+  bool wide24, corr;            // 24-bit slope packing; a slope beyond GR_FLOOR_NOCORR_MAX
+  f32x2 izA;                    // {iz0, A}
+  float B;
+  uint32_t key;                 // ~face
+};
+
+__device__ __forceinline__ EntryView entry_view(const int4 e0, const int4 e1, const int4 e2) {
+  EntryView v;
+  v.c0 = e0.x; v.c1 = e0.y; v.c2 = e0.z; v.w3 = e0.w; v.w4 = e1.x; v.w5 = e1.y;
   const int xw = e2.y, yw = e2.w;
-  const int X0rel = (xw << 8) >> 8;  // biased by TW/2 columns: float(P_x - X0) = float(256 x_c + X0rel)
-  const int Y0rel = (yw << 8) >> 8;  // biased by TH/2 rows
-  const int yc = ((yw << 2) >> 26) + r;  // centred row of the item: the entry's first row + the item's row within the entry
+  v.X0rel = (xw << 8) >> 8;     // biased by TW/2 columns: float(P_x - X0) = float(256 x_c + X0rel)
+  v.Y0rel = (yw << 8) >> 8;     // biased by TH/2 rows
+  v.y_first = (yw << 2) >> 26;
+  v.wide24 = yw < 0;
+  v.corr = (uint32_t)yw >= 0x40000000u;  // compile_entry's flags: 24-bit slopes or a slope beyond 16000
+  v.izA.x = __int_as_float(e1.z); v.izA.y = __int_as_float(e1.w);  // the two words as the entry holds them
+  v.B = __int_as_float(e2.x);
+  v.key = (uint32_t)e2.z;
+  return v;
+}
+
+// the 40-byte form: five 8-byte words (store_entry)
+__device__ __forceinline__ EntryView entry_view(const uint2 s01, const uint2 s23, const uint2 s45, const uint2 s67, const uint2 s89) {
+  EntryView v;
+  v.c0 = (int)s01.x; v.c1 = (int)s01.y;
+  v.c2 = __builtin_amdgcn_sbfe(s23.x, 0, 24);
+  v.w3 = (int)s45.x; v.w4 = (int)s45.y; v.w5 = 0;
+  v.X0rel = __builtin_amdgcn_sbfe(s23.y, 0, 16);
+  v.Y0rel = (int)s23.y >> 16;
+  v.y_first = __builtin_amdgcn_sbfe(s23.x, 24, 6);
+  v.wide24 = false;
+  v.corr = (int)s23.x < 0;
+  v.izA.x = __uint_as_float(s67.x); v.izA.y = __uint_as_float(s67.y);
+  v.B = __uint_as_float(s89.y);
+  v.key = s89.x;
+  return v;
+}
+
+template <int TWL, int TH, int PAD>
+__device__ __forceinline__ void raster_item(unsigned long long *keys, const EntryView &e, const int r, const bool live) {
+  constexpr int TW = 1 << TWL;
+  const int X0rel = e.X0rel, Y0rel = e.Y0rel;
+  const int yc = e.y_first + r;  // centred row of the item: the entry's first row + the item's row within the entry
   // faces with a slope beyond GR_FLOOR_NOCORR_MAX (edges longer than 62 pixels) or 24-bit slopes take the span solver
   // with the exact correction; the choice is made per wave so that the usual case carries no extra instructions
-  const bool wide24 = yw < 0;
-  const bool wide = live && ((uint32_t)yw >= 0x40000000u);  // compile_entry's flags: 24-bit slopes or a slope beyond 16000
+  const bool wide24 = e.wide24;
+  const bool wide = live && e.corr;
   int xs = 0, xe = -1;
   if (__ballot(wide) != 0ull) {
-    if (live) span_solve<TW, true>(e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, wide24, yc, xs, xe);
+    if (live) span_solve<TW, true>(e.c0, e.c1, e.c2, e.w3, e.w4, e.w5, wide24, yc, xs, xe);
   } else {
-    if (live) span_solve<TW, false>(e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, false, yc, xs, xe);
+    if (live) span_solve<TW, false>(e.c0, e.c1, e.c2, e.w3, e.w4, e.w5, false, yc, xs, xe);
   }
   // two pixels per step with packed fp32 math (v_pk_mul_f32 / v_pk_add_f32: same IEEE results as the scalar forms,
   // R4 op for op: z = iz0 + (A * float(P_x - X0) + B * float(P_y - Y0))).  float(P_x - X0) advances by exact float adds
   // (integers below 2^24).
   if (live && xs <= xe) {
-    const float m1 = __int_as_float(e2.x) * (float)(yc * 256 + Y0rel);
+    const float m1 = e.B * (float)(yc * 256 + Y0rel);
     const bool even = ((xe - xs) & 1) != 0;       // an even number of pixels xs .. xe
     const int x0 = even ? xs : xs - 1;            // x0 .. xe is always an even number; pixel xs - 1 is computed, not stored
     const float fx0 = (float)(x0 * 256 + X0rel);
     f32x2 fx = {fx0, fx0 + 256.0f};
     const f32x2 step = {512.0f, 512.0f};
-    f32x2 izA;                                    // {iz0, A}: the two words as the entry holds them
-    izA.x = __int_as_float(e1.z); izA.y = __int_as_float(e1.w);
+    const f32x2 izA = e.izA;                      // {iz0, A}: the two words as the entry holds them
     f32x2 mp;
     mp.x = m1;                                    // the high half is never selected (op_sel_hi)
     // byte offset of the row's centred column 0: the key rows are (TW + PAD) * 8 bytes apart
     const int row = __mul24(yc, (TW + PAD) * 8) + ((TH / 2) * (TW + PAD) + TW / 2) * 8;
     int kp = row + x0 * 8;
     const int kend = row + xe * 8;
-    const uint32_t key_a = (uint32_t)e2.z;
+    const uint32_t key_a = e.key;
     uint32_t key_b = key_a;                       // a second copy: each pixel of a step forms its key in its own pair
     asm("v_mov_b32 %0, %1" : "=v"(key_b) : "v"(key_a));
     auto pixel_pair = [&](bool first_too) {
@@ -1180,9 +1257,9 @@ __device__ __forceinline__ void raster_item(unsigned long long *keys, const int4
 // item -> entry: an entry that starts inside the batch posts gen | lane | slot into the mailbox of its start slot; the
 // words of the current batch are larger than any stale one (gen grows), and among them the latest start is the largest,
 // so an unsigned prefix maximum over the RAW words carries the right entry to every item lane.
-template <int TWL, int TH, int NW, int PAD, typename EntPtr>
+template <int TWL, int TH, int NW, int PAD, bool SHORT>
 __device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, const int tab_base, const int tab_self, uint32_t &gen,
-                                                   EntPtr ent, const int nrows, const int lane,
+                                                   const int4 *ent, const int nrows, const int lane,
                                                    const int first_b, const int dbg) {
   char *const lds = reinterpret_cast<char *>(keys);
   const int incl = wave_incl_scan(nrows);
@@ -1202,8 +1279,15 @@ __device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, con
     const int t = started ? (int)((m >> 6) & 63u) : carry_t;  // always an entry of this chunk, also beyond the last item
     const int r = lane - (started ? (int)(m & 63u) : -carry_r);  // the item's row within its entry
     const bool live = q < total;
-    const int4 e0 = ent[t * 3], e1 = ent[t * 3 + 1], e2 = ent[t * 3 + 2];
-    raster_item<TWL, TH, PAD>(keys, e0, e1, e2, r, live);
+    if (SHORT) {
+      const int4 ea = ent[t * 2], eb = ent[t * 2 + 1];
+      const uint2 s89 = reinterpret_cast<const uint2 *>(ent)[256 + t];
+      raster_item<TWL, TH, PAD>(keys, entry_view(make_uint2(ea.x, ea.y), make_uint2(ea.z, ea.w), make_uint2(eb.x, eb.y),
+                                                 make_uint2(eb.z, eb.w), s89), r, live);
+    } else {
+      const int4 e0 = ent[t * 3], e1 = ent[t * 3 + 1], e2 = ent[t * 3 + 2];
+      raster_item<TWL, TH, PAD>(keys, entry_view(e0, e1, e2), r, live);
+    }
   }
   return (total + 63) >> 6;
 }
@@ -1335,7 +1419,13 @@ __device__ __forceinline__ void tile_list(const BinArgs &a, const uint32_t *__re
 // the workgroup's next tiles; they are waited for together with this tile's (GR_WAIT_CHUNKS) on every path, so that the compiler
 // finds no path on which a request is still open when the next tile starts -- it would wait for this tile's stores there
 // (loads and stores share one in-order counter).
-template <int TWL, int THL, int NT, bool FUSE, int PAD>
+// 16-byte piece q (0 .. 159) of a chunk that holds n (1 .. 64) entries in the short form: the front of the 32-byte parts or the
+// front of the 8-byte parts (store_entry) -- is it needed?
+__device__ __forceinline__ bool short_piece_needed(uint32_t q, uint32_t n) {
+  return (q < 2 * n) | ((q >= 128) & (q < 128 + ((n + 1) >> 1)));  // no short-circuit: one predicate, one branch around the load
+}
+
+template <int TWL, int THL, int NT, bool FUSE, int PAD, bool SHORT>
 __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOut &out, unsigned long long *keys, const int slot,
                                                 const int tile, uint32_t cnt, const int64_t beg, const uint8_t nr_first, int4 ex,
                                                 int4 ex_b, int4 ex_c, int4 ex_d) {
@@ -1351,7 +1441,11 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
   const int64_t plane = (int64_t)slot * P;
   const int tx = tile % a.TX, ty = tile / a.TX;
   const int px0 = tx << TWL, py0 = ty << THL;
-  const int4 *comp = a.comp + (slot * a.ent_cap + beg) * GR_ENT_Q;
+  constexpr int EL = SHORT ? 40 : 48;  // 16-byte pieces of a 64-entry chunk per wave (4 waves): 40 or 48 bytes per entry
+  // the tile's list: the slot's entry memory is laid out for 48-byte entries; the short form packs chunks of 64 40-byte
+  // entries at the front of the tile's segment (tile * cap_tile is a multiple of 64 whenever the short form is chosen)
+  const int4 *comp = SHORT ? reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(a.comp + slot * a.ent_cap * GR_ENT_Q) + beg * 40)
+                           : a.comp + (slot * a.ent_cap + beg) * GR_ENT_Q;
   const uint8_t *nr8 = a.nrow8 + slot * a.ent_cap + beg;
 
 #define GR_WAIT_CHUNKS()                                                                                                  \
@@ -1385,27 +1479,28 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
      // for the first one's stores)
     GR_WAIT_CHUNKS();
 #undef GR_WAIT_CHUNKS
-    if (lane < 48) ent_lds[wv * 48 + lane] = ex;
+    if (lane < EL) ent_lds[wv * EL + lane] = ex;
     __syncthreads();  // keys filled, chunk visible
     GR_PRIO_ITEMS();
     const int nrows = (uint32_t)lane < cnt ? (int)nr_first : 0;
-    const int nb = raster_chunk_gather<TWL, TH, NW, PAD, const int4 *>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot, a.dbg);
+    const int nb = raster_chunk_gather<TWL, TH, NW, PAD, SHORT>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot, a.dbg);
     rot = (rot - nb) & (NW - 1);
   }
 #pragma unroll 1
   for (uint32_t c0 = 64; c0 < cnt; c0 += 64) {
     GR_PRIO_MEM();
     __syncthreads();  // every wave is done with the previous chunk before it is overwritten
-    if (lane < 48) {
-      const uint32_t q = c0 * GR_ENT_Q + wv * 48 + lane;
-      if (q < cnt * GR_ENT_Q) ex = comp[q];
-      ent_lds[wv * 48 + lane] = ex;
+    if (lane < EL) {
+      const uint32_t qc = wv * EL + lane;  // piece of the chunk
+      const uint32_t q = (SHORT ? (c0 >> 1) * 5 : c0 * GR_ENT_Q) + qc;
+      if (SHORT ? short_piece_needed(qc, min(cnt - c0, 64u)) : q < cnt * GR_ENT_Q) ex = comp[q];
+      ent_lds[wv * EL + lane] = ex;
     }
     __syncthreads();
     GR_PRIO_ITEMS();
     const uint32_t e = c0 + (uint32_t)lane;
     const int nrows = e < cnt ? (int)nr8[e] : 0;
-    const int nb = raster_chunk_gather<TWL, TH, NW, PAD, const int4 *>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot, a.dbg);
+    const int nb = raster_chunk_gather<TWL, TH, NW, PAD, SHORT>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot, a.dbg);
     rot = (rot - nb) & (NW - 1);
   }
 
@@ -1452,7 +1547,7 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
 // fused kernel is not (left at the default).  Work items of two consecutive rows (look-up, unpack and the reciprocals paid
 // once per two rows: -16 % VALU instructions) were measured as well: 74 VGPRs and half as many batches per tile for four
 // waves -- 15.6 vs 16.0 without the hint, 16.3 vs 15.3 with it, fused 18.3 vs 17.2 -- dropped.
-template <int TWL, int THL, int NT, bool FUSE, int KT, int PAD>
+template <int TWL, int THL, int NT, bool FUSE, int KT, int PAD, bool SHORT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (THL == 5 ? 7 : 4), 8))) void k_raster_tile(BinArgs a, RasterOut out) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   constexpr int NKEYS = (TW + PAD) * TH;
@@ -1461,7 +1556,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (
   // the kernel's only LDS: keys (17.25 KiB for 64x32) + mailboxes (1 KiB) + one chunk of entries (3 KiB) -> 7 workgroups/CU
   // (20 KiB -- 4 padding keys per row with the mailboxes inside the padding -- gives 8, and loses more to LDS bank
   // conflicts than it gains: plain 16.6 vs 16.3 us per C2 view, fused 19.8 vs 17.9)
-  __shared__ __attribute__((aligned(16))) unsigned long long keys[NKEYS + NMAIL + 64 * 6];
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[NKEYS + NMAIL + 64 * (SHORT ? 5 : 6)];
   static_assert(NT == 256, "the entry copy deals 48 int4 to each of 4 waves");
   static_assert(NKEYS % 2 == 0 && TH % 32 == 0, "key pairs; two 16-row passes per fused group");
   static_assert(KT == 1 || KT == 4, "one tile per workgroup, or a chain of four");
@@ -1471,13 +1566,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (
   const bool spec = a.cap_tile >= 64 && !(a.var & 8);
   const int tile0 = KT * (int)blockIdx.x;
   const int n_tiles = min(KT, a.T - tile0);
-  const uint32_t q = wv * 48 + lane;  // this thread's 16-byte piece of a 3 KiB chunk (lanes 0 .. 47 of every wave)
+  constexpr int EL = SHORT ? 40 : 48;
+  const uint32_t q = wv * EL + lane;  // this thread's 16-byte piece of a 3 KiB (2.5 KiB) chunk (lanes 0 .. 47 (39) of every wave)
+  // 16-byte pieces of the view's entry memory from entry `first` on, and the number of pieces `n` entries take
+  auto pieces = [&](int64_t first) {
+    const int4 *base = a.comp + (int64_t)slot * a.ent_cap * GR_ENT_Q;
+    return SHORT ? reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(base) + first * 40) : base + first * GR_ENT_Q;
+  };
+  auto needed = [](uint32_t q, uint32_t n) { return SHORT ? short_piece_needed(q, min(n, 64u)) : q < n * GR_ENT_Q; };
   uint8_t nr0 = 0, nr1 = 0, nr2 = 0, nr3 = 0;
   int4 ex0, ex1, ex2, ex3;
   if (spec) {
-    const int64_t seg = slot * a.ent_cap + (int64_t)tile0 * a.cap_tile;
-    nr0 = a.nrow8[seg + lane];
-    if (lane < 48) ex0 = a.comp[seg * GR_ENT_Q + q];
+    const int64_t seg = (int64_t)tile0 * a.cap_tile;
+    nr0 = a.nrow8[slot * a.ent_cap + seg + lane];
+    if (lane < EL) ex0 = pieces(seg)[q];
   }
   const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
   uint32_t cnt0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
@@ -1492,22 +1594,33 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (
   const int64_t sbase = slot * a.ent_cap;
   if (!spec) {  // exact binning (or segments under 64 slots): the first chunk can only be requested now
     if ((uint32_t)lane < cnt0) nr0 = a.nrow8[sbase + beg0 + lane];
-    if (lane < 48 && q < cnt0 * GR_ENT_Q) ex0 = a.comp[(sbase + beg0) * GR_ENT_Q + q];
+    if ((lane < EL) & needed(q, cnt0)) ex0 = pieces(beg0)[q];
   }
   if (KT > 1) {
+    // The form of these requests decides where the compiler puts its s_waitcnt vmcnt (loads and stores share one in-order
+    // counter, and its bookkeeping across the loop over tiles 1 .. 3 is conservative).  Short entries, measured on one box
+    // against 48-byte entries at 15.0 / 16.3 us per C2 view (plain / fused): a short-circuit predicate under nested branches
+    // -- the register tuples are split and tile 1's chunk is WAITED for before tile 2's is requested: 15.5 / 16.85; every
+    // lane loading (piece 0 where it needs nothing), no branch -- fine in the fused kernel (16.4), but the ids-only kernel
+    // then waits inside the tile loop, i.e. for the previous tile's STORES: 15.7; one predicate, one branch -- fine in the
+    // ids-only kernel (15.05), an early wait in the fused one.  Hence one form per kernel; tests/test_isa_waits.py counts the
+    // waits of the built kernels so that a compiler or source change that brings one back does not go unnoticed.
     if ((uint32_t)lane < cnt1) nr1 = a.nrow8[sbase + beg1 + lane];
-    if (lane < 48 && q < cnt1 * GR_ENT_Q) ex1 = a.comp[(sbase + beg1) * GR_ENT_Q + q];
+    if (SHORT && FUSE) ex1 = pieces(beg1)[((lane < EL) & needed(q, cnt1)) ? q : 0u];
+    else if ((lane < EL) & needed(q, cnt1)) ex1 = pieces(beg1)[q];
     if ((uint32_t)lane < cnt2) nr2 = a.nrow8[sbase + beg2 + lane];
-    if (lane < 48 && q < cnt2 * GR_ENT_Q) ex2 = a.comp[(sbase + beg2) * GR_ENT_Q + q];
+    if (SHORT && FUSE) ex2 = pieces(beg2)[((lane < EL) & needed(q, cnt2)) ? q : 0u];
+    else if ((lane < EL) & needed(q, cnt2)) ex2 = pieces(beg2)[q];
     if ((uint32_t)lane < cnt3) nr3 = a.nrow8[sbase + beg3 + lane];
-    if (lane < 48 && q < cnt3 * GR_ENT_Q) ex3 = a.comp[(sbase + beg3) * GR_ENT_Q + q];
+    if (SHORT && FUSE) ex3 = pieces(beg3)[((lane < EL) & needed(q, cnt3)) ? q : 0u];
+    else if ((lane < EL) & needed(q, cnt3)) ex3 = pieces(beg3)[q];
   }
-  raster_one_tile<TWL, THL, NT, FUSE, PAD>(a, out, keys, slot, tile0, cnt0, beg0, nr0, ex0, ex1, ex2, ex3);
+  raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT>(a, out, keys, slot, tile0, cnt0, beg0, nr0, ex0, ex1, ex2, ex3);
   if (KT > 1) {
 #pragma unroll 1
     for (int k = 1; k < n_tiles; ++k) {  // ONE copy of the tile code for tiles 1 .. 3: the chunks rotate through ex1
       __syncthreads();                   // every wave has read the previous tile's keys
-      raster_one_tile<TWL, THL, NT, FUSE, PAD>(a, out, keys, slot, tile0 + k, cnt1, beg1, nr1, ex1, ex1, ex1, ex1);
+      raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT>(a, out, keys, slot, tile0 + k, cnt1, beg1, nr1, ex1, ex1, ex1, ex1);
       cnt1 = cnt2; cnt2 = cnt3; beg1 = beg2; beg2 = beg3;
       nr1 = nr2; nr2 = nr3; ex1 = ex2; ex2 = ex3;
     }
@@ -1961,8 +2074,9 @@ struct gr_ctx {
   int opt_var = 0;
   int opt_lds_pad = 0;   // extra dynamic LDS bytes per tile workgroup (occupancy experiments, GR_OPT_DEBUG_LDS)
   int opt_direct_cap = 512;  // single-pass binning: entry slots per tile (0 = always use the exact two-pass path)
-  struct Learned { int64_t F; int T, cap; };
-  Learned learned[8] = {};             // slots per tile learned from overflows, per (mesh size, tile count); [n_learned % 8] is replaced next
+  struct Learned { int64_t F; int T, cap; bool full; };
+  Learned learned[8] = {};             // slots per tile learned from overflows -- and whether the image has faces the 40-byte entry
+                                       // form cannot hold --, per (mesh size, tile count); [n_learned % 8] is replaced next
   int n_learned = 0;
   bool share_learned = true;           // consult / feed the process-wide table (off once GR_OPT_DIRECT_CAP was set by hand)
   int last_T = 0, last_B = 0;          // tile count and launch-group size of the last raster call
@@ -2000,31 +2114,54 @@ std::mutex g_learned_mu;
 gr_ctx::Learned g_learned[32];
 int g_n_learned = 0;
 
-int direct_cap(const gr_ctx *c, int T) {
-  if (c->opt_direct_cap <= 0 || !c->direct_ok) return 0;
+// what is known about images of T tiles of the current mesh: slots per tile (0: nothing learned) and the entry form
+void lookup_learned(const gr_ctx *c, int T, int &cap, bool &full) {
+  cap = 0; full = false;
   for (int i = 0; i < std::min(c->n_learned, 8); ++i)
-    if (c->learned[i].F == c->F && c->learned[i].T == T) return c->learned[i].cap;
+    if (c->learned[i].F == c->F && c->learned[i].T == T) { cap = c->learned[i].cap; full = c->learned[i].full; return; }
   if (c->share_learned) {
     std::lock_guard<std::mutex> lk(g_learned_mu);
     for (int i = 0; i < std::min(g_n_learned, 32); ++i)
-      if (g_learned[i].F == c->F && g_learned[i].T == T) return std::max(g_learned[i].cap, c->opt_direct_cap);
+      if (g_learned[i].F == c->F && g_learned[i].T == T) { cap = g_learned[i].cap; full = g_learned[i].full; return; }
   }
-  return c->opt_direct_cap;
 }
 
-void learn_cap(gr_ctx *c, int T, int cap) {
+int direct_cap(const gr_ctx *c, int T) {
+  if (c->opt_direct_cap <= 0 || !c->direct_ok) return 0;
+  int cap; bool full;
+  lookup_learned(c, T, cap, full);
+  return std::max(cap, c->opt_direct_cap);
+}
+
+// The 40-byte entry form (store_entry) is the default of the single-pass binning; images with faces it cannot hold (93 px
+// and more) are remembered like the slots per tile.  Variant bit 128: always 48 bytes.  The short form is laid out in chunks
+// of 64 entries (store_entry): a tile's segment must be a whole number of chunks -- slots per tile set by hand to anything
+// else: 48 bytes.
+bool entry_short(const gr_ctx *c, int T) {
+  const int dcap = direct_cap(c, T);
+  if (dcap <= 0 || (dcap & 63) || (c->opt_var & 128)) return false;
+  int cap; bool full;
+  lookup_learned(c, T, cap, full);
+  return !full;
+}
+
+// cap > 0: the slots per tile the image needs; full: it needs 48-byte entries (both are kept once learned)
+void learn(gr_ctx *c, int T, int cap, bool full) {
+  int old_cap; bool old_full;
+  lookup_learned(c, T, old_cap, old_full);
+  const gr_ctx::Learned v = {c->F, T, std::max(cap, old_cap), full || old_full};
   int i = 0;
   for (; i < std::min(c->n_learned, 8); ++i)
     if (c->learned[i].F == c->F && c->learned[i].T == T) break;
   if (i == std::min(c->n_learned, 8)) { i = c->n_learned % 8; c->n_learned += 1; }
-  c->learned[i] = {c->F, T, cap};
+  c->learned[i] = v;
   if (!c->share_learned) return;
   std::lock_guard<std::mutex> lk(g_learned_mu);
   int j = 0;
   for (; j < std::min(g_n_learned, 32); ++j)
     if (g_learned[j].F == c->F && g_learned[j].T == T) break;
   if (j == std::min(g_n_learned, 32)) { j = g_n_learned % 32; g_n_learned += 1; }
-  g_learned[j] = {c->F, T, cap};
+  g_learned[j] = v;
 }
 
 int fail(gr_ctx *c, int code, const char *fmt, ...) {
@@ -2125,6 +2262,7 @@ BinArgs make_args(gr_ctx *c, int h, int w, int slot0) {
   a.TX = (w + (1 << a.twl) - 1) >> a.twl; a.TY = (h + (1 << a.thl) - 1) >> a.thl; a.T = a.TX * a.TY; a.Tcap = c->Tcap;
   a.h = h; a.w = w; a.dbg = c->opt_dbg; a.var = c->opt_var;
   a.cap_tile = direct_cap(c, a.T);
+  a.ent40 = entry_short(c, a.T) ? 1 : 0;
   a.group = 0;
   return a;
 }
@@ -2186,8 +2324,11 @@ int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStr
     const size_t pad = (size_t)c->opt_lds_pad;
 #define GR_LAUNCH_TILE(THL_, FUSE_)                                                                                   \
   do {                                                                                                                \
-    if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD>), grid, block, pad, s, a, out);  \
-    else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD>), grid, block, pad, s, a, out);        \
+    if (a.ent40) {                                                                                                    \
+      if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD, true>), grid, block, pad, s, a, out);  \
+      else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD, true>), grid, block, pad, s, a, out);        \
+    } else if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD, false>), grid, block, pad, s, a, out);  \
+    else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD, false>), grid, block, pad, s, a, out);        \
   } while (0)
     if (out.winner) {
       if (a.thl == 6) GR_LAUNCH_TILE(6, true);
@@ -2281,6 +2422,7 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   c->last_stream = s;
   GR_HIP(c, hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 4, s));
   GR_HIP(c, hipMemsetAsync(c->stats + 4, 0xFF, sizeof(unsigned long long), s));  // first overflowed group: none
+  GR_HIP(c, hipMemsetAsync(c->stats + 5, 0, sizeof(unsigned long long), s));     // short-form miss: none
   c->last_n_views = n_views;
   int g = 0;
   for (int v0 = 0; v0 < n_views; v0 += B, ++g) {
@@ -2525,7 +2667,7 @@ int gr_raster_face_ids(gr_ctx *c, const float *cams, int n_views, int h, int w, 
 
 int gr_raster_status(gr_ctx *c, gr_raster_stats *o) {
   if (!c || !o) return GR_EINVAL;
-  unsigned long long st[5] = {0, 0, 0, 0, 0};
+  unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
   GR_HIP(c, hipMemcpyAsync(st, c->stats, sizeof(st), hipMemcpyDeviceToHost, c->last_stream));
   GR_HIP(c, hipStreamSynchronize(c->last_stream));
   o->records = (int64_t)st[0]; o->entries = (int64_t)st[1]; o->max_entries = (int64_t)st[2];
@@ -2535,15 +2677,22 @@ int gr_raster_status(gr_ctx *c, gr_raster_stats *o) {
                                                                 (unsigned long long)c->last_n_views)
                         : c->last_n_views;
   if (st[3] && c->last_direct) {
-    // A tile outgrew its fixed segment.  The counters kept counting, so the need is known: the retry uses segments of
-    // that size if a launch group's entry memory stays within budget, and bins exactly (count, scan, fill) otherwise.
+    // A tile outgrew its fixed segment, or a face did not fit the 40-byte entry form (st[5]).  The counters kept counting,
+    // so the need is known: the retry uses segments of that size if a launch group's entry memory stays within budget, and
+    // bins exactly (count, scan, fill) otherwise; it uses 48-byte entries if the short form was missed.
     const int used = direct_cap(c, c->last_T);
-    const int64_t need = ((int64_t)st[2] + (int64_t)st[2] / 8 + 16 + 63) / 64 * 64;
-    const int64_t bytes = need * (16 * GR_ENT_Q) * (int64_t)c->last_T * (int64_t)std::max(c->last_B, 1);
-    if (need <= 16384 && bytes <= GR_DIRECT_BUDGET) learn_cap(c, c->last_T, (int)need);
-    else c->direct_ok = false;
-    return fail(c, GR_EOVERFLOW, "single-pass binning overflow: a tile received %llu entries (slots per tile %d); "
-                "retry the call", st[2], used);
+    const bool grow = (int64_t)st[2] > used;
+    if (st[5] != 0) learn(c, c->last_T, 0, true);
+    if (grow) {
+      const int64_t need = ((int64_t)st[2] + (int64_t)st[2] / 8 + 16 + 63) / 64 * 64;
+      const int64_t bytes = need * (16 * GR_ENT_Q) * (int64_t)c->last_T * (int64_t)std::max(c->last_B, 1);
+      if (need <= 16384 && bytes <= GR_DIRECT_BUDGET) learn(c, c->last_T, (int)need, false);
+      else c->direct_ok = false;
+      return fail(c, GR_EOVERFLOW, "single-pass binning overflow: a tile received %llu entries (slots per tile %d); "
+                  "retry the call", st[2], used);
+    }
+    return fail(c, GR_EOVERFLOW, "single-pass binning: a face does not fit the 40-byte entry form; retry the call "
+                "(48-byte entries from now on)");
   }
   if (st[3]) {
     // grow on the next call: exact need is known

@@ -106,7 +106,10 @@ enum {
                                size of the launch (default: large launches of light tiles only); 32 = fused votes scan
                                every view's winners (default: only views whose cull pass reached the 256-face chunk);
                                64 = faces over more than 2 x 2 tiles go through a per-view list and a second kernel
-                               (default: expanded inside the set-up kernel)                                        */
+                               (default: expanded inside the set-up kernel); 128 = 48-byte entries always (default:
+                               the single-pass binning writes 40-byte entries and falls back to 48 bytes -- one
+                               GR_EOVERFLOW retry, remembered like the slots per tile -- for images with faces of
+                               93 pixels and more)                                                                  */
   GR_OPT_DEBUG_LDS = 98,    /* extra dynamic LDS bytes per tile workgroup: lowers occupancy (timing experiments)     */
   GR_OPT_DEBUG = 99         /* timing-only ablation mask for tools/ab_kernel.py: OUTPUTS BECOME WRONG          */
 };

@@ -16,10 +16,11 @@ pytestmark = pytest.mark.gpu
 # every raster test runs against each setting of the tuning knobs (include/geograster.h GR_OPT_*): (tile height log2,
 # slots per tile [0 = exact two-pass binning], GR_OPT_VARIANT bits: 1 = one tile per workgroup, 4 = votes on the caller's
 # stream, 8 = no speculative first chunk, 16 = chains of four tiles even in small launches, 32 = fused votes without the
-# chunk bitmaps, 64 = big faces through the view's big list and k_bin_big) -- every combination must give identical results
-VARIANTS = {"tile32_chain": (5, 512, 16), "tile64_single": (6, 512, 1), "tile32_exact_single": (5, 0, 5),
-            "tile64_exact_chain": (6, 0, 16), "tile32_single_nospec": (5, 512, 13), "tile32_chain_nospec_nobitmap": (5, 512, 56),
-            "tile32_chain_biglist": (5, 512, 80)}
+# chunk bitmaps, 64 = big faces through the view's big list and k_bin_big, 128 = 48-byte entries always instead of 40-byte
+# entries with a fallback) -- every combination must give identical results
+VARIANTS = {"tile32_chain": (5, 512, 16), "tile64_single_full": (6, 512, 129), "tile32_exact_single": (5, 0, 5),
+            "tile64_exact_chain": (6, 0, 16), "tile32_single_nospec_full": (5, 512, 141), "tile32_chain_nospec_nobitmap": (5, 512, 56),
+            "tile32_chain_biglist": (5, 512, 80), "tile64_single": (6, 512, 1)}
 
 
 @pytest.fixture(params=list(VARIANTS), autouse=True)

@@ -1,0 +1,68 @@
+"""The tile kernel's `s_waitcnt vmcnt` instructions, counted in the ISA the build produces.
+
+Loads and stores of a wave share ONE in-order memory counter on gfx950, and the compiler's bookkeeping of it across the loop
+over the tiles of a chain is conservative: with a small change of the source (the form of the chunk requests, a register more
+or less) it puts a wait for an already finished chunk load into the tile loop, where it waits for the previous tile's id
+STORES instead -- 5 % of the kernel, invisible in any functional test (measured in round 3, geograster.hip k_raster_tile).
+This test compiles the device code to assembly (no GPU needed) and holds the default kernels to the known-good numbers."""
+import re
+import subprocess
+
+import pytest
+
+from geograypher_amd import build as gbuild
+
+# (fused, short entries) -> s_waitcnt vmcnt instructions of k_raster_tile<6, 5, 256, fused, 4, 5, short>: the waits for the
+# chain's first chunks (once, before the first tile), for later chunks and their row counts inside a tile (2 per copy of the
+# tile code), and -- ids-only kernel -- the empty-tile path and ONE wait between the first tile and the loop over the others
+KNOWN_GOOD = {(False, False): 9, (False, True): 9, (True, False): 6, (True, True): 7}
+
+
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / "geograster.s"
+    flags = [f for f in gbuild.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    cmd = [gbuild.hipcc_path(), *flags, "-S", "--cuda-device-only", f"-I{gbuild.INCLUDE}", "-o", str(out), str(gbuild.SRC)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    return out.read_text().splitlines()
+
+
+def _kernel_body(lines, fused, short):
+    name = "_ZN12_GLOBAL__N_113k_raster_tileILi6ELi5ELi256ELb%dELi4ELi%dELb%dEEEvNS_7BinArgsENS_9RasterOutE:" % (
+        int(fused), _lds_pad(), int(short))
+    start = [i for i, l in enumerate(lines) if l.startswith(name)]
+    assert len(start) == 1, f"kernel symbol not found: {name}"
+    end = next(i for i in range(start[0], len(lines)) if lines[i].startswith(".Lfunc_end"))
+    return lines[start[0]:end]
+
+
+def _lds_pad():
+    m = re.search(r"#define GR_LDS_PAD (\d+)", gbuild.SRC.read_text())
+    return int(m.group(1))
+
+
+@pytest.mark.parametrize("fused,short", sorted(KNOWN_GOOD))
+def test_tile_kernel_has_no_new_memory_waits(device_asm, fused, short):
+    body = _kernel_body(device_asm, fused, short)
+    waits = [(i, l.strip()) for i, l in enumerate(body) if "s_waitcnt" in l and "vmcnt" in l]
+    assert len(waits) <= KNOWN_GOOD[(fused, short)], (
+        f"k_raster_tile<fused={fused}, short={short}> has {len(waits)} vmcnt waits, known-good build has "
+        f"{KNOWN_GOOD[(fused, short)]}: {waits} -- check that none of them sits in the loop over the chain's tiles")
+    # the chain's four chunk requests are issued back to back: no wait between the first and the last of them
+    loads = [i for i, l in enumerate(body) if "global_load_dwordx4" in l]
+    assert len(loads) >= 5
+    first_wait = waits[0][0]
+    # requests: speculative first chunk, exact first chunk (non-speculative path), tiles 1 - 3
+    assert first_wait > loads[4] or short and fused, (first_wait, loads[:6])
+
+
+def test_no_kernel_spills(device_asm):
+    """No kernel of this library uses scratch memory (rocPRIM's radix sort, instantiated for the sparse path, does)."""
+    cur, spills = None, []
+    for l in device_asm:
+        if l.startswith("_Z") and ":" in l:
+            cur = l.split(":")[0]
+        if "ScratchSize:" in l and not l.strip().endswith(" 0") and cur and cur.startswith("_ZN12_GLOBAL__N_1"):
+            spills.append((cur, l.strip()))
+    assert not spills, spills[:5]

@@ -91,3 +91,36 @@ def test_fused_call_resumes_after_a_later_launch_group_overflows(hip):
         hip.set_option(6, 512)
 
 
+
+
+def test_short_entries_fall_back_when_a_later_group_has_a_large_face(hip):
+    """The single-pass binning writes 40-byte entries, which hold faces below 93 pixels.  A call whose SECOND launch group has a
+    camera close to the ground (faces of several hundred pixels) must finish the first group in the short form, report the
+    miss like an overflow, repeat the rest with 48-byte entries -- same ids and votes as the 48-byte form from the start --
+    and remember it: the next call of the context does not retry."""
+    (points, faces), _ = synthetic.config1_scene()
+    C = 3
+    poses = [synthetic.nadir_pose(3.0 * k - 6.0, 2.0 * k - 4.0, 40.0, yaw_deg=20.0 * k) for k in range(4)]
+    poses += [synthetic.nadir_pose(1.0, -2.0, 4.5, yaw_deg=10.0), synthetic.nadir_pose(-5.0, 3.0, 35.0, yaw_deg=50.0)]
+    cams = synthetic.camera_set_from_poses(poses, f=500.0, width=640, height=480)
+    recs = _records(cams)
+    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+    hip.set_option(7, 128)                     # 48-byte entries from the start
+    want = hip.raster_face_ids(recs, 480, 640)
+    assert hip.last_retries == 0
+    for v in (0, 4):
+        np.testing.assert_array_equal(want[v].cpu().numpy(), oracle_c.raster(points, faces, recs[v], 480, 640))
+    labels = np.stack([synthetic.synthetic_labels(want[v].cpu().numpy(), v, C) for v in range(len(cams))])
+    want_v, want_c = hip.new_vote_buffers(C)
+    hip.project_labels(want, labels, C, want_v, want_c)
+    hip.set_option(7, 0)
+    hip.set_option(3, 4)                       # groups: views 0-3 (small faces) | 4-5 (view 4: large faces)
+    hip.set_option(6, 512)                     # forgets what the context has learned
+    got = hip.raster_face_ids(recs[:4], 480, 640)
+    assert hip.last_retries == 0 and torch.equal(got, want[:4])          # small faces only: the short form holds them
+    v2, c2 = hip.new_vote_buffers(C)
+    hip.raster_project_labels(recs, labels, C, v2, c2)
+    assert hip.last_retries == 1 and hip.last_stats["views_done"] == len(cams) and hip.last_stats["overflow"] == 0
+    assert torch.equal(v2, want_v) and torch.equal(c2, want_c)
+    got = hip.raster_face_ids(recs, 480, 640)
+    assert hip.last_retries == 0 and torch.equal(got, want)              # remembered

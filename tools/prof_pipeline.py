@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/prof_pipeline.py [views] [reps] [fused_views] -- the pix2face pipeline (C2 views) and the fused aggregation (C3 views,
+"""tools/prof_pipeline.py [views] [reps] [fused_views] [extra variant bits] -- the pix2face pipeline (C2 views) and the fused aggregation (C3 views,
 votes on the caller's stream) and nothing else, for rocprofv3 --pmc passes: rocprofv3's counter collection does not survive
 torch's own elementwise kernels (segfault inside at::native::gpu_kernel_impl) nor the library's side stream, so the labels
 come from the host and no torch kernel runs."""
@@ -19,7 +19,8 @@ nf = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 H, W, C = 3000, 4000, 4
 points, faces = synthetic.terrain_mesh()
 hip = HipRaster(0)
-hip.set_option(7, 4)  # GR_OPT_VARIANT: fused votes on the caller's stream
+xvar = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+hip.set_option(7, 4 | xvar)  # GR_OPT_VARIANT: fused votes on the caller's stream (+ the variant under study)
 hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
 recs = torch.from_numpy(synthetic.config2_cameras(50).get_raster_records(1.0, near=1.0)[:nv]).cuda()
 ids = torch.empty((nv, H, W), dtype=torch.int32, device="cuda")
