@@ -1125,6 +1125,7 @@ __device__ __forceinline__ void span_solve(int C0, int C1, int C2, int w3, int w
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 
 // Inclusive prefix sum over the 64 lanes with DPP moves only: the LDS pipe (ds_bpermute shuffles included) is the tile
 // kernel's scarcest resource, VALU issue is not (one extra ds_bpermute per 64-item batch costs 0.34 us per C2 view, 48
@@ -1414,26 +1415,24 @@ __device__ __forceinline__ void tile_list(const BinArgs &a, const uint32_t *__re
 #define GR_PRIO_MEM() __builtin_amdgcn_s_setprio(0)
 #define GR_PRIO_ITEMS() __builtin_amdgcn_s_setprio(3)
 
-// One tile: keys in LDS -> chunks of entries -> scanline items -> epilogue.  nr_first / ex: the tile's first chunk (row
-// counts and this lane's 16 bytes of the 3 KiB of entries), requested by the caller.  ex_b .. ex_d: the first chunks of
-// the workgroup's next tiles; they are waited for together with this tile's (GR_WAIT_CHUNKS) on every path, so that the compiler
-// finds no path on which a request is still open when the next tile starts -- it would wait for this tile's stores there
-// (loads and stores share one in-order counter).
 // 16-byte piece q (0 .. 159) of a chunk that holds n (1 .. 64) entries in the short form: the front of the 32-byte parts or the
 // front of the 8-byte parts (store_entry) -- is it needed?
 __device__ __forceinline__ bool short_piece_needed(uint32_t q, uint32_t n) {
   return (q < 2 * n) | ((q >= 128) & (q < 128 + ((n + 1) >> 1)));  // no short-circuit: one predicate, one branch around the load
 }
 
-template <int TWL, int THL, int NT, bool FUSE, int PAD, bool SHORT>
+// One tile: keys in LDS -> chunks of entries -> scanline items -> epilogue.  nr_first / ex: the tile's first chunk (row
+// counts and this lane's 16 bytes of the 3 KiB (2.5 KiB) of entries), requested by the caller -- and waited for by the caller
+// (a chain), or here behind the fill of the key tile (WAIT: one tile per workgroup -- the request's latency overlaps the fill).
+template <int TWL, int THL, int NT, bool FUSE, int PAD, bool SHORT, bool WAIT>
 __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOut &out, unsigned long long *keys, const int slot,
-                                                const int tile, uint32_t cnt, const int64_t beg, const uint8_t nr_first, int4 ex,
-                                                int4 ex_b, int4 ex_c, int4 ex_d) {
+                                                const int tile, uint32_t cnt, const int64_t beg, uint32_t nr_first, v4i ex) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   constexpr int NKEYS = (TW + PAD) * TH;
   constexpr int NW = NT / 64;
   constexpr int NMAIL = NW * 32;  // u64 units: 64 mailbox words per wave
   int4 *ent_lds = reinterpret_cast<int4 *>(keys + NKEYS + NMAIL);
+  v4i *ent_st = reinterpret_cast<v4i *>(ent_lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int ROWS_PER_PASS = NT / TW;
@@ -1448,10 +1447,7 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
                            : a.comp + (slot * a.ent_cap + beg) * GR_ENT_Q;
   const uint8_t *nr8 = a.nrow8 + slot * a.ent_cap + beg;
 
-#define GR_WAIT_CHUNKS()                                                                                                  \
-  asm volatile("" : "+v"(ex.x), "+v"(ex.y), "+v"(ex.z), "+v"(ex.w), "+v"(ex_b.x), "+v"(ex_c.x), "+v"(ex_d.x))
   if (!FUSE && cnt == 0) {  // empty tile (a view that overhangs the mesh): background, without the LDS round trip
-    GR_WAIT_CHUNKS();
     const int col = tid & (TW - 1), gx = px0 + col;
     if (gx < a.w && !(a.dbg & 2)) {
       for (int row = tid >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
@@ -1475,11 +1471,10 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
   }
   uint32_t gen = 0;
   int rot = wv;  // this wave's first batch of the current chunk
-  {  // first chunk: in registers already (no wait on the memory counter here: a second tile of the workgroup would wait
-     // for the first one's stores)
-    GR_WAIT_CHUNKS();
-#undef GR_WAIT_CHUNKS
-    if (lane < EL) ent_lds[wv * EL + lane] = ex;
+  {  // first chunk: in registers already, complete (k_raster_tile waits for every request of the chain before its first
+     // tile: a wait on the memory counter here would wait for the previous tile's stores)
+    if (WAIT) asm volatile("" : "+v"(ex), "+v"(nr_first));
+    if (lane < EL) ent_st[wv * EL + lane] = ex;
     __syncthreads();  // keys filled, chunk visible
     GR_PRIO_ITEMS();
     const int nrows = (uint32_t)lane < cnt ? (int)nr_first : 0;
@@ -1493,8 +1488,8 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
     if (lane < EL) {
       const uint32_t qc = wv * EL + lane;  // piece of the chunk
       const uint32_t q = (SHORT ? (c0 >> 1) * 5 : c0 * GR_ENT_Q) + qc;
-      if (SHORT ? short_piece_needed(qc, min(cnt - c0, 64u)) : q < cnt * GR_ENT_Q) ex = comp[q];
-      ent_lds[wv * EL + lane] = ex;
+      if (SHORT ? short_piece_needed(qc, min(cnt - c0, 64u)) : q < cnt * GR_ENT_Q) ex = reinterpret_cast<const v4i *>(comp)[q];
+      ent_st[wv * EL + lane] = ex;
     }
     __syncthreads();
     GR_PRIO_ITEMS();
@@ -1536,12 +1531,12 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
   }
 }
 
-// K3  the tile kernel.  KT = 4: a workgroup takes four consecutive tiles one after the other.  The first tile's first chunk
-//     is requested before its count is known (the segment address is static; slots beyond the count hold stale data that
-//     nobody reads), the other three EXACTLY, as soon as the four counts are there -- they arrive while the first tile is
-//     rasterized: three of four waits for memory disappear, and so do three quarters of the stale requests (9 MB of the
-//     67 MB a C2 view moves).  All counts are read before any store: they are scalar loads there, and a vector load behind
-//     a tile's stores would wait for those stores (one in-order counter).
+// K3  the tile kernel.  KT = 4: a workgroup takes four consecutive tiles one after the other.  The four counts are read
+//     first (scalar loads), then the first chunks of all four tiles are requested EXACTLY, together, and waited for together
+//     before the first tile starts: one wait for memory per chain instead of four, no stale slots fetched.  (Waiting for
+//     tile k's chunk only when tile k starts would wait for tile k - 1's id stores: loads and stores share one in-order
+//     counter.)  KT = 1 -- heavy scenes, small launches --: the first chunk is requested before the count is known (the
+//     segment address is static; slots beyond the count hold stale data that nobody reads).
 // The ids-only kernel asks the compiler for 7 waves per SIMD -- what its LDS allows anyway: the schedule the compiler picks
 // under that hint is 3-4 % faster (15.8 -> 15.2 us per C2 view, builds alternated on one box with tools/ab_builds.sh); the
 // fused kernel is not (left at the default).  Work items of two consecutive rows (look-up, unpack and the reciprocals paid
@@ -1563,19 +1558,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (
   const int slot = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const bool spec = a.cap_tile >= 64 && !(a.var & 8);
+  // one tile per workgroup: the first chunk is requested before the count is known (one round trip less).  A chain waits
+  // for the exact requests of its tiles 1 - 3 anyway before it starts: requesting its first tile's chunk early saves
+  // nothing there (14.9 us per C2 view either way) and fetches 1.6 MB of stale slots per view -- not done
+  const bool spec = KT == 1 && a.cap_tile >= 64 && !(a.var & 8);
   const int tile0 = KT * (int)blockIdx.x;
   const int n_tiles = min(KT, a.T - tile0);
   constexpr int EL = SHORT ? 40 : 48;
   const uint32_t q = wv * EL + lane;  // this thread's 16-byte piece of a 3 KiB (2.5 KiB) chunk (lanes 0 .. 47 (39) of every wave)
   // 16-byte pieces of the view's entry memory from entry `first` on, and the number of pieces `n` entries take
   auto pieces = [&](int64_t first) {
-    const int4 *base = a.comp + (int64_t)slot * a.ent_cap * GR_ENT_Q;
-    return SHORT ? reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(base) + first * 40) : base + first * GR_ENT_Q;
+    const v4i *base = reinterpret_cast<const v4i *>(a.comp + (int64_t)slot * a.ent_cap * GR_ENT_Q);
+    return SHORT ? reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(base) + first * 40) : base + first * GR_ENT_Q;
   };
   auto needed = [](uint32_t q, uint32_t n) { return SHORT ? short_piece_needed(q, min(n, 64u)) : q < n * GR_ENT_Q; };
-  uint8_t nr0 = 0, nr1 = 0, nr2 = 0, nr3 = 0;
-  int4 ex0, ex1, ex2, ex3;
+  uint32_t nr0 = 0, nr1 = 0, nr2 = 0, nr3 = 0;
+  v4i ex0, ex1, ex2, ex3;  // whole 16-byte register tuples (the wait macro of raster_one_tile names them as such: with the
+                           // components of an int4 struct named one by one the compiler split the tuples after the load -- and
+                           // waited for each load right behind its request)
   if (spec) {
     const int64_t seg = (int64_t)tile0 * a.cap_tile;
     nr0 = a.nrow8[slot * a.ent_cap + seg + lane];
@@ -1597,30 +1597,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (
     if ((lane < EL) & needed(q, cnt0)) ex0 = pieces(beg0)[q];
   }
   if (KT > 1) {
-    // The form of these requests decides where the compiler puts its s_waitcnt vmcnt (loads and stores share one in-order
-    // counter, and its bookkeeping across the loop over tiles 1 .. 3 is conservative).  Short entries, measured on one box
-    // against 48-byte entries at 15.0 / 16.3 us per C2 view (plain / fused): a short-circuit predicate under nested branches
-    // -- the register tuples are split and tile 1's chunk is WAITED for before tile 2's is requested: 15.5 / 16.85; every
-    // lane loading (piece 0 where it needs nothing), no branch -- fine in the fused kernel (16.4), but the ids-only kernel
-    // then waits inside the tile loop, i.e. for the previous tile's STORES: 15.7; one predicate, one branch -- fine in the
-    // ids-only kernel (15.05), an early wait in the fused one.  Hence one form per kernel; tests/test_isa_waits.py counts the
-    // waits of the built kernels so that a compiler or source change that brings one back does not go unnoticed.
     if ((uint32_t)lane < cnt1) nr1 = a.nrow8[sbase + beg1 + lane];
-    if (SHORT && FUSE) ex1 = pieces(beg1)[((lane < EL) & needed(q, cnt1)) ? q : 0u];
-    else if ((lane < EL) & needed(q, cnt1)) ex1 = pieces(beg1)[q];
+    if ((lane < EL) & needed(q, cnt1)) ex1 = pieces(beg1)[q];
     if ((uint32_t)lane < cnt2) nr2 = a.nrow8[sbase + beg2 + lane];
-    if (SHORT && FUSE) ex2 = pieces(beg2)[((lane < EL) & needed(q, cnt2)) ? q : 0u];
-    else if ((lane < EL) & needed(q, cnt2)) ex2 = pieces(beg2)[q];
+    if ((lane < EL) & needed(q, cnt2)) ex2 = pieces(beg2)[q];
     if ((uint32_t)lane < cnt3) nr3 = a.nrow8[sbase + beg3 + lane];
-    if (SHORT && FUSE) ex3 = pieces(beg3)[((lane < EL) & needed(q, cnt3)) ? q : 0u];
-    else if ((lane < EL) & needed(q, cnt3)) ex3 = pieces(beg3)[q];
+    if ((lane < EL) & needed(q, cnt3)) ex3 = pieces(beg3)[q];
   }
-  raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT>(a, out, keys, slot, tile0, cnt0, beg0, nr0, ex0, ex1, ex2, ex3);
+  // ONE wait for everything requested above, named as whole register tuples and BEFORE the first tile: behind this statement
+  // the values are the statement's outputs, not loads in flight, so the compiler's bookkeeping of the (single, in-order)
+  // memory counter has nothing left to wait for in the loop over tiles 1 .. 3 -- where a wait means waiting for the
+  // previous tile's id stores (tests/test_isa_waits.py)
+  if (KT > 1) asm volatile("" : "+v"(ex0), "+v"(ex1), "+v"(ex2), "+v"(ex3), "+v"(nr0), "+v"(nr1), "+v"(nr2), "+v"(nr3));
+  raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, KT == 1>(a, out, keys, slot, tile0, cnt0, beg0, nr0, ex0);
   if (KT > 1) {
 #pragma unroll 1
     for (int k = 1; k < n_tiles; ++k) {  // ONE copy of the tile code for tiles 1 .. 3: the chunks rotate through ex1
       __syncthreads();                   // every wave has read the previous tile's keys
-      raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT>(a, out, keys, slot, tile0 + k, cnt1, beg1, nr1, ex1, ex1, ex1, ex1);
+      raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, false>(a, out, keys, slot, tile0 + k, cnt1, beg1, nr1, ex1);
       cnt1 = cnt2; cnt2 = cnt3; beg1 = beg2; beg2 = beg3;
       nr1 = nr2; nr2 = nr3; ex1 = ex2; ex2 = ex3;
     }

@@ -12,10 +12,10 @@ import pytest
 
 from geograypher_amd import build as gbuild
 
-# (fused, short entries) -> s_waitcnt vmcnt instructions of k_raster_tile<6, 5, 256, fused, 4, 5, short>: the waits for the
-# chain's first chunks (once, before the first tile), for later chunks and their row counts inside a tile (2 per copy of the
-# tile code), and -- ids-only kernel -- the empty-tile path and ONE wait between the first tile and the loop over the others
-KNOWN_GOOD = {(False, False): 9, (False, True): 9, (True, False): 6, (True, True): 7}
+# (fused, short entries) -> s_waitcnt vmcnt instructions of k_raster_tile<6, 5, 256, fused, 4, 5, short>: ONE wait for all
+# requests of the chain before its first tile, and the waits for later chunks and their row counts inside a tile (2 per copy
+# of the tile code, 2 copies) -- none for the empty-tile path, none between or inside the tiles of the chain
+KNOWN_GOOD = {(False, False): 5, (False, True): 5, (True, False): 5, (True, True): 5}
 
 
 @pytest.fixture(scope="module")
@@ -51,10 +51,8 @@ def test_tile_kernel_has_no_new_memory_waits(device_asm, fused, short):
         f"{KNOWN_GOOD[(fused, short)]}: {waits} -- check that none of them sits in the loop over the chain's tiles")
     # the chain's four chunk requests are issued back to back: no wait between the first and the last of them
     loads = [i for i, l in enumerate(body) if "global_load_dwordx4" in l]
-    assert len(loads) >= 5
-    first_wait = waits[0][0]
-    # requests: speculative first chunk, exact first chunk (non-speculative path), tiles 1 - 3
-    assert first_wait > loads[4] or short and fused, (first_wait, loads[:6])
+    assert len(loads) >= 4
+    assert waits[0][0] > loads[3], (waits[:3], loads[:5])
 
 
 def test_no_kernel_spills(device_asm):
