@@ -1584,11 +1584,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (
   const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
   uint32_t cnt0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
   int64_t beg0, beg1 = 0, beg2 = 0, beg3 = 0;
-  tile_list(a, ctrl, tile0, cnt0, beg0);
-  if (KT > 1) {
-    if (n_tiles > 1) tile_list(a, ctrl, tile0 + 1, cnt1, beg1);
-    if (n_tiles > 2) tile_list(a, ctrl, tile0 + 2, cnt2, beg2);
-    if (n_tiles > 3) tile_list(a, ctrl, tile0 + 3, cnt3, beg3);
+  if (KT == 4 && a.cap_tile > 0) {
+    // single-pass binning: the chain's four counters sit side by side, 16-byte aligned -- ONE scalar load instead of four
+    // dependent ones, each behind its own wait (words behind the last tile's belong to the next counter array: valid memory)
+    const uint4 c4 = *reinterpret_cast<const uint4 *>(ctrl + GR_CTRL_HDR + tile0);
+    const uint32_t cap = (uint32_t)a.cap_tile;
+    cnt0 = min(c4.x, cap);
+    cnt1 = n_tiles > 1 ? min(c4.y, cap) : 0u;
+    cnt2 = n_tiles > 2 ? min(c4.z, cap) : 0u;
+    cnt3 = n_tiles > 3 ? min(c4.w, cap) : 0u;
+    beg0 = (int64_t)tile0 * a.cap_tile; beg1 = beg0 + a.cap_tile; beg2 = beg1 + a.cap_tile; beg3 = beg2 + a.cap_tile;
+  } else {
+    tile_list(a, ctrl, tile0, cnt0, beg0);
+    if (KT > 1) {
+      if (n_tiles > 1) tile_list(a, ctrl, tile0 + 1, cnt1, beg1);
+      if (n_tiles > 2) tile_list(a, ctrl, tile0 + 2, cnt2, beg2);
+      if (n_tiles > 3) tile_list(a, ctrl, tile0 + 3, cnt3, beg3);
+    }
   }
   if (a.dbg & 4) cnt0 = cnt1 = cnt2 = cnt3 = 0;
   const int64_t sbase = slot * a.ent_cap;
