@@ -57,7 +57,11 @@ def views_per_launch(raw, sub):
     if path:
         with open(path) as f:
             for r in csv.DictReader(f):
-                d[short(r["Kernel_Name"])].append(int(r["Grid_Size_Y"]) // max(int(r["Workgroup_Size_Y"]), 1))
+                k = short(r["Kernel_Name"])
+                if key_of(k) in ("k_bin_stats", "k_scan_tiles"):   # one workgroup per view along x
+                    d[k].append(int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1))
+                else:
+                    d[k].append(int(r["Grid_Size_Y"]) // max(int(r["Workgroup_Size_Y"]), 1))
     # the vote kernel's grid is one thread per face: its views are those of the fused tile launch it follows
     fused = [k for k in d if key_of(k) == "k_raster_tile_fused"]
     if fused:
