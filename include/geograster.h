@@ -35,7 +35,9 @@ enum {
   GR_ENOMEM = -3,    /* scratch allocation failed                                             */
   GR_ENOMESH = -4,   /* no mesh uploaded                                                      */
   GR_EINDEX = -5,    /* face index outside [0, V) found by gr_mesh_upload                     */
-  GR_EOVERFLOW = -6, /* bin-list capacity exceeded: call gr_raster_status, then retry         */
+  GR_EOVERFLOW = -6, /* gr_raster_status: a tile list outgrew its slots, or a face did not fit
+                        the 40-byte entry form -- the library has noted what the image needs;
+                        repeat the call from view `views_done` on                              */
   GR_ENODEVICE = -7  /* no usable gfx950 device                                               */
 };
 
@@ -128,7 +130,12 @@ int gr_mesh_upload(gr_ctx *ctx, const float *verts, const int32_t *faces, int64_
  * fp32 camera-space depth of the visible face, +inf for background.  Rule-set: DESIGN.md R0-R7. */
 int gr_raster_face_ids(gr_ctx *ctx, const float *cams, int n_views, int h, int w, int32_t *ids, float *depth,
                        void *stream);
-int gr_raster_status(gr_ctx *ctx, gr_raster_stats *out_h); /* synchronises `stream` of the last raster call */
+/* Outcome of the last raster call (synchronises its stream).  GR_EOVERFLOW: the single-pass binning could not finish a launch
+ * group -- a tile received more entries than its segment holds, or a face is too large (93 px and more) for the 40-byte
+ * entries the call started with.  The first `views_done` views are final; the context (and the process-wide table, see
+ * GR_OPT_DIRECT_CAP) now knows the segment size / entry form this mesh and image size need: call again for the remaining
+ * views.  At most one such retry per cause for a given (mesh, image size). */
+int gr_raster_status(gr_ctx *ctx, gr_raster_stats *out_h);
 
 /* render_flat gather -- replaces meshes.py:1921-1937: out[p,:] = face_tex[ids[p],:] where ids[p] != -1 else NaN.
  * ids: n_pix int32; face_tex: F x C f64; out: n_pix x C f64. */
