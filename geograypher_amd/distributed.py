@@ -24,6 +24,19 @@ def shard_views(n_views: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_views, world))
 
 
+def _all_reduce_sum(packed, group=None):
+    """One all-reduce(sum) of `packed`, in place.  RCCL reduces device tensors directly; a gloo group (CPU tests, or ranks that
+    share a machine without RCCL) gets the tensor through host memory."""
+    import torch.distributed as dist
+
+    if packed.is_cuda and dist.get_backend(group) == "gloo":
+        host = packed.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        packed.copy_(host)
+    else:
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+
+
 def all_reduce_votes(votes, counts, group=None):
     """Sum the per-face votes and counts of all ranks in place with ONE collective.
 
@@ -38,7 +51,7 @@ def all_reduce_votes(votes, counts, group=None):
     packed = torch.empty((F, C + 1), dtype=torch.int32, device=votes.device)
     packed[:, :C] = votes
     packed[:, C] = counts
-    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce_sum(packed, group)
     votes.copy_(packed[:, :C])
     counts.copy_(packed[:, C])
     return votes, counts
@@ -58,7 +71,7 @@ def all_reduce_sums(sums, counts, group=None):
     packed = torch.empty((F, C + 1), dtype=torch.float64, device=sums.device)
     packed[:, :C] = sums
     packed[:, C] = counts.to(torch.float64)
-    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce_sum(packed, group)
     sums.copy_(packed[:, :C])
     counts.copy_(packed[:, C].to(counts.dtype))
     return sums, counts
