@@ -97,6 +97,10 @@ def load_library() -> ctypes.CDLL:
             "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
             "geograypher_amd has no CPU fallback for the projection path."
         )
+    # PyTorch-ROCm ships its own HIP runtime.  It has to be in the process BEFORE this library pulls in the system's: with the
+    # library loaded first (e.g. __graft_entry__.build() and smoke() in one process) the later `import torch` leaves the
+    # library's runtime without devices and gr_ctx_create answers GR_ENODEVICE.
+    _torch()
     lib = ctypes.CDLL(str(_LIB_PATH))
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
     lib.gr_version.restype = i32
