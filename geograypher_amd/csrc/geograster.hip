@@ -785,7 +785,7 @@ __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const 
 //   s0 = c_first      s1 = c_mid      s2 = c_last[0:24] | first row (6 bits, centred) << 24 | corr << 31
 //   s3 = X0rel (16) | Y0rel << 16               s4, s5 = the slope words w3, w4        s6, s7 = iz0, A
 //   s8 = ~face (an EVEN word: the key pair)     s9 = B
-// (the tile kernel unpacks it with as many instructions as the 48-byte form: the kernel's time follows its VALU count)
+// (the tile kernel unpacks it with as many instructions as the 48-byte form; a denser packing of the constants cost it five more)
 // 17 % fewer bytes written here and read by the tile kernel than the 48-byte form (the binning tax of DESIGN.md section 10).
 // A face the short form cannot hold raises bit 1 of the view's overflow word: gr_raster_status reports GR_EOVERFLOW like
 // for a tile that outgrew its segment, remembers that this (mesh, image) needs 48-byte entries, and the caller repeats.
