@@ -124,3 +124,19 @@ def test_short_entries_fall_back_when_a_later_group_has_a_large_face(hip):
     assert torch.equal(v2, want_v) and torch.equal(c2, want_c)
     got = hip.raster_face_ids(recs, 480, 640)
     assert hip.last_retries == 0 and torch.equal(got, want)              # remembered
+
+
+def test_slots_per_tile_set_by_hand_to_an_odd_size(hip):
+    """80 slots per tile: not a whole number of 64-entry chunks, so the call starts with 48-byte entries; the C1 views put
+    more than 80 entries into a tile, the call overflows, learns a segment size (a multiple of 64: 40-byte entries from then
+    on) and finishes -- ids equal the oracle's either way."""
+    (points, faces), cams = synthetic.config1_scene()
+    recs = _records(cams)
+    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+    hip.set_option(6, 80)
+    ids = hip.raster_face_ids(recs, 480, 640)
+    assert hip.last_retries >= 1 and hip.last_stats["max_entries"] > 80
+    for v in (0, 5):
+        np.testing.assert_array_equal(ids[v].cpu().numpy(), oracle_c.raster(points, faces, recs[v], 480, 640))
+    again = hip.raster_face_ids(recs, 480, 640)
+    assert hip.last_retries == 0 and torch.equal(again, ids)
