@@ -379,6 +379,12 @@ def run(args, rig=None) -> int:
     roofline["pipeline_GBs"] = round(br_bytes / max(pipeline_ms_per_view * 1e-3, 1e-12) / 1e9, 2)
     roofline["pipeline_frac"] = round(br_bytes / max(pipeline_ms_per_view * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 5)
     roofline["valu"] = valu_bound("k_raster_tile", raster_ms_per_launch, views_per_launch)
+    # the binning tax: HBM bytes the whole pipeline moves per view (committed PMC passes) over its algorithmic bytes B_r
+    tj = _profile_json("traffic.json") or {}
+    moved = [(tj.get(k) or {}).get("hbm_bytes_per_view") for k in ("k_cull_blocks", "k_setup_cull", "k_clip_faces", "k_bin_stats", "k_raster_tile")]
+    if all(m is not None for m in moved):
+        roofline["pipeline_traffic_per_view"] = round(sum(moved), 1)
+        roofline["pipeline_traffic_over_algorithmic"] = round(sum(moved) / br_bytes, 4)
     rooflines = {
         "k_setup_cull": hbm_roofline(
             "set-up stage of pix2face: k_cull_blocks + k_setup_cull + k_clip_faces (one HIP-event pair around the three)",
