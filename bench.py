@@ -832,6 +832,8 @@ def host_image_set(base, images):
     from geograypher_amd.cameras import PhotogrammetryCameraSet
 
     class HostImageSet(PhotogrammetryCameraSet):
+        thread_safe_lookup = True  # in-memory arrays: the view loop may stage view i + 1 on its loader thread
+
         def __init__(self, base, images):
             self.base_camera_set, self.images, self.cameras = base, images, base.cameras
             self._local_to_epsg_4978_transform = base._local_to_epsg_4978_transform

@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
     "gr_last_error",
     "gr_set_profiling",
     "gr_set_option",
+    "gr_learned_cache_file",
     "gr_get_stage_times",
     "gr_mesh_upload",
     "gr_raster_face_ids",
@@ -45,6 +46,7 @@ EXPORTED_SYMBOLS = (
     "gr_warp_nearest_i32",
     "gr_warp_f64",
     "gr_invert_distortion_f64",
+    "gr_resize_image_f64",
     "gr_finalize_votes",
     "gr_finalize_sums_f64",
     "gr_argmax_nonzero_f64",
@@ -146,6 +148,10 @@ def load_library() -> ctypes.CDLL:
     lib.gr_warp_f64.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32, f64, vp, vp]
     lib.gr_invert_distortion_f64.restype = i32
     lib.gr_invert_distortion_f64.argtypes = [vp, ctypes.POINTER(f64), i32, i32, f64, i32, f64, vp, vp, vp]
+    lib.gr_resize_image_f64.restype = i32
+    lib.gr_resize_image_f64.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+    lib.gr_learned_cache_file.restype = i32
+    lib.gr_learned_cache_file.argtypes = [ctypes.c_char_p]
     lib.gr_finalize_votes.restype = i32
     lib.gr_finalize_votes.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp]
     lib.gr_finalize_sums_f64.restype = i32
@@ -153,7 +159,26 @@ def load_library() -> ctypes.CDLL:
     lib.gr_argmax_nonzero_f64.restype = i32
     lib.gr_argmax_nonzero_f64.argtypes = [vp, vp, i64, i32, vp, vp]
     _lib = lib
+    _attach_learned_cache(lib)
     return lib
+
+
+def _attach_learned_cache(lib):
+    """What overflowed raster calls taught the library (slots per tile, entry form per mesh and image size) is kept under
+    the reference's CACHE_FOLDER (constants.py:18, the default of pix2face's `cache_folder`), so that a new process starts
+    with bins that fit.  GEOGRAYPHER_AMD_CACHE=<dir> moves the file, GEOGRAYPHER_AMD_CACHE=off switches persistence off."""
+    import os
+
+    from geograypher_amd.constants import CACHE_FOLDER
+
+    where = os.environ.get("GEOGRAYPHER_AMD_CACHE", str(CACHE_FOLDER))
+    if where.lower() in ("off", "0", ""):
+        return
+    try:
+        Path(where).mkdir(parents=True, exist_ok=True)
+        lib.gr_learned_cache_file(str(Path(where, "geograster_learned.txt")).encode())
+    except OSError:
+        pass  # a read-only home: learn per process, as before
 
 
 def _torch():
@@ -215,7 +240,7 @@ class PairAccumulator:
         self.flags = (GR_FLAG_NEG1_IS_LAST_FACE if neg1_is_last_face else 0) | GR_FLAG_DEFER_CHECK
         self.cap = max(8 * backend.n_faces, 1 << 20)
         self.keys = torch.empty((self.cap,), dtype=torch.int64, device=backend.device)
-        self.key_count = torch.zeros((1,), dtype=torch.int64, device=backend.device)
+        self.key_count = torch.zeros((2,), dtype=torch.int64, device=backend.device)  # {pair count, error flag} (GR_FLAG_DEFER_CHECK)
         self.bound = 0          # upper bound of the pairs in the buffer
         self.parts = []         # (keys, multiplicities) of earlier compactions, host
         self.compactions = 0
@@ -249,8 +274,8 @@ class PairAccumulator:
     def _compact(self):
         torch = _torch()
         b = self.b
-        raw = int(self.key_count.item())
-        if raw >> 32:
+        raw, bad = (int(x) for x in self.key_count.cpu().tolist())
+        if bad:
             raise IndexError(f"gr_project_index_pairs: an image value is not a class index in [0, {self.n_classes})")
         if raw > 0:
             uniq = torch.empty((raw,), dtype=torch.int64, device=b.device)
@@ -610,6 +635,41 @@ class HipRaster:
             self.last_stats = acc.result()
             break
         return ids_out
+
+    # -- get_image(image_scale) behind the file read (row a5) -----------------------------------------------------
+    _RESIZE_DTYPES = {"uint8": 0, "float32": 1, "float64": 2}
+
+    def resize_image(self, image, out_hw=None, divide_by_255: Optional[bool] = None):
+        """cameras.py:154-174 on the device: `image` ((H,W) or (H,W,C); numpy or tensor, uint8 / float32 / float64, in the dtype
+        its file holds) -> float64 tensor of shape out_hw (+ C): uint8 values are divided by 255.0 (`divide_by_255`, default:
+        exactly when the dtype is uint8, as get_image does), then skimage.transform.resize with its defaults
+        (gr_resize_image_f64: anti-aliasing Gaussian + order-1 sampling at half-pixel centres).  out_hw None or the input
+        size: the conversion alone."""
+        torch = _torch()
+        if isinstance(image, torch.Tensor):
+            t = image.to(self.device).contiguous()
+        else:
+            t = torch.as_tensor(np.ascontiguousarray(image)).to(self.device)
+        if t.dtype == torch.bool:
+            t = t.to(torch.uint8)
+        name = str(t.dtype).replace("torch.", "")
+        if name not in self._RESIZE_DTYPES:
+            # every other dtype: widened to float64 first, values kept (scikit-image would rescale integer types by their
+            # range and truncate the filtered image to the integer type; not reproduced: documented in DESIGN.md)
+            t, name = t.to(torch.float64), "float64"
+        if t.ndim not in (2, 3):
+            raise ValueError(f"image must be (H,W) or (H,W,C), got shape {tuple(t.shape)}")
+        h_in, w_in = int(t.shape[0]), int(t.shape[1])
+        C = 1 if t.ndim == 2 else int(t.shape[2])
+        h_out, w_out = (h_in, w_in) if out_hw is None else (int(out_hw[0]), int(out_hw[1]))
+        if divide_by_255 is None:
+            divide_by_255 = name == "uint8"
+        out = torch.empty((h_out, w_out) + tuple(t.shape[2:]), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gr_resize_image_f64(self._ctx, t.data_ptr(), self._RESIZE_DTYPES[name], h_in, w_in, C,
+                                              1 if divide_by_255 else 0, h_out, w_out, out.data_ptr(), self._stream())
+        self._check(rc, "gr_resize_image_f64")
+        return out
 
     # -- distortion warp (row f1) --------------------------------------------------------------------------------
     def upload_map(self, inverse_map):

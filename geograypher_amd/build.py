@@ -1,12 +1,20 @@
-"""Build libgeograster.so in-tree with hipcc for gfx950 (no torch, no cmake: one translation unit, seconds)."""
+"""Build libgeograster.so in-tree with hipcc for gfx950 (no torch, no cmake: a handful of translation units compiled in
+parallel and linked, seconds)."""
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
-SRC = ROOT / "csrc" / "geograster.hip"
-OUT = ROOT / "csrc" / "libgeograster.so"
+CSRC = ROOT / "csrc"
+# translation units of the library (csrc/gr_internal.hpp says what lives where); raster_tile.hip holds the dominant kernel
+SOURCES = [CSRC / n for n in ("geograster.hip", "mesh_upload.hip", "binning.hip", "raster_tile.hip", "project.hip", "warp.hip",
+                              "resize.hip")]
+HEADERS = [CSRC / "gr_internal.hpp", CSRC / "dev_common.hpp"]
+SRC = CSRC / "raster_tile.hip"   # the tile kernel's source (tests/test_isa_waits.py compiles it to assembly)
+OUT = CSRC / "libgeograster.so"
+OBJ = CSRC / "_obj"
 INCLUDE = ROOT.parent / "include"
 
 # -ffp-contract=off: the rule-set of DESIGN.md rounds every floating-point operation individually.
@@ -23,20 +31,39 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (needed to build the gfx950 extension)")
 
 
+def _newest_header() -> float:
+    return max(p.stat().st_mtime for p in HEADERS + [INCLUDE / "geograster.h", Path(__file__)])
+
+
 def needs_build() -> bool:
     if not OUT.is_file():
         return True
-    newest = max(SRC.stat().st_mtime, (INCLUDE / "geograster.h").stat().st_mtime)
+    newest = max(max(p.stat().st_mtime for p in SOURCES), _newest_header())
     return OUT.stat().st_mtime < newest
+
+
+def _compile(src: Path, force: bool) -> Path:
+    obj = OBJ / (src.stem + ".o")
+    if not force and obj.is_file() and obj.stat().st_mtime >= max(src.stat().st_mtime, _newest_header()):
+        return obj
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    cmd = [hipcc_path(), *flags, "-c", f"-I{INCLUDE}", f"-I{CSRC}", "-o", str(obj), str(src)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+    return obj
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return OUT
-    cmd = [hipcc_path(), *HIPCC_FLAGS, f"-I{INCLUDE}", "-o", str(OUT), str(SRC)]
+    OBJ.mkdir(exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(lambda s: _compile(s, force), SOURCES))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(OUT), *[str(o) for o in objs]]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+        raise RuntimeError(f"link failed:\n{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
     if verbose:
         print(" ".join(cmd))
     return OUT

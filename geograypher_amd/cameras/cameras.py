@@ -24,22 +24,7 @@ def _imread(filename) -> np.ndarray:
     from PIL import Image
 
     with Image.open(filename) as im:
-        return np.asarray(im)
-
-
-def _resize_bilinear(image: np.ndarray, out_hw: Tuple[int, int]) -> np.ndarray:
-    """Float resize with half-pixel centres (stands in for skimage.transform.resize, cameras.py:168-172)."""
-    import torch
-
-    t = torch.as_tensor(np.ascontiguousarray(image), dtype=torch.float64)
-    squeeze = t.ndim == 2
-    if squeeze:
-        t = t[..., None]
-    t = t.permute(2, 0, 1)[None]
-    down = out_hw[0] < image.shape[0] or out_hw[1] < image.shape[1]
-    t = torch.nn.functional.interpolate(t, size=out_hw, mode="bilinear", align_corners=False, antialias=down)
-    t = t[0].permute(1, 2, 0)
-    return (t[..., 0] if squeeze else t).numpy()
+        return np.array(im)  # a writable copy (PIL hands out a read-only view)
 
 
 def vtk_like_near_plane(cam_to_world: np.ndarray, bounds: np.ndarray, tolerance: float = 0.001) -> float:
@@ -153,18 +138,39 @@ class PhotogrammetryCamera:
         }
 
     # -- image access --------------------------------------------------------------------------------------------
-    def get_image(self, image_scale: float = 1.0) -> np.ndarray:
-        """reference: cameras.py:154-174 (uint8 images are returned as float in [0, 1])."""
+    def get_image_native(self) -> np.ndarray:
+        """The image as its file holds it (`imread`, cameras.py:157; cached like the reference's float image when
+        `cache_image` is set).  The device paths take this: a uint8 photo crosses the link as uint8 and is divided by 255 and
+        down-scaled there (`HipRaster.resize_image`)."""
+        native = getattr(self, "_image_native", None)
+        if native is None:
+            native = _imread(self.image_filename)
+            if self.cache_image:
+                self._image_native = native
+        return native
+
+    def get_image(self, image_scale: float = 1.0, backend=None) -> np.ndarray:
+        """reference: cameras.py:154-174 -- uint8 images are returned as float in [0, 1]; `image_scale != 1` resizes with
+        scikit-image's `resize` defaults (anti-aliasing Gaussian + order 1).  The resize runs on the device
+        (`gr_resize_image_f64`, pinned to the real scikit-image's output in tests/test_photo_resize.py); there is no CPU
+        resizer in the product: without a GPU a scaled image raises RuntimeError."""
         if self.image is None:
-            image = _imread(self.image_filename)
-            if image.dtype == np.uint8:
-                image = image / 255.0
+            native = self.get_image_native()
+            image = native / 255.0 if native.dtype == np.uint8 else native
             if self.cache_image:
                 self.image = image
         else:
+            native = None
             image = self.image
         if image_scale != 1.0:
-            image = _resize_bilinear(image, (int(image.shape[0] * image_scale), int(image.shape[1] * image_scale)))
+            if backend is None:
+                from geograypher_amd._hip import default_backend
+
+                backend = default_backend()
+            out_hw = (int(image.shape[0] * image_scale), int(image.shape[1] * image_scale))
+            src = native if native is not None else image  # the file dtype when it is at hand (uint8: an eighth of the bytes)
+            resized = backend.resize_image(src, out_hw, divide_by_255=src.dtype == np.uint8)
+            image = resized.cpu().numpy() if hasattr(resized, "cpu") else np.asarray(resized)
         return image
 
     def get_image_filename(self):
@@ -362,6 +368,15 @@ class PhotogrammetryCameraSet:
 
     def get_image_by_index(self, index: int, image_scale: float = 1.0) -> np.ndarray:
         return self[index].get_image(image_scale=image_scale)
+
+    # file reads are independent: the view loop of the mesh class may prefetch them on a loader thread
+    thread_safe_lookup = True
+
+    def get_native_image_by_index(self, index: int) -> np.ndarray:
+        """The image of camera `index` in its file dtype, for the device input pipeline of project_images /
+        aggregate_projected_images: `get_image_by_index(i, s)` == resize(native / 255 if uint8 else native, s), with the
+        division and the resize done on the device."""
+        return self[index].get_image_native()
 
     def get_image_filename(self, index: Union[int, None], absolute=True):
         """reference: cameras.py:883-909"""

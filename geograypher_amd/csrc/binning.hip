@@ -1,0 +1,899 @@
+// geograypher_amd/csrc/binning.hip -- per view: frustum cull of 64-face blocks, face set-up (R1 / R2 / R4), tile counting and
+// -- single-pass binning -- entry compilation straight into the tiles' segments; R7 clipping; the exact two-pass path.
+//   k_cull_blocks -> k_setup_cull (+ k_clip_faces) -> k_bin_stats            (exact: -> k_scan_tiles -> k_fill_compile)
+// Compile with -ffp-contract=off: every floating-point operation below is individually rounded on purpose.
+#include "gr_internal.hpp"
+#include "dev_common.hpp"
+
+using namespace grimpl;
+
+namespace {
+
+struct Vtx {
+  int X, Y;
+  float iz;
+  bool valid;
+  bool front, finite;  // q_z > near; camera-space point finite (R7: which invalid faces are clipped instead of dropped)
+};
+
+// R1 -- vertex transform, fp32, each operation individually rounded
+__device__ __forceinline__ Vtx project_vertex(const float *__restrict__ p, const float *__restrict__ cam) {
+  Vtx v;
+  const float dx = p[0] - cam[9];
+  const float dy = p[1] - cam[10];
+  const float dz = p[2] - cam[11];
+  float m0, m1, m2;
+  m0 = cam[0] * dx; m1 = cam[3] * dy; m2 = cam[6] * dz;
+  const float qx = (m0 + m1) + m2;
+  m0 = cam[1] * dx; m1 = cam[4] * dy; m2 = cam[7] * dz;
+  const float qy = (m0 + m1) + m2;
+  m0 = cam[2] * dx; m1 = cam[5] * dy; m2 = cam[8] * dz;
+  const float qz = (m0 + m1) + m2;
+  v.valid = qz > cam[15];
+  v.front = v.valid;
+  v.finite = isfinite(qx) && isfinite(qy) && isfinite(qz);
+  const float iz = 1.0f / qz;  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
+  const float fx = cam[12] * qx;
+  const float fy = cam[12] * qy;
+  const float sx = cam[13] + fx * iz;
+  const float sy = cam[14] + fy * iz;
+  v.valid = v.valid && (fabsf(sx) < 16384.0f) && (fabsf(sy) < 16384.0f);
+  v.X = (int)floorf(sx * 256.0f + 0.5f);
+  v.Y = (int)floorf(sy * 256.0f + 0.5f);
+  v.iz = iz;
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K1  transform + cull + per-tile counts (+ compiled entries in single-pass mode).   grid (<= 1024, views)
+//     (a) work list: the 64-face blocks whose bounding sphere passed k_cull_blocks (~87 % of a survey mesh is rejected
+//         per view before a single face is read); every wave takes its own blocks;
+//     (b) the face's three vertices are read from the de-indexed soup (36 coalesced bytes per lane);
+//     (c) exact path: survivors compacted with wave ballot + popcount, ONE atomicAdd per wave; record planes written
+//         as consecutive 16-byte slots (full-rate coalesced stores);
+//     (d) tile counting is aggregated per wave as well: neighbouring lanes that hit the same tile share one returning
+//         atomicAdd and receive consecutive list positions; single-pass mode compiles and stores the entries at once,
+//         the exact path leaves that to k_fill_compile (no atomics there for faces over at most 2x2 tiles).
+// ------------------------------------------------------------------------------------------------------------------
+// Lanes of a wave that hit the same tile form a group: leader lane, rank inside the group, group size -- found with
+// ballots and shuffles only (no memory traffic), so that the leaders' atomics can all be issued back to back.  The 64
+// faces of a wave are a compact patch of the mesh (Morton order): a handful of distinct tiles, hence few iterations.
+__device__ __forceinline__ void wave_group(int t, int lane, int &leader, int &rank, int &size) {
+  leader = lane; rank = 0; size = 0;
+  unsigned long long rem = __ballot(t >= 0);
+  while (rem) {
+    const int l = __ffsll((long long)rem) - 1;
+    const int tl = __builtin_amdgcn_readlane(t, l);
+    const unsigned long long m = __ballot(t == tl);
+    if (t == tl) {
+      leader = l;
+      rank = __popcll(m & ((1ull << lane) - 1ull));
+      size = __popcll(m);
+    }
+    rem &= ~m;
+  }
+}
+
+// The same with at most `max_groups` groups looked for: lanes that are left over stand alone (leader = itself, size 1).
+// For the (face, tile) pairs of big faces, where a step of 64 pairs can name 64 different tiles.
+__device__ __forceinline__ void wave_group_capped(int t, int lane, int &leader, int &rank, int &size, int max_groups) {
+  leader = lane; rank = 0; size = 1;
+  unsigned long long rem = __ballot(t >= 0);
+  for (int g = 0; rem && g < max_groups; ++g) {
+    const int l = __ffsll((long long)rem) - 1;
+    const int tl = __builtin_amdgcn_readlane(t, l);
+    const unsigned long long m = __ballot(t == tl);
+    if (t == tl) {
+      leader = l;
+      rank = __popcll(m & ((1ull << lane) - 1ull));
+      size = __popcll(m);
+    }
+    rem &= ~m;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cull_blocks(const float *__restrict__ cams, BinArgs a, int nblk) {
+  const int slot = blockIdx.y;
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
+  uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  bool keep = false;
+  if (b < nblk) {
+    // camera space; planes carry a 2-pixel margin; any NaN keeps the block
+    const float4 sp = a.blk[b];
+    const float dx = sp.x - cam[9], dy = sp.y - cam[10], dz = sp.z - cam[11];
+    const float qx = cam[0] * dx + cam[3] * dy + cam[6] * dz;
+    const float qy = cam[1] * dx + cam[4] * dy + cam[7] * dz;
+    const float qz = cam[2] * dx + cam[5] * dy + cam[8] * dz;
+    const float fe = fabsf(cam[12]), r = sp.w * 1.001f;
+    const float mxl = cam[13] + 2.0f, mxr = (float)a.w - cam[13] + 2.0f;
+    const float myt = cam[14] + 2.0f, myb = (float)a.h - cam[14] + 2.0f;
+    bool out = (qz + r < cam[15]);
+    out = out || (cam[12] * qx + mxl * qz < -r * (fe + fabsf(mxl)));
+    out = out || (-cam[12] * qx + mxr * qz < -r * (fe + fabsf(mxr)));
+    out = out || (cam[12] * qy + myt * qz < -r * (fe + fabsf(myt)));
+    out = out || (-cam[12] * qy + myb * qz < -r * (fe + fabsf(myb)));
+    keep = !out;
+  }
+  const unsigned long long m = __ballot(keep);
+  if (m != 0ull) {
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&ctrl[3], (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    if (keep) a.work[(int64_t)slot * a.work_stride + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)b;
+  }
+  // fused aggregation: which 256-face chunks of caller ids can receive winners in this view.  The workgroup's 256 blocks
+  // are neighbours on the Morton curve and share most of their chunks: the bits are collected in LDS and every non-zero
+  // word leaves the workgroup as one atomicOr.
+  if (a.touched) {
+    extern __shared__ uint32_t bits[];
+    for (int i = threadIdx.x; i < a.tw; i += 256) bits[i] = 0u;
+    __syncthreads();
+    if (keep) {
+      const uint32_t *cl = a.blk_chunks + (int64_t)b * (GR_CHUNK_LIST + 1);
+      const uint32_t n = cl[0];
+      if (n == 0xFFFFFFFFu) atomicOr(&bits[a.tw - 1], 1u);
+      else
+        for (uint32_t i = 0; i < n; ++i) {
+          const uint32_t ch = cl[1 + i];
+          atomicOr(&bits[ch >> 5], 1u << (ch & 31u));
+        }
+    }
+    __syncthreads();
+    uint32_t *dst = a.touched + (int64_t)slot * a.tw;
+    for (int i = threadIdx.x; i < a.tw; i += 256)
+      if (bits[i]) atomicOr(&dst[i], bits[i]);
+  }
+}
+
+__device__ __forceinline__ bool compile_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
+                                              uint8_t *__restrict__ nr8, int64_t idx, const int4 p0, const int4 p1,
+                                              const int4 p2, int px0, int py0, int TW, int TH);
+__device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const int4 p2, int px0, int py0, int TW, int TH,
+                                            int4 &e0, int4 &e1, int4 &e2, int &rows);
+__device__ __forceinline__ void store_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
+                                            uint8_t *__restrict__ nr8, int64_t idx, const int4 e0, const int4 e1, const int4 e2,
+                                            int rows);
+
+// R1 / R2 / R4 for one face of the soup: the record (three int4) that compile_entry turns into per-tile entries, and the
+// range of tiles its pixel bounding box touches.  Returns false for faces that draw nothing in this view; clip_me: the face
+// straddles the near plane or the guard band (R7).  Used by K1 and, for faces over more than 2 x 2 tiles, by k_bin_big:
+// same code, same bits.
+__device__ __forceinline__ bool face_setup(const BinArgs &a, const float *__restrict__ cam, int64_t f, int4 &r0, int4 &r1,
+                                           int4 &r2, int &tx0, int &tx1, int &ty0, int &ty1, bool &clip_me) {
+  // the face's three vertices sit side by side in the soup: one coalesced 36-byte read per lane instead of an index
+  // load followed by three dependent 12-byte gathers (one dependent memory round trip less per wave)
+  const float *sp = a.soup + 9 * f;
+  Vtx v0 = project_vertex(sp, cam);
+  Vtx v1 = project_vertex(sp + 3, cam);
+  Vtx v2 = project_vertex(sp + 6, cam);
+  clip_me = !(v0.valid && v1.valid && v2.valid) && (v0.front || v1.front || v2.front) && v0.finite && v1.finite && v2.finite;
+  if (!(v0.valid && v1.valid && v2.valid)) return false;
+  long long area2 = (long long)(v1.X - v0.X) * (long long)(v2.Y - v0.Y) - (long long)(v2.X - v0.X) * (long long)(v1.Y - v0.Y);
+  if (area2 == 0) return false;
+  if (area2 < 0) {  // both windings are drawn: normalise to positive area
+    Vtx s = v1; v1 = v2; v2 = s;
+    area2 = -area2;
+  }
+  const int Xmin = imin3(v0.X, v1.X, v2.X), Xmax = imax3(v0.X, v1.X, v2.X);
+  const int Ymin = imin3(v0.Y, v1.Y, v2.Y), Ymax = imax3(v0.Y, v1.Y, v2.Y);
+  int jmin = (Xmin - 128 + 255) >> 8, jmax = (Xmax - 128) >> 8;  // R2: pixel centres inside the bbox
+  int imin = (Ymin - 128 + 255) >> 8, imax = (Ymax - 128) >> 8;
+  jmin = max(jmin, 0); imin = max(imin, 0);
+  jmax = min(jmax, a.w - 1); imax = min(imax, a.h - 1);
+  if (jmin > jmax || imin > imax) return false;
+  // R4: gradients of 1/z in double, rounded once to float
+  float A = 0.f, B = 0.f;
+  if (!(a.dbg & 256)) {
+    const double d1 = (double)v1.iz - (double)v0.iz;
+    const double d2 = (double)v2.iz - (double)v0.iz;
+    const double a2 = (double)area2;
+    double n1, n2;
+    n1 = d1 * (double)(v2.Y - v0.Y); n2 = d2 * (double)(v1.Y - v0.Y);
+    A = (float)((n1 - n2) / a2);
+    n1 = d2 * (double)(v1.X - v0.X); n2 = d1 * (double)(v2.X - v0.X);
+    B = (float)((n1 - n2) / a2);
+  }
+  r0 = make_int4(v0.X, v0.Y, v1.X, v1.Y);
+  r1 = make_int4(v2.X, v2.Y, __float_as_int(v0.iz), a.orig[f]);
+  r2 = make_int4(__float_as_int(A), __float_as_int(B), jmin | (jmax << 16), imin | (imax << 16));
+  tx0 = jmin >> a.twl; tx1 = jmax >> a.twl;
+  ty0 = imin >> a.thl; ty1 = imax >> a.thl;
+  return true;
+}
+
+// Single-pass binning of the wave's faces that reach over more than 2 x 2 tiles (`big`: this lane holds one, records r0 .. r2,
+// tile rectangle tx0 .. ty1).  A per-lane walk over the tiles would leave 63 lanes waiting for the largest face -- 112 us per
+// view on a scene with 20 000 trees seen obliquely (canopy and trunk faces of 300 x 40 pixels), where the terrain alone
+// takes 7.  Instead the wave prefix-sums the tile counts of its faces and EXPANDS: the (face, tile) pairs are taken 64 at a
+// time, a pair finds its face by a 6-step search over the prefix sums and pulls the record out of the owning lane's
+// registers (ds_bpermute).  A tile the triangle does not touch takes no list slot.  The pairs of a step that name the same
+// tile (neighbouring faces of one tree do) share ONE returning counter atomic (wave_group_capped: at most 16 groups are
+// looked for, left-over pairs stand alone); all atomics of a step are in flight together.
+__device__ __forceinline__ void bin_big_pairs(const BinArgs &a, uint32_t *__restrict__ ctrl, const int slot, const int lane,
+                                              const bool big, const int4 r0, const int4 r1, const int4 r2, const int tx0,
+                                              const int tx1, const int ty0, const int ty1) {
+  uint32_t *cntS = ctrl + GR_CTRL_HDR;
+  int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
+  uint8_t *nr8 = a.nrow8 + slot * a.ent_cap;
+  const int TW = 1 << a.twl, TH = 1 << a.thl;
+  const int ntx = tx1 - tx0 + 1;
+  const int nt = big ? ntx * (ty1 - ty0 + 1) : 0;
+  const int incl = wave_incl_scan(nt);
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  const int geo = tx0 | (ty0 << 12) | ((ntx - 1) << 24);  // at most 256 x 512 tiles per image (GR_MAX_DIM)
+  for (int k0 = 0; k0 < total; k0 += 64) {
+    const int q = k0 + lane;
+    int t = 0;  // the face of pair q: the first lane whose inclusive sum exceeds q
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1) t += (__shfl(incl, t + step - 1) <= q) ? step : 0;
+    t = min(t, 63);
+    const int ex = __shfl(incl, t) - __shfl(nt, t);
+    const int g = __shfl(geo, t);
+    const int4 p0 = make_int4(__shfl(r0.x, t), __shfl(r0.y, t), __shfl(r0.z, t), __shfl(r0.w, t));
+    const int4 p1 = make_int4(__shfl(r1.x, t), __shfl(r1.y, t), __shfl(r1.z, t), __shfl(r1.w, t));
+    const int4 p2 = make_int4(__shfl(r2.x, t), __shfl(r2.y, t), __shfl(r2.z, t), __shfl(r2.w, t));
+    int tile = -1, rows = 0;
+    int4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0}, e2 = {0, 0, 0, 0};
+    if (q < total) {
+      const int k = q - ex, gtx = g & 0xFFF, gty = (g >> 12) & 0xFFF, gn = (int)((uint32_t)g >> 24) + 1;
+      const int tx = gtx + k % gn, ty = gty + k / gn;
+      if (build_entry(p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH, e0, e1, e2, rows)) tile = ty * a.TX + tx;
+    }
+    int ld, rk, sz;
+    wave_group_capped(tile, lane, ld, rk, sz, 16);
+    uint32_t base = 0;
+    if (tile >= 0 && lane == ld) base = atomicAdd(&cntS[tile], (uint32_t)sz);
+    const uint32_t pos = __shfl(base, ld) + (uint32_t)rk;
+    if (tile >= 0) {
+      if (pos < (uint32_t)a.cap_tile) {
+        store_entry(a, ctrl, comp, nr8, (int64_t)tile * a.cap_tile + pos, e0, e1, e2, rows);
+      } else atomicOr(&ctrl[2], 1u);
+    }
+  }
+}
+
+// DIRECT = true: single-pass binning.  Every tile owns a fixed segment of a.cap_tile entries; the list position
+// returned by the (wave-aggregated) tile counter is final, so the compiled entry is written straight from here and
+// the record planes, k_scan_tiles and k_fill_compile are skipped.  A tile that receives more than cap_tile entries
+// raises the view's overflow word; the caller then repeats the call with the exact two-pass path (DIRECT = false).
+template <bool DIRECT>
+__global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ cams, BinArgs a) {
+  const int slot = blockIdx.y;
+  const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
+  uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  const uint32_t *work = a.work + (int64_t)slot * a.work_stride;
+  // every wave takes its own 64-face block from the view's work list (wave-uniform control flow, no workgroup barrier)
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), wstep = gridDim.x * 4;
+  uint32_t blk_next = work[wave0];       // read alongside the count (any slot of the list is valid memory)
+  const uint32_t n_work = ctrl[3];       // (a) blocks that passed k_cull_blocks for this view
+  uint32_t n_rec = 0;                    // single-pass binning: the wave's record count (a statistic), added once at the end
+  for (uint32_t wi = wave0; wi < n_work; wi += wstep) {
+  const int64_t f = (int64_t)blk_next * GR_BLOCK + lane;
+  if (wi + wstep < n_work) blk_next = work[wi + wstep];
+
+  bool keep = false, clip_me = false;
+  int4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0};
+  int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+  if (f < a.F) keep = face_setup(a, cam, f, r0, r1, r2, tx0, tx1, ty0, ty1, clip_me);
+  // R7: faces that straddle the near plane or the guard band go to the view's clip list (k_clip_faces)
+  const unsigned long long mc = __ballot(clip_me);
+  if (mc) {
+    const int lead = __ffsll((long long)mc) - 1;
+    uint32_t cb = 0;
+    if (lane == lead) cb = atomicAdd(&ctrl[4], (uint32_t)__popcll(mc));
+    cb = __shfl(cb, lead);
+    if (clip_me) a.clip[(int64_t)slot * a.F + cb + __popcll(mc & ((1ull << lane) - 1ull))] = (uint32_t)f;
+  }
+  // wave-level compaction of survivors
+  const unsigned long long m = __ballot(keep);
+  if (m == 0ull) continue;
+  const int n = __popcll(m);
+  const int prefix = __popcll(m & ((1ull << lane) - 1ull));
+  const int leader = __ffsll((long long)m) - 1;
+  // (d) tile counts.  Faces touching at most 2x2 tiles get their list positions here (wave-aggregated atomics);
+  //     larger faces are only counted (cntB) and placed by k_fill_compile.  Groups are found first (registers only),
+  //     then ALL atomics of the wave -- record slot + up to four tile counters -- are issued before any is consumed.
+  const bool small_fp = keep && (tx1 - tx0 <= 1) && (ty1 - ty0 <= 1);
+  uint32_t *cntS = ctrl + GR_CTRL_HDR;
+  uint32_t *cntB = cntS + a.Tcap;
+  const int t00 = small_fp ? ty0 * a.TX + tx0 : -1;
+  const int t01 = (small_fp && tx1 > tx0) ? ty0 * a.TX + tx1 : -1;
+  const int t10 = (small_fp && ty1 > ty0) ? ty1 * a.TX + tx0 : -1;
+  const int t11 = (small_fp && tx1 > tx0 && ty1 > ty0) ? ty1 * a.TX + tx1 : -1;
+  int l0, k0, n0, l1 = lane, k1 = 0, n1 = 0, l2 = lane, k2 = 0, n2 = 0, l3 = lane, k3 = 0, n3 = 0;
+  wave_group(t00, lane, l0, k0, n0);
+  if (__ballot(t01 >= 0)) wave_group(t01, lane, l1, k1, n1);
+  if (__ballot(t10 >= 0)) wave_group(t10, lane, l2, k2, n2);
+  if (__ballot(t11 >= 0)) wave_group(t11, lane, l3, k3, n3);
+  uint32_t base = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+  // record count: a list position for the exact path; a statistic otherwise, kept in a register until the wave is done (one
+  // atomic per block on the view's one address made every wave of the view queue there: same-address atomics are served
+  // one after the other, tools/ubench/atomic_rate.hip)
+  if (DIRECT) n_rec += (uint32_t)n;
+  else if (lane == leader) base = atomicAdd(&ctrl[0], (uint32_t)n);
+  if (t00 >= 0 && lane == l0) b0 = atomicAdd(&cntS[t00], (uint32_t)n0);
+  if (t01 >= 0 && lane == l1) b1 = atomicAdd(&cntS[t01], (uint32_t)n1);
+  if (t10 >= 0 && lane == l2) b2 = atomicAdd(&cntS[t10], (uint32_t)n2);
+  if (t11 >= 0 && lane == l3) b3 = atomicAdd(&cntS[t11], (uint32_t)n3);
+  if (!DIRECT) base = __shfl(base, leader);
+  int4 r3;
+  r3.x = (int)(__shfl(b0, l0) + (uint32_t)k0);
+  r3.y = (int)(__shfl(b1, l1) + (uint32_t)k1);
+  r3.z = (int)(__shfl(b2, l2) + (uint32_t)k2);
+  r3.w = (int)(__shfl(b3, l3) + (uint32_t)k3);
+  if (DIRECT) {
+    // faces over at most 2x2 tiles: positions came from the wave-aggregated counters; the lanes of a group hold
+    // consecutive positions of the same tile segment, so their 48-byte entries are written side by side.  Every such face has
+    // a FIRST tile: one dense round of entry compilation.  Second to fourth tiles are the exception (0.5 per face): instead of
+    // three more rounds in which most lanes wait (the set-up kernel of a forest scene is VALU-bound: SQ counters in
+    // profiles/), those (face, tile) pairs are dealt to the lanes -- prefix sum of the extra tiles per face, 6-step search for
+    // the owning lane, records pulled from its registers (ds_bpermute) -- and take one round together.
+    int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
+    uint8_t *nr8 = a.nrow8 + slot * a.ent_cap;
+    const int TW = 1 << a.twl, TH = 1 << a.thl;
+    if (small_fp && !(a.dbg & 32)) {
+      if ((uint32_t)r3.x < (uint32_t)a.cap_tile) {
+        const int64_t idx = (int64_t)t00 * a.cap_tile + (uint32_t)r3.x;
+        compile_entry(a, ctrl, comp, nr8, idx, r0, r1, r2, tx0 << a.twl, ty0 << a.thl, TW, TH);
+      } else atomicOr(&ctrl[2], 1u);
+    }
+    const int shape = small_fp ? ((tx1 > tx0 ? 1 : 0) | (ty1 > ty0 ? 2 : 0)) : 0;  // which neighbours exist: 1 right, 2 below
+    const int ne = shape == 3 ? 3 : (shape ? 1 : 0);
+    const int incl_e = wave_incl_scan(ne);
+    const int total_e = (a.dbg & (32 | 64)) ? 0 : __builtin_amdgcn_readlane(incl_e, 63);
+    const int geo = tx0 | (ty0 << 12) | (shape << 24);
+    for (int k0 = 0; k0 < total_e; k0 += 64) {
+      const int q = k0 + lane;
+      int t = 0;  // the face of pair q: the first lane whose inclusive sum exceeds q
+#pragma unroll
+      for (int step = 32; step >= 1; step >>= 1) t += (__shfl(incl_e, t + step - 1) <= q) ? step : 0;
+      t = min(t, 63);
+      const int g = __shfl(geo, t);
+      const int sh = (g >> 24) & 3;
+      const int which = q - (__shfl(incl_e, t) - (sh == 3 ? 3 : 1));  // 0 .. 2: the face's extra tile
+      const int k = sh == 3 ? which + 1 : sh;                          // tile slot 1 (right), 2 (below), 3 (below right)
+      const int4 p0 = make_int4(__shfl(r0.x, t), __shfl(r0.y, t), __shfl(r0.z, t), __shfl(r0.w, t));
+      const int4 p1 = make_int4(__shfl(r1.x, t), __shfl(r1.y, t), __shfl(r1.z, t), __shfl(r1.w, t));
+      const int4 p2 = make_int4(__shfl(r2.x, t), __shfl(r2.y, t), __shfl(r2.z, t), __shfl(r2.w, t));
+      const int py = __shfl(r3.y, t), pz = __shfl(r3.z, t), pw = __shfl(r3.w, t);
+      if (q < total_e) {
+        const uint32_t pos = (uint32_t)(k == 1 ? py : k == 2 ? pz : pw);
+        const int tx = (g & 0xFFF) + (k & 1), ty = ((g >> 12) & 0xFFF) + (k >> 1);
+        if (pos < (uint32_t)a.cap_tile) {
+          const int64_t idx = (int64_t)(ty * a.TX + tx) * a.cap_tile + pos;
+          compile_entry(a, ctrl, comp, nr8, idx, p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH);
+        } else atomicOr(&ctrl[2], 1u);
+      }
+    }
+  }
+  if (DIRECT) {
+    // faces over more than 2 x 2 tiles: the wave expands their (face, tile) pairs right here, from the records it holds
+    // (bin_big_pairs).  Variant bit 64: they go to the view's big list instead (the back of the clip buffer, ctrl[5] = count)
+    // and k_bin_big sets them up again, 64 per wave -- one returning atomic per block on ONE address per view.
+    const bool big_fp = keep && !small_fp;
+    const unsigned long long mb = __ballot(big_fp);
+    if (mb) {
+      if (!(a.var & 64)) {
+        bin_big_pairs(a, ctrl, slot, lane, big_fp, r0, r1, r2, tx0, tx1, ty0, ty1);
+      } else {
+        const int lead = __ffsll((long long)mb) - 1;
+        uint32_t bb = 0;
+        if (lane == lead) bb = atomicAdd(&ctrl[5], (uint32_t)__popcll(mb));
+        bb = __shfl(bb, lead);
+        if (big_fp) a.clip[(int64_t)slot * a.F + (a.F - 1 - (int64_t)(bb + __popcll(mb & ((1ull << lane) - 1ull))))] = (uint32_t)f;
+      }
+    }
+  }
+  if (keep && !DIRECT) {
+    int4 *rec = a.rec + slot * a.rec_stride;
+    const int64_t s = (int64_t)base + prefix;
+    rec[s] = r0;
+    rec[a.F + s] = r1;
+    rec[2 * a.F + s] = r2;
+    rec[3 * a.F + s] = r3;
+    if (!small_fp)
+      for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&cntB[ty * a.TX + tx], 1u);
+  }
+  }  // work list loop
+  if (DIRECT && lane == 0 && n_rec) atomicAdd(&ctrl[0], n_rec);
+}
+
+// K2d  (single-pass binning) per view: totals of the per-tile counters for gr_raster_status.  grid (views), 1024 threads
+__global__ __launch_bounds__(1024) void k_bin_stats(BinArgs a) {
+  __shared__ unsigned long long part[16];
+  __shared__ uint32_t pmax[16];
+  const int slot = blockIdx.x;
+  uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  const uint32_t *cnt = ctrl + GR_CTRL_HDR;
+  unsigned long long sum = 0;
+  uint32_t mx = 0;
+  for (int t = threadIdx.x; t < a.T; t += 1024) { const uint32_t c = cnt[t]; sum += c; mx = max(mx, c); }
+  for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); }
+  if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = sum; pmax[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long total = 0; uint32_t m = 0;
+    for (int k = 0; k < 16; ++k) { total += part[k]; m = max(m, pmax[k]); }
+    ctrl[1] = (uint32_t)total;
+    const bool ovf = m > (uint32_t)a.cap_tile || ctrl[2] != 0;
+    atomicAdd(&a.stats[0], (unsigned long long)ctrl[0]);
+    atomicAdd(&a.stats[1], total);
+    atomicMax(&a.stats[2], (unsigned long long)m);  // direct mode: the largest per-tile count
+    if (ovf) { atomicMax(&a.stats[3], 1ull); atomicMin(&a.stats[4], (unsigned long long)a.group); }
+    if (ctrl[2] & 2u) atomicMax(&a.stats[5], 1ull);  // a face the 40-byte entry form cannot hold
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K2  exclusive scan of the per-tile counts (cntS + cntB) of one view.  grid (views), 1024 threads
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan_tiles(BinArgs a) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s;
+  const int slot = blockIdx.x;
+  uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  const uint32_t *cntS = ctrl + GR_CTRL_HDR;
+  const uint32_t *cntB = cntS + a.Tcap;
+  uint32_t *off = ctrl + GR_CTRL_HDR + 2 * a.Tcap;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < a.T; base += 1024) {
+    const int t = base + tid;
+    const uint32_t c = (t < a.T) ? cntS[t] + cntB[t] : 0u;
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int k = 0; k < wv; ++k) wbase += wave_tot[k];
+    const uint32_t carry = carry_s;
+    if (t < a.T) off[t] = carry + wbase + incl - c;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + wbase + incl;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const uint32_t total = carry_s;
+    ctrl[1] = total;
+    const bool ovf = (int64_t)total > a.ent_cap;
+    ctrl[2] = ovf ? 1u : 0u;
+    atomicAdd(&a.stats[0], (unsigned long long)ctrl[0]);
+    atomicAdd(&a.stats[1], (unsigned long long)total);
+    atomicMax(&a.stats[2], (unsigned long long)total);
+    if (ovf) { atomicMax(&a.stats[3], 1ull); atomicMin(&a.stats[4], (unsigned long long)a.group); }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K3  per (face, tile) entry: the face's edge functions re-based to the CENTRE of the tile and stored as a 48-byte
+//     "compiled" entry at its place in the tile's list (build_entry; layout in DESIGN.md section 5):
+//       E'_k(x_c, y_c) = C'_k + a_k x_c + b_k y_c   in units of one pixel, covered <=> all E'_k >= 0 (fill rule folded into C'_k)
+//     One int32 form for every face: all 64-bit set-up arithmetic happens here, once per entry; the tile rasterizer only
+//     streams entries (no index indirection, no 64-bit arithmetic).  12 words:
+//       word  0..3   C'_first C'_middle C'_last | slopes (a_first, a_middle: 16 + 16 bits, or the start of 4 x 24 bits)
+//       word  4..7   slopes (b_first, b_middle) | slopes (24-bit form only) | iz0 | A
+//       word  8..11  B | Xw = X0rel (24 bit) + rows in tile << 24 | ~face | Yw = Y0rel (24 bit) + first row << 24 + flags
+//     Single-pass binning calls it from K1 (compile_entry at the position the tile counter returned); the exact path from
+//     k_fill_compile below (positions of <= 2x2-tile faces come from K1, larger faces take one cursor atomic per tile).
+// ------------------------------------------------------------------------------------------------------------------
+// Faces whose snapped bounding box is smaller than GR_FAST_EXT sub-pixels (93 px) take a short form of the set-up: the
+// face overlaps the tile, so every pixel the tile rasterizer can probe (x in [-2, TW+2], y in [0, TH]) lies within
+// reach = (64 + 3) * 256 + ext < 41152 sub-pixels of every vertex, |dx|, |dy| <= ext, hence
+//   |E| <= (|dx| + |dy|) * reach + 1 < 48000 * 41152 < 2^31   and   |A|, |B| = 256 * |d| < 2^23:
+// every product has 24-bit factors and every value fits int32 -- no 64-bit arithmetic, no per-tile range test.
+// Larger faces take the general form below (identical coverage: both forms are exact).
+#define GR_FAST_EXT 24000
+#define GR_FLOOR_NOCORR_MAX 16000  // largest slope magnitude for which edge_floor<false> is exact (see there)
+__device__ __forceinline__ int pack16(int lo, int hi) { return (lo & 0xFFFF) | (hi << 16); }
+__device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const int4 p2, int px0, int py0, int TW, int TH,
+                                            int4 &e0, int4 &e1, int4 &e2, int &rows) {
+  const int X0 = p0.x, Y0 = p0.y, X1 = p0.z, Y1 = p0.w, X2 = p1.x, Y2 = p1.y;
+  const int Pxo = px0 * 256 + 128, Pyo = py0 * 256 + 128;  // centre of the tile's first pixel
+  const int jlo = max((p2.z & 0xFFFF) - px0, 0), jhi = min((int)((uint32_t)p2.z >> 16) - px0, TW - 1);
+  const int ilo = max((p2.w & 0xFFFF) - py0, 0), ihi = min((int)((uint32_t)p2.w >> 16) - py0, TH - 1);
+  const int dx0 = X1 - X0, dy0 = Y1 - Y0, dx1 = X2 - X1, dy1 = Y2 - Y1, dx2 = X0 - X2, dy2 = Y0 - Y2;
+  const int t0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;  // R3 top-left rule as a bias
+  const int t1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
+  const int t2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
+  const int ext = max(imax3(X0, X1, X2) - imin3(X0, X1, X2), imax3(Y0, Y1, Y2) - imin3(Y0, Y1, Y2));
+  // row word, CENTRED like everything else the tile kernel reads: float(P_y - Y0) of centred row y_c = y - TH/2 is
+  // float(256 y_c + Yw); the entry's first row as y_c (6 bits, signed).  |Pyo - Y0| + 8192 < 2^23 inside the guard band
+  const int yw = ((Pyo - Y0 + (TH / 2) * 256) & 0xFFFFFF) | (((ilo - TH / 2) & 0x3F) << 24);
+  int nr = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;         // rows of the entry in this tile (<= 64)
+  // ONE form for every face, however large: the three edge functions in units of 256 around the tile CENTRE,
+  //   E'_k(x_c, y_c) = C'_k + a_k x_c + b_k y_c,   x_c = x - TW/2, y_c = y - TH/2,   a_k = -dy_k, b_k = dx_k (|.| < 2^23),
+  //   C'_k = floor(C_k / 256) with C_k the exact edge value (fill-rule bias included) at the centre pixel.
+  // Exact because A_k = 256 a_k and B_k = 256 b_k are multiples of 256: E_k >= 0 <=> floor(E_k / 256) >= 0 <=> E'_k >= 0.
+  // C'_k can be as large as 2^39 for a face that spans the guard band, but inside the tile (|x_c| <= TW/2 + 2 with the
+  // solver's reach, |y_c| <= TH/2) the sum a x_c + b y_c stays within M_k = (TW/2 + 2)|a_k| + (TH/2)|b_k|: a C'_k beyond
+  // +-M_k cannot change sign in the tile, so it is CLAMPED to +-(M_k + 1) -- same coverage, and every value the tile
+  // kernel forms fits int32 (M_k < 2^29.1).  The edges are stored in an order the tile kernel relies on: FIRST an edge
+  // with a > 0 (it bounds the span from the left), LAST one with a < 0 (from the right), the remaining one in between
+  // -- a triangle of non-zero area has both kinds (the a_k sum to zero; so do the b_k: the last edge's slopes are not
+  // stored).  The plane of 1/z refers to vertex 0 whatever the edge order.
+  const int Pxc = Pxo + (TW / 2) * 256, Pyc = Pyo + (TH / 2) * 256;  // centre of the tile's centre pixel
+  int c0, c1, c2;
+  if (ext < GR_FAST_EXT) {  // every product has 24-bit factors and every value fits int32: no 64-bit arithmetic, no clamp
+    c0 = (__mul24(dx0, Pyc - Y0) - __mul24(dy0, Pxc - X0) + t0) >> 8;
+    c1 = (__mul24(dx1, Pyc - Y1) - __mul24(dy1, Pxc - X1) + t1) >> 8;
+    c2 = (__mul24(dx2, Pyc - Y2) - __mul24(dy2, Pxc - X2) + t2) >> 8;
+  } else {
+    const long long C0 = ((long long)dx0 * (Pyc - Y0) - (long long)dy0 * (Pxc - X0) + (long long)t0) >> 8;
+    const long long C1 = ((long long)dx1 * (Pyc - Y1) - (long long)dy1 * (Pxc - X1) + (long long)t1) >> 8;
+    const long long C2 = ((long long)dx2 * (Pyc - Y2) - (long long)dy2 * (Pxc - X2) + (long long)t2) >> 8;
+    const long long hx = TW / 2 + 2, hy = TH / 2;
+    const long long M0 = hx * abs(dy0) + hy * abs(dx0) + 1, M1 = hx * abs(dy1) + hy * abs(dx1) + 1,
+                    M2 = hx * abs(dy2) + hy * abs(dx2) + 1;
+    c0 = (int)min(max(C0, -M0), M0);
+    c1 = (int)min(max(C1, -M1), M1);
+    c2 = (int)min(max(C2, -M2), M2);
+  }
+  const int a0 = -dy0, a1 = -dy1, a2 = -dy2;
+  // The bounding box reaches this tile; the triangle itself may not (the far corner of a diagonal face).  An edge whose
+  // value is negative even at the tile corner most in its favour, C' + (TW/2)|a| + (TH/2)|b| < 0, excludes every pixel of
+  // the tile: the entry is DEAD (0 rows: the tile kernel never looks at it); k_bin_big asks before it takes a list slot.
+  const bool touches = nr > 0 && c0 + (TW / 2) * abs(a0) + (TH / 2) * abs(dx0) >= 0 &&
+                       c1 + (TW / 2) * abs(a1) + (TH / 2) * abs(dx1) >= 0 && c2 + (TW / 2) * abs(a2) + (TH / 2) * abs(dx2) >= 0;
+  if (!touches) nr = 0;
+  rows = nr;
+  // float(P_x - X0) of the pixel with CENTRED column x_c = x - TW/2 is float(256 x_c + Xw)
+  const int xw = ((Pxo - X0 + (TW / 2) * 256) & 0xFFFFFF) | (nr << 24);
+  const int kf = a0 > 0 ? 0 : (a1 > 0 ? 1 : 2);   // first: a > 0
+  const int kl = a0 < 0 ? 0 : (a1 < 0 ? 1 : 2);   // last: a < 0
+  const int km = 3 - kf - kl;
+  auto pick = [](int k, int v0, int v1, int v2) { return k == 0 ? v0 : (k == 1 ? v1 : v2); };
+  const int cf = pick(kf, c0, c1, c2), cm = pick(km, c0, c1, c2), cl = pick(kl, c0, c1, c2);
+  const int af = pick(kf, a0, a1, a2), am = pick(km, a0, a1, a2);
+  const int bf = pick(kf, dx0, dx1, dx2), bm = pick(km, dx0, dx1, dx2);
+  // slopes: four values (the last edge's are -(first + middle)).  Two packings: 16 bits each when every slope of the face
+  // fits (faces below 128 pixels: nearly all of them), else 24 bits each, flagged in bit 31 of the Yw word
+  const bool narrow = max(max(abs(a0), abs(a1)), max(abs(a2), max(abs(dx0), max(abs(dx1), abs(dx2))))) <= 32767;
+  int w3, w4, w5;
+  if (narrow) {
+    w3 = pack16(af, am); w4 = pack16(bf, bm);
+    w5 = ext < GR_FAST_EXT ? 0 : 1;  // never read for 16-bit slopes; non-zero tells store_entry that the short form does not fit
+  } else {
+    w3 = (af & 0xFFFFFF) | (am << 24);
+    w4 = ((am >> 8) & 0xFFFF) | (bf << 16);
+    w5 = ((bf >> 16) & 0xFF) | (bm << 8);
+  }
+  e0 = make_int4(cf, cm, cl, w3);
+  e1 = make_int4(w4, w5, p1.z, p2.x);
+  // bit 31: 24-bit slopes; bit 30: some slope magnitude beyond GR_FLOOR_NOCORR_MAX (the span solver must correct its floor)
+  const bool corr = !narrow || max(abs(a0), max(abs(a1), abs(a2))) > GR_FLOOR_NOCORR_MAX;
+  // ~face sits in an EVEN word: the tile kernel forms the 64-bit key (depth << 32 | ~face) in the register pair the entry
+  // was read into, without a move
+  e2 = make_int4(p2.y, xw, (int)~(uint32_t)p1.w, yw | (narrow ? 0 : (int)0x80000000) | (corr ? 0x40000000 : 0));
+  return touches;
+}
+
+// The SHORT form of an entry, 40 bytes (single-pass binning, a.ent40): what a face whose snapped bounding box stays below
+// GR_FAST_EXT sub-pixels (93 px: every face of a survey mesh) needs -- the three edge constants are below 2^23 in magnitude
+// there (|E| < 24000 * 64640 before the shift by 8: build_entry), the offsets of vertex 0 from the tile's centre pixel below
+// 2^15 (half a tile + the face's extent), the slopes fit 16 bits:
+//   s0 = c_first      s1 = c_mid      s2 = c_last[0:24] | first row (6 bits, centred) << 24 | corr << 31
+//   s3 = X0rel (16) | Y0rel << 16               s4, s5 = the slope words w3, w4        s6, s7 = iz0, A
+//   s8 = ~face (an EVEN word: the key pair)     s9 = B
+// (the tile kernel unpacks it with as many instructions as the 48-byte form; a denser packing of the constants cost it five more)
+// 17 % fewer bytes written here and read by the tile kernel than the 48-byte form (the binning tax of DESIGN.md section 10).
+// A face the short form cannot hold raises bit 1 of the view's overflow word: gr_raster_status reports GR_EOVERFLOW like
+// for a tile that outgrew its segment, remembers that this (mesh, image) needs 48-byte entries, and the caller repeats.
+__device__ __forceinline__ void store_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
+                                            uint8_t *__restrict__ nr8, int64_t idx, const int4 e0, const int4 e1, const int4 e2,
+                                            int rows) {
+  if (a.ent40) {
+    // e1.y (the third slope word) is zero for 16-bit slopes; bit 0 of it is build_entry's "too large for the short form"
+    // (the slot was handed out already: it must not keep stale bytes -- an older view's entry, or 48-byte data read as a
+    // 40-byte entry.  Zero rows: no work item of the tile kernel ever looks at it; the view is repeated anyway)
+    if (e1.y != 0 || e2.w < 0) { atomicOr(&ctrl[2], 2u); nr8[idx] = 0; return; }
+    // a chunk of 64 entries (2560 bytes) holds the 64 x {s0 .. s7} first, then the 64 x {s8, s9}: the tile kernel copies the
+    // chunk to LDS as it is and reads an entry with two 16-byte reads and one 8-byte read, all aligned
+    char *chunk = reinterpret_cast<char *>(comp) + (idx >> 6) * 2560;
+    const int t = (int)(idx & 63);
+    int4 *d4 = reinterpret_cast<int4 *>(chunk) + t * 2;
+    d4[0] = make_int4(e0.x, e0.y, (int)(((uint32_t)e0.z & 0xFFFFFFu) | ((uint32_t)e2.w & 0x3F000000u) | (((uint32_t)e2.w << 1) & 0x80000000u)),
+                      (int)(((uint32_t)e2.y & 0xFFFFu) | ((uint32_t)e2.w << 16)));
+    d4[1] = make_int4(e0.w, e1.x, e1.z, e1.w);
+    reinterpret_cast<uint2 *>(chunk + 2048)[t] = make_uint2((uint32_t)e2.z, (uint32_t)e2.x);
+  } else {
+    int4 *dst = comp + idx * GR_ENT_Q;
+    dst[0] = e0; dst[1] = e1; dst[2] = e2;
+  }
+  nr8[idx] = (uint8_t)rows;
+}
+
+__device__ __forceinline__ bool compile_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
+                                              uint8_t *__restrict__ nr8, int64_t idx, const int4 p0, const int4 p1,
+                                              const int4 p2, int px0, int py0, int TW, int TH) {
+  int4 e0, e1, e2;
+  int rows;
+  const bool touches = build_entry(p0, p1, p2, px0, py0, TW, TH, e0, e1, e2, rows);
+  store_entry(a, ctrl, comp, nr8, idx, e0, e1, e2, rows);
+  return touches;
+}
+
+__global__ __launch_bounds__(256) void k_fill_compile(BinArgs a) {
+  const int slot = blockIdx.y;
+  uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  const uint32_t n_rec = ctrl[0];
+  const uint32_t *cntS = ctrl + GR_CTRL_HDR;
+  const uint32_t *off = ctrl + GR_CTRL_HDR + 2 * a.Tcap;
+  uint32_t *cur = ctrl + GR_CTRL_HDR + 3 * a.Tcap;
+  const int4 *rec0 = a.rec + slot * a.rec_stride;
+  int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
+  uint8_t *nr8 = a.nrow8 + slot * a.ent_cap;
+  const int TW = 1 << a.twl, TH = 1 << a.thl;
+  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n_rec; r += gridDim.x * 256) {
+    const int4 p0 = rec0[r], p1 = rec0[a.F + r], p2 = rec0[2 * a.F + r];
+    const int tx0 = (p2.z & 0xFFFF) >> a.twl, tx1 = (int)((uint32_t)p2.z >> 16) >> a.twl;
+    const int ty0 = (p2.w & 0xFFFF) >> a.thl, ty1 = (int)((uint32_t)p2.w >> 16) >> a.thl;
+    const bool small_fp = (tx1 - tx0 <= 1) && (ty1 - ty0 <= 1);
+    int4 pos = {0, 0, 0, 0};
+    if (small_fp) pos = rec0[3 * a.F + r];
+#pragma unroll 1
+    for (int ty = ty0; ty <= ty1; ++ty) {
+#pragma unroll 1
+      for (int tx = tx0; tx <= tx1; ++tx) {
+        const int t = ty * a.TX + tx;
+        const int k = ((ty - ty0) << 1) | (tx - tx0);
+        const uint32_t pk = (uint32_t)(k == 0 ? pos.x : k == 1 ? pos.y : k == 2 ? pos.z : pos.w);
+        const int64_t idx = small_fp ? (int64_t)off[t] + pk : (int64_t)off[t] + cntS[t] + atomicAdd(&cur[t], 1u);
+        if (idx < a.ent_cap) compile_entry(a, ctrl, comp, nr8, idx, p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K3c  R7: faces that straddle the near plane or the guard band (the view's clip list, filled by K1) are clipped in
+//      camera space -- Sutherland-Hodgman against z >= near and |s| <= 16383 px, double precision, every operation
+//      individually rounded, crossings always computed from the inside vertex (two faces sharing an edge get the same
+//      new vertex) -- and the fan of the clipped polygon is binned like any other triangle, with the face's id.  Rare
+//      (a camera inside the scene, faces larger than the guard band): one thread per face, plain atomics, local arrays.
+//      The oracle's orc_clip_face is the same code in C.
+// ------------------------------------------------------------------------------------------------------------------
+struct P3 { double x, y, z; };
+
+__device__ __forceinline__ double clip_plane(const double *pl, P3 p) {
+  const double t1 = pl[0] * p.x, t2 = pl[1] * p.y, t3 = pl[2] * p.z;
+  return ((t1 + t2) + t3) + pl[3];
+}
+
+__device__ __forceinline__ P3 clip_cross(P3 in, double din, P3 out, double dout) {
+  const double t = din / (din - dout);
+  const double ex = out.x - in.x, ey = out.y - in.y, ez = out.z - in.z;
+  const double px = t * ex, py = t * ey, pz = t * ez;
+  P3 r;
+  r.x = in.x + px; r.y = in.y + py; r.z = in.z + pz;
+  return r;
+}
+
+// one triangle of a clipped face: R2 / R4 set-up from three snapped vertices, then binning (no wave aggregation)
+template <bool DIRECT>
+__device__ void emit_triangle(const BinArgs &a, int slot, uint32_t *ctrl, Vtx v0, Vtx v1, Vtx v2, int face) {
+  long long area2 = (long long)(v1.X - v0.X) * (long long)(v2.Y - v0.Y) - (long long)(v2.X - v0.X) * (long long)(v1.Y - v0.Y);
+  if (area2 == 0) return;
+  if (area2 < 0) { Vtx t = v1; v1 = v2; v2 = t; area2 = -area2; }
+  const int Xmin = imin3(v0.X, v1.X, v2.X), Xmax = imax3(v0.X, v1.X, v2.X);
+  const int Ymin = imin3(v0.Y, v1.Y, v2.Y), Ymax = imax3(v0.Y, v1.Y, v2.Y);
+  int jmin = (Xmin - 128 + 255) >> 8, jmax = (Xmax - 128) >> 8;
+  int imin = (Ymin - 128 + 255) >> 8, imax = (Ymax - 128) >> 8;
+  jmin = max(jmin, 0); imin = max(imin, 0);
+  jmax = min(jmax, a.w - 1); imax = min(imax, a.h - 1);
+  if (jmin > jmax || imin > imax) return;
+  const double d1 = (double)v1.iz - (double)v0.iz;
+  const double d2 = (double)v2.iz - (double)v0.iz;
+  const double a2 = (double)area2;
+  double n1, n2;
+  n1 = d1 * (double)(v2.Y - v0.Y); n2 = d2 * (double)(v1.Y - v0.Y);
+  const float A = (float)((n1 - n2) / a2);
+  n1 = d2 * (double)(v1.X - v0.X); n2 = d1 * (double)(v2.X - v0.X);
+  const float B = (float)((n1 - n2) / a2);
+  const int4 r0 = make_int4(v0.X, v0.Y, v1.X, v1.Y);
+  const int4 r1 = make_int4(v2.X, v2.Y, __float_as_int(v0.iz), face);
+  const int4 r2 = make_int4(__float_as_int(A), __float_as_int(B), jmin | (jmax << 16), imin | (imax << 16));
+  const int tx0 = jmin >> a.twl, tx1 = jmax >> a.twl, ty0 = imin >> a.thl, ty1 = imax >> a.thl;
+  uint32_t *cntS = ctrl + GR_CTRL_HDR;
+  uint32_t *cntB = cntS + a.Tcap;
+  if (DIRECT) {
+    int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
+    uint8_t *nr8 = a.nrow8 + slot * a.ent_cap;
+    for (int ty = ty0; ty <= ty1; ++ty)
+      for (int tx = tx0; tx <= tx1; ++tx) {
+        const int t = ty * a.TX + tx;
+        const uint32_t pos = atomicAdd(&cntS[t], 1u);
+        if (pos < (uint32_t)a.cap_tile) {
+          const int64_t idx = (int64_t)t * a.cap_tile + pos;
+          compile_entry(a, ctrl, comp, nr8, idx, r0, r1, r2, tx << a.twl, ty << a.thl, 1 << a.twl, 1 << a.thl);
+        } else atomicOr(&ctrl[2], 1u);
+      }
+  } else {
+    const uint32_t s = atomicAdd(&ctrl[0], 1u);
+    if ((int64_t)s >= a.F) { atomicMax(&a.stats[3], 1ull); atomicMin(&a.stats[4], (unsigned long long)a.group); return; }  // more records than faces: the call is rejected
+    const bool small_fp = (tx1 - tx0 <= 1) && (ty1 - ty0 <= 1);
+    int4 r3 = {0, 0, 0, 0};
+    if (small_fp) {
+      r3.x = (int)atomicAdd(&cntS[ty0 * a.TX + tx0], 1u);
+      if (tx1 > tx0) r3.y = (int)atomicAdd(&cntS[ty0 * a.TX + tx1], 1u);
+      if (ty1 > ty0) r3.z = (int)atomicAdd(&cntS[ty1 * a.TX + tx0], 1u);
+      if (tx1 > tx0 && ty1 > ty0) r3.w = (int)atomicAdd(&cntS[ty1 * a.TX + tx1], 1u);
+    } else {
+      for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&cntB[ty * a.TX + tx], 1u);
+    }
+    int4 *rec = a.rec + slot * a.rec_stride;
+    rec[s] = r0; rec[a.F + s] = r1; rec[2 * a.F + s] = r2; rec[3 * a.F + s] = r3;
+  }
+}
+
+template <bool DIRECT>
+__global__ __launch_bounds__(64) void k_clip_faces(const float *__restrict__ cams, BinArgs a) {
+  // polygon buffers in LDS, one column per thread (dynamically indexed local arrays would put the kernel on scratch
+  // memory, which costs every launch ~10 us even when the clip lists are empty)
+  __shared__ double px[2][8][64], py[2][8][64], pz[2][8][64];
+  __shared__ int sX[8][64], sY[8][64];
+  __shared__ float sZ[8][64];
+  const int slot = blockIdx.y, tid = threadIdx.x;
+  const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
+  uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  const int64_t n_clip = min((int64_t)ctrl[4], a.F);
+  if ((int64_t)blockIdx.x * 64 >= n_clip) return;  // the usual case: nothing to clip in this view
+  const float fe = cam[12], cxp = cam[13], cyp = cam[14], nearp = cam[15];
+  if (!(nearp > 0.0f) || !(fe > 0.0f) || !isfinite(fe) || !isfinite(cxp) || !isfinite(cyp)) return;
+  constexpr double G = 16383.0;
+  for (int64_t i = (int64_t)blockIdx.x * 64 + tid; i < n_clip; i += (int64_t)gridDim.x * 64) {
+    const int64_t f = a.clip[(int64_t)slot * a.F + i];
+    const float *sp = a.soup + 9 * f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // the first half of R1
+      const float *p = sp + 3 * k;
+      const float dx = p[0] - cam[9], dy = p[1] - cam[10], dz = p[2] - cam[11];
+      float m0, m1, m2;
+      m0 = cam[0] * dx; m1 = cam[3] * dy; m2 = cam[6] * dz;
+      px[0][k][tid] = (double)((m0 + m1) + m2);
+      m0 = cam[1] * dx; m1 = cam[4] * dy; m2 = cam[7] * dz;
+      py[0][k][tid] = (double)((m0 + m1) + m2);
+      m0 = cam[2] * dx; m1 = cam[5] * dy; m2 = cam[8] * dz;
+      pz[0][k][tid] = (double)((m0 + m1) + m2);
+    }
+    int n = 3, cur = 0;
+    bool bad = false;
+#pragma unroll
+    for (int pl = 0; pl < 5; ++pl) {
+      // plane pl:  a x + b y + c z + d >= 0   (near plane, then sx <= G, sx >= -G, sy <= G, sy >= -G)
+      const double pa = pl == 1 ? -(double)fe : pl == 2 ? (double)fe : 0.0;
+      const double pb = pl == 3 ? -(double)fe : pl == 4 ? (double)fe : 0.0;
+      const double pc = pl == 0 ? 1.0 : pl == 1 ? G - (double)cxp : pl == 2 ? G + (double)cxp : pl == 3 ? G - (double)cyp
+                                                                                                        : G + (double)cyp;
+      const double pd = pl == 0 ? -(double)nearp : 0.0;
+      const double plane[4] = {pa, pb, pc, pd};
+      if (n == 0 || bad) break;
+      int m = 0;
+      for (int e = 0; e < n; ++e) {
+        const int e1 = (e + 1) % n;
+        const P3 S = {px[cur][e][tid], py[cur][e][tid], pz[cur][e][tid]};
+        const P3 E = {px[cur][e1][tid], py[cur][e1][tid], pz[cur][e1][tid]};
+        const double dS = clip_plane(plane, S), dE = clip_plane(plane, E);
+        const bool inS = dS >= 0.0, inE = dE >= 0.0;
+        P3 o0 = E, o1 = E;
+        int cnt = 0;
+        if (inS && inE) { cnt = 1; }
+        else if (inS && !inE) { o0 = clip_cross(S, dS, E, dE); cnt = 1; }
+        else if (!inS && inE) { o0 = clip_cross(E, dE, S, dS); cnt = 2; }
+        if (cnt >= 1) { if (m < 8) { px[cur ^ 1][m][tid] = o0.x; py[cur ^ 1][m][tid] = o0.y; pz[cur ^ 1][m][tid] = o0.z; } ++m; }
+        if (cnt == 2) { if (m < 8) { px[cur ^ 1][m][tid] = o1.x; py[cur ^ 1][m][tid] = o1.y; pz[cur ^ 1][m][tid] = o1.z; } ++m; }
+      }
+      if (m > 8) bad = true;
+      n = m;
+      cur ^= 1;
+    }
+    if (bad || n < 3) continue;
+    for (int e = 0; e < n; ++e) {
+      const float qx = (float)px[cur][e][tid], qy = (float)py[cur][e][tid], qz = (float)pz[cur][e][tid];
+      if (!(qz > 0.0f)) { bad = true; break; }
+      const float iz = 1.0f / qz;
+      const float fx = fe * qx;
+      const float fy = fe * qy;
+      const float sx = cxp + fx * iz;
+      const float sy = cyp + fy * iz;
+      if (!(fabsf(sx) < 16384.0f) || !(fabsf(sy) < 16384.0f)) { bad = true; break; }
+      sX[e][tid] = (int)floorf(sx * 256.0f + 0.5f);
+      sY[e][tid] = (int)floorf(sy * 256.0f + 0.5f);
+      sZ[e][tid] = iz;
+    }
+    if (bad) continue;
+    const int face = a.orig[f];
+    Vtx v0;
+    v0.X = sX[0][tid]; v0.Y = sY[0][tid]; v0.iz = sZ[0][tid]; v0.valid = v0.front = v0.finite = true;
+    for (int k = 1; k + 1 < n; ++k) {
+      Vtx v1 = v0, v2 = v0;
+      v1.X = sX[k][tid]; v1.Y = sY[k][tid]; v1.iz = sZ[k][tid];
+      v2.X = sX[k + 1][tid]; v2.Y = sY[k + 1][tid]; v2.iz = sZ[k + 1][tid];
+      emit_triangle<DIRECT>(a, slot, ctrl, v0, v1, v2, face);
+    }
+  }
+}
+
+// K1b  (variant bit 64 only: the default expands big faces inside K1) single-pass binning of the view's big list: a wave takes
+//      64 big faces, one per lane (records recomputed from the soup: same code as K1, same bits) and expands their
+//      (face, tile) pairs with bin_big_pairs.
+__global__ __launch_bounds__(256) void k_bin_big(const float *__restrict__ cams, BinArgs a) {
+  const int slot = blockIdx.y;
+  const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
+  uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  const int64_t n_big = min((int64_t)ctrl[5], a.F);
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), wstep = (int64_t)gridDim.x * 4;
+  if (wave0 * 64 >= n_big) return;  // the usual case for terrain: nothing to do
+  for (int64_t i0 = wave0 * 64; i0 < n_big; i0 += wstep * 64) {
+    int4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0};
+    int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+    bool clip_me, keep = false;
+    if (i0 + lane < n_big) keep = face_setup(a, cam, a.clip[(int64_t)slot * a.F + (a.F - 1 - (i0 + lane))], r0, r1, r2, tx0, tx1, ty0, ty1, clip_me);
+    bin_big_pairs(a, ctrl, slot, lane, keep, r0, r1, r2, tx0, tx1, ty0, ty1);
+  }
+}
+
+}  // namespace
+
+namespace grimpl {
+
+// stage 1 of a launch group: cull, set up and bin `nb` views (camera records `cams`) into scratch slots slot0..
+int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int group, hipStream_t s) {
+  BinArgs a = make_args(c, h, w, slot0);
+  a.group = group;
+  GR_HIP(c, hipMemsetAsync(a.ctrl, 0, sizeof(uint32_t) * c->ctrl_stride * nb, s));
+  if (a.dbg & 512) {  // test hook: every entry slot and row count starts as garbage (0xFF), like scratch that an earlier call left behind
+    GR_HIP(c, hipMemsetAsync(a.comp, 0xFF, sizeof(int4) * GR_ENT_Q * (size_t)c->ent_cap * nb, s));
+    GR_HIP(c, hipMemsetAsync(a.nrow8, 0xFF, (size_t)c->ent_cap * nb, s));
+  }
+  {
+    Timed t(c, s, ST_SETUP);
+    const int nblk = (int)ceil_div(c->F, GR_BLOCK);
+    hipLaunchKernelGGL(k_cull_blocks, dim3((unsigned)ceil_div(nblk, 256), nb), dim3(256), a.touched ? sizeof(uint32_t) * a.tw : 0, s,
+                       cams, a, nblk);
+    // k_setup_cull: a wave per surviving 64-face block would mostly pay for starting waves (a survey view keeps a tenth of
+    // the blocks: C2 7.5 -> 6.1 us per view with an eighth of the workgroups): about nblk / 32 waves per view take a few
+    // blocks each -- but never fewer than 16 k waves per launch, so that a call with a few views still fills the machine.
+    // (Requesting the next block's soup one iteration ahead was measured on top of this: 100 VGPRs, no gain.)
+    const int gmax = std::min((nblk + 3) / 4, 1024);
+    const unsigned gsetup = (unsigned)std::max(1, std::min(gmax, std::max(nblk / 128, 4096 / std::max(nb, 1))));
+    if (a.cap_tile > 0) {
+      hipLaunchKernelGGL(k_setup_cull<true>, dim3(gsetup, nb), dim3(256), 0, s, cams, a);
+      if (a.var & 64) hipLaunchKernelGGL(k_bin_big, dim3(256, nb), dim3(256), 0, s, cams, a);
+      hipLaunchKernelGGL(k_clip_faces<true>, dim3(8, nb), dim3(64), 0, s, cams, a);
+    } else {
+      hipLaunchKernelGGL(k_setup_cull<false>, dim3(gsetup, nb), dim3(256), 0, s, cams, a);
+      hipLaunchKernelGGL(k_clip_faces<false>, dim3(8, nb), dim3(64), 0, s, cams, a);
+    }
+  }
+  c->last_direct = a.cap_tile > 0;
+  if (a.cap_tile > 0) {
+    Timed t(c, s, ST_SCAN);
+    hipLaunchKernelGGL(k_bin_stats, dim3(nb), dim3(1024), 0, s, a);
+  } else {
+    {
+      Timed t(c, s, ST_SCAN);
+      hipLaunchKernelGGL(k_scan_tiles, dim3(nb), dim3(1024), 0, s, a);
+    }
+    {
+      Timed t(c, s, ST_FILL);
+      const unsigned g = (unsigned)std::min<int64_t>(ceil_div(c->F, 256), 1024);
+      hipLaunchKernelGGL(k_fill_compile, dim3(g, nb), dim3(256), 0, s, a);
+    }
+  }
+  GR_HIP(c, hipGetLastError());
+  return GR_OK;
+}
+
+}  // namespace grimpl

@@ -1,0 +1,612 @@
+// geograypher_amd/csrc/raster_tile.hip -- k_raster_tile, the dominant kernel: a 64 x 32 tile of depth|id keys in LDS, one
+// scanline of one triangle per lane, ds_max_u64 resolve; ids or fused per-face winners out.
+// Compile with -ffp-contract=off: every floating-point operation below is individually rounded on purpose.
+#include "gr_internal.hpp"
+#include "dev_common.hpp"
+
+using namespace grimpl;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------
+// K4  tile rasterizer (the dominant kernel).  grid (T, views), 256 threads = 4 waves, one 64 x TH tile per workgroup.
+//     depth|id keys (u64: 1/z bits << 32 | ~face) live in LDS; visibility is resolved with ds_max_u64, so the result
+//     does not depend on list order.
+//       phase 1  the tile's list is taken in CHUNKS of 64 entries.  A chunk is copied once into a 3 KiB LDS buffer
+//                shared by the workgroup (one 16-byte load + one ds_write_b128 per lane, 48 lanes per wave); in
+//                single-pass mode the first chunk and its 64 row counts (the nrow8 stream) are requested before the
+//                tile's count is known (the segment address is static: one memory round trip instead of two);
+//       phase 2  every wave prefix-sums the same 64 row counts with DPP moves: the chunk's work is total_rows
+//                (entry, row) items, taken 64 at a time; the 64-item batches are dealt to the waves round-robin (an
+//                average C2 tile has 6.5 batches: 7 are issued, where a per-wave split of the ENTRIES issued 8); an
+//                item finds its entry through the wave's LDS mailboxes (starts post, items read, a DPP prefix
+//                maximum carries the latest start forward) and reads the entry's 12 words with three ds_read_b128
+//                (12 LDS cycles per batch; the register-resident entries of round 1 cost twelve ds_bpermute = 48);
+//       phase 3  ONE SCANLINE OF ONE TRIANGLE PER LANE: the exact covered span [xs, xe] comes from the three edge
+//                inequalities (span_solve: probe-free float floor division, exact by construction -- edge_floor), then
+//                the lane walks the span two pixels at a time and issues one ds_max_u64 per covered pixel.
+//     What bounds it: VALU issue (74-80 % of the SIMD cycles), then the LDS pipe (62-66 %); 7 workgroups
+//     fit a CU (21.25 KiB of LDS each).
+//     Epilogues: ids -> 16-byte stores (4 pixels per lane); fused projection -> per-face winners (see fused_winners).
+// ------------------------------------------------------------------------------------------------------------------
+// LDS image of a tile: rows of TW keys padded by GR_LDS_PAD keys (stride 69 keys = 552 B).  The rows of one triangle
+// walk their spans in step; with a row offset of 5 key-banks a pile-up on one bank needs a left edge that recedes
+// 5 px per row (a pad of 1 piled up every 45-degree edge: 530 of 1820 LDS cycles per tile were bank conflicts), and a
+// pixel's address advances by a plain +8 bytes along the scanline (no wrap arithmetic in the inner loop).
+#ifndef GR_LDS_PAD
+#define GR_LDS_PAD 5
+#endif
+template <int TWL, int PAD>
+__device__ __forceinline__ int lds_idx(int row, int col) {
+  return __mul24(row, (1 << TWL) + PAD) + col;
+}
+
+// floor(E / m) for an integer edge value E (|E| < 2^23 wherever the result matters) and an edge slope magnitude
+// 0 <= m < 2^15, clamped to [-66, 65] (-67 / 66 with the correction): the scanline solver of the tile kernel.
+//   g = (E + 0.5) * rcp(m) in fp32.  (E + 0.5) / m is never an integer and at least 0.5 / m away from one; the fp32 error
+//   of g (v_rcp_f32: 1 ulp, one rounded multiply) is below 66 * 1.8e-7 = 1.2e-5 wherever |g| <= 66.  For m <= 16000
+//   the gap is 3.1e-5: floor(g) IS floor(E / m) -- checked exhaustively on the CPU against integer division with the
+//   reciprocal perturbed by up to 3.5 ulp (tests/test_span_floor.py) -- so no probe of the edge function is needed.
+//   CORR (m up to 32767): one exact remainder puts a proposal that is off by one right.
+//   m == 0 (an edge parallel to the scanline): g = +-inf, clamped to "no constraint" / "empty" by the sign of E.
+template <bool CORR>
+__device__ __forceinline__ int edge_floor(int E, int m, float mf) {
+  float g = ((float)E + 0.5f) * __builtin_amdgcn_rcpf(mf);
+  g = __builtin_amdgcn_fmed3f(g, -34.0f, 33.0f);  // centred columns -32 .. 31, plus the solver's reach
+  int fl;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(fl) : "v"(g));  // (int)floorf(g) in one instruction
+  if (CORR) {
+    const int rem = E - __mul24(fl, m);
+    fl += (rem >= m ? 1 : 0) - (rem < 0 ? 1 : 0);
+  }
+  return fl;
+}
+
+// exact covered span [xs, xe] of one scanline in CENTRED tile coordinates (x_c = x - TW/2 in [-TW/2, TW/2 - 1],
+// y_c = y - TH/2): the first edge (a > 0) bounds it from the left, x_c >= ceil(-E'/a) = -floor(E'/a); the last (a < 0)
+// from the right, x_c <= floor(E'/|a|); the middle one does either (a == 0 works as either).  WIDE = false: every lane's
+// slopes are packed in 16 bits and at most GR_FLOOR_NOCORR_MAX; WIDE = true: any packing, exact correction.
+template <int TW, bool WIDE>
+__device__ __forceinline__ void span_solve(int C0, int C1, int C2, int w3, int w4, int w5, bool wide24, int yc, int &xs, int &xe) {
+  int a0 = (int)((uint32_t)w3 << 16) >> 16, a1 = w3 >> 16, b0 = (int)((uint32_t)w4 << 16) >> 16, b1 = w4 >> 16;
+  if (WIDE) {
+    const int A0 = (int)((uint32_t)w3 << 8) >> 8, A1 = (int)((((uint32_t)w3 >> 24) | ((uint32_t)w4 << 8)) << 8) >> 8;
+    const int B0 = (int)((((uint32_t)w4 >> 16) | ((uint32_t)w5 << 16)) << 8) >> 8, B1 = w5 >> 8;
+    a0 = wide24 ? A0 : a0; a1 = wide24 ? A1 : a1; b0 = wide24 ? B0 : b0; b1 = wide24 ? B1 : b1;
+  }
+  const int m2 = a0 + a1, b2 = -(b0 + b1);   // the last edge: a2 = -(a0 + a1) < 0, stored nowhere
+  const int m1 = a1 < 0 ? -a1 : a1;
+  const int f0 = edge_floor<WIDE>(C0 + __mul24(b0, yc), a0, (float)a0);
+  const int f1 = edge_floor<WIDE>(C1 + __mul24(b1, yc), m1, (float)m1);
+  const int f2 = edge_floor<WIDE>(C2 + __mul24(b2, yc), m2, (float)m2);
+  xs = max(-(TW / 2), -f0);
+  xe = min(TW / 2 - 1, f2);
+  const int lo = max(xs, -f1), hi = min(xe, f1);
+  xs = a1 > 0 ? lo : xs;
+  xe = a1 > 0 ? xe : hi;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// Phase 3 for ONE work item: scanline `q - et` of the entry whose 12 words (e0, e1, e2) the lane holds.
+// The tile kernel is VALU-issue bound (SQ_ACTIVE_INST_VALU: 85 % of the SIMD cycles), so this function is written for
+// instruction count: packed fp32 operands are broadcast by op_sel instead of being copied into register pairs, the
+// 64-bit key is formed in the pair the entry word ~face was read into, an odd span is extended to the LEFT (only the
+// first step has a spare slot, steered to the row's padding key), and the row addresses come from one multiply-add.
+// The fields of an entry the scanline code works with, from either form (store_entry).
+struct EntryView {
+  int c0, c1, c2, w3, w4, w5;   // edge constants, slope words
+  int X0rel, Y0rel, y_first;    // float(P - vertex 0) offsets of the centred pixel (0, 0); the entry's first row, centred
+  bool wide24, corr;            // 24-bit slope packing; a slope beyond GR_FLOOR_NOCORR_MAX
+  f32x2 izA;                    // {iz0, A}
+  float B;
+  uint32_t key;                 // ~face
+};
+
+__device__ __forceinline__ EntryView entry_view(const int4 e0, const int4 e1, const int4 e2) {
+  EntryView v;
+  v.c0 = e0.x; v.c1 = e0.y; v.c2 = e0.z; v.w3 = e0.w; v.w4 = e1.x; v.w5 = e1.y;
+  const int xw = e2.y, yw = e2.w;
+  v.X0rel = (xw << 8) >> 8;     // biased by TW/2 columns: float(P_x - X0) = float(256 x_c + X0rel)
+  v.Y0rel = (yw << 8) >> 8;     // biased by TH/2 rows
+  v.y_first = (yw << 2) >> 26;
+  v.wide24 = yw < 0;
+  v.corr = (uint32_t)yw >= 0x40000000u;  // compile_entry's flags: 24-bit slopes or a slope beyond 16000
+  v.izA.x = __int_as_float(e1.z); v.izA.y = __int_as_float(e1.w);  // the two words as the entry holds them
+  v.B = __int_as_float(e2.x);
+  v.key = (uint32_t)e2.z;
+  return v;
+}
+
+// the 40-byte form: five 8-byte words (store_entry)
+__device__ __forceinline__ EntryView entry_view(const uint2 s01, const uint2 s23, const uint2 s45, const uint2 s67, const uint2 s89) {
+  EntryView v;
+  v.c0 = (int)s01.x; v.c1 = (int)s01.y;
+  v.c2 = __builtin_amdgcn_sbfe(s23.x, 0, 24);
+  v.w3 = (int)s45.x; v.w4 = (int)s45.y; v.w5 = 0;
+  v.X0rel = __builtin_amdgcn_sbfe(s23.y, 0, 16);
+  v.Y0rel = (int)s23.y >> 16;
+  v.y_first = __builtin_amdgcn_sbfe(s23.x, 24, 6);
+  v.wide24 = false;
+  v.corr = (int)s23.x < 0;
+  v.izA.x = __uint_as_float(s67.x); v.izA.y = __uint_as_float(s67.y);
+  v.B = __uint_as_float(s89.y);
+  v.key = s89.x;
+  return v;
+}
+
+template <int TWL, int TH, int PAD>
+__device__ __forceinline__ void raster_item(unsigned long long *keys, const EntryView &e, const int r, const bool live) {
+  constexpr int TW = 1 << TWL;
+  const int X0rel = e.X0rel, Y0rel = e.Y0rel;
+  const int yc = e.y_first + r;  // centred row of the item: the entry's first row + the item's row within the entry
+  // faces with a slope beyond GR_FLOOR_NOCORR_MAX (edges longer than 62 pixels) or 24-bit slopes take the span solver
+  // with the exact correction; the choice is made per wave so that the usual case carries no extra instructions
+  const bool wide24 = e.wide24;
+  const bool wide = live && e.corr;
+  int xs = 0, xe = -1;
+  if (__ballot(wide) != 0ull) {
+    if (live) span_solve<TW, true>(e.c0, e.c1, e.c2, e.w3, e.w4, e.w5, wide24, yc, xs, xe);
+  } else {
+    if (live) span_solve<TW, false>(e.c0, e.c1, e.c2, e.w3, e.w4, e.w5, false, yc, xs, xe);
+  }
+  // two pixels per step with packed fp32 math (v_pk_mul_f32 / v_pk_add_f32: same IEEE results as the scalar forms,
+  // R4 op for op: z = iz0 + (A * float(P_x - X0) + B * float(P_y - Y0))).  float(P_x - X0) advances by exact float adds
+  // (integers below 2^24).
+  if (live && xs <= xe) {
+    const float m1 = e.B * (float)(yc * 256 + Y0rel);
+    const bool even = ((xe - xs) & 1) != 0;       // an even number of pixels xs .. xe
+    const int x0 = even ? xs : xs - 1;            // x0 .. xe is always an even number; pixel xs - 1 is computed, not stored
+    const float fx0 = (float)(x0 * 256 + X0rel);
+    f32x2 fx = {fx0, fx0 + 256.0f};
+    const f32x2 step = {512.0f, 512.0f};
+    const f32x2 izA = e.izA;                      // {iz0, A}: the two words as the entry holds them
+    f32x2 mp;
+    mp.x = m1;                                    // the high half is never selected (op_sel_hi)
+    // byte offset of the row's centred column 0: the key rows are (TW + PAD) * 8 bytes apart
+    const int row = __mul24(yc, (TW + PAD) * 8) + ((TH / 2) * (TW + PAD) + TW / 2) * 8;
+    int kp = row + x0 * 8;
+    const int kend = row + xe * 8;
+    const uint32_t key_a = e.key;
+    uint32_t key_b = key_a;                       // a second copy: each pixel of a step forms its key in its own pair
+    asm("v_mov_b32 %0, %1" : "=v"(key_b) : "v"(key_a));
+    auto pixel_pair = [&](bool first_too) {
+      f32x2 t, z;
+      asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t) : "v"(izA), "v"(fx));   // A * fx
+      asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(mp), "v"(t));                   // + m1
+      asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(z) : "v"(izA), "v"(t));                  // iz0 +
+      const int zb0 = max(__float_as_int(z.x), 1), zb1 = max(__float_as_int(z.y), 1);
+      unsigned long long *const k = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(keys) + kp);
+      if (first_too) atomicMax(k, ((unsigned long long)(uint32_t)zb0 << 32) | key_a);
+      atomicMax(k + 1, ((unsigned long long)(uint32_t)zb1 << 32) | key_b);
+      kp += 16;
+      fx += step;
+    };
+    pixel_pair(even);
+    while (kp < kend) pixel_pair(true);
+  }
+}
+
+// Phases 2-3 for one CHUNK of up to 64 entries staged in LDS (`ent`, 48 bytes each).  Every wave of the workgroup scans
+// the same 64 row counts; batch b of the chunk belongs to wave (b + rot) % NW.  tab: the wave's 64 mailbox words in LDS,
+// gen: the wave's batch counter (mailbox generation).  Returns the number of batches of the chunk.
+// item -> entry: an entry that starts inside the batch posts gen | lane | slot into the mailbox of its start slot; the
+// words of the current batch are larger than any stale one (gen grows), and among them the latest start is the largest,
+// so an unsigned prefix maximum over the RAW words carries the right entry to every item lane.
+template <int TWL, int TH, int NW, int PAD, bool SHORT>
+__device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, const int tab_base, const int tab_self, uint32_t &gen,
+                                                   const int4 *ent, const int nrows, const int lane,
+                                                   const int first_b, const int dbg) {
+  char *const lds = reinterpret_cast<char *>(keys);
+  const int incl = wave_incl_scan(nrows);
+  int total = __builtin_amdgcn_readlane(incl, 63);
+  const int excl = incl - nrows;
+  if (dbg & 1) total = 0;
+  for (int k0 = first_b * 64; k0 < total; k0 += 64 * NW) {
+    const int q = k0 + lane;
+    gen += 1u << 12;
+    const int slot = excl - k0;
+    if (nrows > 0 && slot >= 0 && slot < 64)
+      *reinterpret_cast<uint32_t *>(lds + tab_base + slot * 4) = gen | (uint32_t)(lane << 6) | (uint32_t)slot;
+    const int carry_t = __popcll(__ballot(incl <= k0));  // the entry that holds item k0: it exists (k0 < total), <= 63
+    const int carry_r = k0 - __builtin_amdgcn_readlane(excl, carry_t);  // row of item k0 within that entry
+    const uint32_t m = wave_incl_max(*reinterpret_cast<const uint32_t *>(lds + tab_self));
+    const bool started = m >= gen;                       // some entry starts at or before this lane's item in the batch
+    const int t = started ? (int)((m >> 6) & 63u) : carry_t;  // always an entry of this chunk, also beyond the last item
+    const int r = lane - (started ? (int)(m & 63u) : -carry_r);  // the item's row within its entry
+    const bool live = q < total;
+    if (SHORT) {
+      const int4 ea = ent[t * 2], eb = ent[t * 2 + 1];
+      const uint2 s89 = reinterpret_cast<const uint2 *>(ent)[256 + t];
+      raster_item<TWL, TH, PAD>(keys, entry_view(make_uint2(ea.x, ea.y), make_uint2(ea.z, ea.w), make_uint2(eb.x, eb.y),
+                                                 make_uint2(eb.z, eb.w), s89), r, live);
+    } else {
+      const int4 e0 = ent[t * 3], e1 = ent[t * 3 + 1], e2 = ent[t * 3 + 2];
+      raster_item<TWL, TH, PAD>(keys, entry_view(e0, e1, e2), r, live);
+    }
+  }
+  return (total + 63) >> 6;
+}
+
+// ids-only epilogue.  16-byte stores where the rows allow it: a lane owns 4 consecutive pixels of a row (16 lanes per
+// 64-pixel row, 16 rows per pass); the four low dwords sit 8 bytes apart in LDS (two ds_read2_b32), id = ~low (0 for an
+// empty pixel -> -1).  Images whose width is not a multiple of 4 take one pixel per lane.
+template <int TWL, int TH, int NT, int PAD>
+__device__ __forceinline__ void store_ids(const unsigned long long *keys, const BinArgs &a, int32_t *ids_plane, int te,
+                                          int px0, int py0) {
+  // (exchanging every key with the empty one here -- ds_wrxchg_rtn_b64, so that the workgroup's next tile needs no fill --
+  // was measured: returning LDS atomics are slow, 17.0 vs 15.6 us per C2 view)
+  const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
+  const int rows_here = min(TH, a.h - py0);
+  const bool vec = ((a.w & 3) == 0) && ((reinterpret_cast<uintptr_t>(ids_plane) & 15) == 0);
+  if (vec) {
+    const int c4 = (te & 15) * 4, rr = te >> 4;
+    const int gx4 = px0 + c4;
+    if (gx4 >= a.w) return;
+    int32_t *dst = ids_plane + (int64_t)(py0 + rr) * a.w + gx4;
+    const int64_t dstep = (int64_t)(NT / 16) * a.w;
+    for (int row = rr; row < rows_here; row += NT / 16, dst += dstep) {
+      const uint32_t *kr = klo + 2 * lds_idx<TWL, PAD>(row, c4);
+      *reinterpret_cast<int4 *>(dst) = make_int4((int)~kr[0], (int)~kr[2], (int)~kr[4], (int)~kr[6]);
+    }
+  } else {
+    constexpr int TW = 1 << TWL;
+    const int col = te & (TW - 1), gx = px0 + col;
+    if (gx >= a.w) return;
+    int32_t *dst = ids_plane + (int64_t)(py0 + (te >> TWL)) * a.w + gx;
+    const int64_t dstep = (int64_t)(NT / TW) * a.w;
+    for (int row = te >> TWL; row < rows_here; row += NT / TW, dst += dstep) *dst = (int32_t)~klo[2 * lds_idx<TWL, PAD>(row, col)];
+  }
+}
+
+// Fused projection epilogue (aggregate_projected_images fast path): the last pixel, in row-major order, of every face
+// the tile shows goes to winner[face] with a global atomicMax of pixel + 1 -- meshes.py:1987-2001, where numpy's fancy
+// assignment lets the last pixel of a face win.  A pixel can only be that last pixel if none of right / below-left /
+// below / below-right shows the same face (a face's consecutive scanlines touch at least diagonally unless it is a steep
+// sliver; extra candidates are harmless): 1.7 candidates per visible face on C2.  The fused kernel has almost no memory
+// traffic, so this epilogue is priced in INSTRUCTIONS: a lane owns 4 consecutive pixels of TWO consecutive rows (three
+// row reads serve both), all LDS reads are issued up front, the neighbours across lanes come from DPP row shifts (a
+// 16-lane DPP row is exactly one 64-pixel tile row: lanes outside keep the `old` operand), every comparison is made on
+// the RAW low dword of the key (~face: negative for a face, 0 for plain background; "differs" sentinels 1 and 2 can never
+// equal one), the candidate conditions are plain mask arithmetic, and nothing waits on global memory: the label of the
+// winning pixel is looked up by the vote kernel.  Background needs no mapping: the tile was filled with the id that
+// background aliases (F - 1 with GR_FLAG_NEG1_IS_LAST_FACE, else -1 = raw 0, which no candidate test accepts).
+// Unknown neighbours count as "differs": 1 across a tile edge, 2 outside the image (EDGE tiles only).
+template <int TWL, int TH, int NT, int PAD, bool EDGE>
+__device__ __forceinline__ void fused_winners(const unsigned long long *keys, const BinArgs &a, uint32_t *__restrict__ win,
+                                              int te, int px0, int py0, int dbg) {
+  static_assert(TWL == 6 && NT == 256 && TH % 32 == 0, "16 lanes x 4 pixels per tile row, 16 row pairs per pass");
+  const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
+  const int c4 = (te & 15) * 4, rp = te >> 4;  // row pair 0 .. 15 of a pass
+#pragma unroll
+  for (int pass = 0; pass < TH / 32; ++pass) {
+    const int r0 = 2 * rp + 32 * pass;          // rows r0, r0 + 1; the row below them is r0 + 2
+    int c[3][6];                                // c[k][j + 1]: raw key of row r0 + k, column c4 + j, j = -1 .. 4
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (k < 2 || r0 + 2 < TH) {
+        const uint32_t *kr = klo + 2 * lds_idx<TWL, PAD>(r0 + k, c4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[k][j + 1] = (int)kr[2 * j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[k][j + 1] = 1;  // the tile below: unknown
+      }
+    }
+    const int gy = py0 + r0;
+    if (EDGE) {
+      if (gy >= a.h) continue;
+      if (gy + 1 >= a.h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[1][j + 1] = 2;
+      }
+      if (gy + 2 >= a.h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[2][j + 1] = 2;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      c[k][5] = __builtin_amdgcn_update_dpp(1, c[k][1], 0x101 /* row_shl:1: lane + 1 */, 0xf, 0xf, false);
+      if (k > 0) c[k][0] = __builtin_amdgcn_update_dpp(1, c[k][4], 0x111 /* row_shr:1: lane - 1 */, 0xf, 0xf, false);
+    }
+    const uint32_t p1 = (uint32_t)(gy * a.w + px0 + c4 + 1);  // linear pixel index + 1 of the lane's first pixel (h, w <= 16384)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (EDGE && gy + k >= a.h) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int f = c[k][j + 1];
+        bool cand = (f < 0) & (c[k + 1][j + 1] != f) & (c[k + 1][j] != f);
+        if (EDGE) {
+          const int gx = px0 + c4 + j;
+          cand = cand & (gx < a.w) & ((gx + 1 >= a.w) | ((c[k][j + 2] != f) & (c[k + 1][j + 2] != f)));
+        } else {
+          cand = cand & (c[k][j + 2] != f) & (c[k + 1][j + 2] != f);
+        }
+        if (cand && !(dbg & 8)) atomicMax(win + ~f, p1 + (uint32_t)(k * a.w + j));
+      }
+    }
+  }
+}
+
+// the tile's entry list: count and first slot (single-pass binning: the tile's fixed segment; exact binning: the scan's offset)
+__device__ __forceinline__ void tile_list(const BinArgs &a, const uint32_t *__restrict__ ctrl, int tile, uint32_t &cnt, int64_t &beg) {
+  if (a.cap_tile > 0) {
+    cnt = min(ctrl[GR_CTRL_HDR + tile], (uint32_t)a.cap_tile);
+    beg = (int64_t)tile * a.cap_tile;
+  } else {
+    cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
+    beg = ctrl[GR_CTRL_HDR + 2 * a.Tcap + tile];
+    if (beg >= a.ent_cap) cnt = 0;
+    else if (beg + cnt > a.ent_cap) cnt = (uint32_t)(a.ent_cap - beg);
+  }
+}
+
+// Wave priority: a wave raises its priority for the scanline phase (the VALU-bound part) and drops it for the phases that
+// wait on memory and barriers (tile fill, chunk loads, epilogue), so that the SIMD's issue slots go to the waves that can use
+// them.  Builds alternated on one box (profiles/r03_ab/prio.log): plain 15.26 -> 15.00 us per C2 view, fused 16.93 -> 16.45;
+// the reverse order loses 1-2 %, equal priorities are neutral.
+#define GR_PRIO_MEM() __builtin_amdgcn_s_setprio(0)
+#define GR_PRIO_ITEMS() __builtin_amdgcn_s_setprio(3)
+
+// 16-byte piece q (0 .. 159) of a chunk that holds n (1 .. 64) entries in the short form: the front of the 32-byte parts or the
+// front of the 8-byte parts (store_entry) -- is it needed?
+__device__ __forceinline__ bool short_piece_needed(uint32_t q, uint32_t n) {
+  return (q < 2 * n) | ((q >= 128) & (q < 128 + ((n + 1) >> 1)));  // no short-circuit: one predicate, one branch around the load
+}
+
+// One tile: keys in LDS -> chunks of entries -> scanline items -> epilogue.  nr_first / ex: the tile's first chunk (row
+// counts and this lane's 16 bytes of the 3 KiB (2.5 KiB) of entries), requested by the caller -- and waited for by the caller
+// (a chain), or here behind the fill of the key tile (WAIT: one tile per workgroup -- the request's latency overlaps the fill).
+template <int TWL, int THL, int NT, bool FUSE, int PAD, bool SHORT, bool WAIT>
+__device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOut &out, unsigned long long *keys, const int slot,
+                                                const int tile, uint32_t cnt, const int64_t beg, uint32_t nr_first, v4i ex) {
+  constexpr int TW = 1 << TWL, TH = 1 << THL;
+  constexpr int NKEYS = (TW + PAD) * TH;
+  constexpr int NW = NT / 64;
+  constexpr int NMAIL = NW * 32;  // u64 units: 64 mailbox words per wave
+  int4 *ent_lds = reinterpret_cast<int4 *>(keys + NKEYS + NMAIL);
+  v4i *ent_st = reinterpret_cast<v4i *>(ent_lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int ROWS_PER_PASS = NT / TW;
+  const int64_t P = (int64_t)a.h * a.w;
+  const int64_t plane = (int64_t)slot * P;
+  const int tx = tile % a.TX, ty = tile / a.TX;
+  const int px0 = tx << TWL, py0 = ty << THL;
+  constexpr int EL = SHORT ? 40 : 48;  // 16-byte pieces of a 64-entry chunk per wave (4 waves): 40 or 48 bytes per entry
+  // the tile's list: the slot's entry memory is laid out for 48-byte entries; the short form packs chunks of 64 40-byte
+  // entries at the front of the tile's segment (tile * cap_tile is a multiple of 64 whenever the short form is chosen)
+  const int4 *comp = SHORT ? reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(a.comp + slot * a.ent_cap * GR_ENT_Q) + beg * 40)
+                           : a.comp + (slot * a.ent_cap + beg) * GR_ENT_Q;
+  const uint8_t *nr8 = a.nrow8 + slot * a.ent_cap + beg;
+
+  if (!FUSE && cnt == 0) {  // empty tile (a view that overhangs the mesh): background, without the LDS round trip
+    const int col = tid & (TW - 1), gx = px0 + col;
+    if (gx < a.w && !(a.dbg & 2)) {
+      for (int row = tid >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
+        const int64_t p = plane + (int64_t)(py0 + row) * a.w + gx;
+        if (out.ids) out.ids[p] = -1;
+        if (out.depth) out.depth[p] = INFINITY;
+      }
+    }
+    return;
+  }
+  const int tab_base = NKEYS * 8 + wv * 256;  // byte offset of the wave's 64 mailbox words, behind the keys
+  const int tab_self = tab_base + lane * 4;
+  {  // fill the tile (16-byte LDS stores): depth 0 | the id background stands for; mailboxes zero
+    const int bg = (FUSE && out.compat) ? (int)out.F - 1 : -1;
+    const unsigned long long fill = (unsigned long long)(uint32_t)~bg;
+    ulonglong2 *k2 = reinterpret_cast<ulonglong2 *>(keys);
+#pragma unroll
+    for (int i = 0; i < (NKEYS / 2 + NT - 1) / NT; ++i)
+      if (i * NT + tid < NKEYS / 2) k2[i * NT + tid] = make_ulonglong2(fill, fill);
+    for (int i = tid; i < NMAIL / 2; i += NT) k2[NKEYS / 2 + i] = make_ulonglong2(0ull, 0ull);
+  }
+  uint32_t gen = 0;
+  int rot = wv;  // this wave's first batch of the current chunk
+  {  // first chunk: in registers already, complete (k_raster_tile waits for every request of the chain before its first
+     // tile: a wait on the memory counter here would wait for the previous tile's stores)
+    if (WAIT) asm volatile("" : "+v"(ex), "+v"(nr_first));
+    if (lane < EL) ent_st[wv * EL + lane] = ex;
+    __syncthreads();  // keys filled, chunk visible
+    GR_PRIO_ITEMS();
+    const int nrows = (uint32_t)lane < cnt ? (int)nr_first : 0;
+    const int nb = raster_chunk_gather<TWL, TH, NW, PAD, SHORT>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot, a.dbg);
+    rot = (rot - nb) & (NW - 1);
+  }
+#pragma unroll 1
+  for (uint32_t c0 = 64; c0 < cnt; c0 += 64) {
+    GR_PRIO_MEM();
+    __syncthreads();  // every wave is done with the previous chunk before it is overwritten
+    if (lane < EL) {
+      const uint32_t qc = wv * EL + lane;  // piece of the chunk
+      const uint32_t q = (SHORT ? (c0 >> 1) * 5 : c0 * GR_ENT_Q) + qc;
+      if (SHORT ? short_piece_needed(qc, min(cnt - c0, 64u)) : q < cnt * GR_ENT_Q) ex = reinterpret_cast<const v4i *>(comp)[q];
+      ent_st[wv * EL + lane] = ex;
+    }
+    __syncthreads();
+    GR_PRIO_ITEMS();
+    const uint32_t e = c0 + (uint32_t)lane;
+    const int nrows = e < cnt ? (int)nr8[e] : 0;
+    const int nb = raster_chunk_gather<TWL, TH, NW, PAD, SHORT>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot, a.dbg);
+    rot = (rot - nb) & (NW - 1);
+  }
+
+  int te = tid;
+  asm volatile("" : "+v"(te));  // the epilogue's addresses are derived here, not hoisted above the scanline phase
+  GR_PRIO_MEM();
+  __syncthreads();              // keys complete
+  if (a.dbg & 2) return;
+  if (FUSE) {
+    uint32_t *win = out.winner + slot * out.F;
+    const bool edge = px0 + TW > a.w || py0 + TH + 1 > a.h;
+    if (edge) fused_winners<TWL, TH, NT, PAD, true>(keys, a, win, te, px0, py0, a.dbg);
+    else fused_winners<TWL, TH, NT, PAD, false>(keys, a, win, te, px0, py0, a.dbg);
+    if (out.ids) {  // the id image as well (rare): background is where no fragment landed (depth bits 0)
+      const int col = te & (TW - 1), gx = px0 + col;
+      if (gx < a.w)
+        for (int row = te >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
+          const unsigned long long key = keys[lds_idx<TWL, PAD>(row, col)];
+          out.ids[plane + (int64_t)(py0 + row) * a.w + gx] = (key >> 32) ? (int32_t)~(uint32_t)key : -1;
+        }
+    }
+  } else if (out.ids && !out.depth) {
+    store_ids<TWL, TH, NT, PAD>(keys, a, out.ids + plane, te, px0, py0);
+  } else {
+    const int col = te & (TW - 1), gx = px0 + col;
+    if (gx < a.w)
+      for (int row = te >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
+        const unsigned long long key = keys[lds_idx<TWL, PAD>(row, col)];
+        const int64_t p = plane + (int64_t)(py0 + row) * a.w + gx;
+        if (out.ids) out.ids[p] = (int32_t)~(uint32_t)key;  // low dword = ~face, 0 when empty: ~0 = -1
+        if (out.depth) out.depth[p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
+      }
+  }
+}
+
+// K3  the tile kernel.  KT = 4: a workgroup takes four consecutive tiles one after the other.  The four counts are read
+//     first (scalar loads), then the first chunks of all four tiles are requested EXACTLY, together, and waited for together
+//     before the first tile starts: one wait for memory per chain instead of four, no stale slots fetched.  (Waiting for
+//     tile k's chunk only when tile k starts would wait for tile k - 1's id stores: loads and stores share one in-order
+//     counter.)  KT = 1 -- heavy scenes, small launches --: the first chunk is requested before the count is known (the
+//     segment address is static; slots beyond the count hold stale data that nobody reads).
+// The ids-only kernel asks the compiler for 7 waves per SIMD -- what its LDS allows anyway: the schedule the compiler picks
+// under that hint is 3-4 % faster (15.8 -> 15.2 us per C2 view, builds alternated on one box with tools/ab_builds.sh); the
+// fused kernel is not (left at the default).  Work items of two consecutive rows (look-up, unpack and the reciprocals paid
+// once per two rows: -16 % VALU instructions) were measured as well: 74 VGPRs and half as many batches per tile for four
+// waves -- 15.6 vs 16.0 without the hint, 16.3 vs 15.3 with it, fused 18.3 vs 17.2 -- dropped.
+template <int TWL, int THL, int NT, bool FUSE, int KT, int PAD, bool SHORT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (THL == 5 ? 7 : 4), 8))) void k_raster_tile(BinArgs a, RasterOut out) {
+  constexpr int TW = 1 << TWL, TH = 1 << THL;
+  constexpr int NKEYS = (TW + PAD) * TH;
+  constexpr int NW = NT / 64;
+  constexpr int NMAIL = NW * 32;
+  // the kernel's only LDS: keys (17.25 KiB for 64x32) + mailboxes (1 KiB) + one chunk of entries (3 KiB) -> 7 workgroups/CU
+  // (20 KiB -- 4 padding keys per row with the mailboxes inside the padding -- gives 8, and loses more to LDS bank
+  // conflicts than it gains: plain 16.6 vs 16.3 us per C2 view, fused 19.8 vs 17.9)
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[NKEYS + NMAIL + 64 * (SHORT ? 5 : 6)];
+  static_assert(NT == 256, "the entry copy deals 48 int4 to each of 4 waves");
+  static_assert(NKEYS % 2 == 0 && TH % 32 == 0, "key pairs; two 16-row passes per fused group");
+  static_assert(KT == 1 || KT == 4, "one tile per workgroup, or a chain of four");
+  const int slot = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  // one tile per workgroup: the first chunk is requested before the count is known (one round trip less).  A chain waits
+  // for the exact requests of its tiles 1 - 3 anyway before it starts: requesting its first tile's chunk early saves
+  // nothing there (14.9 us per C2 view either way) and fetches 1.6 MB of stale slots per view -- not done
+  const bool spec = KT == 1 && a.cap_tile >= 64 && !(a.var & 8);
+  const int tile0 = KT * (int)blockIdx.x;
+  const int n_tiles = min(KT, a.T - tile0);
+  constexpr int EL = SHORT ? 40 : 48;
+  const uint32_t q = wv * EL + lane;  // this thread's 16-byte piece of a 3 KiB (2.5 KiB) chunk (lanes 0 .. 47 (39) of every wave)
+  // 16-byte pieces of the view's entry memory from entry `first` on, and the number of pieces `n` entries take
+  auto pieces = [&](int64_t first) {
+    const v4i *base = reinterpret_cast<const v4i *>(a.comp + (int64_t)slot * a.ent_cap * GR_ENT_Q);
+    return SHORT ? reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(base) + first * 40) : base + first * GR_ENT_Q;
+  };
+  auto needed = [](uint32_t q, uint32_t n) { return SHORT ? short_piece_needed(q, min(n, 64u)) : q < n * GR_ENT_Q; };
+  uint32_t nr0 = 0, nr1 = 0, nr2 = 0, nr3 = 0;
+  v4i ex0, ex1, ex2, ex3;  // whole 16-byte register tuples (the wait macro of raster_one_tile names them as such: with the
+                           // components of an int4 struct named one by one the compiler split the tuples after the load -- and
+                           // waited for each load right behind its request)
+  if (spec) {
+    const int64_t seg = (int64_t)tile0 * a.cap_tile;
+    nr0 = a.nrow8[slot * a.ent_cap + seg + lane];
+    if (lane < EL) ex0 = pieces(seg)[q];
+  }
+  const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  // fused projection: a view whose binning did not finish (a tile outgrew its segment, a face missed the 40-byte form) is
+  // repeated by the caller and its launch group does not vote -- its winners are not wanted, and a list with a hole in it is
+  // not walked at all (one scalar load beside the counters')
+  if (FUSE && ctrl[2] != 0u) return;
+  uint32_t cnt0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
+  int64_t beg0, beg1 = 0, beg2 = 0, beg3 = 0;
+  if (KT == 4 && a.cap_tile > 0) {
+    // single-pass binning: the chain's four counters sit side by side, 16-byte aligned -- ONE scalar load instead of four
+    // dependent ones, each behind its own wait (words behind the last tile's belong to the next counter array: valid memory)
+    const uint4 c4 = *reinterpret_cast<const uint4 *>(ctrl + GR_CTRL_HDR + tile0);
+    const uint32_t cap = (uint32_t)a.cap_tile;
+    cnt0 = min(c4.x, cap);
+    cnt1 = n_tiles > 1 ? min(c4.y, cap) : 0u;
+    cnt2 = n_tiles > 2 ? min(c4.z, cap) : 0u;
+    cnt3 = n_tiles > 3 ? min(c4.w, cap) : 0u;
+    beg0 = (int64_t)tile0 * a.cap_tile; beg1 = beg0 + a.cap_tile; beg2 = beg1 + a.cap_tile; beg3 = beg2 + a.cap_tile;
+  } else {
+    tile_list(a, ctrl, tile0, cnt0, beg0);
+    if (KT > 1) {
+      if (n_tiles > 1) tile_list(a, ctrl, tile0 + 1, cnt1, beg1);
+      if (n_tiles > 2) tile_list(a, ctrl, tile0 + 2, cnt2, beg2);
+      if (n_tiles > 3) tile_list(a, ctrl, tile0 + 3, cnt3, beg3);
+    }
+  }
+  if (a.dbg & 4) cnt0 = cnt1 = cnt2 = cnt3 = 0;
+  const int64_t sbase = slot * a.ent_cap;
+  if (!spec) {  // exact binning (or segments under 64 slots): the first chunk can only be requested now
+    if ((uint32_t)lane < cnt0) nr0 = a.nrow8[sbase + beg0 + lane];
+    if ((lane < EL) & needed(q, cnt0)) ex0 = pieces(beg0)[q];
+  }
+  if (KT > 1) {
+    if ((uint32_t)lane < cnt1) nr1 = a.nrow8[sbase + beg1 + lane];
+    if ((lane < EL) & needed(q, cnt1)) ex1 = pieces(beg1)[q];
+    if ((uint32_t)lane < cnt2) nr2 = a.nrow8[sbase + beg2 + lane];
+    if ((lane < EL) & needed(q, cnt2)) ex2 = pieces(beg2)[q];
+    if ((uint32_t)lane < cnt3) nr3 = a.nrow8[sbase + beg3 + lane];
+    if ((lane < EL) & needed(q, cnt3)) ex3 = pieces(beg3)[q];
+  }
+  // ONE wait for everything requested above, named as whole register tuples and BEFORE the first tile: behind this statement
+  // the values are the statement's outputs, not loads in flight, so the compiler's bookkeeping of the (single, in-order)
+  // memory counter has nothing left to wait for in the loop over tiles 1 .. 3 -- where a wait means waiting for the
+  // previous tile's id stores (tests/test_isa_waits.py)
+  if (KT > 1) asm volatile("" : "+v"(ex0), "+v"(ex1), "+v"(ex2), "+v"(ex3), "+v"(nr0), "+v"(nr1), "+v"(nr2), "+v"(nr3));
+  raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, KT == 1>(a, out, keys, slot, tile0, cnt0, beg0, nr0, ex0);
+  if (KT > 1) {
+#pragma unroll 1
+    for (int k = 1; k < n_tiles; ++k) {  // ONE copy of the tile code for tiles 1 .. 3: the chunks rotate through ex1
+      __syncthreads();                   // every wave has read the previous tile's keys
+      raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, false>(a, out, keys, slot, tile0 + k, cnt1, beg1, nr1, ex1);
+      cnt1 = cnt2; cnt2 = cnt3; beg1 = beg2; beg2 = beg3;
+      nr1 = nr2; nr2 = nr3; ex1 = ex2; ex2 = ex3;
+    }
+  }
+}
+
+}  // namespace
+
+namespace grimpl {
+
+// stage 2: rasterize the binned views of scratch slots slot0.. into out (already offset to the group's first view)
+int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStream_t s) {
+  BinArgs a = make_args(c, h, w, slot0);
+  {
+    Timed t(c, s, ST_RASTER);
+    // Four consecutive tiles per workgroup -- unless the image needed more than the default 512 slots per tile (a scene
+    // with heavy tiles: chains of them make a few workgroups very long; hostile workload 57.9 vs 30.4 us per view at
+    // 1000x750) or the launch has too few tiles to keep every CU busy with chains.
+    const bool chain = (a.var & 1) == 0 && ((a.var & 16) != 0 || (a.cap_tile > 0 && a.cap_tile <= 512 && (int64_t)a.T * nb >= 16384));
+    const dim3 grid(chain ? (unsigned)((a.T + 3) >> 2) : (unsigned)a.T, nb), block(256);
+    const size_t pad = (size_t)c->opt_lds_pad;
+#define GR_LAUNCH_TILE(THL_, FUSE_)                                                                                   \
+  do {                                                                                                                \
+    if (a.ent40) {                                                                                                    \
+      if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD, true>), grid, block, pad, s, a, out);  \
+      else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD, true>), grid, block, pad, s, a, out);        \
+    } else if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD, false>), grid, block, pad, s, a, out);  \
+    else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD, false>), grid, block, pad, s, a, out);        \
+  } while (0)
+    if (out.winner) {
+      if (a.thl == 6) GR_LAUNCH_TILE(6, true);
+      else GR_LAUNCH_TILE(5, true);
+    } else if (a.thl == 6) GR_LAUNCH_TILE(6, false);
+    else GR_LAUNCH_TILE(5, false);
+#undef GR_LAUNCH_TILE
+    c->prof_raster_launches += 1;
+  }
+  c->prof_views += nb;
+  GR_HIP(c, hipGetLastError());
+  return GR_OK;
+}
+
+}  // namespace grimpl

@@ -1,0 +1,177 @@
+// geograypher_amd/csrc/resize.hip -- the photo down-scale of the aggregation path.
+//
+// Replaces `PhotogrammetryCamera.get_image(image_scale)` behind the file read (geograypher/cameras/cameras.py:154-174):
+//     if image.dtype == uint8: image = image / 255.0
+//     if image_scale != 1:     image = skimage.transform.resize(image, (int(h * s), int(w * s)))
+// reached per view from project_images (meshes.py:1988 -> cameras.py:866-867).  scikit-image's resize with its defaults
+// (skimage/transform/_warps.py; published algorithm restated in oracle/oracle_resize.py, pinned to the real library's output):
+//   1. factor = n_in / n_out per axis, sigma = max(0, (factor - 1) / 2)
+//   2. scipy.ndimage.gaussian_filter(image, sigma, mode="mirror"): separable, rows first; radius int(4 sigma + 0.5); weights
+//      exp(-x^2 / (2 sigma^2)) normalised; every output = centre tap, then the pairs from the outside in (NI_Correlate1D)
+//   3. order-1 sampling at coord = (i + 0.5) * factor - 0.5, the four taps floor / ceil of both coordinates, mirrored
+// The image crosses the link in its FILE dtype (a 4000 x 3000 RGB photo: 36 MB of uint8 instead of 288 MB of float64, or of a
+// CPU-resized float64 image) and is widened here.  Only what the output needs is filtered: the two filtered source rows
+// every output row samples (K1: rows pass into context scratch, 2 h_out x w_in x C doubles), then the two filtered columns
+// of every output pixel and the bilinear blend (K2).  float64 throughout, every operation individually rounded
+// (-ffp-contract=off), in the reference's order: results agree with scikit-image to ~1e-13 (its own affine-map estimation
+// noise), tests/test_photo_resize.py.
+#include "gr_internal.hpp"
+
+using namespace grimpl;
+
+namespace {
+
+#define GR_RESIZE_MAX_RADIUS 1024  // kernel radius int(4 sigma + 0.5): scales down to ~1/500
+
+// index that position i (any integer) reads under the "mirror" boundary  d c b | a b c d | c b a
+__device__ __forceinline__ int mirror_idx(int i, int n) {
+  if (n == 1) return 0;
+  const int period = 2 * (n - 1);
+  i %= period;
+  if (i < 0) i += period;
+  return i >= n ? period - i : i;
+}
+
+// w[0 .. radius] of the normalised Gaussian (w[0]: centre) into LDS, by the whole workgroup
+__device__ __forceinline__ void gaussian_weights_lds(double *w, double sigma, int radius) {
+  __shared__ double total;
+  for (int t = threadIdx.x; t <= radius; t += blockDim.x)
+    w[t] = radius == 0 ? 1.0 : exp(-0.5 / (sigma * sigma) * (double)(t * t));
+  __syncthreads();
+  if (threadIdx.x == 0) {  // the sum in numpy's element order: x = -radius .. radius
+    double s = 0.0;
+    for (int t = radius; t >= 1; --t) s += w[t];
+    for (int t = 0; t <= radius; ++t) s += w[t];
+    total = s;
+  }
+  __syncthreads();
+  const double s = total;
+  __syncthreads();
+  for (int t = threadIdx.x; t <= radius; t += blockDim.x) w[t] = w[t] / s;
+  __syncthreads();
+}
+
+template <typename T>
+__device__ __forceinline__ double widen(T v, const double *lut);
+template <>
+__device__ __forceinline__ double widen<uint8_t>(uint8_t v, const double *lut) { return lut[v]; }
+template <>
+__device__ __forceinline__ double widen<float>(float v, const double *) { return (double)v; }
+template <>
+__device__ __forceinline__ double widen<double>(double v, const double *) { return v; }
+
+// K1  rows pass: tmp[k][e], k = 2 i + {0, 1}: the row-filtered source row floor / ceil of output row i's sampling position,
+//     e = col * C + channel.  grid (ceil(E / 256), 2 h_out)
+template <typename T>
+__global__ __launch_bounds__(256) void k_resize_rows(const T *__restrict__ src, int h_in, int64_t E, int div255, double fr,
+                                                     double sigma, int radius, double *__restrict__ tmp) {
+  extern __shared__ double lds[];
+  double *w = lds;                  // radius + 1 weights
+  double *lut = lds + radius + 1;   // uint8 -> value / 255.0 (or the value itself)
+  gaussian_weights_lds(w, sigma, radius);
+  if (sizeof(T) == 1) {
+    lut[threadIdx.x] = div255 ? (double)threadIdx.x / 255.0 : (double)threadIdx.x;
+    __syncthreads();
+  }
+  const int k = blockIdx.y;
+  const double coord = ((double)(k >> 1) + 0.5) * fr - 0.5;
+  const int r = (k & 1) ? (int)ceil(coord) : (int)floor(coord);
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  double acc = widen<T>(src[(int64_t)mirror_idx(r, h_in) * E + e], lut) * w[0];
+  for (int j = radius; j >= 1; --j) {
+    const double a = widen<T>(src[(int64_t)mirror_idx(r - j, h_in) * E + e], lut);
+    const double b = widen<T>(src[(int64_t)mirror_idx(r + j, h_in) * E + e], lut);
+    acc = acc + (a + b) * w[j];
+  }
+  tmp[(int64_t)k * E + e] = acc;
+}
+
+// K2  columns pass + bilinear blend.  grid (ceil(w_out * C / 256), h_out)
+__global__ __launch_bounds__(256) void k_resize_cols(const double *__restrict__ tmp, int w_in, int C, int w_out, double fr,
+                                                     double fc, double sigma, int radius, double *__restrict__ out) {
+  extern __shared__ double lds[];
+  double *w = lds;
+  gaussian_weights_lds(w, sigma, radius);
+  const int i = blockIdx.y;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= w_out * C) return;
+  const int j = idx / C, ch = idx - j * C;
+  const int64_t E = (int64_t)w_in * C;
+  const double cr = ((double)i + 0.5) * fr - 0.5, cc = ((double)j + 0.5) * fc - 0.5;
+  const double dr = cr - floor(cr), dc = cc - floor(cc);
+  const int c0 = (int)floor(cc), c1 = (int)ceil(cc);
+  const double *row0 = tmp + (int64_t)(2 * i) * E + ch, *row1 = row0 + E;
+  auto filt = [&](const double *row, int c) {
+    double acc = row[(int64_t)mirror_idx(c, w_in) * C] * w[0];
+    for (int t = radius; t >= 1; --t)
+      acc = acc + (row[(int64_t)mirror_idx(c - t, w_in) * C] + row[(int64_t)mirror_idx(c + t, w_in) * C]) * w[t];
+    return acc;
+  };
+  const double v00 = filt(row0, c0), v01 = c1 == c0 ? v00 : filt(row0, c1);
+  const double v10 = filt(row1, c0), v11 = c1 == c0 ? v10 : filt(row1, c1);
+  const double top = (1.0 - dc) * v00 + dc * v01;
+  const double bottom = (1.0 - dc) * v10 + dc * v11;
+  out[(int64_t)i * w_out * C + idx] = (1.0 - dr) * top + dr * bottom;
+}
+
+// scale 1: the conversion alone (cameras.py:157-159)
+template <typename T>
+__global__ __launch_bounds__(256) void k_convert_f64(const T *__restrict__ src, int64_t n, int div255, double *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double v = (double)src[i];
+  out[i] = (sizeof(T) == 1 && div255) ? v / 255.0 : v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gr_resize_image_f64(gr_ctx *c, const void *src, int dtype, int h_in, int w_in, int C, int divide_by_255, int h_out,
+                        int w_out, double *out, void *stream) {
+  if (!c) return GR_EINVAL;
+  if (!src || !out || h_in <= 0 || w_in <= 0 || C <= 0 || h_out <= 0 || w_out <= 0 || (int64_t)w_in * C > 0x7FFFFFFFll ||
+      (int64_t)w_out * C > 0x7FFFFFFFll || h_in > (1 << 24) || w_in > (1 << 24))
+    return fail(c, GR_EINVAL, "bad resize args %dx%dx%d -> %dx%d", h_in, w_in, C, h_out, w_out);
+  if (dtype != GR_DTYPE_U8 && dtype != GR_DTYPE_F32 && dtype != GR_DTYPE_F64) return fail(c, GR_EINVAL, "unknown image dtype %d", dtype);
+  hipStream_t s = (hipStream_t)stream;
+  GR_HIP(c, hipSetDevice(c->device));
+  const int64_t E = (int64_t)w_in * C;
+  if (h_out == h_in && w_out == w_in) {
+    const int64_t n = (int64_t)h_in * E;
+    const dim3 g((unsigned)ceil_div(n, 256)), b(256);
+    if (dtype == GR_DTYPE_U8) hipLaunchKernelGGL(k_convert_f64<uint8_t>, g, b, 0, s, (const uint8_t *)src, n, divide_by_255, out);
+    else if (dtype == GR_DTYPE_F32) hipLaunchKernelGGL(k_convert_f64<float>, g, b, 0, s, (const float *)src, n, 0, out);
+    else GR_HIP(c, hipMemcpyAsync(out, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    GR_HIP(c, hipGetLastError());
+    return GR_OK;
+  }
+  const double fr = (double)h_in / (double)h_out, fc = (double)w_in / (double)w_out;
+  const double sr = std::max(0.0, (fr - 1.0) / 2.0), sc = std::max(0.0, (fc - 1.0) / 2.0);
+  const int rr = sr > 1e-15 ? (int)(4.0 * sr + 0.5) : 0, rc = sc > 1e-15 ? (int)(4.0 * sc + 0.5) : 0;  // scipy: truncate = 4.0
+  if (rr > GR_RESIZE_MAX_RADIUS || rc > GR_RESIZE_MAX_RADIUS)
+    return fail(c, GR_EINVAL, "resize %dx%d -> %dx%d: anti-aliasing kernel radius %d exceeds %d", h_in, w_in, h_out, w_out,
+                std::max(rr, rc), GR_RESIZE_MAX_RADIUS);
+  int rc_ = grow(c, c->resize_tmp, c->resize_have, (int64_t)2 * h_out * E, "resize rows");
+  if (rc_) return rc_;
+  note_stream(c, s);
+  {
+    const dim3 g((unsigned)ceil_div(E, 256), (unsigned)(2 * h_out)), b(256);
+    const size_t lds = sizeof(double) * (size_t)(rr + 1 + 256);
+    if (dtype == GR_DTYPE_U8)
+      hipLaunchKernelGGL(k_resize_rows<uint8_t>, g, b, lds, s, (const uint8_t *)src, h_in, E, divide_by_255, fr, sr, rr, c->resize_tmp);
+    else if (dtype == GR_DTYPE_F32)
+      hipLaunchKernelGGL(k_resize_rows<float>, g, b, lds, s, (const float *)src, h_in, E, 0, fr, sr, rr, c->resize_tmp);
+    else
+      hipLaunchKernelGGL(k_resize_rows<double>, g, b, lds, s, (const double *)src, h_in, E, 0, fr, sr, rr, c->resize_tmp);
+  }
+  {
+    const dim3 g((unsigned)ceil_div((int64_t)w_out * C, 256), (unsigned)h_out), b(256);
+    hipLaunchKernelGGL(k_resize_cols, g, b, sizeof(double) * (size_t)(rc + 1), s, c->resize_tmp, w_in, C, w_out, fr, fc, sc, rc, out);
+  }
+  GR_HIP(c, hipGetLastError());
+  return GR_OK;
+}
+
+}  // extern "C"

@@ -25,11 +25,20 @@ class TexturedPhotogrammetryMeshChunked(TexturedPhotogrammetryMesh):
     """Drop-in for the reference's chunked class; `n_clusters`, `buffer_dist_meters` and `vis_clusters` are accepted and
     ignored (the GPU path needs no chunking)."""
 
+    def _say_unchunked(self, what, n_clusters, buffer_dist_meters, vis_clusters):
+        """One log line per call: the chunking arguments are accepted for signature compatibility and have no effect."""
+        self.logger.info(
+            f"{what}: n_clusters={n_clusters}, buffer_dist_meters={buffer_dist_meters}, vis_clusters={vis_clusters} are "
+            "ignored -- the GPU path culls and bins the whole mesh per view, no camera clustering or sub-mesh cropping; "
+            "views are processed in CAMERA order (the reference goes cluster by cluster, derived_meshes.py:206, 281)"
+        )
+
     def render_flat(self, cameras, batch_size: int = 1, render_img_scale: float = 1, n_clusters: int = 8,
                     buffer_dist_meters: float = CHUNKED_MESH_BUFFER_DIST_METERS, vis_clusters: bool = False,
                     **pix2face_kwargs):
         """reference: derived_meshes.py:153-220.  NOTE: the reference yields the renders cluster by cluster, i.e. in
         KMeans cluster order; here they come in camera order."""
+        self._say_unchunked("render_flat", n_clusters, buffer_dist_meters, vis_clusters)
         yield from super().render_flat(cameras, batch_size=batch_size, render_img_scale=render_img_scale,
                                        **pix2face_kwargs)
 
@@ -37,6 +46,7 @@ class TexturedPhotogrammetryMeshChunked(TexturedPhotogrammetryMesh):
                                    n_clusters: int = 8, buffer_dist_meters: float = CHUNKED_MESH_BUFFER_DIST_METERS,
                                    vis_clusters: bool = False, **kwargs):
         """reference: derived_meshes.py:222-317 (same return structure as the base class)."""
+        self._say_unchunked("aggregate_projected_images", n_clusters, buffer_dist_meters, vis_clusters)
         return super().aggregate_projected_images(cameras, batch_size=batch_size,
                                                   aggregate_img_scale=aggregate_img_scale, **kwargs)
 

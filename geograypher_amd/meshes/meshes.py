@@ -468,27 +468,52 @@ class TexturedPhotogrammetryMesh:
         order = [b + i for b in range(0, batch_stop, batch_size) for i in range(batch_size)]
         slots = [None, None]        # pinned staging tensors
         slot_free = [None, None]    # event after the last copy out of the slot
+        # File-backed photos of a plain camera set (cameras.py:154-174 not overridden): the image is staged in its FILE dtype
+        # and `get_image`'s own arithmetic -- / 255.0 for uint8, skimage's resize for aggregate_img_scale != 1 -- runs on the
+        # device (HipRaster.resize_image): a 4000 x 3000 RGB photo crosses the link as 36 MB of uint8 instead of a float64
+        # image, and no CPU resizer exists in the product.
+        native_files = (
+            type(cameras).get_image_by_index is PhotogrammetryCameraSet.get_image_by_index
+            and len(cameras.cameras) > 0
+            and all(type(cam).get_image is PhotogrammetryCamera.get_image for cam in cameras.cameras)
+            and hasattr(self.backend, "resize_image")
+        )
+        # a loader thread stages view i + 1 while the device works on view i -- only where look-ups are known to be
+        # independent (file reads; a camera set or segmentor that says so): an arbitrary segmentor may run its own GPU work
+        # or keep state that must not run beside pix2face on another thread
+        threaded = native_files or bool(
+            getattr(cameras, "thread_safe_lookup", False)
+            or getattr(getattr(cameras, "segmentor", None), "thread_safe_lookup", False)
+        )
+        native = {"uint8": torch.uint8, "int8": torch.int8, "int16": torch.int16, "int32": torch.int32, "int64": torch.int64,
+                  "float16": torch.float16, "float32": torch.float32, "float64": torch.float64}
 
         def stage(k, pos, copy_pool):
-            img = np.asarray(cameras.get_image_by_index(order[pos], aggregate_img_scale))
+            """-> (host tensor, n_channels, resize target or None)"""
+            resize_to = None
+            if native_files:
+                img = np.asarray(cameras.get_native_image_by_index(order[pos]))
+                out_hw = (int(img.shape[0] * aggregate_img_scale), int(img.shape[1] * aggregate_img_scale))
+                if aggregate_img_scale != 1.0 or img.dtype == np.uint8:
+                    resize_to = (out_hw, img.dtype == np.uint8)  # target size, `/ 255.0` first (cameras.py:158-159)
+            else:
+                img = np.asarray(cameras.get_image_by_index(order[pos], aggregate_img_scale))
             n_channels = 1 if img.ndim == 2 else img.shape[-1]
             flat = np.reshape(img, (img.shape[0], img.shape[1], -1))
             if flat.dtype == np.bool_:
                 flat = flat.view(np.uint8)
-            native = {"uint8": torch.uint8, "int8": torch.int8, "int16": torch.int16, "int32": torch.int32, "int64": torch.int64,
-                      "float16": torch.float16, "float32": torch.float32, "float64": torch.float64}
             tdtype = native.get(flat.dtype.name)
             if tdtype is None:  # anything else takes the reference's route: float64 on the host
                 flat, tdtype = flat.astype(np.float64), torch.float64
             if not on_gpu:
-                return torch.from_numpy(np.ascontiguousarray(flat)), n_channels
+                return torch.from_numpy(np.ascontiguousarray(flat)), n_channels, resize_to
             if slot_free[k] is not None:
                 slot_free[k].synchronize()  # the copy that read this slot two views ago is done
             if slots[k] is None or slots[k].shape != flat.shape or slots[k].dtype != tdtype:
                 try:
                     slots[k] = torch.empty(flat.shape, dtype=tdtype, pin_memory=True)
                 except RuntimeError:  # no pinned memory left: pageable upload
-                    return torch.from_numpy(np.ascontiguousarray(flat)), n_channels
+                    return torch.from_numpy(np.ascontiguousarray(flat)), n_channels, resize_to
             dst = slots[k].numpy()
             rows = flat.shape[0]
             if flat.nbytes >= (32 << 20) and rows >= 8:  # numpy releases the interpreter lock inside large copies
@@ -496,10 +521,22 @@ class TexturedPhotogrammetryMesh:
                 list(copy_pool.map(lambda r0: np.copyto(dst[r0:r0 + step], flat[r0:r0 + step]), range(0, rows, step)))
             else:
                 np.copyto(dst, flat)
-            return slots[k], n_channels
+            return slots[k], n_channels, resize_to
+
+        class _Now:  # a finished "future": staging on the caller's thread
+            def __init__(self, value):
+                self._value = value
+
+            def result(self):
+                return self._value
 
         with ThreadPoolExecutor(max_workers=1) as loader, ThreadPoolExecutor(max_workers=8) as copy_pool:
-            pending = loader.submit(stage, 0, 0, copy_pool) if order else None
+            def submit(k, pos):
+                if pos >= len(order):
+                    return None
+                return loader.submit(stage, k, pos, copy_pool) if threaded else None
+
+            pending = submit(0, 0)
             pos = 0
             for batch_start in range(0, batch_stop, batch_size):
                 batch_inds = list(range(batch_start, batch_start + batch_size))
@@ -511,10 +548,12 @@ class TexturedPhotogrammetryMesh:
                 if isinstance(batch_pix2face, np.ndarray):  # distortion applied on the host
                     batch_pix2face = self.backend._dev(batch_pix2face.astype(np.int32), torch.int32)
                 for i in range(batch_pix2face.shape[0]):
-                    host, n_channels = pending.result()
+                    if pending is None:  # not threaded: the view is fetched when it is consumed, like the reference does
+                        pending = _Now(stage(pos & 1, pos, copy_pool))
+                    host, n_channels, resize_to = pending.result()
                     k = pos & 1
                     pos += 1
-                    pending = loader.submit(stage, pos & 1, pos, copy_pool) if pos < len(order) else None
+                    pending = submit(pos & 1, pos)
                     if on_gpu:
                         dev_img = host.to(self.backend.device, non_blocking=True)
                         if host.is_pinned():
@@ -522,6 +561,8 @@ class TexturedPhotogrammetryMesh:
                             slot_free[k].record(torch.cuda.current_stream(self.backend.device))
                     else:
                         dev_img = host
+                    if resize_to is not None:  # get_image's own arithmetic, on the device (cameras.py:158-172)
+                        dev_img = self.backend.resize_image(dev_img, resize_to[0], divide_by_255=resize_to[1])
                     if check_null_image and dev_img.is_floating_point() and not bool(torch.isfinite(dev_img).any()):
                         yield batch_start + i, batch_pix2face[i], None, n_channels
                         continue

@@ -12,13 +12,13 @@ def find_argmax_nonzero_value(array, keepdims: bool = False, axis: int = 1, back
     """
     import torch
 
-    from geograypher_amd._hip import HipRaster
+    from geograypher_amd._hip import default_backend
 
     if axis not in (1, -1) or getattr(array, "ndim", 2) != 2:
         raise ValueError("the device implementation reduces the last axis of a 2-D (F, C) array")
     is_tensor = isinstance(array, torch.Tensor)
-    if backend is None:
-        backend = HipRaster(array.device.index if is_tensor and array.is_cuda else None)
+    if backend is None:  # the shared context of the device (never a new context, stats buffers and library handle per call)
+        backend = default_backend(array.device.index if is_tensor and array.is_cuda else None)
     out = backend.argmax_nonzero(array)
     if keepdims:
         out = out[:, None]

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GR_VERSION 110 /* 0.1.1: gr_raster_stats.views_done, 32-bit pixel-only winner keys */
+#define GR_VERSION 120 /* 0.2.0: gr_resize_image_f64, gr_learned_cache_file, mesh-signature keyed learned table */
 
 enum {
   GR_OK = 0,
@@ -44,8 +44,9 @@ enum {
 /* flags for the projection / aggregation entry points */
 enum {
   GR_FLAG_NEG1_IS_LAST_FACE = 1, /* reproduce meshes.py:1998-2001: pix2face == -1 writes the LAST face */
-  GR_FLAG_DEFER_CHECK = 2        /* gr_project_index_pairs: do not synchronise; a value outside [0, n_classes) sets bit 32 of
-                                    *key_count instead of failing the call (the caller reads the counter once, at the end) */
+  GR_FLAG_DEFER_CHECK = 2        /* gr_project_index_pairs: do not synchronise; key_count then points to TWO 64-bit words,
+                                    {pair count, error flag}: a value outside [0, n_classes) makes key_count[1] non-zero
+                                    instead of failing the call (the caller reads both words once, at the end)          */
 };
 
 /* camera record: 16 floats per view, see DESIGN.md R0.
@@ -112,10 +113,25 @@ enum {
                                the single-pass binning writes 40-byte entries and falls back to 48 bytes -- one
                                GR_EOVERFLOW retry, remembered like the slots per tile -- for images with faces of
                                93 pixels and more)                                                                  */
+  GR_OPT_SHARE_LEARNED = 8, /* 1 (default): consult and feed the process-wide table of learned slots per tile / entry forms
+                               (and its file, gr_learned_cache_file); 0: this context learns for itself only.  Setting
+                               GR_OPT_DIRECT_CAP by hand switches it off; this option switches it back on            */
+  GR_OPT_DIRECT_BUDGET_MB = 9, /* entry memory one launch group may take, MiB (default 24576).  Scratch of the single-pass
+                               binning = views per launch group (<= 64) x tiles x slots per tile x 48 B -- 9.3 GB for 64
+                               views of 4000 x 3000 at the default 512 slots --; a launch group shrinks until it fits, and
+                               an image whose learned slots would not fit even one view bins exactly instead            */
   GR_OPT_DEBUG_LDS = 98,    /* extra dynamic LDS bytes per tile workgroup: lowers occupancy (timing experiments)     */
   GR_OPT_DEBUG = 99         /* timing-only ablation mask for tools/ab_kernel.py: OUTPUTS BECOME WRONG          */
 };
 int gr_set_option(gr_ctx *ctx, int key, int value);
+
+/* Persist what overflowed calls taught the library -- slots per tile and entry form per (mesh signature, tile count); the
+ * signature is the face count, vertex count and vertex bounds of the upload -- in a small text file, so that a NEW process
+ * starts with segments that fit (no GR_EOVERFLOW retry on its first call).  Reads `path_h` now (a missing file is fine) and
+ * rewrites it whenever something new is learned (atomic rename).  Process-wide; NULL or "" switches persistence off.
+ * The reference keeps its caches under CACHE_FOLDER (constants.py:18; pix2face's cache_folder argument, meshes.py:1683):
+ * the Python binding points this at CACHE_FOLDER/geograster_learned.txt. */
+int gr_learned_cache_file(const char *path_h);
 int gr_get_stage_times(gr_ctx *ctx, gr_stage_times *out_h);
 
 /* mesh -- replaces the per-view mesh + colour upload of meshes.py:1776-1817 (plotter.clear/add_mesh) and the
@@ -182,7 +198,7 @@ int gr_gather_texture_u8(gr_ctx *ctx, const int32_t *ids, int64_t n_pix, const d
  * key_cap; pairs beyond it are dropped but still counted in *key_count).  Calls APPEND: the caller zeroes *key_count and may
  * collect the pairs of many calls in one buffer before counting them once (gr_count_pairs).  Synchronises `stream` and
  * returns GR_EINDEX when a value is outside [0, n_classes) -- unless GR_FLAG_DEFER_CHECK is set: then the call only enqueues
- * work and such a value sets bit 32 of *key_count (the count itself stays below 2^31). */
+ * work, key_count must point to two 64-bit words (both zeroed by the caller) and such a value makes key_count[1] non-zero. */
 int gr_project_index_pairs(gr_ctx *ctx, const int32_t *ids, const double *img, int n_views, int h, int w,
                            int64_t n_classes, uint32_t *counts, uint64_t *keys, int64_t key_cap, uint64_t *key_count,
                            int flags, void *stream);
@@ -214,6 +230,18 @@ int gr_warp_f64(gr_ctx *ctx, const double *in, int h_in, int w_in, int C, const 
  * (index + 0.5) / scale otherwise).  map_rows / map_cols: h x w f64, the layout gr_warp_* consume. */
 int gr_invert_distortion_f64(gr_ctx *ctx, const double *par_h, int h, int w, double image_scale, int max_iters,
                              double fill, double *map_rows, double *map_cols, void *stream);
+
+/* get_image(image_scale) behind the file read -- replaces cameras.py:154-174: `image / 255.0` for uint8 images, then
+ * skimage.transform.resize(image, (int(h * s), int(w * s))) with its defaults (order 1, mode "reflect", anti-aliasing
+ * Gaussian sigma = (n_in / n_out - 1) / 2 per axis through scipy.ndimage.gaussian_filter(mode="mirror"), half-pixel-centre
+ * sampling) -- called per view by project_images (meshes.py:1988 via cameras.py:866-867).  src: h_in x w_in x C image in its
+ * FILE dtype (GR_DTYPE_*: the photo crosses the link as uint8, not as float64); divide_by_255 != 0 (uint8 only): values are
+ * divided by 255.0 first, as get_image does; out: h_out x w_out x C f64.  Equal sizes: the conversion alone.  Agrees with
+ * scikit-image 0.18.3 and with the >= 0.19 formulation (the pinned 0.21.0) to 1e-12 (tests/test_photo_resize.py).  Uses
+ * context scratch (2 x h_out x w_in x C doubles). */
+enum { GR_DTYPE_U8 = 0, GR_DTYPE_F32 = 1, GR_DTYPE_F64 = 2 };
+int gr_resize_image_f64(gr_ctx *ctx, const void *src, int dtype, int h_in, int w_in, int C, int divide_by_255, int h_out,
+                        int w_out, double *out, void *stream);
 
 /* finalise -- meshes.py:2069-2082: summed[counts==0] = NaN; average = summed / counts.
  * votes_u32 (F x C) is converted to f64 `summed`; average and summed are F x C f64, counts_f64 is F f64. */

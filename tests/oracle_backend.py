@@ -6,7 +6,7 @@ geograypher_amd.meshes) without a GPU.  Test-only: nothing under geograypher_amd
 import numpy as np
 import torch
 
-from oracle import oracle_c, oracle_np, oracle_warp
+from oracle import oracle_c, oracle_np, oracle_resize, oracle_warp
 
 
 class OracleBackend:
@@ -140,6 +140,15 @@ class OracleBackend:
         with np.errstate(divide="ignore", invalid="ignore"):
             avg = s / c[:, None]
         return torch.from_numpy(avg), torch.from_numpy(s), torch.from_numpy(c)
+
+    def resize_image(self, image, out_hw=None, divide_by_255=None):
+        img = image.numpy() if isinstance(image, torch.Tensor) else np.asarray(image)
+        if divide_by_255 is None:
+            divide_by_255 = img.dtype == np.uint8
+        img = img / 255.0 if divide_by_255 else img.astype(np.float64)
+        if out_hw is not None and tuple(out_hw) != img.shape[:2]:
+            img = oracle_resize.resize_antialias(img, out_hw)
+        return torch.from_numpy(np.ascontiguousarray(img))
 
     def upload_map(self, inverse_map):
         return torch.from_numpy(np.ascontiguousarray(inverse_map, dtype=np.float64))
