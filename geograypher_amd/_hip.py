@@ -13,7 +13,10 @@ from typing import Optional
 
 import numpy as np
 
-_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libgeograster.so"
+import os as _os
+
+# GEOGRAYPHER_AMD_LIB: a diagnostic build of the same library (geograypher_amd.build.build_variant) instead of the product's
+_LIB_PATH = Path(_os.environ.get("GEOGRAYPHER_AMD_LIB") or Path(__file__).resolve().parent / "csrc" / "libgeograster.so")
 _lib = None
 
 GR_OK = 0
@@ -78,6 +81,8 @@ class RasterStats(ctypes.Structure):
         ("entry_cap", ctypes.c_int64),
         ("overflow", ctypes.c_int32),
         ("views_done", ctypes.c_int32),
+        ("blocks", ctypes.c_int64),
+        ("chunk_visits", ctypes.c_int64),
     ]
 
     def as_dict(self):
@@ -195,6 +200,8 @@ class _StatsAccumulator:
     def __init__(self):
         self.records = 0.0
         self.entries = 0.0
+        self.blocks = 0.0
+        self.chunk_visits = 0.0
         self.max_entries = 0
         self.views = 0
         self.last = None
@@ -204,6 +211,8 @@ class _StatsAccumulator:
         share = done / max(n_views, 1)
         self.records += st.records * share
         self.entries += st.entries * share
+        self.blocks += st.blocks * share
+        self.chunk_visits += st.chunk_visits * share
         self.max_entries = max(self.max_entries, int(st.max_entries))
         self.views += done
         self.last = st
@@ -211,7 +220,7 @@ class _StatsAccumulator:
     def result(self) -> dict:
         d = self.last.as_dict()
         d.update(records=int(round(self.records)), entries=int(round(self.entries)), max_entries=self.max_entries,
-                 views_done=self.views)
+                 views_done=self.views, blocks=int(round(self.blocks)), chunk_visits=int(round(self.chunk_visits)))
         return d
 
 

@@ -54,6 +54,31 @@ def _compile(src: Path, force: bool) -> Path:
     return obj
 
 
+def build_variant(tag: str, defines) -> Path:
+    """A diagnostic build beside the product library: csrc/libgeograster_<tag>.so compiled with extra -D flags (e.g.
+    GR_STAMPS: in-kernel phase stamps of the tile kernel, tools/tile_phases.py).  Load it with GEOGRAYPHER_AMD_LIB=<path>."""
+    out = CSRC / f"libgeograster_{tag}.so"
+    obj_dir = CSRC / f"_obj_{tag}"
+    obj_dir.mkdir(exist_ok=True)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + [f"-D{d}" for d in defines]
+
+    def one(src):
+        obj = obj_dir / (src.stem + ".o")
+        cmd = [hipcc_path(), *flags, "-c", f"-I{INCLUDE}", f"-I{CSRC}", "-o", str(obj), str(src)]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(one, SOURCES))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out), *[str(o) for o in objs]]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"link failed:\n{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return OUT

@@ -416,10 +416,29 @@ __global__ __launch_bounds__(1024) void k_bin_stats(BinArgs a) {
   for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); }
   if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = sum; pmax[threadIdx.x >> 6] = mx; }
   __syncthreads();
+  // fused aggregation: the 256-face chunks of caller ids this view's vote pass will visit (bits of the view's chunk bitmap; the
+  // "all" word stands for every chunk) -- what prices k_vote_labels' algorithmic bytes (gr_raster_stats.chunk_visits)
+  unsigned long long chunks = 0;
+  if (a.touched) {
+    const uint32_t *tv = a.touched + (int64_t)slot * a.tw;
+    if (tv[a.tw - 1]) chunks = threadIdx.x == 0 ? (unsigned long long)((a.F + 255) >> 8) : 0ull;
+    else
+      for (int i = threadIdx.x; i < a.tw - 1; i += 1024) chunks += (unsigned long long)__popc(tv[i]);
+    for (int o = 32; o > 0; o >>= 1) chunks += __shfl_xor(chunks, o);
+    __syncthreads();  // part[] is reused below
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = chunks;
+    __syncthreads();
+    if (threadIdx.x == 0) { chunks = 0; for (int k = 0; k < 16; ++k) chunks += part[k]; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     unsigned long long total = 0; uint32_t m = 0;
     for (int k = 0; k < 16; ++k) { total += part[k]; m = max(m, pmax[k]); }
     ctrl[1] = (uint32_t)total;
+    atomicAdd(&a.stats[6], (unsigned long long)ctrl[3]);   // 64-face blocks that passed the frustum cull
+    if (chunks) atomicAdd(&a.stats[7], chunks);
     const bool ovf = m > (uint32_t)a.cap_tile || ctrl[2] != 0;
     atomicAdd(&a.stats[0], (unsigned long long)ctrl[0]);
     atomicAdd(&a.stats[1], total);

@@ -177,7 +177,7 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   note_stream(c, s);
   GR_HIP(c, hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 4, s));
   GR_HIP(c, hipMemsetAsync(c->stats + 4, 0xFF, sizeof(unsigned long long), s));  // first overflowed group: none
-  GR_HIP(c, hipMemsetAsync(c->stats + 5, 0, sizeof(unsigned long long), s));     // short-form miss: none
+  GR_HIP(c, hipMemsetAsync(c->stats + 5, 0, sizeof(unsigned long long) * 3, s)); // short-form miss: none; blocks, chunk visits
   c->last_n_views = n_views;
   int g = 0;
   for (int v0 = 0; v0 < n_views; v0 += B, ++g) {
@@ -244,6 +244,9 @@ int gr_ctx_create(int device, gr_ctx **out) {
     return GR_ENOMEM;
   }
   (void)hipMemset(c->stats, 0, sizeof(unsigned long long) * 8);
+#ifdef GR_STAMPS
+  if (hipMalloc(&c->stamps, sizeof(unsigned long long) * 16) == hipSuccess) (void)hipMemset(c->stamps, 0, sizeof(unsigned long long) * 16);
+#endif
   *out = c;
   return GR_OK;
 }
@@ -336,6 +339,17 @@ int gr_learned_cache_file(const char *path_h) {
   return GR_OK;
 }
 
+#ifdef GR_STAMPS
+// diagnostic build only (tools/tile_phases.py): read and clear the tile kernel's phase-cycle sums (synchronises the device)
+int gr_debug_read_stamps(gr_ctx *c, unsigned long long *out16_h) {
+  if (!c || !out16_h || !c->stamps) return GR_EINVAL;
+  GR_HIP(c, hipDeviceSynchronize());
+  GR_HIP(c, hipMemcpy(out16_h, c->stamps, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
+  GR_HIP(c, hipMemset(c->stamps, 0, sizeof(unsigned long long) * 16));
+  return GR_OK;
+}
+#endif
+
 int gr_get_stage_times(gr_ctx *c, gr_stage_times *o) {
   if (!c || !o) return GR_EINVAL;
   float acc[ST_N] = {0};
@@ -362,11 +376,12 @@ int gr_raster_face_ids(gr_ctx *c, const float *cams, int n_views, int h, int w, 
 
 int gr_raster_status(gr_ctx *c, gr_raster_stats *o) {
   if (!c || !o) return GR_EINVAL;
-  unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   GR_HIP(c, hipMemcpyAsync(st, c->stats, sizeof(st), hipMemcpyDeviceToHost, c->last_stream));
   GR_HIP(c, hipStreamSynchronize(c->last_stream));
   o->records = (int64_t)st[0]; o->entries = (int64_t)st[1]; o->max_entries = (int64_t)st[2];
   o->entry_cap = c->ent_cap; o->overflow = (int32_t)st[3];
+  o->blocks = (int64_t)st[6]; o->chunk_visits = (int64_t)st[7];
   // views of the last call whose results are complete: every launch group in front of the first one that overflowed
   o->views_done = st[3] ? (int32_t)std::min<unsigned long long>(st[4] * (unsigned long long)std::max(c->last_B, 1),
                                                                 (unsigned long long)c->last_n_views)

@@ -66,6 +66,9 @@ struct BinArgs {
   int cap_tile;          // > 0: single-pass binning, every tile owns cap_tile entry slots (list base = tile * cap_tile)
   int ent40;             // 1: entries are written in the SHORT form (40 bytes, store_entry below); single-pass binning only
   int var;               // variant bits (GR_OPT_VARIANT): 1 = one tile per workgroup instead of four, 4 = votes on the caller's stream, 8 = no speculative first chunk, 16 = chains of four whatever the launch looks like, 32 = votes without chunk bitmaps
+#ifdef GR_STAMPS
+  unsigned long long *stamps;  // diagnostic build: [16] cycles per tile-kernel phase, summed over waves (raster_tile.hip)
+#endif
   int dbg;               // timing-only ablation mask (GR_OPT_DEBUG): 1 skip scanline loop, 2 skip id stores, 4 skip triangles,
                          // fused epilogue: 8 skip winner atomics, 16 skip label loads; set-up: 32 no entry compilation, 64 no
                          // second-to-fourth tiles of small faces, 256 no depth gradients; 512 (a TEST hook, results stay right):
@@ -145,6 +148,9 @@ struct gr_ctx {
   hipEvent_t ev_raster[2] = {nullptr, nullptr}, ev_vote[2] = {nullptr, nullptr};
   void *sort_tmp = nullptr;
   size_t sort_bytes = 0;
+#ifdef GR_STAMPS
+  unsigned long long *stamps = nullptr;  // diagnostic build: phase cycles of the tile kernel, summed since the last read
+#endif
   double *resize_tmp = nullptr;        // rows pass of gr_resize_image_f64: [2 h_out][w_in * C]
   int64_t resize_have = 0;
   hipStream_t last_stream = nullptr;   // of the last raster call (gr_raster_status reads its outcome there)
@@ -252,6 +258,9 @@ inline BinArgs make_args(gr_ctx *c, int h, int w, int slot0) {
   a.cap_tile = c->cur_cap;          // the call's snapshot: every launch group, bin pass and tile pass alike
   a.ent40 = c->cur_ent40 ? 1 : 0;
   a.group = 0;
+#ifdef GR_STAMPS
+  a.stamps = c->stamps;
+#endif
   return a;
 }
 

@@ -351,6 +351,24 @@ __device__ __forceinline__ void tile_list(const BinArgs &a, const uint32_t *__re
 #define GR_PRIO_MEM() __builtin_amdgcn_s_setprio(0)
 #define GR_PRIO_ITEMS() __builtin_amdgcn_s_setprio(3)
 
+// Diagnostic build only (-DGR_STAMPS, tools/tile_phases.py; the production library has none of this): every wave reads the
+// shader clock (s_memtime) at the phase boundaries of a tile and adds the cycles of each phase to a per-wave accumulator;
+// at the end of the kernel lane 0 of every wave adds them to a.stamps[phase] (and the wave count to a.stamps[15]).  A stamp
+// waits for the wave's outstanding LDS operations (lgkmcnt): the latency of an operation is charged to the phase that issued it.
+//   0 prologue (counters, chunk requests, the ONE wait)   1 key fill + chunk staging   2 barrier behind the fill
+//   3 scanline items, first chunk   4 later chunks (barriers, loads, staging, items)   5 barrier behind the items
+//   6 epilogue (key reads, id stores / winner atomics)   7 barrier between the tiles of a chain   8 empty-tile path
+#ifdef GR_STAMPS
+struct StampAcc { unsigned long long t, acc[9]; };
+#define GR_STAMP_ARG , StampAcc &sa
+#define GR_STAMP_PASS , sa
+#define GR_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); sa.acc[k] += t_ - sa.t; sa.t = t_; } while (0)
+#else
+#define GR_STAMP_ARG
+#define GR_STAMP_PASS
+#define GR_STAMP(k) do { } while (0)
+#endif
+
 // 16-byte piece q (0 .. 159) of a chunk that holds n (1 .. 64) entries in the short form: the front of the 32-byte parts or the
 // front of the 8-byte parts (store_entry) -- is it needed?
 __device__ __forceinline__ bool short_piece_needed(uint32_t q, uint32_t n) {
@@ -362,7 +380,7 @@ __device__ __forceinline__ bool short_piece_needed(uint32_t q, uint32_t n) {
 // (a chain), or here behind the fill of the key tile (WAIT: one tile per workgroup -- the request's latency overlaps the fill).
 template <int TWL, int THL, int NT, bool FUSE, int PAD, bool SHORT, bool WAIT>
 __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOut &out, unsigned long long *keys, const int slot,
-                                                const int tile, uint32_t cnt, const int64_t beg, uint32_t nr_first, v4i ex) {
+                                                const int tile, uint32_t cnt, const int64_t beg, uint32_t nr_first, v4i ex GR_STAMP_ARG) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   constexpr int NKEYS = (TW + PAD) * TH;
   constexpr int NW = NT / 64;
@@ -392,6 +410,7 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
         if (out.depth) out.depth[p] = INFINITY;
       }
     }
+    GR_STAMP(8);
     return;
   }
   const int tab_base = NKEYS * 8 + wv * 256;  // byte offset of the wave's 64 mailbox words, behind the keys
@@ -411,11 +430,14 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
      // tile: a wait on the memory counter here would wait for the previous tile's stores)
     if (WAIT) asm volatile("" : "+v"(ex), "+v"(nr_first));
     if (lane < EL) ent_st[wv * EL + lane] = ex;
+    GR_STAMP(1);
     __syncthreads();  // keys filled, chunk visible
+    GR_STAMP(2);
     GR_PRIO_ITEMS();
     const int nrows = (uint32_t)lane < cnt ? (int)nr_first : 0;
     const int nb = raster_chunk_gather<TWL, TH, NW, PAD, SHORT>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot, a.dbg);
     rot = (rot - nb) & (NW - 1);
+    GR_STAMP(3);
   }
 #pragma unroll 1
   for (uint32_t c0 = 64; c0 < cnt; c0 += 64) {
@@ -433,12 +455,14 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
     const int nrows = e < cnt ? (int)nr8[e] : 0;
     const int nb = raster_chunk_gather<TWL, TH, NW, PAD, SHORT>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot, a.dbg);
     rot = (rot - nb) & (NW - 1);
+    GR_STAMP(4);
   }
 
   int te = tid;
   asm volatile("" : "+v"(te));  // the epilogue's addresses are derived here, not hoisted above the scanline phase
   GR_PRIO_MEM();
   __syncthreads();              // keys complete
+  GR_STAMP(5);
   if (a.dbg & 2) return;
   if (FUSE) {
     uint32_t *win = out.winner + slot * out.F;
@@ -465,6 +489,7 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
         if (out.depth) out.depth[p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
       }
   }
+  GR_STAMP(6);
 }
 
 // K3  the tile kernel.  KT = 4: a workgroup takes four consecutive tiles one after the other.  The four counts are read
@@ -494,6 +519,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (
   const int slot = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#ifdef GR_STAMPS
+  StampAcc sa;
+  for (int k = 0; k < 9; ++k) sa.acc[k] = 0;
+  sa.t = __builtin_amdgcn_s_memtime();
+#endif
   // one tile per workgroup: the first chunk is requested before the count is known (one round trip less).  A chain waits
   // for the exact requests of its tiles 1 - 3 anyway before it starts: requesting its first tile's chunk early saves
   // nothing there (14.9 us per C2 view either way) and fetches 1.6 MB of stale slots per view -- not done
@@ -561,16 +591,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (
   // memory counter has nothing left to wait for in the loop over tiles 1 .. 3 -- where a wait means waiting for the
   // previous tile's id stores (tests/test_isa_waits.py)
   if (KT > 1) asm volatile("" : "+v"(ex0), "+v"(ex1), "+v"(ex2), "+v"(ex3), "+v"(nr0), "+v"(nr1), "+v"(nr2), "+v"(nr3));
-  raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, KT == 1>(a, out, keys, slot, tile0, cnt0, beg0, nr0, ex0);
+  GR_STAMP(0);
+  raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, KT == 1>(a, out, keys, slot, tile0, cnt0, beg0, nr0, ex0 GR_STAMP_PASS);
   if (KT > 1) {
 #pragma unroll 1
     for (int k = 1; k < n_tiles; ++k) {  // ONE copy of the tile code for tiles 1 .. 3: the chunks rotate through ex1
       __syncthreads();                   // every wave has read the previous tile's keys
-      raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, false>(a, out, keys, slot, tile0 + k, cnt1, beg1, nr1, ex1);
+      GR_STAMP(7);
+      raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, false>(a, out, keys, slot, tile0 + k, cnt1, beg1, nr1, ex1 GR_STAMP_PASS);
       cnt1 = cnt2; cnt2 = cnt3; beg1 = beg2; beg2 = beg3;
       nr1 = nr2; nr2 = nr3; ex1 = ex2; ex2 = ex3;
     }
   }
+#ifdef GR_STAMPS
+  if (lane == 0 && a.stamps) {
+    for (int k = 0; k < 9; ++k) atomicAdd(&a.stamps[k], sa.acc[k]);
+    atomicAdd(&a.stamps[15], 1ull);                 // waves
+    atomicAdd(&a.stamps[14], (unsigned long long)n_tiles);  // tile visits x waves
+  }
+#endif
 }
 
 }  // namespace

@@ -79,6 +79,10 @@ typedef struct gr_raster_stats {
   int64_t entry_cap;    /* current per-view capacity                                           */
   int32_t overflow;     /* != 0: some view exceeded entry_cap, output incomplete               */
   int32_t views_done;   /* leading views of the last call whose outputs / votes are complete    */
+  int64_t blocks;       /* 64-face blocks that passed the per-view frustum cull, summed over views (single-pass binning):
+                           what a culled pass has to read of the mesh is blocks x 64 x 36 B + 16 B per block tested   */
+  int64_t chunk_visits; /* fused aggregation: 256-face chunks of caller ids the vote pass visits, summed over views
+                           (each visit reads and resets 256 winners: 256 x 8 B of k_vote_labels' algorithmic bytes)   */
 } gr_raster_stats;
 
 int gr_version(void);

@@ -75,13 +75,16 @@ class _BenchStub(OracleBackend):
 
 class _StubRig:
     dist_backend = "gloo"
+    overrides = {}
 
     def __init__(self):
         import bench
 
-        self.workload = bench.Workload(n_side=24, extent=400.0, H=48, W=64, f=48.0, views_per_rank=3, c3_views=6,
-                                       c4_views_per_rank=4, n_classes=4, c5_n_side=30, c5_extent=800.0, c5_H=40, c5_W=60,
-                                       c5_f=45.0, c5_views_total=8, c5_views_per_rank=4, c5_classes=10, c5_raster_views=2)
+        kw = dict(n_side=24, extent=400.0, H=48, W=64, f=48.0, views_per_rank=3, c3_views=6, c4_views_per_rank=4, n_classes=4,
+                  c5_n_side=30, c5_extent=800.0, c5_H=40, c5_W=60, c5_f=45.0, c5_views_total=8, c5_views_per_rank=4,
+                  c5_classes=10, c5_raster_views=2, min_leg_s=0.0)
+        kw.update(self.overrides)
+        self.workload = bench.Workload(**kw)
 
     def device(self, local_rank):
         return torch.device("cpu")
@@ -104,10 +107,12 @@ class _StubRig:
         return False
 
 
-def _rank(rank, world, port, out_dir, gpus_flag):
+def _rank(rank, world, port, out_dir, gpus_flag, overrides=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
     sys.modules.pop("bench", None)
     import bench
+
+    _StubRig.overrides = dict(overrides or {})
 
     args = bench.parse_args(["--gpus", str(gpus_flag), "--steps", "2", "--warmup", "1", "--windows", "2", "--min-timed-s", "0"])
     buf = io.StringIO()
@@ -117,8 +122,8 @@ def _rank(rank, world, port, out_dir, gpus_flag):
         json.dump({"rc": rc, "stdout": buf.getvalue()}, fh)
 
 
-def _run(tmp_path, world, gpus_flag):
-    mp.spawn(_rank, args=(world, _free_port(), str(tmp_path), gpus_flag), nprocs=world, join=True)
+def _run(tmp_path, world, gpus_flag, overrides=None):
+    mp.spawn(_rank, args=(world, _free_port(), str(tmp_path), gpus_flag, overrides), nprocs=world, join=True)
     return [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
 
 
@@ -165,3 +170,19 @@ def test_one_rank_equals_the_sum_of_its_views(tmp_path):
 def test_a_line_that_claims_more_gpus_than_answered_is_refused(tmp_path):
     res = _run(tmp_path, 2, 3)
     assert [r["rc"] for r in res] == [3, 3] and all(r["stdout"].strip() == "" for r in res)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_rank_without_views_still_joins_every_collective(tmp_path, world):
+    """Fewer views than ranks in the c4 and c5 legs (one view each): the ranks whose shard is empty must still walk through
+    every barrier, every MAX reduction and the packed vote reduce -- a rank that skipped one would hang the job (here: the
+    test would time out) -- and the reduced votes are those of the one view."""
+    res = _run(tmp_path, world, world, overrides=dict(c4_views_total=1, c5_views_total=1))
+    assert [r["rc"] for r in res] == [0] * world
+    line = json.loads(res[0]["stdout"].strip().splitlines()[-1])
+    assert line["n_gpus"] == world and line["ranks_seen"] == world
+    assert [r["rank"] for r in line["ranks"]] == list(range(world))        # the rank -> device map of the line
+    assert line["c4"]["views_per_gpu"] == 1 and line["c5"]["views_per_gpu"] == 1      # rank 0 holds the one view
+    assert line["c4"]["face_observations_after_reduce"] > 0 and line["c5"]["face_observations_after_reduce"] > 0
+    assert line["c4"]["reps"] >= 3 and line["c5"]["aggregate_reps"] >= 2

@@ -140,3 +140,162 @@ def test_slots_per_tile_set_by_hand_to_an_odd_size(hip):
         np.testing.assert_array_equal(ids[v].cpu().numpy(), oracle_c.raster(points, faces, recs[v], 480, 640))
     again = hip.raster_face_ids(recs, 480, 640)
     assert hip.last_retries == 0 and torch.equal(again, ids)
+
+
+def _big_face_scene():
+    (points, faces), _ = synthetic.config1_scene()
+    poses = [synthetic.nadir_pose(1.0, -2.0, 4.5, yaw_deg=10.0)]            # a camera 4.5 m above the ground: faces of hundreds of px
+    poses += [synthetic.nadir_pose(3.0 * k - 6.0, 2.0 * k - 4.0, 40.0, yaw_deg=20.0 * k) for k in range(5)]
+    cams = synthetic.camera_set_from_poses(poses, f=500.0, width=640, height=480)
+    return points, faces, cams, _records(cams)
+
+
+def test_short_form_miss_leaves_no_stale_entry(hip):
+    """Round-3 advisor finding: a face the 40-byte entry form cannot hold took a list slot and wrote nothing -- the slot kept
+    whatever an earlier call had left there, the fused tile kernel rasterized it and issued winner atomics with a garbage face
+    id.  Debug bit 512 poisons every entry slot and row count with 0xFF before each launch group is binned: with the miss in
+    the FIRST group of a fused call the result must still be the unfused projection's (the missed slot is a null entry, the
+    view's tiles are not walked by the fused kernel, the retry takes 48-byte entries), and the winner scratch must be clean
+    for the calls that follow."""
+    points, faces, cams, recs = _big_face_scene()
+    C = 3
+    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+    hip.set_option(7, 128)
+    want = hip.raster_face_ids(recs, 480, 640)
+    np.testing.assert_array_equal(want[0].cpu().numpy(), oracle_c.raster(points, faces, recs[0], 480, 640))
+    labels = np.stack([synthetic.synthetic_labels(want[v].cpu().numpy(), v, C) for v in range(len(cams))])
+    want_v, want_c = hip.new_vote_buffers(C)
+    hip.project_labels(want, labels, C, want_v, want_c)
+    try:
+        hip.set_option(7, 0)
+        hip.set_option(6, 512)      # forgets the entry form: the call starts with 40-byte entries
+        hip.set_option(99, 512)     # poisoned scratch
+        v2, c2 = hip.new_vote_buffers(C)
+        hip.raster_project_labels(recs, labels, C, v2, c2)
+        assert hip.last_retries == 1 and hip.last_stats["views_done"] == len(cams)
+        assert torch.equal(v2, want_v) and torch.equal(c2, want_c)
+        # nothing stale is left in the winner scratch: the same call again (no retry now) gives the same votes once more
+        v3, c3 = hip.new_vote_buffers(C)
+        hip.raster_project_labels(recs, labels, C, v3, c3)
+        assert hip.last_retries == 0
+        assert torch.equal(v3, want_v) and torch.equal(c3, want_c)
+        got = hip.raster_face_ids(recs, 480, 640)
+        assert torch.equal(got, want)
+    finally:
+        hip.set_option(99, 0)
+
+
+def test_second_context_and_new_process_start_sized(hip, tmp_path):
+    """What an overflowed call taught one context is shared process-wide under the MESH SIGNATURE (face count, vertex count,
+    vertex bounds) and written to the cache file: a second context for the same mesh and image starts without a retry, a
+    context for ANOTHER mesh with as many faces inherits nothing, and a new process that points the library at the same file
+    starts sized as well."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    from geograypher_amd._hip import HipRaster, load_library
+
+    lib = load_library()
+    cache = tmp_path / "learned.txt"
+    assert lib.gr_learned_cache_file(str(cache).encode()) == 0
+    try:
+        (points, faces), cams = synthetic.config1_scene()
+        far = synthetic.camera_set_from_poses([synthetic.nadir_pose(2.0 * k - 3.0, 1.0 - k, 300.0 + 5.0 * k, yaw_deg=15.0 * k)
+                                               for k in range(3)], f=500.0, width=640, height=480)
+        recs = _records(far)
+        a = HipRaster(0)   # fresh contexts: sharing is on (the session fixture has set options by hand)
+        a.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+        ids_a = a.raster_face_ids(recs, 480, 640)
+        assert a.last_retries >= 1 and a.last_stats["max_entries"] > 512      # the whole mesh in a few tiles
+        np.testing.assert_array_equal(ids_a[1].cpu().numpy(), oracle_c.raster(points, faces, recs[1], 480, 640))
+        assert cache.is_file() and len([l for l in cache.read_text().splitlines() if not l.startswith("#")]) >= 1
+        b = HipRaster(0)
+        b.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+        ids_b = b.raster_face_ids(recs, 480, 640)
+        assert b.last_retries == 0 and torch.equal(ids_a, ids_b)
+        # another mesh with the same number of faces (vertices moved): nothing inherited -> it overflows by itself
+        c = HipRaster(0)
+        moved = points.copy()
+        moved[:, 0] += 0.125
+        c.upload_mesh(moved.astype(np.float32), faces.astype(np.int32))
+        c.raster_face_ids(recs, 480, 640)
+        assert c.last_retries >= 1
+        # a context that opted out learns for itself only
+        d = HipRaster(0)
+        d.set_option(8, 0)
+        d.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+        d.raster_face_ids(recs, 480, 640)
+        assert d.last_retries >= 1
+        for ctx in (a, b, c, d):
+            ctx.close()
+        # a NEW PROCESS with the same cache file starts sized
+        child = (
+            "import sys, numpy as np, torch\n"
+            f"sys.path.insert(0, {str(Path(__file__).resolve().parents[1])!r})\n"
+            "from geograypher_amd._hip import HipRaster\n"
+            "from geograypher_amd.utils import synthetic\n"
+            "(points, faces), _ = synthetic.config1_scene()\n"
+            "far = synthetic.camera_set_from_poses([synthetic.nadir_pose(2.0 * k - 3.0, 1.0 - k, 300.0 + 5.0 * k, yaw_deg=15.0 * k) for k in range(3)], f=500.0, width=640, height=480)\n"
+            "h = HipRaster(0)\n"
+            "h.upload_mesh(points.astype(np.float32), faces.astype(np.int32))\n"
+            "h.raster_face_ids(far.get_raster_records(1.0, near=0.05), 480, 640)\n"
+            "print('RETRIES', h.last_retries)\n"
+        )
+        env = dict(os.environ, GEOGRAYPHER_AMD_CACHE=str(tmp_path))
+        (tmp_path / "geograster_learned.txt").write_text(cache.read_text())
+        res = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        assert "RETRIES 0" in res.stdout, res.stdout
+    finally:
+        lib.gr_learned_cache_file(None)
+
+
+def test_entry_memory_budget_option_shrinks_the_launch_group(hip):
+    """GR_OPT_DIRECT_BUDGET_MB: with a budget of 64 MiB a launch group of C1 views holds fewer views (70 tiles x 512 slots x
+    48 B = 1.7 MB per view: 37 views), results stay bit-exact; the documented scratch formula is what the library uses."""
+    (points, faces), cams = synthetic.config1_scene()
+    recs = np.concatenate([_records(cams)] * 8, axis=0)   # 64 views
+    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+    want = hip.raster_face_ids(recs, 480, 640)
+    try:
+        hip.set_option(9, 4)     # 4 MiB: two views per launch group
+        hip.set_profiling(True)
+        got = hip.raster_face_ids(recs, 480, 640)
+        st = hip.stage_times()
+        hip.set_profiling(False)
+        per_view = 10 * 15 * 512 * 48
+        assert st["raster_launches"] == -(-64 // ((4 << 20) // per_view)), st
+        assert torch.equal(got, want)
+        with pytest.raises(ValueError):
+            hip.set_option(9, 0)
+    finally:
+        hip.set_option(9, 24 << 10)
+
+
+def test_argmax_uses_the_shared_context(hip):
+    """find_argmax_nonzero_value(backend=None) takes the device's default backend: no new library context per call."""
+    from geograypher_amd import _hip
+    from geograypher_amd.utils.indexing import find_argmax_nonzero_value
+
+    arr = np.array([[0.0, 2.0, 1.0], [0.0, 0.0, 0.0], [np.nan, 1.0, 0.0], [3.0, 3.0, 1.0]])
+    first = find_argmax_nonzero_value(arr)
+    np.testing.assert_array_equal(np.isnan(first), [False, True, True, False])
+    assert first[0] == 1 and first[3] == 0
+    shared = _hip.default_backend()
+    created = []
+    orig = _hip.HipRaster.__init__
+
+    def counting(self, *a, **k):
+        created.append(1)
+        orig(self, *a, **k)
+
+    _hip.HipRaster.__init__ = counting
+    try:
+        for _ in range(3):
+            find_argmax_nonzero_value(arr)
+            find_argmax_nonzero_value(torch.from_numpy(arr).cuda())
+    finally:
+        _hip.HipRaster.__init__ = orig
+    assert not created and _hip.default_backend() is shared

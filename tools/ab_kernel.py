@@ -18,8 +18,11 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from geograypher_amd._hip import HipRaster
 from geograypher_amd.utils import synthetic
 
+import os
+
 H, W, C = 3000, 4000, 4
 DEFAULT = ["base:0", "xcd:64"]
+WORKLOAD = os.environ.get("AB_WORKLOAD", "c2")  # c2: 1.2 M faces, 4000 x 3000; c5: 5 M faces, 6000 x 4000 (20 views)
 
 
 def main():
@@ -32,8 +35,13 @@ def main():
         name = parts[0]
         nums = [int(x) for x in parts[1:]] + [None] * 8
         variants.append((name, nums[0] or 0, nums[1] or 0, nums[2] or 5, 512 if nums[3] is None else nums[3], nums[4] or 0, nums[5] or 4, nums[6] or 64, nums[7] or 2048))
-    points, faces = synthetic.terrain_mesh()
-    cams = synthetic.config2_cameras(50)
+    global H, W
+    if WORKLOAD == "c5":
+        H, W = 4000, 6000
+        (points, faces), cams = synthetic.config5_scene(n_views=max(nv, 1))
+    else:
+        points, faces = synthetic.terrain_mesh()
+        cams = synthetic.config2_cameras(50)
     recs = torch.from_numpy(cams.get_raster_records(1.0, near=1.0)[:nv]).cuda()
     hip = HipRaster(0)
     hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))

@@ -9,6 +9,15 @@ import sys
 from collections import defaultdict
 
 
+def kernel_sha():
+    """sha256 of the library sources the counters were measured on (bench.kernel_source_sha256): bench.py drops the figures of
+    traffic.json / valu.json from its line as soon as the tree holds other kernels."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    return bench.kernel_source_sha256()
+
+
 def find(pattern):
     hits = glob.glob(pattern, recursive=True)
     return hits[0] if hits else None
@@ -131,6 +140,7 @@ def main():
                              "launches": v["launches"], "views_per_launch": nv, "hbm_bytes_per_view": (fm + wm) * 1e6 / max(nv, 1),
                              "source": f"profiles/summary_{tag}.txt"}
     traffic["_source"] = f"tools/profile.sh {tag}: summary_{tag}.txt"
+    traffic["_kernel_sha256"] = kernel_sha()
     with open(os.path.join(raw, "traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
     # valu.json: wave-level VALU instructions per view of the kernels the bench prices against the VALU-issue roofline
@@ -157,6 +167,7 @@ def main():
                                "lds_busy_in_pmc_pass": lds_busy, "lds_bank_conflict_share": conf, "launches": n,
                                "source": f"profiles/summary_{tag}.txt"}
     valu["_source"] = f"tools/profile.sh {tag}: summary_{tag}.txt"
+    valu["_kernel_sha256"] = kernel_sha()
     with open(os.path.join(raw, "valu.json"), "w") as f:
         json.dump(valu, f, indent=1)
     with open(out_txt, "w") as f:
