@@ -874,6 +874,14 @@ def leg_workload2(rig, local_rank, dev):
     out = {"workload": f"C2 terrain + 20 000 trees ({ffaces.shape[0]} faces, cone canopies on cylinder trunks: "
                        "geograypher/utils/example_data.py:30-112 restated), 20 cameras tilted 30-45 degrees"}
     cold = {}
+    # an EMPTY learned-binning cache for this leg: `overflow_retries_cold` is what a process pays that has never seen the
+    # scene; the cache file it leaves behind is what a NEW process starts from (`overflow_retries_new_process`)
+    import tempfile
+
+    from geograypher_amd import _hip
+
+    cache_dir = tempfile.mkdtemp(prefix="geograster_cache_")
+    _hip.load_library().gr_learned_cache_file(str(Path(cache_dir, "geograster_learned.txt")).encode())
     hip_cold = rig.make_raster(local_rank)
     hip_cold.upload_mesh(fpts.astype(np.float32), ffaces.astype(np.int32))
     for scale in (1.0, 0.25):
@@ -884,6 +892,27 @@ def leg_workload2(rig, local_rank, dev):
         cold[scale] = int(hip_cold.last_retries)
         del o2
     del hip_cold
+    new_process = {}
+    try:  # a fresh process (a child: never exec from a GPU process) that finds the cache file: no overflowed first pass
+        child = (
+            "import sys, json, numpy as np, torch\n"
+            f"sys.path.insert(0, {str(ROOT)!r})\n"
+            "from geograypher_amd._hip import HipRaster\n"
+            "from geograypher_amd.utils import synthetic\n"
+            "pts, faces = synthetic.forest_scene(); cams = synthetic.oblique_cameras(20)\n"
+            "h = HipRaster(0); h.upload_mesh(pts.astype(np.float32), faces.astype(np.int32)); out = {}\n"
+            "for scale in (1.0, 0.25):\n"
+            "    hh, ww = cams[0].get_image_size(scale)\n"
+            "    h.raster_face_ids(cams.get_raster_records(scale, near=1.0)[:4], hh, ww)\n"
+            "    out[str(scale)] = int(h.last_retries)\n"
+            "print('RETRIES', json.dumps(out))\n"
+        )
+        res = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, GEOGRAYPHER_AMD_CACHE=cache_dir), capture_output=True,
+                             text=True, timeout=300)
+        line = [l for l in res.stdout.splitlines() if l.startswith("RETRIES")]
+        new_process = json.loads(line[-1].split(" ", 1)[1]) if line else {"failed": res.stderr[-300:]}
+    except Exception as exc:
+        new_process = {"failed": repr(exc)}
     hip2 = rig.make_raster(local_rank)
     hip2.upload_mesh(fpts.astype(np.float32), ffaces.astype(np.int32))
     for scale in (1.0, 0.25):
@@ -918,6 +947,7 @@ def leg_workload2(rig, local_rank, dev):
             "max_entries_per_tile": int(st2["max_entries"]),
             "overflow_retries_first_call": int(retries),
             "overflow_retries_cold": cold[scale],
+            "overflow_retries_new_process": new_process.get(f"{scale:g}" if f"{scale:g}" in new_process else str(scale), new_process.get("failed")),
             "oracle_parity_view_3": same,
             "covered_fraction": round(float((want >= 0).mean()), 4),
         }

@@ -114,7 +114,8 @@ int ensure_bins(gr_ctx *c, int n_slots, int T) {
   if (direct) cap = std::max<int64_t>(cap, (int64_t)T * dcap);
   // The layout (strides) is that of THIS call; a buffer is re-allocated only when the call needs more elements than the
   // buffer has (a huge image with a small launch group and a small image with a full one share the same memory).
-  const int64_t ctrl_stride = ((GR_CTRL_HDR + 4 * (int64_t)T) + 63) / 64 * 64;
+  const int Tcap = (T + 3) & ~3;  // the per-tile counter arrays start 16-byte aligned (a chain reads four counters at once)
+  const int64_t ctrl_stride = ((GR_CTRL_HDR + 4 * (int64_t)Tcap) + 63) / 64 * 64;
   const int64_t work_stride = ceil_div(F, GR_BLOCK) + 4;
   int rc = grow(c, c->ctrl, c->ctrl_have, ctrl_stride * n_slots, "bin control");
   if (!rc) rc = grow(c, c->comp, c->comp_have, GR_ENT_Q * cap * n_slots, "entry list");
@@ -123,7 +124,7 @@ int ensure_bins(gr_ctx *c, int n_slots, int T) {
   if (!rc) rc = grow(c, c->clip, c->clip_have, F * n_slots, "clip list");
   if (!rc && !direct) rc = grow(c, c->rec, c->rec_have, 4 * F * n_slots, "record planes");  // exact path only
   if (rc) return rc;
-  c->slots = n_slots; c->Tcap = T; c->ent_cap = cap; c->ctrl_stride = ctrl_stride; c->work_stride = work_stride;
+  c->slots = n_slots; c->Tcap = Tcap; c->ent_cap = cap; c->ctrl_stride = ctrl_stride; c->work_stride = work_stride;
   c->rec_F = F; c->rec_stride = 4 * F;
   return GR_OK;
 }
@@ -245,7 +246,7 @@ int gr_ctx_create(int device, gr_ctx **out) {
   }
   (void)hipMemset(c->stats, 0, sizeof(unsigned long long) * 8);
 #ifdef GR_STAMPS
-  if (hipMalloc(&c->stamps, sizeof(unsigned long long) * 16) == hipSuccess) (void)hipMemset(c->stamps, 0, sizeof(unsigned long long) * 16);
+  if (hipMalloc(&c->stamps, sizeof(unsigned long long) * 16 * 1024) == hipSuccess) (void)hipMemset(c->stamps, 0, sizeof(unsigned long long) * 16 * 1024);
 #endif
   *out = c;
   return GR_OK;
@@ -344,8 +345,11 @@ int gr_learned_cache_file(const char *path_h) {
 int gr_debug_read_stamps(gr_ctx *c, unsigned long long *out16_h) {
   if (!c || !out16_h || !c->stamps) return GR_EINVAL;
   GR_HIP(c, hipDeviceSynchronize());
-  GR_HIP(c, hipMemcpy(out16_h, c->stamps, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
-  GR_HIP(c, hipMemset(c->stamps, 0, sizeof(unsigned long long) * 16));
+  std::vector<unsigned long long> all(16 * 1024);
+  GR_HIP(c, hipMemcpy(all.data(), c->stamps, sizeof(unsigned long long) * all.size(), hipMemcpyDeviceToHost));
+  GR_HIP(c, hipMemset(c->stamps, 0, sizeof(unsigned long long) * all.size()));
+  for (int k = 0; k < 16; ++k) out16_h[k] = 0;
+  for (size_t i = 0; i < all.size(); ++i) out16_h[i & 15] += all[i];
   return GR_OK;
 }
 #endif

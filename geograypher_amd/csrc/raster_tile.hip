@@ -6,6 +6,10 @@
 
 using namespace grimpl;
 
+#ifndef GR_EXP
+#define GR_EXP 0   // experiment bits of A/B builds (geograypher_amd.build.build_variant, tools/ab_libs.py); 0 in the product
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -136,9 +140,18 @@ __device__ __forceinline__ EntryView entry_view(const uint2 s01, const uint2 s23
   return v;
 }
 
-template <int TWL, int TH, int PAD>
+// COL: a COLUMN entry (binning.hip, build_entry<true>): the face was compiled with the roles of x and y exchanged, because its
+// part of the tile is much taller than wide (tree trunks, canopy slivers: 4 x 32 pixels are 4 column items instead of 32
+// scanline items).  The item is one COLUMN of the triangle, its "row" the real column, its span real rows xs .. xe; every
+// formula below is the same (the entry holds A and B, the offsets and the slopes exchanged), only the tile's extent along the
+// walk is TH instead of TW and a step moves by one key ROW (TW + PAD keys) instead of one key.  Lanes of one entry then
+// sit 8 bytes apart at every step: no bank conflicts between them.  Row and column entries are kept in separate lists
+// per tile and never share a batch.
+template <int TWL, int TH, int PAD, bool COL>
 __device__ __forceinline__ void raster_item(unsigned long long *keys, const EntryView &e, const int r, const bool live) {
-  constexpr int TW = 1 << TWL;
+  constexpr int TW = COL ? TH : (1 << TWL);              // extent of the tile along the walk
+  constexpr int KROW = ((1 << TWL) + PAD) * 8;           // bytes between two key rows
+  constexpr int STEP = COL ? KROW : 8;                   // bytes from one pixel of the walk to the next
   const int X0rel = e.X0rel, Y0rel = e.Y0rel;
   const int yc = e.y_first + r;  // centred row of the item: the entry's first row + the item's row within the entry
   // faces with a slope beyond GR_FLOOR_NOCORR_MAX (edges longer than 62 pixels) or 24-bit slopes take the span solver
@@ -164,10 +177,10 @@ __device__ __forceinline__ void raster_item(unsigned long long *keys, const Entr
     const f32x2 izA = e.izA;                      // {iz0, A}: the two words as the entry holds them
     f32x2 mp;
     mp.x = m1;                                    // the high half is never selected (op_sel_hi)
-    // byte offset of the row's centred column 0: the key rows are (TW + PAD) * 8 bytes apart
-    const int row = __mul24(yc, (TW + PAD) * 8) + ((TH / 2) * (TW + PAD) + TW / 2) * 8;
-    int kp = row + x0 * 8;
-    const int kend = row + xe * 8;
+    // byte offset of the item's centred position 0 along the walk: the key rows are KROW bytes apart
+    const int row = (COL ? yc * 8 : __mul24(yc, KROW)) + ((TH / 2) * ((1 << TWL) + PAD) + (1 << TWL) / 2) * 8;
+    int kp = row + x0 * STEP;
+    const int kend = row + xe * STEP;
     const uint32_t key_a = e.key;
     uint32_t key_b = key_a;                       // a second copy: each pixel of a step forms its key in its own pair
     asm("v_mov_b32 %0, %1" : "=v"(key_b) : "v"(key_a));
@@ -179,8 +192,8 @@ __device__ __forceinline__ void raster_item(unsigned long long *keys, const Entr
       const int zb0 = max(__float_as_int(z.x), 1), zb1 = max(__float_as_int(z.y), 1);
       unsigned long long *const k = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(keys) + kp);
       if (first_too) atomicMax(k, ((unsigned long long)(uint32_t)zb0 << 32) | key_a);
-      atomicMax(k + 1, ((unsigned long long)(uint32_t)zb1 << 32) | key_b);
-      kp += 16;
+      atomicMax(k + STEP / 8, ((unsigned long long)(uint32_t)zb1 << 32) | key_b);
+      kp += 2 * STEP;
       fx += step;
     };
     pixel_pair(even);
@@ -194,7 +207,7 @@ __device__ __forceinline__ void raster_item(unsigned long long *keys, const Entr
 // item -> entry: an entry that starts inside the batch posts gen | lane | slot into the mailbox of its start slot; the
 // words of the current batch are larger than any stale one (gen grows), and among them the latest start is the largest,
 // so an unsigned prefix maximum over the RAW words carries the right entry to every item lane.
-template <int TWL, int TH, int NW, int PAD, bool SHORT>
+template <int TWL, int TH, int NW, int PAD, bool SHORT, bool COL = false>
 __device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, const int tab_base, const int tab_self, uint32_t &gen,
                                                    const int4 *ent, const int nrows, const int lane,
                                                    const int first_b, const int dbg) {
@@ -219,11 +232,11 @@ __device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, con
     if (SHORT) {
       const int4 ea = ent[t * 2], eb = ent[t * 2 + 1];
       const uint2 s89 = reinterpret_cast<const uint2 *>(ent)[256 + t];
-      raster_item<TWL, TH, PAD>(keys, entry_view(make_uint2(ea.x, ea.y), make_uint2(ea.z, ea.w), make_uint2(eb.x, eb.y),
+      raster_item<TWL, TH, PAD, COL>(keys, entry_view(make_uint2(ea.x, ea.y), make_uint2(ea.z, ea.w), make_uint2(eb.x, eb.y),
                                                  make_uint2(eb.z, eb.w), s89), r, live);
     } else {
       const int4 e0 = ent[t * 3], e1 = ent[t * 3 + 1], e2 = ent[t * 3 + 2];
-      raster_item<TWL, TH, PAD>(keys, entry_view(e0, e1, e2), r, live);
+      raster_item<TWL, TH, PAD, COL>(keys, entry_view(e0, e1, e2), r, live);
     }
   }
   return (total + 63) >> 6;
@@ -246,10 +259,46 @@ __device__ __forceinline__ void store_ids(const unsigned long long *keys, const 
     if (gx4 >= a.w) return;
     int32_t *dst = ids_plane + (int64_t)(py0 + rr) * a.w + gx4;
     const int64_t dstep = (int64_t)(NT / 16) * a.w;
+#if !(GR_EXP & 1)
+    // Conflict-free key reads.  The four low dwords of a lane's pixels sit 8 bytes apart and the 16 lanes of a row 32 bytes
+    // apart: as ds_read2_b32 (32 banks of 4 bytes; low dwords only ever touch the 16 even ones) every access is a 4-way bank
+    // conflict -- 32 LDS cycles per wave and pass where 8 suffice.  Whole keys through ds_read_b64 use all 64 banks, two per
+    // lane, in groups of 32 lanes (two tile rows); the lanes of the upper half of a row read their keys in the order 2, 3, 0, 1:
+    // key slots 4 pi + {0 | 2} mod 32 are 16 different even residues, the next row (69 keys further) takes the odd ones --
+    // 32 lanes, 32 different bank pairs, for every one of the four reads.
+    const bool up = (te & 15) >= 8;
+    const int rot = up ? 16 : 0;
+    const uint32_t kb = (uint32_t)(uintptr_t)reinterpret_cast<const char *>(keys);
+    auto read4 = [&](int row, unsigned long long (&k)[4]) {
+      const uint32_t base = kb + 8u * (uint32_t)lds_idx<TWL, PAD>(row, c4);
+      asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %5\n\tds_read_b64 %3, %5 offset:8"
+                   : "=&v"(k[0]), "=&v"(k[1]), "=&v"(k[2]), "=&v"(k[3]) : "v"(base + rot), "v"(base + (16 - rot)) : "memory");
+    };
+    auto ids_of = [&](const unsigned long long (&k)[4]) {
+      const uint32_t a0 = (uint32_t)k[0], a1 = (uint32_t)k[1], b0 = (uint32_t)k[2], b1 = (uint32_t)k[3];
+      return make_int4((int)~(up ? b0 : a0), (int)~(up ? b1 : a1), (int)~(up ? a0 : b0), (int)~(up ? a1 : b1));
+    };
+    if (TH == 2 * (NT / 16) && rows_here == TH) {  // a whole tile: both passes' reads in flight together, ONE wait
+      unsigned long long k0[4], k1[4];
+      read4(rr, k0);
+      read4(rr + NT / 16, k1);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k0[0]), "+v"(k0[1]), "+v"(k0[2]), "+v"(k0[3]), "+v"(k1[0]), "+v"(k1[1]), "+v"(k1[2]), "+v"(k1[3]) : : "memory");
+      *reinterpret_cast<int4 *>(dst) = ids_of(k0);
+      *reinterpret_cast<int4 *>(dst + dstep) = ids_of(k1);
+    } else {
+      for (int row = rr; row < rows_here; row += NT / 16, dst += dstep) {
+        unsigned long long k[4];
+        read4(row, k);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]) : : "memory");
+        *reinterpret_cast<int4 *>(dst) = ids_of(k);
+      }
+    }
+#else
     for (int row = rr; row < rows_here; row += NT / 16, dst += dstep) {
       const uint32_t *kr = klo + 2 * lds_idx<TWL, PAD>(row, c4);
       *reinterpret_cast<int4 *>(dst) = make_int4((int)~kr[0], (int)~kr[2], (int)~kr[4], (int)~kr[6]);
     }
+#endif
   } else {
     constexpr int TW = 1 << TWL;
     const int col = te & (TW - 1), gx = px0 + col;
@@ -286,9 +335,24 @@ __device__ __forceinline__ void fused_winners(const unsigned long long *keys, co
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       if (k < 2 || r0 + 2 < TH) {
+#if !(GR_EXP & 1)
+        // whole keys through ds_read_b64, the upper half of a row's lanes in the order 2, 3, 0, 1 (see store_ids): the 4-way bank
+        // conflict of the dword reads becomes a 2-way one (the two half-groups of 32 lanes read rows two apart here)
+        const bool up = (te & 15) >= 8;
+        const int rot = up ? 16 : 0;
+        const char *kb = reinterpret_cast<const char *>(keys) + 8 * lds_idx<TWL, PAD>(r0 + k, c4);
+        unsigned long long k0, k1, k2, k3;
+        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %5\n\tds_read_b64 %3, %5 offset:8\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3)
+                     : "v"((uint32_t)(uintptr_t)(kb + rot)), "v"((uint32_t)(uintptr_t)(kb + (16 - rot))) : "memory");
+        const int a0 = (int)(uint32_t)k0, a1 = (int)(uint32_t)k1, b0 = (int)(uint32_t)k2, b1 = (int)(uint32_t)k3;
+        c[k][1] = up ? b0 : a0; c[k][2] = up ? b1 : a1; c[k][3] = up ? a0 : b0; c[k][4] = up ? a1 : b1;
+#else
         const uint32_t *kr = klo + 2 * lds_idx<TWL, PAD>(r0 + k, c4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) c[k][j + 1] = (int)kr[2 * j];
+#endif
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) c[k][j + 1] = 1;  // the tile below: unknown
@@ -348,8 +412,17 @@ __device__ __forceinline__ void tile_list(const BinArgs &a, const uint32_t *__re
 // wait on memory and barriers (tile fill, chunk loads, epilogue), so that the SIMD's issue slots go to the waves that can use
 // them.  Builds alternated on one box (profiles/r03_ab/prio.log): plain 15.26 -> 15.00 us per C2 view, fused 16.93 -> 16.45;
 // the reverse order loses 1-2 %, equal priorities are neutral.
-#define GR_PRIO_MEM() __builtin_amdgcn_s_setprio(0)
-#define GR_PRIO_ITEMS() __builtin_amdgcn_s_setprio(3)
+#ifndef GR_PRIO_I
+#define GR_PRIO_I 3   // scanline phase
+#endif
+#ifndef GR_PRIO_M
+#define GR_PRIO_M 0   // fill, chunk loads, barriers
+#endif
+#ifndef GR_PRIO_E
+#define GR_PRIO_E 0   // epilogue
+#endif
+#define GR_PRIO_MEM() __builtin_amdgcn_s_setprio(GR_PRIO_M)
+#define GR_PRIO_ITEMS() __builtin_amdgcn_s_setprio(GR_PRIO_I)
 
 // Diagnostic build only (-DGR_STAMPS, tools/tile_phases.py; the production library has none of this): every wave reads the
 // shader clock (s_memtime) at the phase boundaries of a tile and adds the cycles of each phase to a per-wave accumulator;
@@ -380,7 +453,8 @@ __device__ __forceinline__ bool short_piece_needed(uint32_t q, uint32_t n) {
 // (a chain), or here behind the fill of the key tile (WAIT: one tile per workgroup -- the request's latency overlaps the fill).
 template <int TWL, int THL, int NT, bool FUSE, int PAD, bool SHORT, bool WAIT>
 __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOut &out, unsigned long long *keys, const int slot,
-                                                const int tile, uint32_t cnt, const int64_t beg, uint32_t nr_first, v4i ex GR_STAMP_ARG) {
+                                                const int tile, uint32_t cnt, const uint32_t cntc, const int64_t beg, uint32_t nr_first,
+                                                v4i ex GR_STAMP_ARG) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   constexpr int NKEYS = (TW + PAD) * TH;
   constexpr int NW = NT / 64;
@@ -401,7 +475,7 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
                            : a.comp + (slot * a.ent_cap + beg) * GR_ENT_Q;
   const uint8_t *nr8 = a.nrow8 + slot * a.ent_cap + beg;
 
-  if (!FUSE && cnt == 0) {  // empty tile (a view that overhangs the mesh): background, without the LDS round trip
+  if (!FUSE && cnt == 0 && cntc == 0) {  // empty tile (a view that overhangs the mesh): background, without the LDS round trip
     const int col = tid & (TW - 1), gx = px0 + col;
     if (gx < a.w && !(a.dbg & 2)) {
       for (int row = tid >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
@@ -457,11 +531,38 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
     rot = (rot - nb) & (NW - 1);
     GR_STAMP(4);
   }
+  // The tile's COLUMN entries (single-pass binning: faces whose part of the tile is much taller than wide, binning.hip): a
+  // second list, filled from the BACK of the tile's segment -- slot cap - 1 downwards --, taken in whole chunks of 64 slots
+  // from the top; a chunk's slots below the list's end hold nothing (0 rows).  Rare on survey terrain (none: no extra
+  // barrier), most of the work items of a scene of tree trunks and canopy slivers.
+#pragma unroll 1
+  for (uint32_t c0 = 0; c0 < cntc; c0 += 64) {
+    GR_PRIO_MEM();
+    __syncthreads();  // every wave is done with the previous chunk before it is overwritten
+    const int first = a.cap_tile - (int)c0 - 64;   // the chunk's slot 0 within the tile's segment (negative: the segment is shorter)
+    const int lowest = a.cap_tile - (int)cntc;     // the list's last entry
+    if (lane < EL) {
+      const int qc = wv * EL + lane;               // piece of the chunk
+      const int eq = first + (SHORT ? 0 : qc / GR_ENT_Q);  // (short form: whole chunks; the segment is a whole number of them)
+      if (SHORT ? first >= 0 : eq >= lowest)
+        ex = SHORT ? reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(comp) + (int64_t)first * 40)[qc]
+                   : reinterpret_cast<const v4i *>(comp + (int64_t)first * GR_ENT_Q)[qc];
+      ent_st[wv * EL + lane] = ex;
+    }
+    __syncthreads();
+    GR_PRIO_ITEMS();
+    const int e = first + lane;
+    const int nrows = e >= lowest ? (int)nr8[e] : 0;
+    const int nb = raster_chunk_gather<TWL, TH, NW, PAD, SHORT, true>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot, a.dbg);
+    rot = (rot - nb) & (NW - 1);
+    GR_STAMP(4);
+  }
 
   int te = tid;
   asm volatile("" : "+v"(te));  // the epilogue's addresses are derived here, not hoisted above the scanline phase
   GR_PRIO_MEM();
   __syncthreads();              // keys complete
+  if (GR_PRIO_E != GR_PRIO_M) __builtin_amdgcn_s_setprio(GR_PRIO_E);
   GR_STAMP(5);
   if (a.dbg & 2) return;
   if (FUSE) {
@@ -489,6 +590,7 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
         if (out.depth) out.depth[p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
       }
   }
+  if (GR_PRIO_E != GR_PRIO_M) __builtin_amdgcn_s_setprio(GR_PRIO_M);
   GR_STAMP(6);
 }
 
@@ -553,6 +655,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (
   // not walked at all (one scalar load beside the counters')
   if (FUSE && ctrl[2] != 0u) return;
   uint32_t cnt0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
+  uint32_t col0 = 0, col1 = 0, col2 = 0, col3 = 0;  // column entries (the tile's second list; single-pass binning only)
   int64_t beg0, beg1 = 0, beg2 = 0, beg3 = 0;
   if (KT == 4 && a.cap_tile > 0) {
     // single-pass binning: the chain's four counters sit side by side, 16-byte aligned -- ONE scalar load instead of four
@@ -564,15 +667,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (
     cnt2 = n_tiles > 2 ? min(c4.z, cap) : 0u;
     cnt3 = n_tiles > 3 ? min(c4.w, cap) : 0u;
     beg0 = (int64_t)tile0 * a.cap_tile; beg1 = beg0 + a.cap_tile; beg2 = beg1 + a.cap_tile; beg3 = beg2 + a.cap_tile;
+    const uint4 k4 = *reinterpret_cast<const uint4 *>(ctrl + GR_CTRL_HDR + a.Tcap + tile0);  // Tcap is a multiple of 4
+    col0 = min(k4.x, cap - cnt0);
+    col1 = n_tiles > 1 ? min(k4.y, cap - cnt1) : 0u;
+    col2 = n_tiles > 2 ? min(k4.z, cap - cnt2) : 0u;
+    col3 = n_tiles > 3 ? min(k4.w, cap - cnt3) : 0u;
   } else {
+    if (a.cap_tile > 0) col0 = ctrl[GR_CTRL_HDR + a.Tcap + tile0];
     tile_list(a, ctrl, tile0, cnt0, beg0);
+    if (a.cap_tile > 0) col0 = min(col0, (uint32_t)a.cap_tile - cnt0);
     if (KT > 1) {
       if (n_tiles > 1) tile_list(a, ctrl, tile0 + 1, cnt1, beg1);
       if (n_tiles > 2) tile_list(a, ctrl, tile0 + 2, cnt2, beg2);
       if (n_tiles > 3) tile_list(a, ctrl, tile0 + 3, cnt3, beg3);
     }
   }
-  if (a.dbg & 4) cnt0 = cnt1 = cnt2 = cnt3 = 0;
+  if (a.dbg & 4) cnt0 = cnt1 = cnt2 = cnt3 = col0 = col1 = col2 = col3 = 0;
   const int64_t sbase = slot * a.ent_cap;
   if (!spec) {  // exact binning (or segments under 64 slots): the first chunk can only be requested now
     if ((uint32_t)lane < cnt0) nr0 = a.nrow8[sbase + beg0 + lane];
@@ -592,22 +702,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (
   // previous tile's id stores (tests/test_isa_waits.py)
   if (KT > 1) asm volatile("" : "+v"(ex0), "+v"(ex1), "+v"(ex2), "+v"(ex3), "+v"(nr0), "+v"(nr1), "+v"(nr2), "+v"(nr3));
   GR_STAMP(0);
-  raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, KT == 1>(a, out, keys, slot, tile0, cnt0, beg0, nr0, ex0 GR_STAMP_PASS);
+  raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, KT == 1>(a, out, keys, slot, tile0, cnt0, col0, beg0, nr0, ex0 GR_STAMP_PASS);
   if (KT > 1) {
 #pragma unroll 1
     for (int k = 1; k < n_tiles; ++k) {  // ONE copy of the tile code for tiles 1 .. 3: the chunks rotate through ex1
       __syncthreads();                   // every wave has read the previous tile's keys
       GR_STAMP(7);
-      raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, false>(a, out, keys, slot, tile0 + k, cnt1, beg1, nr1, ex1 GR_STAMP_PASS);
-      cnt1 = cnt2; cnt2 = cnt3; beg1 = beg2; beg2 = beg3;
+      raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, false>(a, out, keys, slot, tile0 + k, cnt1, col1, beg1, nr1, ex1 GR_STAMP_PASS);
+      cnt1 = cnt2; cnt2 = cnt3; beg1 = beg2; beg2 = beg3; col1 = col2; col2 = col3;
       nr1 = nr2; nr2 = nr3; ex1 = ex2; ex2 = ex3;
     }
   }
 #ifdef GR_STAMPS
-  if (lane == 0 && a.stamps) {
-    for (int k = 0; k < 9; ++k) atomicAdd(&a.stamps[k], sa.acc[k]);
-    atomicAdd(&a.stamps[15], 1ull);                 // waves
-    atomicAdd(&a.stamps[14], (unsigned long long)n_tiles);  // tile visits x waves
+  if (lane == 0 && a.stamps) {  // 1024 slots of 16 words: same-address atomics are served one per 11 ns
+    unsigned long long *st = a.stamps + 16 * ((blockIdx.x * 4 + wv + blockIdx.y * 977) & 1023);
+    for (int k = 0; k < 9; ++k) atomicAdd(&st[k], sa.acc[k]);
+    atomicAdd(&st[15], 1ull);                 // waves
+    atomicAdd(&st[14], (unsigned long long)n_tiles);  // tile visits x waves
   }
 #endif
 }

@@ -46,6 +46,7 @@ def main():
     hip = HipRaster(0)
     hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
     ids = torch.empty((nv, H, W), dtype=torch.int32, device="cuda")
+    torch.manual_seed(0)
     labels = torch.randint(0, C, (nv, H, W), dtype=torch.uint8, device="cuda")
     votes, counts = hip.new_vote_buffers(C)
     ref_ids = ref_votes = ref_counts = None
@@ -89,8 +90,17 @@ def main():
             hip.set_profiling(False)
             acc[name]["fused"].append({k: st[k] / st["views"] * 1e3 for k in ("setup_ms", "raster_ms", "vote_ms")})
     setopt(0, 0, 5, 512)
+    checksum = None
+    if os.environ.get("AB_CHECKSUM"):  # for A/B of library builds (tools/ab_libs.py): a digest of the reference ids and votes
+        import hashlib
+
+        h = hashlib.sha256()
+        h.update(ref_ids.cpu().numpy().tobytes())
+        h.update(ref_votes.cpu().numpy().tobytes())
+        h.update(ref_counts.cpu().numpy().tobytes())
+        checksum = h.hexdigest()[:16]
     for name, var, dbg, thl, cap, ldspad, kt, batch, pfd in variants:
-        out = {"variant": name, "var": var, "dbg": dbg, "thl": thl, "cap": cap, "ldspad": ldspad, "kt": kt, "batch": batch, "pfd": pfd}
+        out = {"variant": name, "checksum": checksum, "var": var, "dbg": dbg, "thl": thl, "cap": cap, "ldspad": ldspad, "kt": kt, "batch": batch, "pfd": pfd}
         for kind in ("plain", "fused"):
             runs = acc[name][kind]
             out[kind] = {k: round(statistics.median(r[k] for r in runs), 2) for k in runs[0]}
