@@ -248,7 +248,7 @@ __device__ __forceinline__ void bin_big_pairs(const BinArgs &a, uint32_t *__rest
       // (13 px) never qualify, their tiles keep ONE list and pay nothing -- and at least three times as tall as wide.
       const int ncol = min((int)((uint32_t)p2.z >> 16), px0 + TW - 1) - max(p2.z & 0xFFFF, px0) + 1;
       const int nrow = min((int)((uint32_t)p2.w >> 16), py0 + TH - 1) - max(p2.w & 0xFFFF, py0) + 1;
-      col = !(a.var & 256) && nrow >= 24 && nrow >= 3 * ncol;
+      col = GR_COLLIST && !(a.var & 256) && nrow >= 24 && nrow >= 3 * ncol;
       bool touches;
       if (__ballot(col) != 0ull && col) {
         // the transposed face: x <-> y, vertices 1 and 2 swapped (positive area), A <-> B, the bounding box words exchanged

@@ -30,6 +30,9 @@
 #define GR_CTRL_HDR 8       // ctrl words before the tile arrays: rec_count, total_entries, overflow, work_count, clip_count, big_count
 #define GR_MAX_DIM 16384    // h, w limit (guard band and 16-bit bbox packing)
 #define GR_BLOCK 64         // faces per block of the Morton-ordered soup: one wave, one bounding sphere
+#ifndef GR_COLLIST
+#define GR_COLLIST 1        // column entries: a second per-tile list for faces much taller than wide (binning.hip, raster_tile.hip)
+#endif
 #define GR_CHUNK_LIST 16    // chunks of 256 caller face ids listed per block (k_block_chunks)
 
 namespace grimpl {

@@ -260,23 +260,21 @@ __device__ __forceinline__ void store_ids(const unsigned long long *keys, const 
     int32_t *dst = ids_plane + (int64_t)(py0 + rr) * a.w + gx4;
     const int64_t dstep = (int64_t)(NT / 16) * a.w;
 #if !(GR_EXP & 1)
-    // Conflict-free key reads.  The four low dwords of a lane's pixels sit 8 bytes apart and the 16 lanes of a row 32 bytes
-    // apart: as ds_read2_b32 (32 banks of 4 bytes; low dwords only ever touch the 16 even ones) every access is a 4-way bank
-    // conflict -- 32 LDS cycles per wave and pass where 8 suffice.  Whole keys through ds_read_b64 use all 64 banks, two per
-    // lane, in groups of 32 lanes (two tile rows); the lanes of the upper half of a row read their keys in the order 2, 3, 0, 1:
-    // key slots 4 pi + {0 | 2} mod 32 are 16 different even residues, the next row (69 keys further) takes the odd ones --
-    // 32 lanes, 32 different bank pairs, for every one of the four reads.
-    const bool up = (te & 15) >= 8;
-    const int rot = up ? 16 : 0;
+    // Whole keys through ds_read_b64.  The four low dwords of a lane's pixels sit 8 bytes apart and the 16 lanes of a row
+    // 32 bytes apart: as ds_read2_b32 (32 banks of 4 bytes; low dwords only ever touch the 16 even ones) every access is a
+    // 4-way bank conflict, 32 LDS cycles per wave and pass.  ds_read_b64 uses all 64 banks, two per lane, in groups of 32
+    // lanes (two tile rows, an odd number of keys apart: even and odd key slots): 2-way, 16 cycles.  (Conflict-FREE, 8
+    // cycles, is possible -- the upper half of a row's lanes reads its keys in the order 2, 3, 0, 1 -- at the price of four
+    // v_cndmask per pass to put the ids back in order: measured -3.3 % on the ids kernel against the dword reads, but the
+    // kernel's VALU pipes are the busier ones (84 % against 55 %): the plain order is the default.)
     const uint32_t kb = (uint32_t)(uintptr_t)reinterpret_cast<const char *>(keys);
     auto read4 = [&](int row, unsigned long long (&k)[4]) {
       const uint32_t base = kb + 8u * (uint32_t)lds_idx<TWL, PAD>(row, c4);
-      asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %5\n\tds_read_b64 %3, %5 offset:8"
-                   : "=&v"(k[0]), "=&v"(k[1]), "=&v"(k[2]), "=&v"(k[3]) : "v"(base + rot), "v"(base + (16 - rot)) : "memory");
+      asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24"
+                   : "=&v"(k[0]), "=&v"(k[1]), "=&v"(k[2]), "=&v"(k[3]) : "v"(base) : "memory");
     };
     auto ids_of = [&](const unsigned long long (&k)[4]) {
-      const uint32_t a0 = (uint32_t)k[0], a1 = (uint32_t)k[1], b0 = (uint32_t)k[2], b1 = (uint32_t)k[3];
-      return make_int4((int)~(up ? b0 : a0), (int)~(up ? b1 : a1), (int)~(up ? a0 : b0), (int)~(up ? a1 : b1));
+      return make_int4((int)~(uint32_t)k[0], (int)~(uint32_t)k[1], (int)~(uint32_t)k[2], (int)~(uint32_t)k[3]);
     };
     if (TH == 2 * (NT / 16) && rows_here == TH) {  // a whole tile: both passes' reads in flight together, ONE wait
       unsigned long long k0[4], k1[4];
@@ -336,18 +334,13 @@ __device__ __forceinline__ void fused_winners(const unsigned long long *keys, co
     for (int k = 0; k < 3; ++k) {
       if (k < 2 || r0 + 2 < TH) {
 #if !(GR_EXP & 1)
-        // whole keys through ds_read_b64, the upper half of a row's lanes in the order 2, 3, 0, 1 (see store_ids): the 4-way bank
-        // conflict of the dword reads becomes a 2-way one (the two half-groups of 32 lanes read rows two apart here)
-        const bool up = (te & 15) >= 8;
-        const int rot = up ? 16 : 0;
-        const char *kb = reinterpret_cast<const char *>(keys) + 8 * lds_idx<TWL, PAD>(r0 + k, c4);
+        // whole keys through ds_read_b64 (see store_ids): the 4-way bank conflict of the dword reads becomes a 2-way one
+        const uint32_t kbase = (uint32_t)(uintptr_t)(reinterpret_cast<const char *>(keys) + 8 * lds_idx<TWL, PAD>(r0 + k, c4));
         unsigned long long k0, k1, k2, k3;
-        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %5\n\tds_read_b64 %3, %5 offset:8\n\t"
+        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24\n\t"
                      "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3)
-                     : "v"((uint32_t)(uintptr_t)(kb + rot)), "v"((uint32_t)(uintptr_t)(kb + (16 - rot))) : "memory");
-        const int a0 = (int)(uint32_t)k0, a1 = (int)(uint32_t)k1, b0 = (int)(uint32_t)k2, b1 = (int)(uint32_t)k3;
-        c[k][1] = up ? b0 : a0; c[k][2] = up ? b1 : a1; c[k][3] = up ? a0 : b0; c[k][4] = up ? a1 : b1;
+                     : "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3) : "v"(kbase) : "memory");
+        c[k][1] = (int)(uint32_t)k0; c[k][2] = (int)(uint32_t)k1; c[k][3] = (int)(uint32_t)k2; c[k][4] = (int)(uint32_t)k3;
 #else
         const uint32_t *kr = klo + 2 * lds_idx<TWL, PAD>(r0 + k, c4);
 #pragma unroll
@@ -432,7 +425,7 @@ __device__ __forceinline__ void tile_list(const BinArgs &a, const uint32_t *__re
 //   3 scanline items, first chunk   4 later chunks (barriers, loads, staging, items)   5 barrier behind the items
 //   6 epilogue (key reads, id stores / winner atomics)   7 barrier between the tiles of a chain   8 empty-tile path
 #ifdef GR_STAMPS
-struct StampAcc { unsigned long long t, acc[9]; };
+struct StampAcc { unsigned long long t, acc[9], t0, r0; };  // t0 / r0: shader clock and 100 MHz real-time clock at the wave's start
 #define GR_STAMP_ARG , StampAcc &sa
 #define GR_STAMP_PASS , sa
 #define GR_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); sa.acc[k] += t_ - sa.t; sa.t = t_; } while (0)
@@ -535,6 +528,7 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
   // second list, filled from the BACK of the tile's segment -- slot cap - 1 downwards --, taken in whole chunks of 64 slots
   // from the top; a chunk's slots below the list's end hold nothing (0 rows).  Rare on survey terrain (none: no extra
   // barrier), most of the work items of a scene of tree trunks and canopy slivers.
+#if GR_COLLIST
 #pragma unroll 1
   for (uint32_t c0 = 0; c0 < cntc; c0 += 64) {
     GR_PRIO_MEM();
@@ -557,6 +551,7 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
     rot = (rot - nb) & (NW - 1);
     GR_STAMP(4);
   }
+#endif
 
   int te = tid;
   asm volatile("" : "+v"(te));  // the epilogue's addresses are derived here, not hoisted above the scanline phase
@@ -624,7 +619,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (
 #ifdef GR_STAMPS
   StampAcc sa;
   for (int k = 0; k < 9; ++k) sa.acc[k] = 0;
-  sa.t = __builtin_amdgcn_s_memtime();
+  sa.t = sa.t0 = __builtin_amdgcn_s_memtime();
+  sa.r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   // one tile per workgroup: the first chunk is requested before the count is known (one round trip less).  A chain waits
   // for the exact requests of its tiles 1 - 3 anyway before it starts: requesting its first tile's chunk early saves
@@ -667,15 +663,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (
     cnt2 = n_tiles > 2 ? min(c4.z, cap) : 0u;
     cnt3 = n_tiles > 3 ? min(c4.w, cap) : 0u;
     beg0 = (int64_t)tile0 * a.cap_tile; beg1 = beg0 + a.cap_tile; beg2 = beg1 + a.cap_tile; beg3 = beg2 + a.cap_tile;
+#if GR_COLLIST
     const uint4 k4 = *reinterpret_cast<const uint4 *>(ctrl + GR_CTRL_HDR + a.Tcap + tile0);  // Tcap is a multiple of 4
     col0 = min(k4.x, cap - cnt0);
     col1 = n_tiles > 1 ? min(k4.y, cap - cnt1) : 0u;
     col2 = n_tiles > 2 ? min(k4.z, cap - cnt2) : 0u;
     col3 = n_tiles > 3 ? min(k4.w, cap - cnt3) : 0u;
+#endif
   } else {
+#if GR_COLLIST
     if (a.cap_tile > 0) col0 = ctrl[GR_CTRL_HDR + a.Tcap + tile0];
+#endif
     tile_list(a, ctrl, tile0, cnt0, beg0);
-    if (a.cap_tile > 0) col0 = min(col0, (uint32_t)a.cap_tile - cnt0);
+    if (GR_COLLIST && a.cap_tile > 0) col0 = min(col0, (uint32_t)a.cap_tile - cnt0);
     if (KT > 1) {
       if (n_tiles > 1) tile_list(a, ctrl, tile0 + 1, cnt1, beg1);
       if (n_tiles > 2) tile_list(a, ctrl, tile0 + 2, cnt2, beg2);
@@ -717,6 +717,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (
   if (lane == 0 && a.stamps) {  // 1024 slots of 16 words: same-address atomics are served one per 11 ns
     unsigned long long *st = a.stamps + 16 * ((blockIdx.x * 4 + wv + blockIdx.y * 977) & 1023);
     for (int k = 0; k < 9; ++k) atomicAdd(&st[k], sa.acc[k]);
+    atomicAdd(&st[12], __builtin_amdgcn_s_memtime() - sa.t0);      // wave lifetime in shader cycles ...
+    atomicAdd(&st[13], __builtin_amdgcn_s_memrealtime() - sa.r0);  // ... and in 10 ns ticks: their ratio x 100 MHz is the clock under load
     atomicAdd(&st[15], 1ull);                 // waves
     atomicAdd(&st[14], (unsigned long long)n_tiles);  // tile visits x waves
   }

@@ -448,7 +448,7 @@ class TexturedPhotogrammetryMesh:
                     yield rendered[i]
 
     # -- project_images ------------------------------------------------------------------------------------------
-    def _iter_view_inputs(self, cameras, batch_size, aggregate_img_scale, check_null_image, pix2face_kwargs):
+    def _iter_view_inputs(self, cameras, batch_size, aggregate_img_scale, check_null_image, pix2face_kwargs, loader_threads=None):
         """Shared view loop of project_images / aggregate_projected_images (reference: meshes.py:1970-1996):
         yields (view index, ids (h,w) int32 device tensor, image (h,w,C) device tensor or None for a null image,
         n_channels).  Trailing cameras that do not fill a batch are dropped, as in the reference (1976-1977).
@@ -488,11 +488,25 @@ class TexturedPhotogrammetryMesh:
         native = {"uint8": torch.uint8, "int8": torch.int8, "int16": torch.int16, "int32": torch.int32, "int64": torch.int64,
                   "float16": torch.float16, "float32": torch.float32, "float64": torch.float64}
 
+        # file-backed photos: the DECODE (PNG / JPEG inflate, one core per image) is what binds, so a window of the next views
+        # is decoded ahead by a pool of threads (PIL releases the interpreter lock while it decodes); staging and upload of
+        # view i + 1 still overlap the device work on view i
+        import os as _os
+
+        n_dec = int(loader_threads or min(16, _os.cpu_count() or 1)) if native_files else 0
+        decoded = {}
+
+        def decode_ahead(pool, pos):
+            for p in range(pos, min(pos + max(n_dec, 1), len(order))):
+                if p not in decoded:
+                    decoded[p] = pool.submit(cameras.get_native_image_by_index, order[p])
+
         def stage(k, pos, copy_pool):
             """-> (host tensor, n_channels, resize target or None)"""
             resize_to = None
             if native_files:
-                img = np.asarray(cameras.get_native_image_by_index(order[pos]))
+                decode_ahead(dec_pool, pos)
+                img = np.asarray(decoded.pop(pos).result())
                 out_hw = (int(img.shape[0] * aggregate_img_scale), int(img.shape[1] * aggregate_img_scale))
                 if aggregate_img_scale != 1.0 or img.dtype == np.uint8:
                     resize_to = (out_hw, img.dtype == np.uint8)  # target size, `/ 255.0` first (cameras.py:158-159)
@@ -530,7 +544,8 @@ class TexturedPhotogrammetryMesh:
             def result(self):
                 return self._value
 
-        with ThreadPoolExecutor(max_workers=1) as loader, ThreadPoolExecutor(max_workers=8) as copy_pool:
+        with ThreadPoolExecutor(max_workers=1) as loader, ThreadPoolExecutor(max_workers=8) as copy_pool, \
+                ThreadPoolExecutor(max_workers=max(n_dec, 1)) as dec_pool:
             def submit(k, pos):
                 if pos >= len(order):
                     return None
@@ -580,8 +595,9 @@ class TexturedPhotogrammetryMesh:
         (reference: meshes.py:1944-2002).  Per view the LAST pixel (row-major) mapped to a face provides its value;
         with `neg1_is_last_face` background pixels address the last face exactly like numpy's index -1 does."""
         n_faces = self.faces.shape[0]
+        loader_threads = pix2face_kwargs.pop("loader_threads", None)
         for _, ids, img, n_channels in self._iter_view_inputs(
-            cameras, batch_size, aggregate_img_scale, check_null_image, pix2face_kwargs
+            cameras, batch_size, aggregate_img_scale, check_null_image, pix2face_kwargs, loader_threads
         ):
             if img is None:
                 yield np.full((n_faces, n_channels), fill_value=np.nan)
@@ -735,10 +751,10 @@ class TexturedPhotogrammetryMesh:
         sums = counts = first = None
         if shard:  # this rank's views; the per-view arithmetic does not depend on the other views
             my_cams = cameras.get_subset_cameras(view_inds[rank::world])
-            gen = self._iter_view_inputs(my_cams, 1, aggregate_img_scale, check_null_image, kwargs) if len(my_cams) else iter(())
+            gen = self._iter_view_inputs(my_cams, 1, aggregate_img_scale, check_null_image, kwargs, loader_threads) if len(my_cams) else iter(())
             total = len(my_cams)
         else:
-            gen = self._iter_view_inputs(cameras, batch_size, aggregate_img_scale, check_null_image, kwargs)
+            gen = self._iter_view_inputs(cameras, batch_size, aggregate_img_scale, check_null_image, kwargs, loader_threads)
             total = len(cameras)
         n_channels = None
         for _, ids, img, n_channels in tqdm(gen, total=total, desc="Aggregating projected viewpoints"):

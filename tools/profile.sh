@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-SKIP="--no-cpu-baseline --no-workload2 --no-c4 --no-c5 --no-api"
+SKIP="--no-cpu-baseline --no-workload2 --no-c4 --no-c5 --no-api --no-io"
 BENCH="python3 $REPO/bench.py --steps 20 --warmup 2 --windows 2 --min-timed-s 0 $SKIP"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.log 2>&1
 echo "trace rc=$?" >> $OUT/trace_bench.log

@@ -96,7 +96,7 @@ def main():
     out_txt = os.path.join(raw, f"summary_{tag}.txt")
     lines = []
     path, rows = kernel_stats(raw)
-    lines.append(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 2 --windows 2 --min-timed-s 0 --no-cpu-baseline --no-workload2 --no-c4 --no-c5 --no-api   [{tag}]")
+    lines.append(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 2 --windows 2 --min-timed-s 0 --no-cpu-baseline --no-workload2 --no-c4 --no-c5 --no-api --no-io   [{tag}]")
     lines.append(f"# source: {path}")
     # median from the per-launch trace of the same run (the first launches after a mesh upload run cold and pull the mean up)
     trace = kernel_trace_durations(raw, "trace")

@@ -88,6 +88,10 @@ def main():
         "wave_lifetime_cycles_per_tile": round(total / max(visits, 1), 1),
         # sum of wave lifetimes / (kernel time x 256 CUs): resident waves per CU if the clock were 100 MHz x s_memtime ticks
         "wave_cycles_total": total,
+        # shader clock under load: wave lifetimes in shader cycles (s_memtime) over the same in 10 ns ticks (s_memrealtime)
+        "shader_clock_GHz": round(cyc[12] / max(cyc[13], 1) * 0.1, 3),
+        # waves resident per CU on average = sum of wave lifetimes (real time) / (kernel time x 256 CUs)
+        "mean_resident_waves_per_cu": round(cyc[13] * 1e-8 / (kernel_s * 256), 2),
         "mean_resident_waves_per_cu_at_2p4GHz": round(total / (kernel_s * 2.4e9 * 256), 2),
     }
     print(json.dumps(out))
