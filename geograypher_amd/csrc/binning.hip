@@ -151,7 +151,6 @@ __global__ __launch_bounds__(256) void k_cull_blocks(const float *__restrict__ c
 __device__ __forceinline__ bool compile_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
                                               uint8_t *__restrict__ nr8, int64_t idx, const int4 p0, const int4 p1,
                                               const int4 p2, int px0, int py0, int TW, int TH);
-template <bool COL = false>
 __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const int4 p2, int px0, int py0, int TW, int TH,
                                             int4 &e0, int4 &e1, int4 &e2, int &rows);
 __device__ __forceinline__ void store_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
@@ -187,7 +186,7 @@ __device__ __forceinline__ bool face_setup(const BinArgs &a, const float *__rest
   if (jmin > jmax || imin > imax) return false;
   // R4: gradients of 1/z in double, rounded once to float
   float A = 0.f, B = 0.f;
-  if (!(a.dbg & 256)) {
+  if (!(GR_DBG(a) & 256)) {
     const double d1 = (double)v1.iz - (double)v0.iz;
     const double d2 = (double)v2.iz - (double)v0.iz;
     const double a2 = (double)area2;
@@ -237,37 +236,20 @@ __device__ __forceinline__ void bin_big_pairs(const BinArgs &a, uint32_t *__rest
     const int4 p1 = make_int4(__shfl(r1.x, t), __shfl(r1.y, t), __shfl(r1.z, t), __shfl(r1.w, t));
     const int4 p2 = make_int4(__shfl(r2.x, t), __shfl(r2.y, t), __shfl(r2.z, t), __shfl(r2.w, t));
     int tile = -1, rows = 0;
-    bool col = false;
     int4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0}, e2 = {0, 0, 0, 0};
     if (q < total) {
       const int k = q - ex, gtx = g & 0xFFF, gty = (g >> 12) & 0xFFF, gn = (int)((uint32_t)g >> 24) + 1;
       const int tx = gtx + k % gn, ty = gty + k / gn;
-      const int px0 = tx << a.twl, py0 = ty << a.thl;
-      // COLUMN entry?  The face's bounding box inside this tile is much taller than wide (a tree trunk, a canopy sliver:
-      // 32 rows of 4 pixels): as columns it is 4 work items instead of 32.  At least 24 rows -- the faces of a survey mesh
-      // (13 px) never qualify, their tiles keep ONE list and pay nothing -- and at least three times as tall as wide.
-      const int ncol = min((int)((uint32_t)p2.z >> 16), px0 + TW - 1) - max(p2.z & 0xFFFF, px0) + 1;
-      const int nrow = min((int)((uint32_t)p2.w >> 16), py0 + TH - 1) - max(p2.w & 0xFFFF, py0) + 1;
-      col = GR_COLLIST && !(a.var & 256) && nrow >= 24 && nrow >= 3 * ncol;
-      bool touches;
-      if (__ballot(col) != 0ull && col) {
-        // the transposed face: x <-> y, vertices 1 and 2 swapped (positive area), A <-> B, the bounding box words exchanged
-        const int4 t0 = make_int4(p0.y, p0.x, p1.y, p1.x), t1 = make_int4(p0.w, p0.z, p1.z, p1.w);
-        const int4 t2 = make_int4(p2.y, p2.x, p2.w, p2.z);
-        touches = build_entry<true>(t0, t1, t2, py0, px0, TH, TW, e0, e1, e2, rows);
-      } else touches = build_entry<false>(p0, p1, p2, px0, py0, TW, TH, e0, e1, e2, rows);
-      if (touches) tile = ty * a.TX + tx;
+      if (build_entry(p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH, e0, e1, e2, rows)) tile = ty * a.TX + tx;
     }
-    // row entries take slots from the front of the tile's segment (counter cntS), column entries from its back (counter
-    // cntC: the array the exact path uses for cntB); the lists meeting is an overflow like any other (k_bin_stats)
     int ld, rk, sz;
-    wave_group_capped(tile >= 0 ? 2 * tile + (col ? 1 : 0) : -1, lane, ld, rk, sz, 16);
+    wave_group_capped(tile, lane, ld, rk, sz, 16);
     uint32_t base = 0;
-    if (tile >= 0 && lane == ld) base = atomicAdd(col ? &cntS[a.Tcap + tile] : &cntS[tile], (uint32_t)sz);
+    if (tile >= 0 && lane == ld) base = atomicAdd(&cntS[tile], (uint32_t)sz);
     const uint32_t pos = __shfl(base, ld) + (uint32_t)rk;
     if (tile >= 0) {
       if (pos < (uint32_t)a.cap_tile) {
-        store_entry(a, ctrl, comp, nr8, (int64_t)tile * a.cap_tile + (col ? (uint32_t)a.cap_tile - 1u - pos : pos), e0, e1, e2, rows);
+        store_entry(a, ctrl, comp, nr8, (int64_t)tile * a.cap_tile + pos, e0, e1, e2, rows);
       } else atomicOr(&ctrl[2], 1u);
     }
   }
@@ -353,7 +335,7 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ca
     int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
     uint8_t *nr8 = a.nrow8 + slot * a.ent_cap;
     const int TW = 1 << a.twl, TH = 1 << a.thl;
-    if (small_fp && !(a.dbg & 32)) {
+    if (small_fp && !(GR_DBG(a) & 32)) {
       if ((uint32_t)r3.x < (uint32_t)a.cap_tile) {
         const int64_t idx = (int64_t)t00 * a.cap_tile + (uint32_t)r3.x;
         compile_entry(a, ctrl, comp, nr8, idx, r0, r1, r2, tx0 << a.twl, ty0 << a.thl, TW, TH);
@@ -362,7 +344,7 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ca
     const int shape = small_fp ? ((tx1 > tx0 ? 1 : 0) | (ty1 > ty0 ? 2 : 0)) : 0;  // which neighbours exist: 1 right, 2 below
     const int ne = shape == 3 ? 3 : (shape ? 1 : 0);
     const int incl_e = wave_incl_scan(ne);
-    const int total_e = (a.dbg & (32 | 64)) ? 0 : __builtin_amdgcn_readlane(incl_e, 63);
+    const int total_e = (GR_DBG(a) & (32 | 64)) ? 0 : __builtin_amdgcn_readlane(incl_e, 63);
     const int geo = tx0 | (ty0 << 12) | (shape << 24);
     for (int k0 = 0; k0 < total_e; k0 += 64) {
       const int q = k0 + lane;
@@ -430,7 +412,7 @@ __global__ __launch_bounds__(1024) void k_bin_stats(BinArgs a) {
   const uint32_t *cnt = ctrl + GR_CTRL_HDR;
   unsigned long long sum = 0;
   uint32_t mx = 0;
-  for (int t = threadIdx.x; t < a.T; t += 1024) { const uint32_t c = cnt[t] + cnt[a.Tcap + t]; sum += c; mx = max(mx, c); }  // row + column entries
+  for (int t = threadIdx.x; t < a.T; t += 1024) { const uint32_t c = cnt[t]; sum += c; mx = max(mx, c); }
   for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); }
   if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = sum; pmax[threadIdx.x >> 6] = mx; }
   __syncthreads();
@@ -532,13 +514,6 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(BinArgs a) {
 #define GR_FAST_EXT 24000
 #define GR_FLOOR_NOCORR_MAX 16000  // largest slope magnitude for which edge_floor<false> is exact (see there)
 __device__ __forceinline__ int pack16(int lo, int hi) { return (lo & 0xFFFF) | (hi << 16); }
-// COL: a COLUMN entry -- the caller hands over the TRANSPOSED face (x and y of every vertex, of the bounding box and of the
-// tile exchanged, vertices 1 and 2 swapped so that the area stays positive, A and B exchanged: column_record below) and gets
-// the entry of a triangle whose "scanlines" are the real columns; the tile kernel walks them down the key rows
-// (raster_item<COL>).  The transposed edge (a -> b) is the real edge (b -> a) as a function of the real pixel, so the only
-// thing that is not symmetric is the fill rule: the REAL edge is a top or left edge iff dy_real < 0 or (dy_real = 0 and
-// dx_real > 0), and dx_real = -dy', dy_real = -dx'.
-template <bool COL>
 __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const int4 p2, int px0, int py0, int TW, int TH,
                                             int4 &e0, int4 &e1, int4 &e2, int &rows) {
   const int X0 = p0.x, Y0 = p0.y, X1 = p0.z, Y1 = p0.w, X2 = p1.x, Y2 = p1.y;
@@ -546,10 +521,9 @@ __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const 
   const int jlo = max((p2.z & 0xFFFF) - px0, 0), jhi = min((int)((uint32_t)p2.z >> 16) - px0, TW - 1);
   const int ilo = max((p2.w & 0xFFFF) - py0, 0), ihi = min((int)((uint32_t)p2.w >> 16) - py0, TH - 1);
   const int dx0 = X1 - X0, dy0 = Y1 - Y0, dx1 = X2 - X1, dy1 = Y2 - Y1, dx2 = X0 - X2, dy2 = Y0 - Y2;
-  auto top_left = [](int dx, int dy) { return COL ? ((dx > 0) || (dx == 0 && dy < 0)) : ((dy < 0) || (dy == 0 && dx > 0)); };
-  const int t0 = top_left(dx0, dy0) ? 0 : -1;  // R3 top-left rule as a bias
-  const int t1 = top_left(dx1, dy1) ? 0 : -1;
-  const int t2 = top_left(dx2, dy2) ? 0 : -1;
+  const int t0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;  // R3 top-left rule as a bias
+  const int t1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
+  const int t2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
   const int ext = max(imax3(X0, X1, X2) - imin3(X0, X1, X2), imax3(Y0, Y1, Y2) - imin3(Y0, Y1, Y2));
   // row word, CENTRED like everything else the tile kernel reads: float(P_y - Y0) of centred row y_c = y - TH/2 is
   // float(256 y_c + Yw); the entry's first row as y_c (6 bits, signed).  |Pyo - Y0| + 8192 < 2^23 inside the guard band
@@ -662,7 +636,7 @@ __device__ __forceinline__ bool compile_entry(const BinArgs &a, uint32_t *__rest
                                               const int4 p2, int px0, int py0, int TW, int TH) {
   int4 e0, e1, e2;
   int rows;
-  const bool touches = build_entry<false>(p0, p1, p2, px0, py0, TW, TH, e0, e1, e2, rows);
+  const bool touches = build_entry(p0, p1, p2, px0, py0, TW, TH, e0, e1, e2, rows);
   store_entry(a, ctrl, comp, nr8, idx, e0, e1, e2, rows);
   return touches;
 }

@@ -30,10 +30,15 @@
 #define GR_CTRL_HDR 8       // ctrl words before the tile arrays: rec_count, total_entries, overflow, work_count, clip_count, big_count
 #define GR_MAX_DIM 16384    // h, w limit (guard band and 16-bit bbox packing)
 #define GR_BLOCK 64         // faces per block of the Morton-ordered soup: one wave, one bounding sphere
-#ifndef GR_COLLIST
-#define GR_COLLIST 1        // column entries: a second per-tile list for faces much taller than wide (binning.hip, raster_tile.hip)
-#endif
-#define GR_CHUNK_LIST 16    // chunks of 256 caller face ids listed per block (k_block_chunks)
+#define GR_CHUNK_LIST 16
+// The timing-only ablation masks (GR_OPT_DEBUG: skip the scanline loop, the epilogue, the triangles, ...) exist in the
+// DIAGNOSTIC build only (-DGR_ABLATE: tools/ab_kernel.py builds and loads it when a variant asks for a mask): the product's
+// kernels carry none of those branches.  (Bit 512, the scratch-poisoning test hook, is host code and stays.)
+#ifdef GR_ABLATE
+#define GR_DBG(a) ((a).dbg)
+#else
+#define GR_DBG(a) 0
+#endif    // chunks of 256 caller face ids listed per block (k_block_chunks)
 
 namespace grimpl {
 

@@ -140,18 +140,9 @@ __device__ __forceinline__ EntryView entry_view(const uint2 s01, const uint2 s23
   return v;
 }
 
-// COL: a COLUMN entry (binning.hip, build_entry<true>): the face was compiled with the roles of x and y exchanged, because its
-// part of the tile is much taller than wide (tree trunks, canopy slivers: 4 x 32 pixels are 4 column items instead of 32
-// scanline items).  The item is one COLUMN of the triangle, its "row" the real column, its span real rows xs .. xe; every
-// formula below is the same (the entry holds A and B, the offsets and the slopes exchanged), only the tile's extent along the
-// walk is TH instead of TW and a step moves by one key ROW (TW + PAD keys) instead of one key.  Lanes of one entry then
-// sit 8 bytes apart at every step: no bank conflicts between them.  Row and column entries are kept in separate lists
-// per tile and never share a batch.
-template <int TWL, int TH, int PAD, bool COL>
+template <int TWL, int TH, int PAD>
 __device__ __forceinline__ void raster_item(unsigned long long *keys, const EntryView &e, const int r, const bool live) {
-  constexpr int TW = COL ? TH : (1 << TWL);              // extent of the tile along the walk
-  constexpr int KROW = ((1 << TWL) + PAD) * 8;           // bytes between two key rows
-  constexpr int STEP = COL ? KROW : 8;                   // bytes from one pixel of the walk to the next
+  constexpr int TW = 1 << TWL;
   const int X0rel = e.X0rel, Y0rel = e.Y0rel;
   const int yc = e.y_first + r;  // centred row of the item: the entry's first row + the item's row within the entry
   // faces with a slope beyond GR_FLOOR_NOCORR_MAX (edges longer than 62 pixels) or 24-bit slopes take the span solver
@@ -177,10 +168,10 @@ __device__ __forceinline__ void raster_item(unsigned long long *keys, const Entr
     const f32x2 izA = e.izA;                      // {iz0, A}: the two words as the entry holds them
     f32x2 mp;
     mp.x = m1;                                    // the high half is never selected (op_sel_hi)
-    // byte offset of the item's centred position 0 along the walk: the key rows are KROW bytes apart
-    const int row = (COL ? yc * 8 : __mul24(yc, KROW)) + ((TH / 2) * ((1 << TWL) + PAD) + (1 << TWL) / 2) * 8;
-    int kp = row + x0 * STEP;
-    const int kend = row + xe * STEP;
+    // byte offset of the row's centred column 0: the key rows are (TW + PAD) * 8 bytes apart
+    const int row = __mul24(yc, (TW + PAD) * 8) + ((TH / 2) * (TW + PAD) + TW / 2) * 8;
+    int kp = row + x0 * 8;
+    const int kend = row + xe * 8;
     const uint32_t key_a = e.key;
     uint32_t key_b = key_a;                       // a second copy: each pixel of a step forms its key in its own pair
     asm("v_mov_b32 %0, %1" : "=v"(key_b) : "v"(key_a));
@@ -192,8 +183,8 @@ __device__ __forceinline__ void raster_item(unsigned long long *keys, const Entr
       const int zb0 = max(__float_as_int(z.x), 1), zb1 = max(__float_as_int(z.y), 1);
       unsigned long long *const k = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(keys) + kp);
       if (first_too) atomicMax(k, ((unsigned long long)(uint32_t)zb0 << 32) | key_a);
-      atomicMax(k + STEP / 8, ((unsigned long long)(uint32_t)zb1 << 32) | key_b);
-      kp += 2 * STEP;
+      atomicMax(k + 1, ((unsigned long long)(uint32_t)zb1 << 32) | key_b);
+      kp += 16;
       fx += step;
     };
     pixel_pair(even);
@@ -207,7 +198,7 @@ __device__ __forceinline__ void raster_item(unsigned long long *keys, const Entr
 // item -> entry: an entry that starts inside the batch posts gen | lane | slot into the mailbox of its start slot; the
 // words of the current batch are larger than any stale one (gen grows), and among them the latest start is the largest,
 // so an unsigned prefix maximum over the RAW words carries the right entry to every item lane.
-template <int TWL, int TH, int NW, int PAD, bool SHORT, bool COL = false>
+template <int TWL, int TH, int NW, int PAD, bool SHORT>
 __device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, const int tab_base, const int tab_self, uint32_t &gen,
                                                    const int4 *ent, const int nrows, const int lane,
                                                    const int first_b, const int dbg) {
@@ -232,11 +223,11 @@ __device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, con
     if (SHORT) {
       const int4 ea = ent[t * 2], eb = ent[t * 2 + 1];
       const uint2 s89 = reinterpret_cast<const uint2 *>(ent)[256 + t];
-      raster_item<TWL, TH, PAD, COL>(keys, entry_view(make_uint2(ea.x, ea.y), make_uint2(ea.z, ea.w), make_uint2(eb.x, eb.y),
+      raster_item<TWL, TH, PAD>(keys, entry_view(make_uint2(ea.x, ea.y), make_uint2(ea.z, ea.w), make_uint2(eb.x, eb.y),
                                                  make_uint2(eb.z, eb.w), s89), r, live);
     } else {
       const int4 e0 = ent[t * 3], e1 = ent[t * 3 + 1], e2 = ent[t * 3 + 2];
-      raster_item<TWL, TH, PAD, COL>(keys, entry_view(e0, e1, e2), r, live);
+      raster_item<TWL, TH, PAD>(keys, entry_view(e0, e1, e2), r, live);
     }
   }
   return (total + 63) >> 6;
@@ -245,14 +236,14 @@ __device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, con
 // ids-only epilogue.  16-byte stores where the rows allow it: a lane owns 4 consecutive pixels of a row (16 lanes per
 // 64-pixel row, 16 rows per pass); the four low dwords sit 8 bytes apart in LDS (two ds_read2_b32), id = ~low (0 for an
 // empty pixel -> -1).  Images whose width is not a multiple of 4 take one pixel per lane.
-template <int TWL, int TH, int NT, int PAD>
+template <int TWL, int TH, int NT, int PAD, bool PLAIN>
 __device__ __forceinline__ void store_ids(const unsigned long long *keys, const BinArgs &a, int32_t *ids_plane, int te,
                                           int px0, int py0) {
   // (exchanging every key with the empty one here -- ds_wrxchg_rtn_b64, so that the workgroup's next tile needs no fill --
   // was measured: returning LDS atomics are slow, 17.0 vs 15.6 us per C2 view)
   const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
   const int rows_here = min(TH, a.h - py0);
-  const bool vec = ((a.w & 3) == 0) && ((reinterpret_cast<uintptr_t>(ids_plane) & 15) == 0);
+  const bool vec = PLAIN || (((a.w & 3) == 0) && ((reinterpret_cast<uintptr_t>(ids_plane) & 15) == 0));
   if (vec) {
     const int c4 = (te & 15) * 4, rr = te >> 4;
     const int gx4 = px0 + c4;
@@ -297,7 +288,7 @@ __device__ __forceinline__ void store_ids(const unsigned long long *keys, const 
       *reinterpret_cast<int4 *>(dst) = make_int4((int)~kr[0], (int)~kr[2], (int)~kr[4], (int)~kr[6]);
     }
 #endif
-  } else {
+  } else if (!PLAIN) {
     constexpr int TW = 1 << TWL;
     const int col = te & (TW - 1), gx = px0 + col;
     if (gx >= a.w) return;
@@ -444,10 +435,11 @@ __device__ __forceinline__ bool short_piece_needed(uint32_t q, uint32_t n) {
 // One tile: keys in LDS -> chunks of entries -> scanline items -> epilogue.  nr_first / ex: the tile's first chunk (row
 // counts and this lane's 16 bytes of the 3 KiB (2.5 KiB) of entries), requested by the caller -- and waited for by the caller
 // (a chain), or here behind the fill of the key tile (WAIT: one tile per workgroup -- the request's latency overlaps the fill).
-template <int TWL, int THL, int NT, bool FUSE, int PAD, bool SHORT, bool WAIT>
+// PLAIN: the ids-only kernel of the usual call -- ids to an image whose rows take 16-byte stores, no depth image: the epilogue's
+// other forms (depth, one pixel per lane) are not in the kernel at all (the cold paths cost the hot one registers and schedule)
+template <int TWL, int THL, int NT, bool FUSE, int PAD, bool SHORT, bool WAIT, bool PLAIN>
 __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOut &out, unsigned long long *keys, const int slot,
-                                                const int tile, uint32_t cnt, const uint32_t cntc, const int64_t beg, uint32_t nr_first,
-                                                v4i ex GR_STAMP_ARG) {
+                                                const int tile, uint32_t cnt, const int64_t beg, uint32_t nr_first, v4i ex GR_STAMP_ARG) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   constexpr int NKEYS = (TW + PAD) * TH;
   constexpr int NW = NT / 64;
@@ -468,9 +460,17 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
                            : a.comp + (slot * a.ent_cap + beg) * GR_ENT_Q;
   const uint8_t *nr8 = a.nrow8 + slot * a.ent_cap + beg;
 
-  if (!FUSE && cnt == 0 && cntc == 0) {  // empty tile (a view that overhangs the mesh): background, without the LDS round trip
+  if (!FUSE && cnt == 0) {  // empty tile (a view that overhangs the mesh): background, without the LDS round trip
+    if (PLAIN) {  // 16-byte stores: a lane owns 4 consecutive pixels of a row, 16 rows per pass
+      const int gx4 = px0 + (tid & 15) * 4;
+      if (gx4 < a.w && !(GR_DBG(a) & 2))
+        for (int row = tid >> 4; row < TH && py0 + row < a.h; row += NT / 16)
+          *reinterpret_cast<int4 *>(out.ids + plane + (int64_t)(py0 + row) * a.w + gx4) = make_int4(-1, -1, -1, -1);
+      GR_STAMP(8);
+      return;
+    }
     const int col = tid & (TW - 1), gx = px0 + col;
-    if (gx < a.w && !(a.dbg & 2)) {
+    if (gx < a.w && !(GR_DBG(a) & 2)) {
       for (int row = tid >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
         const int64_t p = plane + (int64_t)(py0 + row) * a.w + gx;
         if (out.ids) out.ids[p] = -1;
@@ -502,7 +502,7 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
     GR_STAMP(2);
     GR_PRIO_ITEMS();
     const int nrows = (uint32_t)lane < cnt ? (int)nr_first : 0;
-    const int nb = raster_chunk_gather<TWL, TH, NW, PAD, SHORT>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot, a.dbg);
+    const int nb = raster_chunk_gather<TWL, TH, NW, PAD, SHORT>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot, GR_DBG(a));
     rot = (rot - nb) & (NW - 1);
     GR_STAMP(3);
   }
@@ -520,51 +520,22 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
     GR_PRIO_ITEMS();
     const uint32_t e = c0 + (uint32_t)lane;
     const int nrows = e < cnt ? (int)nr8[e] : 0;
-    const int nb = raster_chunk_gather<TWL, TH, NW, PAD, SHORT>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot, a.dbg);
+    const int nb = raster_chunk_gather<TWL, TH, NW, PAD, SHORT>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot, GR_DBG(a));
     rot = (rot - nb) & (NW - 1);
     GR_STAMP(4);
   }
-  // The tile's COLUMN entries (single-pass binning: faces whose part of the tile is much taller than wide, binning.hip): a
-  // second list, filled from the BACK of the tile's segment -- slot cap - 1 downwards --, taken in whole chunks of 64 slots
-  // from the top; a chunk's slots below the list's end hold nothing (0 rows).  Rare on survey terrain (none: no extra
-  // barrier), most of the work items of a scene of tree trunks and canopy slivers.
-#if GR_COLLIST
-#pragma unroll 1
-  for (uint32_t c0 = 0; c0 < cntc; c0 += 64) {
-    GR_PRIO_MEM();
-    __syncthreads();  // every wave is done with the previous chunk before it is overwritten
-    const int first = a.cap_tile - (int)c0 - 64;   // the chunk's slot 0 within the tile's segment (negative: the segment is shorter)
-    const int lowest = a.cap_tile - (int)cntc;     // the list's last entry
-    if (lane < EL) {
-      const int qc = wv * EL + lane;               // piece of the chunk
-      const int eq = first + (SHORT ? 0 : qc / GR_ENT_Q);  // (short form: whole chunks; the segment is a whole number of them)
-      if (SHORT ? first >= 0 : eq >= lowest)
-        ex = SHORT ? reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(comp) + (int64_t)first * 40)[qc]
-                   : reinterpret_cast<const v4i *>(comp + (int64_t)first * GR_ENT_Q)[qc];
-      ent_st[wv * EL + lane] = ex;
-    }
-    __syncthreads();
-    GR_PRIO_ITEMS();
-    const int e = first + lane;
-    const int nrows = e >= lowest ? (int)nr8[e] : 0;
-    const int nb = raster_chunk_gather<TWL, TH, NW, PAD, SHORT, true>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot, a.dbg);
-    rot = (rot - nb) & (NW - 1);
-    GR_STAMP(4);
-  }
-#endif
-
   int te = tid;
   asm volatile("" : "+v"(te));  // the epilogue's addresses are derived here, not hoisted above the scanline phase
   GR_PRIO_MEM();
   __syncthreads();              // keys complete
   if (GR_PRIO_E != GR_PRIO_M) __builtin_amdgcn_s_setprio(GR_PRIO_E);
   GR_STAMP(5);
-  if (a.dbg & 2) return;
+  if (GR_DBG(a) & 2) return;
   if (FUSE) {
     uint32_t *win = out.winner + slot * out.F;
     const bool edge = px0 + TW > a.w || py0 + TH + 1 > a.h;
-    if (edge) fused_winners<TWL, TH, NT, PAD, true>(keys, a, win, te, px0, py0, a.dbg);
-    else fused_winners<TWL, TH, NT, PAD, false>(keys, a, win, te, px0, py0, a.dbg);
+    if (edge) fused_winners<TWL, TH, NT, PAD, true>(keys, a, win, te, px0, py0, GR_DBG(a));
+    else fused_winners<TWL, TH, NT, PAD, false>(keys, a, win, te, px0, py0, GR_DBG(a));
     if (out.ids) {  // the id image as well (rare): background is where no fragment landed (depth bits 0)
       const int col = te & (TW - 1), gx = px0 + col;
       if (gx < a.w)
@@ -573,9 +544,9 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
           out.ids[plane + (int64_t)(py0 + row) * a.w + gx] = (key >> 32) ? (int32_t)~(uint32_t)key : -1;
         }
     }
-  } else if (out.ids && !out.depth) {
-    store_ids<TWL, TH, NT, PAD>(keys, a, out.ids + plane, te, px0, py0);
-  } else {
+  } else if (PLAIN || (out.ids && !out.depth)) {
+    store_ids<TWL, TH, NT, PAD, PLAIN>(keys, a, out.ids + plane, te, px0, py0);
+  } else if (!PLAIN) {
     const int col = te & (TW - 1), gx = px0 + col;
     if (gx < a.w)
       for (int row = te >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
@@ -600,7 +571,7 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
 // fused kernel is not (left at the default).  Work items of two consecutive rows (look-up, unpack and the reciprocals paid
 // once per two rows: -16 % VALU instructions) were measured as well: 74 VGPRs and half as many batches per tile for four
 // waves -- 15.6 vs 16.0 without the hint, 16.3 vs 15.3 with it, fused 18.3 vs 17.2 -- dropped.
-template <int TWL, int THL, int NT, bool FUSE, int KT, int PAD, bool SHORT>
+template <int TWL, int THL, int NT, bool FUSE, int KT, int PAD, bool SHORT, bool PLAIN = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (THL == 5 ? 7 : 4), 8))) void k_raster_tile(BinArgs a, RasterOut out) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   constexpr int NKEYS = (TW + PAD) * TH;
@@ -651,7 +622,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (
   // not walked at all (one scalar load beside the counters')
   if (FUSE && ctrl[2] != 0u) return;
   uint32_t cnt0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
-  uint32_t col0 = 0, col1 = 0, col2 = 0, col3 = 0;  // column entries (the tile's second list; single-pass binning only)
   int64_t beg0, beg1 = 0, beg2 = 0, beg3 = 0;
   if (KT == 4 && a.cap_tile > 0) {
     // single-pass binning: the chain's four counters sit side by side, 16-byte aligned -- ONE scalar load instead of four
@@ -663,26 +633,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (
     cnt2 = n_tiles > 2 ? min(c4.z, cap) : 0u;
     cnt3 = n_tiles > 3 ? min(c4.w, cap) : 0u;
     beg0 = (int64_t)tile0 * a.cap_tile; beg1 = beg0 + a.cap_tile; beg2 = beg1 + a.cap_tile; beg3 = beg2 + a.cap_tile;
-#if GR_COLLIST
-    const uint4 k4 = *reinterpret_cast<const uint4 *>(ctrl + GR_CTRL_HDR + a.Tcap + tile0);  // Tcap is a multiple of 4
-    col0 = min(k4.x, cap - cnt0);
-    col1 = n_tiles > 1 ? min(k4.y, cap - cnt1) : 0u;
-    col2 = n_tiles > 2 ? min(k4.z, cap - cnt2) : 0u;
-    col3 = n_tiles > 3 ? min(k4.w, cap - cnt3) : 0u;
-#endif
   } else {
-#if GR_COLLIST
-    if (a.cap_tile > 0) col0 = ctrl[GR_CTRL_HDR + a.Tcap + tile0];
-#endif
     tile_list(a, ctrl, tile0, cnt0, beg0);
-    if (GR_COLLIST && a.cap_tile > 0) col0 = min(col0, (uint32_t)a.cap_tile - cnt0);
     if (KT > 1) {
       if (n_tiles > 1) tile_list(a, ctrl, tile0 + 1, cnt1, beg1);
       if (n_tiles > 2) tile_list(a, ctrl, tile0 + 2, cnt2, beg2);
       if (n_tiles > 3) tile_list(a, ctrl, tile0 + 3, cnt3, beg3);
     }
   }
-  if (a.dbg & 4) cnt0 = cnt1 = cnt2 = cnt3 = col0 = col1 = col2 = col3 = 0;
+  if (GR_DBG(a) & 4) cnt0 = cnt1 = cnt2 = cnt3 = 0;
   const int64_t sbase = slot * a.ent_cap;
   if (!spec) {  // exact binning (or segments under 64 slots): the first chunk can only be requested now
     if ((uint32_t)lane < cnt0) nr0 = a.nrow8[sbase + beg0 + lane];
@@ -702,14 +661,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (
   // previous tile's id stores (tests/test_isa_waits.py)
   if (KT > 1) asm volatile("" : "+v"(ex0), "+v"(ex1), "+v"(ex2), "+v"(ex3), "+v"(nr0), "+v"(nr1), "+v"(nr2), "+v"(nr3));
   GR_STAMP(0);
-  raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, KT == 1>(a, out, keys, slot, tile0, cnt0, col0, beg0, nr0, ex0 GR_STAMP_PASS);
+  static_assert(!(FUSE && PLAIN), "the plain kernel writes ids only");
+  raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, KT == 1, PLAIN>(a, out, keys, slot, tile0, cnt0, beg0, nr0, ex0 GR_STAMP_PASS);
   if (KT > 1) {
 #pragma unroll 1
     for (int k = 1; k < n_tiles; ++k) {  // ONE copy of the tile code for tiles 1 .. 3: the chunks rotate through ex1
       __syncthreads();                   // every wave has read the previous tile's keys
       GR_STAMP(7);
-      raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, false>(a, out, keys, slot, tile0 + k, cnt1, col1, beg1, nr1, ex1 GR_STAMP_PASS);
-      cnt1 = cnt2; cnt2 = cnt3; beg1 = beg2; beg2 = beg3; col1 = col2; col2 = col3;
+      raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, false, PLAIN>(a, out, keys, slot, tile0 + k, cnt1, beg1, nr1, ex1 GR_STAMP_PASS);
+      cnt1 = cnt2; cnt2 = cnt3; beg1 = beg2; beg2 = beg3;
       nr1 = nr2; nr2 = nr3; ex1 = ex2; ex2 = ex3;
     }
   }
@@ -740,19 +700,25 @@ int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStr
     const bool chain = (a.var & 1) == 0 && ((a.var & 16) != 0 || (a.cap_tile > 0 && a.cap_tile <= 512 && (int64_t)a.T * nb >= 16384));
     const dim3 grid(chain ? (unsigned)((a.T + 3) >> 2) : (unsigned)a.T, nb), block(256);
     const size_t pad = (size_t)c->opt_lds_pad;
-#define GR_LAUNCH_TILE(THL_, FUSE_)                                                                                   \
+#define GR_LAUNCH_TILE(THL_, FUSE_, PLAIN_)                                                                           \
   do {                                                                                                                \
     if (a.ent40) {                                                                                                    \
-      if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD, true>), grid, block, pad, s, a, out);  \
-      else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD, true>), grid, block, pad, s, a, out);        \
-    } else if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD, false>), grid, block, pad, s, a, out);  \
-    else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD, false>), grid, block, pad, s, a, out);        \
+      if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD, true, PLAIN_>), grid, block, pad, s, a, out);  \
+      else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD, true, PLAIN_>), grid, block, pad, s, a, out);        \
+    } else if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD, false, PLAIN_>), grid, block, pad, s, a, out);  \
+    else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD, false, PLAIN_>), grid, block, pad, s, a, out);        \
   } while (0)
+    // the usual ids-only call: rows of whole 16-byte pieces, every view's plane 16-byte aligned, no depth image
+    const bool plain = !out.winner && out.ids && !out.depth && (w & 3) == 0 && (reinterpret_cast<uintptr_t>(out.ids) & 15) == 0 &&
+                       !(a.var & 512);
     if (out.winner) {
-      if (a.thl == 6) GR_LAUNCH_TILE(6, true);
-      else GR_LAUNCH_TILE(5, true);
-    } else if (a.thl == 6) GR_LAUNCH_TILE(6, false);
-    else GR_LAUNCH_TILE(5, false);
+      if (a.thl == 6) GR_LAUNCH_TILE(6, true, false);
+      else GR_LAUNCH_TILE(5, true, false);
+    } else if (plain) {
+      if (a.thl == 6) GR_LAUNCH_TILE(6, false, true);
+      else GR_LAUNCH_TILE(5, false, true);
+    } else if (a.thl == 6) GR_LAUNCH_TILE(6, false, false);
+    else GR_LAUNCH_TILE(5, false, false);
 #undef GR_LAUNCH_TILE
     c->prof_raster_launches += 1;
   }

@@ -116,7 +116,8 @@ enum {
                                (default: expanded inside the set-up kernel); 128 = 48-byte entries always (default:
                                the single-pass binning writes 40-byte entries and falls back to 48 bytes -- one
                                GR_EOVERFLOW retry, remembered like the slots per tile -- for images with faces of
-                               93 pixels and more)                                                                  */
+                               93 pixels and more); 512 = the general ids kernel (depth output, any width) also for calls
+                               the plain one would take (ids only, rows of whole 16-byte pieces)                        */
   GR_OPT_SHARE_LEARNED = 8, /* 1 (default): consult and feed the process-wide table of learned slots per tile / entry forms
                                (and its file, gr_learned_cache_file); 0: this context learns for itself only.  Setting
                                GR_OPT_DIRECT_CAP by hand switches it off; this option switches it back on            */

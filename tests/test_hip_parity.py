@@ -20,7 +20,9 @@ pytestmark = pytest.mark.gpu
 # entries with a fallback) -- every combination must give identical results
 VARIANTS = {"tile32_chain": (5, 512, 16), "tile64_single_full": (6, 512, 129), "tile32_exact_single": (5, 0, 5),
             "tile64_exact_chain": (6, 0, 16), "tile32_single_nospec_full": (5, 512, 141), "tile32_chain_nospec_nobitmap": (5, 512, 56),
-            "tile32_chain_biglist": (5, 512, 80), "tile64_single": (6, 512, 1)}
+            "tile32_chain_biglist": (5, 512, 80), "tile64_single": (6, 512, 1),
+            # 512: the general ids kernel (depth / odd widths) also where the plain one (16-byte id stores only) would run
+            "tile32_chain_general_ids": (5, 512, 528), "tile64_single_general_ids": (6, 512, 513)}
 
 
 @pytest.fixture(params=list(VARIANTS), autouse=True)

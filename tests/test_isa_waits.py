@@ -12,12 +12,10 @@ import pytest
 
 from geograypher_amd import build as gbuild
 
-# (fused, short entries) -> s_waitcnt vmcnt instructions of k_raster_tile<6, 5, 256, fused, 4, 5, short>: ONE wait for all
-# requests of the chain before its first tile, and the waits for later chunks and their row counts inside a tile -- the
-# loop over the later chunks of the row list and (round 4) the loop over the chunks of the COLUMN list, 2 each per copy of
-# the tile code, 2 copies -- none for the empty-tile path, none between or inside the tiles of a chain of tiles that hold one
-# chunk of row entries and no column entries (every tile of a survey mesh)
-KNOWN_GOOD = {(False, False): 9, (False, True): 9, (True, False): 9, (True, True): 9}
+# (fused, short entries) -> s_waitcnt vmcnt instructions of k_raster_tile<6, 5, 256, fused, 4, 5, short, plain>: ONE wait for all
+# requests of the chain before its first tile, and the waits for later chunks and their row counts inside a tile (2 per copy
+# of the tile code, 2 copies) -- none for the empty-tile path, none between or inside the tiles of the chain
+KNOWN_GOOD = {(False, False): 5, (False, True): 5, (True, False): 5, (True, True): 5}
 
 
 def _device_asm(src, out):
@@ -35,8 +33,9 @@ def device_asm(tmp_path_factory):
 
 
 def _kernel_body(lines, fused, short):
-    name = "_ZN12_GLOBAL__N_113k_raster_tileILi6ELi5ELi256ELb%dELi4ELi%dELb%dEEEvN6grimpl7BinArgsENS1_9RasterOutE:" % (
-        int(fused), _lds_pad(), int(short))
+    # the kernels of the usual calls: fused aggregation, and the PLAIN ids kernel (last template flag)
+    name = "_ZN12_GLOBAL__N_113k_raster_tileILi6ELi5ELi256ELb%dELi4ELi%dELb%dELb%dEEEvN6grimpl7BinArgsENS1_9RasterOutE:" % (
+        int(fused), _lds_pad(), int(short), int(not fused))
     start = [i for i, l in enumerate(lines) if l.startswith(name)]
     assert len(start) == 1, f"kernel symbol not found: {name}"
     end = next(i for i in range(start[0], len(lines)) if lines[i].startswith(".Lfunc_end"))

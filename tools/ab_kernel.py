@@ -7,6 +7,7 @@ Every variant with dbg == 0 must reproduce the first variant's ids and votes bit
 variant: median HIP-event stage times in microseconds per view.
 """
 import json
+import os
 import statistics
 import sys
 from pathlib import Path
@@ -15,10 +16,16 @@ import numpy as np
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+# a variant with an ablation mask (third field) needs the DIAGNOSTIC build: the product's kernels carry no ablation branches
+if any(len(sp.split(":")) > 2 and sp.split(":")[2] not in ("", "0") for sp in sys.argv[3:]) and not os.environ.get("GEOGRAYPHER_AMD_LIB"):
+    from geograypher_amd import build as _gbuild
+
+    _lib = _gbuild.CSRC / "libgeograster_ablate.so"
+    if not _lib.is_file() or _lib.stat().st_mtime < max(p.stat().st_mtime for p in _gbuild.SOURCES + _gbuild.HEADERS):
+        _gbuild.build_variant("ablate", ["GR_ABLATE"])
+    os.environ["GEOGRAYPHER_AMD_LIB"] = str(_lib)
 from geograypher_amd._hip import HipRaster
 from geograypher_amd.utils import synthetic
-
-import os
 
 H, W, C = 3000, 4000, 4
 DEFAULT = ["base:0", "xcd:64"]
