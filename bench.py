@@ -773,7 +773,7 @@ def leg_c5(rig, wl, rank, world, local_rank, dev, distributed, barrier, max_over
             hip5.raster_face_ids(recs[:nr], H5, W5, out=ids5[:nr], check=False)
     hip5.set_profiling(True)
     reps, t_raster = 0, 0.0
-    while reps == 0 or (t_raster < wl.min_leg_s and reps < 200):
+    while reps == 0 or (t_raster < wl.min_leg_s and reps < 2000):
         barrier()
         t0 = time.perf_counter()
         for _ in range(5):

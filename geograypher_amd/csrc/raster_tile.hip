@@ -6,6 +6,19 @@
 
 using namespace grimpl;
 
+// EIGHT workgroups per CU (round 4): 64 x 32 keys with 2 padding keys per row (16.5 KiB) + mailboxes (1 KiB) + one chunk of
+// 40-byte entries (2.5 KiB) = 20 480 bytes = an eighth of the CU's LDS, at most 80 SGPRs (the hardware admits
+// floor(800 / (ceil(sgpr / 16) * 16 + 16)) workgroups of 256 threads: 81 SGPRs would make it seven), at most 64 VGPRs.
+// The closed-network model of DESIGN.md section 5 gives an eighth workgroup +2-3 % VALU utilisation; measured, builds
+// alternated on one box (profiles/r04_ab/ab_wg8.log): ids kernel 13.85 -> 13.55 us per C2 view, fused and config 5 unchanged.
+// (Round 2's 8-workgroup variant -- 4 padding keys, mailboxes inside the padding -- lost to the bank conflicts of the
+// epilogue's dword reads, which are gone: DESIGN.md.)  Kernels with 48-byte entries stage 3 KiB and stay at seven.
+#ifndef GR_WPE
+#define GR_WPE 8       // waves per SIMD the 64 x 32 kernels ask the compiler for (what their LDS allows)
+#endif
+#ifndef GR_NUM_SGPR
+#define GR_NUM_SGPR 80
+#endif
 #ifndef GR_EXP
 #define GR_EXP 0   // experiment bits of A/B builds (geograypher_amd.build.build_variant, tools/ab_libs.py); 0 in the product
 #endif
@@ -33,12 +46,13 @@ namespace {
 //     fit a CU (21.25 KiB of LDS each).
 //     Epilogues: ids -> 16-byte stores (4 pixels per lane); fused projection -> per-face winners (see fused_winners).
 // ------------------------------------------------------------------------------------------------------------------
-// LDS image of a tile: rows of TW keys padded by GR_LDS_PAD keys (stride 69 keys = 552 B).  The rows of one triangle
-// walk their spans in step; with a row offset of 5 key-banks a pile-up on one bank needs a left edge that recedes
-// 5 px per row (a pad of 1 piled up every 45-degree edge: 530 of 1820 LDS cycles per tile were bank conflicts), and a
-// pixel's address advances by a plain +8 bytes along the scanline (no wrap arithmetic in the inner loop).
+// LDS image of a tile: rows of TW keys padded by GR_LDS_PAD keys (stride 66 keys = 528 B).  The rows of one triangle
+// walk their spans in step; with a row offset of 2 key-banks a pile-up on one bank needs a left edge that recedes
+// 2 px per row (a pad of 1 piled up every 45-degree edge: 530 of 1820 LDS cycles per tile were bank conflicts; rounds 1-3
+// used 5, 3 / 5 / 7 measured alike, 9 and 11 worse: DESIGN.md), and a pixel's address advances by a plain +8 bytes along
+// the scanline (no wrap arithmetic in the inner loop).  2 is what leaves room for an eighth workgroup per CU (above).
 #ifndef GR_LDS_PAD
-#define GR_LDS_PAD 5
+#define GR_LDS_PAD 2
 #endif
 template <int TWL, int PAD>
 __device__ __forceinline__ int lds_idx(int row, int col) {
@@ -572,7 +586,8 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
 // once per two rows: -16 % VALU instructions) were measured as well: 74 VGPRs and half as many batches per tile for four
 // waves -- 15.6 vs 16.0 without the hint, 16.3 vs 15.3 with it, fused 18.3 vs 17.2 -- dropped.
 template <int TWL, int THL, int NT, bool FUSE, int KT, int PAD, bool SHORT, bool PLAIN = false>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(FUSE ? 1 : (THL == 5 ? 7 : 4), 8))) void k_raster_tile(BinArgs a, RasterOut out) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(THL == 5 ? GR_WPE : (FUSE ? 1 : 4), 8)))
+__attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile(BinArgs a, RasterOut out) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   constexpr int NKEYS = (TW + PAD) * TH;
   constexpr int NW = NT / 64;
