@@ -563,7 +563,7 @@ def run(args, rig=None) -> int:
                     labels4[c0 + k] = device_labels(ids[k], mine[c0 + k], N_CLASSES)
             hip.raster_project_labels(recs4, labels4, N_CLASSES, votes4, counts4, check=True)  # sizing / warm-up pass
         t_local, t_reduce = [], []
-        while len(t_local) < 3 or (sum(t_local) + sum(t_reduce) < wl.min_leg_s and len(t_local) < 50):
+        while len(t_local) < 3 or (sum(t_local) + sum(t_reduce) < wl.min_leg_s and len(t_local) < 400):
             votes4.zero_()
             counts4.zero_()
             barrier()
