@@ -25,6 +25,11 @@ using namespace grimpl;
 
 namespace {
 
+#ifdef GR_STAMPS
+// diagnostic build: work-item statistics -- [0] items, [1] items whose span is empty, [2] pixels drawn, [3] batches
+__device__ unsigned long long g_item_stats[4];
+#endif
+
 // ------------------------------------------------------------------------------------------------------------------
 // K4  tile rasterizer (the dominant kernel).  grid (T, views), 256 threads = 4 waves, one 64 x TH tile per workgroup.
 //     depth|id keys (u64: 1/z bits << 32 | ~face) live in LDS; visibility is resolved with ds_max_u64, so the result
@@ -172,6 +177,19 @@ __device__ __forceinline__ void raster_item(unsigned long long *keys, const Entr
   // two pixels per step with packed fp32 math (v_pk_mul_f32 / v_pk_add_f32: same IEEE results as the scalar forms,
   // R4 op for op: z = iz0 + (A * float(P_x - X0) + B * float(P_y - Y0))).  float(P_x - X0) advances by exact float adds
   // (integers below 2^24).
+#ifdef GR_STAMPS
+  {
+    const unsigned long long ml = __ballot(live), me = __ballot(live && xs > xe);
+    int px = (live && xs <= xe) ? xe - xs + 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) px += __shfl_xor(px, o);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&g_item_stats[0], (unsigned long long)__popcll(ml));
+      atomicAdd(&g_item_stats[1], (unsigned long long)__popcll(me));
+      atomicAdd(&g_item_stats[2], (unsigned long long)px);
+      atomicAdd(&g_item_stats[3], 1ull);
+    }
+  }
+#endif
   if (live && xs <= xe) {
     const float m1 = e.B * (float)(yc * 256 + Y0rel);
     const bool even = ((xe - xs) & 1) != 0;       // an even number of pixels xs .. xe
@@ -701,6 +719,16 @@ __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile(BinArgs a, Rast
 }
 
 }  // namespace
+
+#ifdef GR_STAMPS
+extern "C" int gr_debug_read_item_stats(unsigned long long *out4_h) {  // diagnostic build: read and clear (tools/tile_phases.py)
+  if (hipDeviceSynchronize() != hipSuccess) return GR_EHIP;
+  if (hipMemcpyFromSymbol(out4_h, HIP_SYMBOL(g_item_stats), sizeof(unsigned long long) * 4) != hipSuccess) return GR_EHIP;
+  const unsigned long long z[4] = {0, 0, 0, 0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_item_stats), z, sizeof(z)) != hipSuccess) return GR_EHIP;
+  return GR_OK;
+}
+#endif
 
 namespace grimpl {
 

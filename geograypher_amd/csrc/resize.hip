@@ -132,7 +132,7 @@ int gr_resize_image_f64(gr_ctx *c, const void *src, int dtype, int h_in, int w_i
                         int w_out, double *out, void *stream) {
   if (!c) return GR_EINVAL;
   if (!src || !out || h_in <= 0 || w_in <= 0 || C <= 0 || h_out <= 0 || w_out <= 0 || (int64_t)w_in * C > 0x7FFFFFFFll ||
-      (int64_t)w_out * C > 0x7FFFFFFFll || h_in > (1 << 24) || w_in > (1 << 24))
+      (int64_t)w_out * C > 0x7FFFFFFFll || h_in > (1 << 24) || w_in > (1 << 24) || h_out > 32767 /* grid.y = 2 h_out */)
     return fail(c, GR_EINVAL, "bad resize args %dx%dx%d -> %dx%d", h_in, w_in, C, h_out, w_out);
   if (dtype != GR_DTYPE_U8 && dtype != GR_DTYPE_F32 && dtype != GR_DTYPE_F64) return fail(c, GR_EINVAL, "unknown image dtype %d", dtype);
   hipStream_t s = (hipStream_t)stream;

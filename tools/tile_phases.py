@@ -68,6 +68,11 @@ def main():
     read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
     buf = (ctypes.c_uint64 * 16)()
     assert read(hip._ctx, buf) == 0   # clear
+    items = hip.lib.gr_debug_read_item_stats
+    items.restype = ctypes.c_int
+    items.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    ibuf = (ctypes.c_uint64 * 4)()
+    assert items(ibuf) == 0           # clear
     reps = 5
     hip.set_profiling(True)
     for _ in range(reps):
@@ -76,6 +81,8 @@ def main():
     hip.set_profiling(False)
     assert read(hip._ctx, buf) == 0
     cyc = [int(x) for x in buf]
+    assert items(ibuf) == 0
+    it = [int(x) for x in ibuf]
     waves, visits = cyc[15], cyc[14]
     total = sum(cyc[:9])
     raster_us_per_view = st["raster_ms"] / st["views"] * 1e3
@@ -85,6 +92,9 @@ def main():
         "raster_us_per_view": round(raster_us_per_view, 2),
         "cycles_per_tile_visit": {PHASES[k]: round(cyc[k] / max(visits, 1), 1) for k in range(9)},
         "share": {PHASES[k]: round(cyc[k] / max(total, 1), 4) for k in range(9)},
+        "items_per_view": round(it[0] / (reps * nv)), "empty_span_items_share": round(it[1] / max(it[0], 1), 4),
+        "pixels_per_nonempty_item": round(it[2] / max(it[0] - it[1], 1), 2), "batches_per_view": round(it[3] / (reps * nv)),
+        "items_per_batch": round(it[0] / max(it[3], 1), 1),
         "wave_lifetime_cycles_per_tile": round(total / max(visits, 1), 1),
         # sum of wave lifetimes / (kernel time x 256 CUs): resident waves per CU if the clock were 100 MHz x s_memtime ticks
         "wave_cycles_total": total,
