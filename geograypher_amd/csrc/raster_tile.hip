@@ -27,7 +27,8 @@ namespace {
 
 #ifdef GR_STAMPS
 // diagnostic build: work-item statistics -- [0] items, [1] items whose span is empty, [2] pixels drawn, [3] batches
-__device__ unsigned long long g_item_stats[4];
+// (1024 slots: same-address atomics are served one per 11 ns)
+__device__ unsigned long long g_item_stats[1024][4];
 #endif
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -183,10 +184,11 @@ __device__ __forceinline__ void raster_item(unsigned long long *keys, const Entr
     int px = (live && xs <= xe) ? xe - xs + 1 : 0;
     for (int o = 32; o > 0; o >>= 1) px += __shfl_xor(px, o);
     if ((threadIdx.x & 63) == 0) {
-      atomicAdd(&g_item_stats[0], (unsigned long long)__popcll(ml));
-      atomicAdd(&g_item_stats[1], (unsigned long long)__popcll(me));
-      atomicAdd(&g_item_stats[2], (unsigned long long)px);
-      atomicAdd(&g_item_stats[3], 1ull);
+      unsigned long long *st = g_item_stats[(blockIdx.x * 4 + (threadIdx.x >> 6) + blockIdx.y * 977) & 1023];
+      atomicAdd(&st[0], (unsigned long long)__popcll(ml));
+      atomicAdd(&st[1], (unsigned long long)__popcll(me));
+      atomicAdd(&st[2], (unsigned long long)px);
+      atomicAdd(&st[3], 1ull);
     }
   }
 #endif
@@ -723,9 +725,13 @@ __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile(BinArgs a, Rast
 #ifdef GR_STAMPS
 extern "C" int gr_debug_read_item_stats(unsigned long long *out4_h) {  // diagnostic build: read and clear (tools/tile_phases.py)
   if (hipDeviceSynchronize() != hipSuccess) return GR_EHIP;
-  if (hipMemcpyFromSymbol(out4_h, HIP_SYMBOL(g_item_stats), sizeof(unsigned long long) * 4) != hipSuccess) return GR_EHIP;
-  const unsigned long long z[4] = {0, 0, 0, 0};
-  if (hipMemcpyToSymbol(HIP_SYMBOL(g_item_stats), z, sizeof(z)) != hipSuccess) return GR_EHIP;
+  static unsigned long long all[1024][4];
+  if (hipMemcpyFromSymbol(all, HIP_SYMBOL(g_item_stats), sizeof(all)) != hipSuccess) return GR_EHIP;
+  for (int k = 0; k < 4; ++k) out4_h[k] = 0;
+  for (int i = 0; i < 1024; ++i)
+    for (int k = 0; k < 4; ++k) out4_h[k] += all[i][k];
+  memset(all, 0, sizeof(all));
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_item_stats), all, sizeof(all)) != hipSuccess) return GR_EHIP;
   return GR_OK;
 }
 #endif

@@ -7,7 +7,7 @@ cp $P/trace/trace_kernel_stats.csv profiles/r04_kernel_stats.csv
 tail -1 $F/bench.json > profiles/r04_bench.json
 grep '^{' $P/trace_bench.log | tail -1 > profiles/r04_bench_under_rocprof.json
 tail -4 $F/gpu_tests.log > profiles/r04_gpu_tests.log
-cp $F/phases_c2.log profiles/r04_ab/tile_phases_c2.log; cp $F/phases_c5.log profiles/r04_ab/tile_phases_c5.log
+cp $F/phases_c2.log profiles/r04_ab/tile_phases_c2_final.log; cp $F/phases_c5.log profiles/r04_ab/tile_phases_c5_final.log
 python3 - <<'PY'
 import csv, glob, collections
 out = collections.defaultdict(lambda: collections.defaultdict(list))
