@@ -110,6 +110,27 @@ __device__ __forceinline__ void span_solve(int C0, int C1, int C2, int w3, int w
   xe = a1 > 0 ? xe : hi;
 }
 
+// The same span from the INTERCEPT form of an entry (binning.hip, pq_form: p_k = (C'_k + 0.5) / m_k, q_k = b_k / m_k, exactness
+// argued there): one fused multiply-add, one clamp and one floor per edge.  The clamps do the tile's column range as well:
+// the first edge's floor stays <= TW/2 (xs >= -TW/2), the last edge's <= TW/2 - 1; a floor of -34 on either side is "empty".
+template <int TW>
+__device__ __forceinline__ void span_solve_pq(float p0, float q0, float p1, float q1, float p2, float q2, bool mid_left, int yc,
+                                              int &xs, int &xe) {
+  const float yf = (float)yc;
+  const float g0 = __builtin_amdgcn_fmed3f(__builtin_fmaf(q0, yf, p0), -34.0f, (float)(TW / 2));
+  const float g1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(q1, yf, p1), -34.0f, 33.0f);
+  const float g2 = __builtin_amdgcn_fmed3f(__builtin_fmaf(q2, yf, p2), -34.0f, (float)(TW / 2) - 0.5f);
+  int f0, f1, f2;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(f0) : "v"(g0));
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(f1) : "v"(g1));
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(f2) : "v"(g2));
+  xs = -f0;
+  xe = f2;
+  const int lo = max(xs, -f1), hi = min(xe, f1);
+  xs = mid_left ? lo : xs;
+  xe = mid_left ? xe : hi;
+}
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -122,7 +143,8 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 struct EntryView {
   int c0, c1, c2, w3, w4, w5;   // edge constants, slope words
   int X0rel, Y0rel, y_first;    // float(P - vertex 0) offsets of the centred pixel (0, 0); the entry's first row, centred
-  bool wide24, corr;            // 24-bit slope packing; a slope beyond GR_FLOOR_NOCORR_MAX
+  bool wide24, corr;            // 24-bit slope packing; a slope beyond GR_FLOOR_NOCORR_MAX (48-byte form: integer words at all)
+  bool mid_left;                // 48-byte intercept form: the middle edge bounds the span from the left
   f32x2 izA;                    // {iz0, A}
   float B;
   uint32_t key;                 // ~face
@@ -136,7 +158,8 @@ __device__ __forceinline__ EntryView entry_view(const int4 e0, const int4 e1, co
   v.Y0rel = (yw << 8) >> 8;     // biased by TH/2 rows
   v.y_first = (yw << 2) >> 26;
   v.wide24 = yw < 0;
-  v.corr = (uint32_t)yw >= 0x40000000u;  // compile_entry's flags: 24-bit slopes or a slope beyond 16000
+  v.corr = (uint32_t)yw >= 0x40000000u;  // store_entry's flags: integer words (24-bit slopes, a slope beyond 16000), not intercepts
+  v.mid_left = xw < 0;
   v.izA.x = __int_as_float(e1.z); v.izA.y = __int_as_float(e1.w);  // the two words as the entry holds them
   v.B = __int_as_float(e2.x);
   v.key = (uint32_t)e2.z;
@@ -154,13 +177,14 @@ __device__ __forceinline__ EntryView entry_view(const uint2 s01, const uint2 s23
   v.y_first = __builtin_amdgcn_sbfe(s23.x, 24, 6);
   v.wide24 = false;
   v.corr = (int)s23.x < 0;
+  v.mid_left = false;
   v.izA.x = __uint_as_float(s67.x); v.izA.y = __uint_as_float(s67.y);
   v.B = __uint_as_float(s89.y);
   v.key = s89.x;
   return v;
 }
 
-template <int TWL, int TH, int PAD>
+template <int TWL, int TH, int PAD, bool PQ>
 __device__ __forceinline__ void raster_item(unsigned long long *keys, const EntryView &e, const int r, const bool live) {
   constexpr int TW = 1 << TWL;
   const int X0rel = e.X0rel, Y0rel = e.Y0rel;
@@ -170,7 +194,13 @@ __device__ __forceinline__ void raster_item(unsigned long long *keys, const Entr
   const bool wide24 = e.wide24;
   const bool wide = live && e.corr;
   int xs = 0, xe = -1;
-  if (__ballot(wide) != 0ull) {
+  if (PQ) {  // 48-byte entries: intercepts, or -- long edges -- integer words for the correcting solver; rarely both in a wave
+    if (wide)
+      span_solve<TW, true>(e.c0, e.c1, e.c2, e.w3, e.w4, e.w5, wide24, yc, xs, xe);
+    else if (live)
+      span_solve_pq<TW>(__int_as_float(e.c0), __int_as_float(e.c1), __int_as_float(e.c2), __int_as_float(e.w3),
+                        __int_as_float(e.w4), __int_as_float(e.w5), e.mid_left, yc, xs, xe);
+  } else if (__ballot(wide) != 0ull) {
     if (live) span_solve<TW, true>(e.c0, e.c1, e.c2, e.w3, e.w4, e.w5, wide24, yc, xs, xe);
   } else {
     if (live) span_solve<TW, false>(e.c0, e.c1, e.c2, e.w3, e.w4, e.w5, false, yc, xs, xe);
@@ -243,13 +273,28 @@ __device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, con
   if (dbg & 1) total = 0;
   for (int k0 = first_b * 64; k0 < total; k0 += 64 * NW) {
     const int q = k0 + lane;
-    gen += 1u << 12;
     const int slot = excl - k0;
-    if (nrows > 0 && slot >= 0 && slot < 64)
-      *reinterpret_cast<uint32_t *>(lds + tab_base + slot * 4) = gen | (uint32_t)(lane << 6) | (uint32_t)slot;
+    uint32_t m;
+    if (SHORT) {
+      gen += 1u << 12;
+      if (nrows > 0 && slot >= 0 && slot < 64)
+        *reinterpret_cast<uint32_t *>(lds + tab_base + slot * 4) = gen | (uint32_t)(lane << 6) | (uint32_t)slot;
+      m = *reinterpret_cast<const uint32_t *>(lds + tab_self);
+    } else {
+      // 16-bit mailbox words (48-byte entries: the 512 bytes this saves are what lets an eighth workgroup fit a CU): a 4-bit
+      // generation; when it wraps -- and at the tile's first batch -- the wave wipes its mailbox
+      gen += 1u << 12;
+      if (!(gen & 0xF000u)) {
+        *reinterpret_cast<uint16_t *>(lds + tab_self) = (uint16_t)0;
+        gen = 1u << 12;
+      }
+      if (nrows > 0 && slot >= 0 && slot < 64)
+        *reinterpret_cast<uint16_t *>(lds + tab_base + slot * 2) = (uint16_t)(gen | (uint32_t)(lane << 6) | (uint32_t)slot);
+      m = *reinterpret_cast<const uint16_t *>(lds + tab_self);
+    }
     const int carry_t = __popcll(__ballot(incl <= k0));  // the entry that holds item k0: it exists (k0 < total), <= 63
     const int carry_r = k0 - __builtin_amdgcn_readlane(excl, carry_t);  // row of item k0 within that entry
-    const uint32_t m = wave_incl_max(*reinterpret_cast<const uint32_t *>(lds + tab_self));
+    m = wave_incl_max(m);
     const bool started = m >= gen;                       // some entry starts at or before this lane's item in the batch
     const int t = started ? (int)((m >> 6) & 63u) : carry_t;  // always an entry of this chunk, also beyond the last item
     const int r = lane - (started ? (int)(m & 63u) : -carry_r);  // the item's row within its entry
@@ -257,11 +302,11 @@ __device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, con
     if (SHORT) {
       const int4 ea = ent[t * 2], eb = ent[t * 2 + 1];
       const uint2 s89 = reinterpret_cast<const uint2 *>(ent)[256 + t];
-      raster_item<TWL, TH, PAD>(keys, entry_view(make_uint2(ea.x, ea.y), make_uint2(ea.z, ea.w), make_uint2(eb.x, eb.y),
-                                                 make_uint2(eb.z, eb.w), s89), r, live);
+      raster_item<TWL, TH, PAD, false>(keys, entry_view(make_uint2(ea.x, ea.y), make_uint2(ea.z, ea.w), make_uint2(eb.x, eb.y),
+                                                        make_uint2(eb.z, eb.w), s89), r, live);
     } else {
       const int4 e0 = ent[t * 3], e1 = ent[t * 3 + 1], e2 = ent[t * 3 + 2];
-      raster_item<TWL, TH, PAD>(keys, entry_view(e0, e1, e2), r, live);
+      raster_item<TWL, TH, PAD, true>(keys, entry_view(e0, e1, e2), r, live);
     }
   }
   return (total + 63) >> 6;
@@ -477,7 +522,7 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   constexpr int NKEYS = (TW + PAD) * TH;
   constexpr int NW = NT / 64;
-  constexpr int NMAIL = NW * 32;  // u64 units: 64 mailbox words per wave
+  constexpr int NMAIL = NW * (SHORT ? 32 : 16);  // u64 units: 64 mailbox words per wave (32-bit; 16-bit beside 48-byte entries)
   int4 *ent_lds = reinterpret_cast<int4 *>(keys + NKEYS + NMAIL);
   v4i *ent_st = reinterpret_cast<v4i *>(ent_lds);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -514,8 +559,8 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
     GR_STAMP(8);
     return;
   }
-  const int tab_base = NKEYS * 8 + wv * 256;  // byte offset of the wave's 64 mailbox words, behind the keys
-  const int tab_self = tab_base + lane * 4;
+  const int tab_base = NKEYS * 8 + wv * (SHORT ? 256 : 128);  // byte offset of the wave's 64 mailbox words, behind the keys
+  const int tab_self = tab_base + lane * (SHORT ? 4 : 2);
   {  // fill the tile (16-byte LDS stores): depth 0 | the id background stands for; mailboxes zero
     const int bg = (FUSE && out.compat) ? (int)out.F - 1 : -1;
     const unsigned long long fill = (unsigned long long)(uint32_t)~bg;
@@ -523,9 +568,10 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
 #pragma unroll
     for (int i = 0; i < (NKEYS / 2 + NT - 1) / NT; ++i)
       if (i * NT + tid < NKEYS / 2) k2[i * NT + tid] = make_ulonglong2(fill, fill);
-    for (int i = tid; i < NMAIL / 2; i += NT) k2[NKEYS / 2 + i] = make_ulonglong2(0ull, 0ull);
+    if (SHORT)
+      for (int i = tid; i < NMAIL / 2; i += NT) k2[NKEYS / 2 + i] = make_ulonglong2(0ull, 0ull);
   }
-  uint32_t gen = 0;
+  uint32_t gen = SHORT ? 0u : 0xF000u;  // 16-bit mailboxes: the first batch finds the generation wrapped and wipes the mailbox
   int rot = wv;  // this wave's first batch of the current chunk
   {  // first chunk: in registers already, complete (k_raster_tile waits for every request of the chain before its first
      // tile: a wait on the memory counter here would wait for the previous tile's stores)
@@ -611,7 +657,7 @@ __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile(BinArgs a, Rast
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   constexpr int NKEYS = (TW + PAD) * TH;
   constexpr int NW = NT / 64;
-  constexpr int NMAIL = NW * 32;
+  constexpr int NMAIL = NW * (SHORT ? 32 : 16);
   // the kernel's only LDS: keys (17.25 KiB for 64x32) + mailboxes (1 KiB) + one chunk of entries (3 KiB) -> 7 workgroups/CU
   // (20 KiB -- 4 padding keys per row with the mailboxes inside the padding -- gives 8, and loses more to LDS bank
   // conflicts than it gains: plain 16.6 vs 16.3 us per C2 view, fused 19.8 vs 17.9)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""tools/ab_libs.py <rounds> <workloads: c2,c5> <tag[:GR_EXP bits]> ... -- A/B of library BUILDS on one box.  GPU box only.
+"""tools/ab_libs.py <rounds> <workloads: c2,c5> <tag[:GR_EXP bits[:GR_OPT_VARIANT bits]]> ... -- A/B of library BUILDS on one
+box.  GPU box only.
 
 Every tag is a build of the library: `base` = the product's libgeograster.so, anything else libgeograster_<tag>.so (built here
 with -DGR_EXP=<bits> when missing).  Rounds x builds x workloads, alternating (box-to-box spread is larger than most kernel
@@ -22,22 +23,24 @@ def main():
     workloads = sys.argv[2].split(",")
     libs = []
     for spec in sys.argv[3:]:
-        tag, _, bits = spec.partition(":")
+        tag, _, rest = spec.partition(":")
+        bits, _, var = rest.partition(":")
+        name = f"{tag}/{var}" if var else tag
         if tag == "base":
-            libs.append((tag, gbuild.build()))
+            libs.append((name, gbuild.build(), var or "0"))
             continue
         path = gbuild.CSRC / f"libgeograster_{tag}.so"
         if not path.is_file():
             gbuild.build_variant(tag, [f"GR_EXP={bits or 0}"])
-        libs.append((tag, path))
-    acc = {(t, w): [] for t, _ in libs for w in workloads}
+        libs.append((name, path, var or "0"))
+    acc = {(t, w): [] for t, _, _ in libs for w in workloads}
     sums = {}
     for r in range(rounds):
         for w in workloads:
-            for tag, path in libs:
+            for tag, path, var in libs:
                 env = dict(os.environ, GEOGRAYPHER_AMD_LIB=str(path), AB_WORKLOAD=w, AB_CHECKSUM="1")
                 nv, reps = ("20", "4") if w == "c5" else ("50", "5")
-                res = subprocess.run([sys.executable, str(ROOT / "tools" / "ab_kernel.py"), nv, reps, "x:0"], env=env,
+                res = subprocess.run([sys.executable, str(ROOT / "tools" / "ab_kernel.py"), nv, reps, f"x:{var}"], env=env,
                                      capture_output=True, text=True)
                 lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
                 if res.returncode != 0 or not lines:
@@ -54,7 +57,7 @@ def main():
                       f"fused {d['fused']['raster_ms']:6.2f} vote {d['fused']['vote_ms']:5.2f}", flush=True)
     print("--- medians (us per view)")
     for w in workloads:
-        for tag, _ in libs:
+        for tag, _, _ in libs:
             runs = acc[(tag, w)]
             if not runs:
                 continue
