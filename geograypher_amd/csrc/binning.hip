@@ -607,39 +607,6 @@ __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const 
 // 17 % fewer bytes written here and read by the tile kernel than the 48-byte form (the binning tax of DESIGN.md section 10).
 // A face the short form cannot hold raises bit 1 of the view's overflow word: gr_raster_status reports GR_EOVERFLOW like
 // for a tile that outgrew its segment, remembers that this (mesh, image) needs 48-byte entries, and the caller repeats.
-// The INTERCEPT form of a 48-byte entry (round 4).  The tile kernel's work item is one scanline y_c of one entry: it needs
-//   f_k(y_c) = floor((C'_k + b_k y_c) / m_k),  m_k = |a_k|,  for the three edges
-// and it is bound by VALU issue; an entry is visited by ten work items on a survey mesh (one per row).  So the divisions move
-// here, where they are paid once per entry: the six integer words C'_k, a_k, b_k become
-//   p_k = (C'_k + 0.5) / m_k,   q_k = b_k / m_k        (fp32; v_rcp_f32 and one rounded multiply each)
-// and the item evaluates g = fma(q_k, y_c, p_k), clamps, floors: 3 instructions per edge instead of 8 + a quarter-rate
-// reciprocal + the unpacking of the slopes.  floor(g) IS f_k:
-//   (E + 0.5) / m is at least 0.5 / m away from an integer (E an integer).  With u = 2^-24: r = rcp(m) is within 2u
-//   (1 ulp), p and q within 3u of their values, the fma adds one rounding of the result, and |p| <= G + |q| |y_c| wherever
-//   |g| <= G = 35 (beyond that the clamp decides, on the right side):
-//     |g^ - g| <= u (4 G + 6 |q| |y_c|) = u (140 + 6 Y |b| / m),   Y = 32 rows either side of the centre at most
-//   which is below 0.5 / m  <=>  140 m + 192 |b| < 2^23.  Entries whose six slopes stay within GR_FLOOR_NOCORR_MAX = 16000
-//   (edges up to 62 px: 5.3 M against 8.4 M) take this form; |C'| < 2^23 for them (build_entry), so C' + 0.5 is exact.
-//   tests/test_span_floor.py checks the bound against integer division with the reciprocal perturbed by +-3 ulp.
-// An edge parallel to the scanline (a = 0: only the middle edge can be) has no intercept: p, q = (C' + 0.5, b) * 2^20 give
-// g the sign of E' and a magnitude the clamp cuts -- "no constraint" or "empty", as the integer solver decides it.
-// Every other entry (longer edges, 24-bit slopes) keeps the integer words and takes the solver with the exact correction:
-// bit 30 of the row word.  Bit 31 of the column word: the middle edge bounds the span from the left (a > 0).
-__device__ __forceinline__ void pq_form(int4 &e0, int4 &e1, int4 &e2) {
-  const int af = (e0.w << 16) >> 16, am = e0.w >> 16, bf = (e1.x << 16) >> 16, bm = e1.x >> 16;
-  const int al = af + am, bl = -(bf + bm);  // the last edge: a = -al < 0
-  const bool fits = (uint32_t)e2.w < 0x40000000u && max(abs(bf), max(abs(bm), abs(bl))) <= GR_FLOOR_NOCORR_MAX && af > 0 && al > 0;
-  if (!fits) { e2.w |= 0x40000000; return; }
-  const int mm = abs(am);
-  const float rf = __builtin_amdgcn_rcpf((float)af), rl = __builtin_amdgcn_rcpf((float)al);
-  const float rm = mm ? __builtin_amdgcn_rcpf((float)mm) : 1048576.0f;
-  const float pf = ((float)e0.x + 0.5f) * rf, pm = ((float)e0.y + 0.5f) * rm, pl = ((float)e0.z + 0.5f) * rl;
-  const float qf = (float)bf * rf, qm = (float)bm * rm, ql = (float)bl * rl;
-  e0 = make_int4(__float_as_int(pf), __float_as_int(qf), __float_as_int(pm), __float_as_int(qm));
-  e1.x = __float_as_int(pl); e1.y = __float_as_int(ql);
-  if (am > 0) e2.y |= (int)0x80000000;
-}
-
 __device__ __forceinline__ void store_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
                                             uint8_t *__restrict__ nr8, int64_t idx, const int4 e0, const int4 e1, const int4 e2,
                                             int rows) {
@@ -659,10 +626,7 @@ __device__ __forceinline__ void store_entry(const BinArgs &a, uint32_t *__restri
     reinterpret_cast<uint2 *>(chunk + 2048)[t] = make_uint2((uint32_t)e2.z, (uint32_t)e2.x);
   } else {
     int4 *dst = comp + idx * GR_ENT_Q;
-    int4 f0 = e0, f1 = e1, f2 = e2;
-    if (a.var & 2048) f2.w |= 0x40000000;  // integer words for every entry: the solver with the exact correction (tests, A/B)
-    else pq_form(f0, f1, f2);
-    dst[0] = f0; dst[1] = f1; dst[2] = f2;
+    dst[0] = e0; dst[1] = e1; dst[2] = e2;
   }
   nr8[idx] = (uint8_t)rows;
 }

@@ -6,13 +6,18 @@
 
 using namespace grimpl;
 
-// EIGHT workgroups per CU (round 4): 64 x 32 keys with 2 padding keys per row (16.5 KiB) + mailboxes (1 KiB) + one chunk of
-// 40-byte entries (2.5 KiB) = 20 480 bytes = an eighth of the CU's LDS, at most 80 SGPRs (the hardware admits
-// floor(800 / (ceil(sgpr / 16) * 16 + 16)) workgroups of 256 threads: 81 SGPRs would make it seven), at most 64 VGPRs.
+// EIGHT workgroups per CU (round 4): 20 480 bytes of LDS at most -- an eighth of the CU's --, at most 80 SGPRs (the hardware
+// admits floor(800 / (ceil(sgpr / 16) * 16 + 16)) workgroups of 256 threads: 81 SGPRs would make it seven), at most 64 VGPRs.
+//   40-byte entries: 64 x 32 keys with 3 padding keys per row (16.75 KiB) + mailboxes (0.5 KiB) + one chunk (2.5 KiB) = 20 224
+//   48-byte entries: 2 padding keys per row (16.5 KiB) + mailboxes (0.5 KiB) + one chunk (3 KiB)                      = 20 480
 // The closed-network model of DESIGN.md section 5 gives an eighth workgroup +2-3 % VALU utilisation; measured, builds
-// alternated on one box (profiles/r04_ab/ab_wg8.log): ids kernel 13.85 -> 13.55 us per C2 view, fused and config 5 unchanged.
+// alternated on one box (profiles/r04_ab/ab_wg8.log): ids kernel 13.85 -> 13.55 us per C2 view with 40-byte entries; the
+// 48-byte kernels reached eight when the mailbox words went from 32 to 16 bits (raster_chunk_gather): hostile workload 119.1
+// -> 114.9 us of tile kernel per view (profiles/r04_ab/mailbox16_forest.log).  The same 512 bytes gave the 40-byte kernels
+// their third padding key: an ODD row stride is what the epilogues' 8-byte reads want (store_ids) -- fused kernel 15.8 ->
+// 14.85 us per C2 view, 32.0 -> 30.4 on config 5; ids kernel unchanged; 4 keys: no better than 2 (profiles/r04_ab/lds_pad_mailbox16.log).
 // (Round 2's 8-workgroup variant -- 4 padding keys, mailboxes inside the padding -- lost to the bank conflicts of the
-// epilogue's dword reads, which are gone: DESIGN.md.)  Kernels with 48-byte entries stage 3 KiB and stay at seven.
+// epilogue's dword reads, which are gone: DESIGN.md.)
 #ifndef GR_WPE
 #define GR_WPE 8       // waves per SIMD the 64 x 32 kernels ask the compiler for (what their LDS allows)
 #endif
@@ -48,17 +53,20 @@ __device__ unsigned long long g_item_stats[1024][4];
 //       phase 3  ONE SCANLINE OF ONE TRIANGLE PER LANE: the exact covered span [xs, xe] comes from the three edge
 //                inequalities (span_solve: probe-free float floor division, exact by construction -- edge_floor), then
 //                the lane walks the span two pixels at a time and issues one ds_max_u64 per covered pixel.
-//     What bounds it: VALU issue (74-80 % of the SIMD cycles), then the LDS pipe (62-66 %); 7 workgroups
-//     fit a CU (21.25 KiB of LDS each).
+//     What bounds it: VALU issue (81-85 % of the SIMD cycles), then the LDS pipe (62-67 %); 8 workgroups
+//     fit a CU (20 KiB of LDS each).
 //     Epilogues: ids -> 16-byte stores (4 pixels per lane); fused projection -> per-face winners (see fused_winners).
 // ------------------------------------------------------------------------------------------------------------------
-// LDS image of a tile: rows of TW keys padded by GR_LDS_PAD keys (stride 66 keys = 528 B).  The rows of one triangle
-// walk their spans in step; with a row offset of 2 key-banks a pile-up on one bank needs a left edge that recedes
-// 2 px per row (a pad of 1 piled up every 45-degree edge: 530 of 1820 LDS cycles per tile were bank conflicts; rounds 1-3
-// used 5, 3 / 5 / 7 measured alike, 9 and 11 worse: DESIGN.md), and a pixel's address advances by a plain +8 bytes along
-// the scanline (no wrap arithmetic in the inner loop).  2 is what leaves room for an eighth workgroup per CU (above).
+// LDS image of a tile: rows of TW keys padded by PAD keys (stride 67 keys = 536 B with 40-byte entries, 66 with 48-byte ones).
+// The rows of one triangle walk their spans in step; with a row offset of p key-banks a pile-up on one bank needs a left edge
+// that recedes p px per row (a pad of 1 piled up every 45-degree edge: 530 of 1820 LDS cycles per tile were bank conflicts;
+// rounds 1-3 used 5; 3 / 5 / 7 measured alike, 9 and 11 worse: DESIGN.md), and a pixel's address advances by a plain +8 bytes
+// along the scanline (no wrap arithmetic in the inner loop).  3 and 2 are what leaves room for an eighth workgroup per CU (above).
 #ifndef GR_LDS_PAD
-#define GR_LDS_PAD 2
+#define GR_LDS_PAD 3       // kernels with 40-byte entries
+#endif
+#ifndef GR_LDS_PAD48
+#define GR_LDS_PAD48 2     // kernels with 48-byte entries
 #endif
 template <int TWL, int PAD>
 __device__ __forceinline__ int lds_idx(int row, int col) {
@@ -110,27 +118,6 @@ __device__ __forceinline__ void span_solve(int C0, int C1, int C2, int w3, int w
   xe = a1 > 0 ? xe : hi;
 }
 
-// The same span from the INTERCEPT form of an entry (binning.hip, pq_form: p_k = (C'_k + 0.5) / m_k, q_k = b_k / m_k, exactness
-// argued there): one fused multiply-add, one clamp and one floor per edge.  The clamps do the tile's column range as well:
-// the first edge's floor stays <= TW/2 (xs >= -TW/2), the last edge's <= TW/2 - 1; a floor of -34 on either side is "empty".
-template <int TW>
-__device__ __forceinline__ void span_solve_pq(float p0, float q0, float p1, float q1, float p2, float q2, bool mid_left, int yc,
-                                              int &xs, int &xe) {
-  const float yf = (float)yc;
-  const float g0 = __builtin_amdgcn_fmed3f(__builtin_fmaf(q0, yf, p0), -34.0f, (float)(TW / 2));
-  const float g1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(q1, yf, p1), -34.0f, 33.0f);
-  const float g2 = __builtin_amdgcn_fmed3f(__builtin_fmaf(q2, yf, p2), -34.0f, (float)(TW / 2) - 0.5f);
-  int f0, f1, f2;
-  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(f0) : "v"(g0));
-  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(f1) : "v"(g1));
-  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(f2) : "v"(g2));
-  xs = -f0;
-  xe = f2;
-  const int lo = max(xs, -f1), hi = min(xe, f1);
-  xs = mid_left ? lo : xs;
-  xe = mid_left ? xe : hi;
-}
-
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -143,8 +130,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 struct EntryView {
   int c0, c1, c2, w3, w4, w5;   // edge constants, slope words
   int X0rel, Y0rel, y_first;    // float(P - vertex 0) offsets of the centred pixel (0, 0); the entry's first row, centred
-  bool wide24, corr;            // 24-bit slope packing; a slope beyond GR_FLOOR_NOCORR_MAX (48-byte form: integer words at all)
-  bool mid_left;                // 48-byte intercept form: the middle edge bounds the span from the left
+  bool wide24, corr;            // 24-bit slope packing; a slope beyond GR_FLOOR_NOCORR_MAX
   f32x2 izA;                    // {iz0, A}
   float B;
   uint32_t key;                 // ~face
@@ -158,8 +144,7 @@ __device__ __forceinline__ EntryView entry_view(const int4 e0, const int4 e1, co
   v.Y0rel = (yw << 8) >> 8;     // biased by TH/2 rows
   v.y_first = (yw << 2) >> 26;
   v.wide24 = yw < 0;
-  v.corr = (uint32_t)yw >= 0x40000000u;  // store_entry's flags: integer words (24-bit slopes, a slope beyond 16000), not intercepts
-  v.mid_left = xw < 0;
+  v.corr = (uint32_t)yw >= 0x40000000u;  // compile_entry's flags: 24-bit slopes or a slope beyond 16000
   v.izA.x = __int_as_float(e1.z); v.izA.y = __int_as_float(e1.w);  // the two words as the entry holds them
   v.B = __int_as_float(e2.x);
   v.key = (uint32_t)e2.z;
@@ -177,14 +162,13 @@ __device__ __forceinline__ EntryView entry_view(const uint2 s01, const uint2 s23
   v.y_first = __builtin_amdgcn_sbfe(s23.x, 24, 6);
   v.wide24 = false;
   v.corr = (int)s23.x < 0;
-  v.mid_left = false;
   v.izA.x = __uint_as_float(s67.x); v.izA.y = __uint_as_float(s67.y);
   v.B = __uint_as_float(s89.y);
   v.key = s89.x;
   return v;
 }
 
-template <int TWL, int TH, int PAD, bool PQ>
+template <int TWL, int TH, int PAD>
 __device__ __forceinline__ void raster_item(unsigned long long *keys, const EntryView &e, const int r, const bool live) {
   constexpr int TW = 1 << TWL;
   const int X0rel = e.X0rel, Y0rel = e.Y0rel;
@@ -194,13 +178,7 @@ __device__ __forceinline__ void raster_item(unsigned long long *keys, const Entr
   const bool wide24 = e.wide24;
   const bool wide = live && e.corr;
   int xs = 0, xe = -1;
-  if (PQ) {  // 48-byte entries: intercepts, or -- long edges -- integer words for the correcting solver; rarely both in a wave
-    if (wide)
-      span_solve<TW, true>(e.c0, e.c1, e.c2, e.w3, e.w4, e.w5, wide24, yc, xs, xe);
-    else if (live)
-      span_solve_pq<TW>(__int_as_float(e.c0), __int_as_float(e.c1), __int_as_float(e.c2), __int_as_float(e.w3),
-                        __int_as_float(e.w4), __int_as_float(e.w5), e.mid_left, yc, xs, xe);
-  } else if (__ballot(wide) != 0ull) {
+  if (__ballot(wide) != 0ull) {
     if (live) span_solve<TW, true>(e.c0, e.c1, e.c2, e.w3, e.w4, e.w5, wide24, yc, xs, xe);
   } else {
     if (live) span_solve<TW, false>(e.c0, e.c1, e.c2, e.w3, e.w4, e.w5, false, yc, xs, xe);
@@ -274,27 +252,19 @@ __device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, con
   for (int k0 = first_b * 64; k0 < total; k0 += 64 * NW) {
     const int q = k0 + lane;
     const int slot = excl - k0;
-    uint32_t m;
-    if (SHORT) {
-      gen += 1u << 12;
-      if (nrows > 0 && slot >= 0 && slot < 64)
-        *reinterpret_cast<uint32_t *>(lds + tab_base + slot * 4) = gen | (uint32_t)(lane << 6) | (uint32_t)slot;
-      m = *reinterpret_cast<const uint32_t *>(lds + tab_self);
-    } else {
-      // 16-bit mailbox words (48-byte entries: the 512 bytes this saves are what lets an eighth workgroup fit a CU): a 4-bit
-      // generation; when it wraps -- and at the tile's first batch -- the wave wipes its mailbox
-      gen += 1u << 12;
-      if (!(gen & 0xF000u)) {
-        *reinterpret_cast<uint16_t *>(lds + tab_self) = (uint16_t)0;
-        gen = 1u << 12;
-      }
-      if (nrows > 0 && slot >= 0 && slot < 64)
-        *reinterpret_cast<uint16_t *>(lds + tab_base + slot * 2) = (uint16_t)(gen | (uint32_t)(lane << 6) | (uint32_t)slot);
-      m = *reinterpret_cast<const uint16_t *>(lds + tab_self);
+    // 16-bit mailbox words (512 bytes of mailboxes: with 1 KiB of them the 48-byte kernels did not fit eight workgroups on a
+    // CU, and the 40-byte ones had no room for a third padding key).  A 4-bit generation: when it wraps -- and at the tile's
+    // first batch -- the wave wipes its mailbox
+    gen += 1u << 12;
+    if (!(gen & 0xF000u)) {
+      *reinterpret_cast<uint16_t *>(lds + tab_self) = (uint16_t)0;
+      gen = 1u << 12;
     }
+    if (nrows > 0 && slot >= 0 && slot < 64)
+      *reinterpret_cast<uint16_t *>(lds + tab_base + slot * 2) = (uint16_t)(gen | (uint32_t)(lane << 6) | (uint32_t)slot);
+    const uint32_t m = wave_incl_max((uint32_t)*reinterpret_cast<const uint16_t *>(lds + tab_self));
     const int carry_t = __popcll(__ballot(incl <= k0));  // the entry that holds item k0: it exists (k0 < total), <= 63
     const int carry_r = k0 - __builtin_amdgcn_readlane(excl, carry_t);  // row of item k0 within that entry
-    m = wave_incl_max(m);
     const bool started = m >= gen;                       // some entry starts at or before this lane's item in the batch
     const int t = started ? (int)((m >> 6) & 63u) : carry_t;  // always an entry of this chunk, also beyond the last item
     const int r = lane - (started ? (int)(m & 63u) : -carry_r);  // the item's row within its entry
@@ -302,11 +272,11 @@ __device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, con
     if (SHORT) {
       const int4 ea = ent[t * 2], eb = ent[t * 2 + 1];
       const uint2 s89 = reinterpret_cast<const uint2 *>(ent)[256 + t];
-      raster_item<TWL, TH, PAD, false>(keys, entry_view(make_uint2(ea.x, ea.y), make_uint2(ea.z, ea.w), make_uint2(eb.x, eb.y),
-                                                        make_uint2(eb.z, eb.w), s89), r, live);
+      raster_item<TWL, TH, PAD>(keys, entry_view(make_uint2(ea.x, ea.y), make_uint2(ea.z, ea.w), make_uint2(eb.x, eb.y),
+                                                 make_uint2(eb.z, eb.w), s89), r, live);
     } else {
       const int4 e0 = ent[t * 3], e1 = ent[t * 3 + 1], e2 = ent[t * 3 + 2];
-      raster_item<TWL, TH, PAD, true>(keys, entry_view(e0, e1, e2), r, live);
+      raster_item<TWL, TH, PAD>(keys, entry_view(e0, e1, e2), r, live);
     }
   }
   return (total + 63) >> 6;
@@ -522,7 +492,7 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   constexpr int NKEYS = (TW + PAD) * TH;
   constexpr int NW = NT / 64;
-  constexpr int NMAIL = NW * (SHORT ? 32 : 16);  // u64 units: 64 mailbox words per wave (32-bit; 16-bit beside 48-byte entries)
+  constexpr int NMAIL = NW * 16;  // u64 units: 64 16-bit mailbox words per wave
   int4 *ent_lds = reinterpret_cast<int4 *>(keys + NKEYS + NMAIL);
   v4i *ent_st = reinterpret_cast<v4i *>(ent_lds);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -559,19 +529,17 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
     GR_STAMP(8);
     return;
   }
-  const int tab_base = NKEYS * 8 + wv * (SHORT ? 256 : 128);  // byte offset of the wave's 64 mailbox words, behind the keys
-  const int tab_self = tab_base + lane * (SHORT ? 4 : 2);
-  {  // fill the tile (16-byte LDS stores): depth 0 | the id background stands for; mailboxes zero
+  const int tab_base = NKEYS * 8 + wv * 128;  // byte offset of the wave's 64 mailbox words, behind the keys
+  const int tab_self = tab_base + lane * 2;
+  {  // fill the tile (16-byte LDS stores): depth 0 | the id background stands for (the waves wipe their mailboxes themselves)
     const int bg = (FUSE && out.compat) ? (int)out.F - 1 : -1;
     const unsigned long long fill = (unsigned long long)(uint32_t)~bg;
     ulonglong2 *k2 = reinterpret_cast<ulonglong2 *>(keys);
 #pragma unroll
     for (int i = 0; i < (NKEYS / 2 + NT - 1) / NT; ++i)
       if (i * NT + tid < NKEYS / 2) k2[i * NT + tid] = make_ulonglong2(fill, fill);
-    if (SHORT)
-      for (int i = tid; i < NMAIL / 2; i += NT) k2[NKEYS / 2 + i] = make_ulonglong2(0ull, 0ull);
   }
-  uint32_t gen = SHORT ? 0u : 0xF000u;  // 16-bit mailboxes: the first batch finds the generation wrapped and wipes the mailbox
+  uint32_t gen = 0xF000u;  // the first batch finds the generation wrapped and wipes the wave's mailbox
   int rot = wv;  // this wave's first batch of the current chunk
   {  // first chunk: in registers already, complete (k_raster_tile waits for every request of the chain before its first
      // tile: a wait on the memory counter here would wait for the previous tile's stores)
@@ -646,8 +614,8 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
 //     tile k's chunk only when tile k starts would wait for tile k - 1's id stores: loads and stores share one in-order
 //     counter.)  KT = 1 -- heavy scenes, small launches --: the first chunk is requested before the count is known (the
 //     segment address is static; slots beyond the count hold stale data that nobody reads).
-// The ids-only kernel asks the compiler for 7 waves per SIMD -- what its LDS allows anyway: the schedule the compiler picks
-// under that hint is 3-4 % faster (15.8 -> 15.2 us per C2 view, builds alternated on one box with tools/ab_builds.sh); the
+// The 64 x 32 kernels ask the compiler for GR_WPE = 8 waves per SIMD -- what their LDS allows (round 3: 7; the schedule the
+// compiler picked under that hint was 3-4 % faster than without, 15.8 -> 15.2 us per C2 view, builds alternated on one box); the
 // fused kernel is not (left at the default).  Work items of two consecutive rows (look-up, unpack and the reciprocals paid
 // once per two rows: -16 % VALU instructions) were measured as well: 74 VGPRs and half as many batches per tile for four
 // waves -- 15.6 vs 16.0 without the hint, 16.3 vs 15.3 with it, fused 18.3 vs 17.2 -- dropped.
@@ -657,10 +625,8 @@ __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile(BinArgs a, Rast
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   constexpr int NKEYS = (TW + PAD) * TH;
   constexpr int NW = NT / 64;
-  constexpr int NMAIL = NW * (SHORT ? 32 : 16);
-  // the kernel's only LDS: keys (17.25 KiB for 64x32) + mailboxes (1 KiB) + one chunk of entries (3 KiB) -> 7 workgroups/CU
-  // (20 KiB -- 4 padding keys per row with the mailboxes inside the padding -- gives 8, and loses more to LDS bank
-  // conflicts than it gains: plain 16.6 vs 16.3 us per C2 view, fused 19.8 vs 17.9)
+  constexpr int NMAIL = NW * 16;
+  // the kernel's only LDS: keys + 0.5 KiB of mailboxes + one chunk of entries (2.5 or 3 KiB): 8 workgroups/CU for 64 x 32 (top)
   __shared__ __attribute__((aligned(16))) unsigned long long keys[NKEYS + NMAIL + 64 * (SHORT ? 5 : 6)];
   static_assert(NT == 256, "the entry copy deals 48 int4 to each of 4 waves");
   static_assert(NKEYS % 2 == 0 && TH % 32 == 0, "key pairs; two 16-row passes per fused group");
@@ -800,8 +766,8 @@ int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStr
     if (a.ent40) {                                                                                                    \
       if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD, true, PLAIN_>), grid, block, pad, s, a, out);  \
       else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD, true, PLAIN_>), grid, block, pad, s, a, out);        \
-    } else if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD, false, PLAIN_>), grid, block, pad, s, a, out);  \
-    else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD, false, PLAIN_>), grid, block, pad, s, a, out);        \
+    } else if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD48, false, PLAIN_>), grid, block, pad, s, a, out);  \
+    else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD48, false, PLAIN_>), grid, block, pad, s, a, out);        \
   } while (0)
     // the usual ids-only call: rows of whole 16-byte pieces, every view's plane 16-byte aligned, no depth image
     const bool plain = !out.winner && out.ids && !out.depth && (w & 3) == 0 && (reinterpret_cast<uintptr_t>(out.ids) & 15) == 0 &&

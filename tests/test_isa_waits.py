@@ -35,15 +35,15 @@ def device_asm(tmp_path_factory):
 def _kernel_body(lines, fused, short):
     # the kernels of the usual calls: fused aggregation, and the PLAIN ids kernel (last template flag)
     name = "_ZN12_GLOBAL__N_113k_raster_tileILi6ELi5ELi256ELb%dELi4ELi%dELb%dELb%dEEEvN6grimpl7BinArgsENS1_9RasterOutE:" % (
-        int(fused), _lds_pad(), int(short), int(not fused))
+        int(fused), _lds_pad(short), int(short), int(not fused))
     start = [i for i, l in enumerate(lines) if l.startswith(name)]
     assert len(start) == 1, f"kernel symbol not found: {name}"
     end = next(i for i in range(start[0], len(lines)) if lines[i].startswith(".Lfunc_end"))
     return lines[start[0]:end]
 
 
-def _lds_pad():
-    m = re.search(r"#define GR_LDS_PAD (\d+)", gbuild.SRC.read_text())
+def _lds_pad(short=True):
+    m = re.search(r"#define GR_LDS_PAD%s (\d+)" % ("" if short else "48"), gbuild.SRC.read_text())
     return int(m.group(1))
 
 
