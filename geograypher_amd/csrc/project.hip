@@ -126,7 +126,14 @@ __global__ __launch_bounds__(256) void k_vote_values(uint32_t *__restrict__ winn
                                                      double *__restrict__ sums, uint32_t *__restrict__ counts) {
   const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (f >= F) return;
+  // meshes.py:2060-2062 to the letter: summed = np.nansum([summed, projection], axis=0) drops a NaN of the RUNNING sum as
+  // well as one of the projection -- a sum that went NaN (+inf of one view met -inf of another) starts again from zero at the
+  // next view, whether that view shows the face or not.  (Found by tools/fuzz_stages.py; rounds 1-3 kept the NaN.)
+  double *const acc = sums + f * C;
+  for (int ch = 0; ch < C; ++ch)
+    if (isnan(acc[ch])) acc[ch] = 0.0;  // left by an earlier launch: this launch holds a next view
   uint32_t c = 0;
+  int last_seen = -1;
   for (int v0 = 0; v0 < n_views; v0 += 8) {  // eight views' winners are requested together, then consumed in view order
     uint32_t keyv[8];
 #pragma unroll
@@ -142,11 +149,18 @@ __global__ __launch_bounds__(256) void k_vote_values(uint32_t *__restrict__ winn
       for (int ch = 0; ch < C; ++ch) {
         const double x = row[ch];
         if (isfinite(x)) any_finite = true;
-        if (!isnan(x)) sums[f * C + ch] += x;  // nansum: NaN counts as 0 (meshes.py:2060-2062)
+        double a = acc[ch];
+        if (isnan(a)) a = 0.0;          // the running sum's NaN counts as 0 ...
+        if (!isnan(x)) a += x;          // ... like the projection's
+        acc[ch] = a;
       }
       if (any_finite) ++c;
+      last_seen = v;
     }
   }
+  if (last_seen >= 0 && last_seen < n_views - 1)  // a NaN made at the face's last view here is dropped by the view behind it
+    for (int ch = 0; ch < C; ++ch)
+      if (isnan(acc[ch])) acc[ch] = 0.0;
   if (c) counts[f] += c;
 }
 

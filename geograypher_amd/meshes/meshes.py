@@ -771,6 +771,10 @@ class TexturedPhotogrammetryMesh:
                 first = proj if first is None else first
             if img is not None:
                 self.backend.project_values(ids, img, sums, counts, neg1_is_last_face=self.neg1_is_last_face)
+            else:
+                # a skipped (null) image still passes through np.nansum([summed, all-NaN projection]) in the reference
+                # (meshes.py:2060-2062), which drops a NaN of the running sum (+inf met -inf) like every other view does
+                torch.nan_to_num_(sums, nan=0.0, posinf=float("inf"), neginf=float("-inf"))
         if shard:
             if sums is None:  # a rank without views still takes part in the collective
                 n_channels = int(np.asarray(cameras.get_image_by_index(view_inds[0], aggregate_img_scale)).reshape(

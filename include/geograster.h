@@ -172,7 +172,10 @@ int gr_project_labels_u8(gr_ctx *ctx, const int32_t *ids, const uint8_t *labels,
                          uint32_t *votes, uint32_t *counts, int flags, void *stream);
 
 /* same for continuous images (cameras.py:154-177 float images): img n_views x h x w x C f64 (NaN allowed).
- * sums[f*C+c] += value (NaN counts as 0, meshes.py:2060-2062); counts[f] += any(isfinite(row)) (2064-2067). */
+ * sums[f*C+c] = nz(sums[f*C+c]) + nz(value) view by view, nz(NaN) = 0 -- np.nansum([summed, projection], axis=0) of
+ * meshes.py:2060-2062 to the letter: a running sum that went NaN (+inf met -inf) counts as 0 at the next view of the call
+ * or of the next call on the same buffers, whether that view shows the face or not; counts[f] += any(isfinite(row))
+ * (2064-2067). */
 int gr_project_values_f64(gr_ctx *ctx, const int32_t *ids, const double *img, int n_views, int h, int w, int C,
                           double *sums, uint32_t *counts, int flags, void *stream);
 

@@ -121,7 +121,10 @@ class OracleBackend:
         for k in range(ids.shape[0]):
             proj = oracle_np.project_image(ids[k].astype(np.int64), img[k], self.n_faces,
                                            neg1_is_last_face=neg1_is_last_face)
-            sums += torch.from_numpy(np.where(np.isnan(proj), 0.0, proj))
+            # np.nansum([summed, projection], axis=0) (meshes.py:2060-2062): a NaN of the running sum is dropped like one of the projection
+            s_np = sums.numpy()
+            with np.errstate(invalid="ignore"):  # inf - inf
+                s_np[...] = np.where(np.isnan(s_np), 0.0, s_np) + np.where(np.isnan(proj), 0.0, proj)
             counts += torch.from_numpy(np.any(np.isfinite(proj), axis=1).astype(np.int32))
 
     def finalize_votes(self, votes, counts):

@@ -154,3 +154,37 @@ def test_sparse_path_counts_once_and_survives_compaction(kind, request):
         acc2.add(torch.zeros((h, w), dtype=torch.int32, device=be.device), np.full((h, w), float(nc + 3)))
         with pytest.raises(IndexError):
             acc2.finish()
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+@pytest.mark.parametrize("null_last", [False, True])
+def test_float_path_drops_a_running_nan_like_the_reference(kind, request, null_last):
+    """meshes.py:2060-2062, `np.nansum([summed, projection], axis=0)` view by view: a running sum that went NaN (+inf of one view
+    met -inf of the next) counts as 0 at the view after -- also when that view is a null image that check_null_image skips."""
+    points, faces, cams, h, w = _scene(4)
+    rng = np.random.default_rng(11)
+    imgs = [np.full((h, w, 2), np.inf), np.full((h, w, 2), -np.inf), rng.normal(0, 1, (h, w, 2)), rng.normal(0, 1, (h, w, 2))]
+    imgs[1][::2, :, 1] = 4.0       # channel 1: inf - inf only on the odd rows
+    imgs[3][:, ::3] = np.inf       # the last view makes NaNs of its own (inf - inf never happens: view 2 is finite) ...
+    imgs[2][:, ::3, 0] = -np.inf   # ... except here: -inf from view 2, +inf from view 3 -> NaN that nothing drops
+    if null_last:
+        imgs[3] = np.full((h, w, 2), np.nan)
+    backend = _backend(kind, request)
+    mesh = TexturedPhotogrammetryMesh((points, faces), backend=backend, log_level="ERROR")
+    avg, info = mesh.aggregate_projected_images(_ImageSet(cams, imgs), aggregate_img_scale=0.25, check_null_image=True)
+    from geograypher_amd.cameras.cameras import vtk_like_near_planes
+
+    lo, hi = points.min(axis=0), points.max(axis=0)
+    nears = vtk_like_near_planes(np.stack([np.asarray(c.cam_to_world_transform, dtype=np.float64) for c in cams.cameras]),
+                                 np.array([lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]]))
+    recs = cams.get_raster_records(0.25, near=list(nears))
+    F = faces.shape[0]
+    projs = [oracle_np.project_image(oracle_c.raster(points, faces, recs[v], h, w).astype(np.int64), imgs[v], F, check_null_image=True)
+             for v in range(4)]
+    with np.errstate(invalid="ignore"):
+        want_avg, want = oracle_np.aggregate(projs, F)
+    seen = want["projection_counts"] > 0
+    assert np.isnan(want["summed_projections"][seen]).any() == (not null_last)  # a NaN survives only where the LAST view makes it
+    np.testing.assert_array_equal(info["projection_counts"], want["projection_counts"])
+    np.testing.assert_allclose(info["summed_projections"], want["summed_projections"], rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(avg, want_avg, rtol=1e-12, equal_nan=True)

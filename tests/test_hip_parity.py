@@ -305,6 +305,45 @@ def test_projection_kernels_against_reference_golden(hip, golden):
     _same(hip.argmax_nonzero(golden["argmax_in"]).cpu().numpy(), golden["argmax_out_flat"])
 
 
+@pytest.mark.parametrize("calls", [1, 3])
+def test_running_nan_of_the_float_sums_is_dropped_like_numpy_nansum(hip, calls):
+    """meshes.py:2060-2062: `summed = np.nansum([summed, projection], axis=0)` treats a NaN of the RUNNING sum as 0 too: a face
+    whose sum went NaN (+inf in one view, -inf in a later one) starts again from zero at the next view -- whether that view
+    shows the face or not, whether it arrives in the same call or the next; only a NaN made by the very last view survives.
+    (Found by tools/fuzz_stages.py.)"""
+    F, h, w, C = 7, 2, 6, 2
+    hip.upload_mesh(np.zeros((3, 3), dtype=np.float32), np.zeros((F, 3), dtype=np.int32))
+    inf = np.inf
+    ids = np.full((6, h, w), -1, dtype=np.int32)
+    img = np.zeros((6, h, w, C))
+    # pixel (0, k) of view v shows face k with value val[v][k]; None: the view does not show the face
+    val = [[inf, inf, inf, 1.0, inf, np.nan],
+           [-inf, -inf, 2.0, -inf, None, 3.0],
+           [5.0, None, -inf, inf, None, None],
+           [None, None, None, None, -inf, None],
+           [None, None, 7.0, None, None, inf],
+           [None, None, None, None, None, -inf]]
+    for v, row in enumerate(val):
+        for k, x in enumerate(row):
+            if x is not None:
+                ids[v, 0, k] = k
+                img[v, 0, k] = (x, 1.0 if x == x else np.nan)
+    projs = [oracle_np.project_image(ids[v].astype(np.int64), img[v], F, neg1_is_last_face=False) for v in range(6)]
+    want_avg, want = oracle_np.aggregate(projs, F)
+    # what the reference makes of it: 5 | 0 (dropped by an unseen view) | 7 | inf | NaN... checked, not assumed:
+    assert want["summed_projections"][0, 0] == 5.0 and want["summed_projections"][1, 0] == 0.0
+    assert np.isnan(want["summed_projections"][5, 0]) and np.isnan(want["summed_projections"][6, 0])
+    sums = torch.zeros((F, C), dtype=torch.float64, device="cuda")
+    cnt = torch.zeros((F,), dtype=torch.int32, device="cuda")
+    step = 6 // calls
+    for v0 in range(0, 6, step):
+        hip.project_values(ids[v0:v0 + step], img[v0:v0 + step], sums, cnt, neg1_is_last_face=False)
+    avg, summed, counts = (t.cpu().numpy() for t in hip.finalize_sums(sums, cnt))
+    _same(summed, want["summed_projections"])
+    _same(avg, want_avg)
+    _same(counts, want["projection_counts"])
+
+
 @pytest.mark.parametrize("compat", [True, False])
 def test_label_votes_bit_exact_vs_oracle(hip, compat):
     (points, faces), cams = synthetic.config1_scene()
