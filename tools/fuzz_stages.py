@@ -10,6 +10,7 @@ Per seed: F faces, N views of h x w ids (piecewise-constant patches + noise, -1 
   argmax_nonzero      (utils/indexing.py:9-32)                                                       exact
   project_index_pairs (derived_meshes.py:470-520: sparse (face, class) pairs)                       exact
   resize_image        (cameras.py:154-174: /255 + scikit-image resize; uint8 / float32 / float64)    1e-12 absolute
+  warp_image          (utils/image.py:72-126: nearest / bilinear through a coordinate map)           exact / 1e-12
 on images with NaN / inf / negative zeros / out-of-range values where the reference's code admits them."""
 import json
 import sys
@@ -22,7 +23,7 @@ import torch
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 from geograypher_amd._hip import HipRaster
-from oracle import oracle_np, oracle_resize
+from oracle import oracle_np, oracle_resize, oracle_warp
 
 
 DEV = "cuda"
@@ -146,6 +147,34 @@ def one(hip, seed):
     tol = 1e-12 * max(1.0, float(np.abs(want).max()))
     if not err <= tol:
         bad.append(f"resize_image {dt} {shape} -> {(ho, wo)}: max |diff| {err:.3e}")
+    # warp (utils/image.py:72-126 without the float round trip): coordinate maps with ties at k + 0.5, positions on and beyond
+    # the border (scipy's "grid-constant": the fill value is interpolated in within one pixel outside), both orders
+    hs, ws = int(rng.integers(1, 60)), int(rng.integers(1, 80))
+    Hm, Wm = int(rng.integers(1, 70)), int(rng.integers(1, 90))
+    rr, cc = np.meshgrid(np.linspace(-2, hs + 1, Hm), np.linspace(-2, ws + 1, Wm), indexing="ij")
+    m = np.stack([rr + rng.normal(0, 1, rr.shape) * rng.choice([0.0, 0.3, 3.0]), cc + rng.normal(0, 1, cc.shape) * rng.choice([0.0, 0.3, 3.0])])
+    snap = rng.random(m.shape) < 0.3
+    m = np.where(snap, np.round(m * 2) / 2, m)  # integers and exact halves
+    wdt = rng.choice(["int32", "int64", "uint8", "float64", "float32"])
+    wshape = (hs, ws) if rng.random() < 0.6 else (hs, ws, int(rng.integers(1, 4)))
+    wimg = rng.integers(-5 if "int" in wdt and wdt != "uint8" else 0, 200, wshape).astype(wdt) if "float" not in wdt else rng.normal(0, 10, wshape).astype(wdt)
+    order = int(rng.integers(0, 2))
+    fill = float(rng.choice([0, -1, 7])) if wdt != "uint8" else float(rng.choice([0, 7]))
+    mt = hip.upload_map(m)
+    gotw = hip.warp_image(wimg, mt, order=order, fill_value=fill)
+    wantw = oracle_warp.warp_exact(wimg, m, order, fill)
+    gotw = np.asarray(gotw)
+    if gotw.shape != wantw.shape or gotw.dtype != wantw.dtype:
+        bad.append(f"warp_image {wdt} order {order}: shape/dtype {gotw.shape} {gotw.dtype} vs {wantw.shape} {wantw.dtype}")
+    elif order == 0 or "int" in wdt:
+        # (an order-1 result is truncated to the integer type: a value within rounding of an integer may fall either way)
+        diff = gotw.astype(np.float64) != wantw.astype(np.float64)
+        if order == 1:
+            diff = np.abs(gotw.astype(np.float64) - wantw.astype(np.float64)) > 1
+        if diff.any():
+            bad.append(f"warp_image {wdt} {wshape} order {order} fill {fill}: {int(diff.sum())} values differ")
+    elif not np.allclose(gotw, wantw, rtol=0, atol=1e-12 * max(1.0, float(np.abs(wantw).max())) if wdt == "float64" else 1e-5):
+        bad.append(f"warp_image {wdt} {wshape} order 1: max |diff| {float(np.abs(gotw.astype(np.float64) - wantw).max()):.3e}")
     return {"seed": seed, "F": F, "views": n, "image": f"{w}x{h}", "C": C, "resize": f"{dt} {wi}x{hi}->{wo}x{ho}"}, bad
 
 
