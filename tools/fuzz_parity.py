@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/fuzz_parity.py <seconds> [first_seed] -- randomised differential campaign: the HIP path against the C oracle (oracle/)
+"""tools/fuzz_parity.py <seconds> [first_seed] [big] -- randomised differential campaign: the HIP path against the C oracle (oracle/)
 on scenes the test-suite's fixed seeds do not reach.  GPU box only; a checker like the tests (the product never calls the oracle).
 
 Every iteration draws, from its seed: a scene (triangle soup of log-uniform sizes, an axis-aligned lattice with exact ties, a
@@ -8,7 +8,9 @@ jittered height field, or a mix; optional zero-area / coincident / behind-the-ca
 ~700 x 500 (odd widths included), a near plane, and a setting of the tuning knobs (tile height, slots per tile incl. exact
 binning and tiny segments that overflow, GR_OPT_VARIANT bits, views per launch group).  Checked bit for bit: face ids, depth
 bits, and -- when the scene has at least one face -- label votes and counts of the fused aggregation (both background
-conventions).  Prints one line per failure with the seed (re-run: `fuzz_parity.py 1 <seed>`), and a JSON summary."""
+conventions).  `big`: images of 500-2000 pixels a side and scenes of up to 300 000 faces (launches large enough for the chained
+kernels to be chosen by themselves).  Prints one line per failure with the seed (re-run: `fuzz_parity.py 1 <seed>`), and a JSON
+summary."""
 import json
 import sys
 import time
@@ -26,6 +28,9 @@ from oracle import oracle_c
 VARIANT_BITS = [1, 4, 8, 16, 32, 64, 128, 512]
 
 
+BIG = False
+
+
 def scene(rng):
     kind = rng.integers(0, 4)
     parts_p, parts_f, off = [], [], 0
@@ -37,7 +42,7 @@ def scene(rng):
         off += points.shape[0]
 
     if kind in (0, 3):  # soup
-        n = int(np.exp(rng.uniform(np.log(20), np.log(20000))))
+        n = int(np.exp(rng.uniform(np.log(20), np.log(150000 if BIG else 20000))))
         spread = rng.uniform(2, 30)
         centers = rng.uniform(-spread, spread, (n, 1, 3)) * np.array([1, 1, rng.uniform(0.02, 0.5)])
         size = np.exp(rng.uniform(np.log(0.005), np.log(rng.choice([0.3, 5.0, 60.0])), (n, 1, 1)))
@@ -48,12 +53,12 @@ def scene(rng):
             tri[k:2 * k] = tri[2 * k:3 * k]              # coincident faces: the lower id wins
         add(tri.reshape(-1, 3), np.arange(3 * n).reshape(n, 3))
     if kind in (1, 3):  # axis-aligned lattice: exact ties, a == 0 / b == 0 edges
-        g = int(rng.integers(3, 120))
+        g = int(rng.integers(3, 380 if BIG else 120))
         ext = rng.uniform(1, 20)
         xs, ys = np.meshgrid(np.linspace(-ext, ext, g + 1), np.linspace(-ext, ext, g + 1))
         add(np.stack([xs.ravel(), ys.ravel(), np.full(xs.size, rng.uniform(-0.5, 0.5))], axis=1), synthetic.grid_faces(g + 1, g + 1))
     if kind == 2:  # jittered height field
-        g = int(rng.integers(8, 200))
+        g = int(rng.integers(8, 390 if BIG else 200))
         ext = rng.uniform(5, 60)
         xs, ys = np.meshgrid(np.linspace(-ext, ext, g), np.linspace(-ext, ext, g))
         cell = 2 * ext / (g - 1)
@@ -97,7 +102,9 @@ def cameras(rng, points, w, h):
 def one(hip, seed):
     rng = np.random.default_rng(seed)
     points, faces = scene(rng)
-    if rng.random() < 0.15:
+    if BIG:
+        h, w = int(rng.integers(500, 1500)), int(rng.integers(500, 2000))
+    elif rng.random() < 0.15:
         h, w = [(1, 1), (2, 3), (3, 70), (65, 33), (64, 64), (33, 257)][int(rng.integers(0, 6))]
     else:
         h, w = int(rng.integers(8, 500)), int(rng.integers(8, 700))
@@ -144,8 +151,10 @@ def one(hip, seed):
 
 
 def main():
+    global BIG
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
+    BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
     hip = HipRaster(0)
     t0 = time.time()
     n = views = pixels = faces = 0
