@@ -27,13 +27,14 @@ def _imread(filename) -> np.ndarray:
         return np.array(im)  # a writable copy (PIL hands out a read-only view)
 
 
-def vtk_like_near_plane(cam_to_world: np.ndarray, bounds: np.ndarray, tolerance: float = 0.001) -> float:
-    """Near clipping distance the reference's renderer would pick for this camera and mesh bounds.
+def vtk_like_clipping_range(cam_to_world: np.ndarray, bounds: np.ndarray, tolerance: float = 0.001):
+    """(near, far) clipping distances the reference's renderer would pick for this camera and mesh bounds.
 
     The pyvista path never sets a clipping range (cameras.py:446-477), so VTK derives one from the actor bounds
     (`vtkRenderer::ResetCameraClippingRange`): the range of the 8 bounding-box corners along the view direction,
     widened by 1 % plus half its extent, with the near plane kept at >= `tolerance` x far (0.001 for depth buffers
-    deeper than 16 bit).  Restated from the published VTK algorithm; VTK is not runnable here (parity unpinned).
+    deeper than 16 bit).  Restated from the published VTK algorithm; VTK is not runnable here (parity unpinned).  The far
+    plane lies beyond every corner of the bounds by construction, so only the near plane can ever cut the mesh.
     bounds: (xmin, xmax, ymin, ymax, zmin, zmax) in the cameras' local frame.
     """
     forward = cam_to_world[:3, 2]
@@ -49,7 +50,12 @@ def vtk_like_near_plane(cam_to_world: np.ndarray, bounds: np.ndarray, tolerance:
         near = 0.01 * far
     if near < tolerance * far:
         near = tolerance * far
-    return float(near)
+    return float(near), float(far)
+
+
+def vtk_like_near_plane(cam_to_world: np.ndarray, bounds: np.ndarray, tolerance: float = 0.001) -> float:
+    """The near distance of `vtk_like_clipping_range` (the only one of the two planes that can cut the mesh)."""
+    return vtk_like_clipping_range(cam_to_world, bounds, tolerance)[0]
 
 
 def vtk_like_near_planes(cam_to_worlds: np.ndarray, bounds: np.ndarray, tolerance: float = 0.001) -> np.ndarray:

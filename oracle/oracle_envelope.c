@@ -1,12 +1,17 @@
 /*
  * oracle/oracle_envelope.c -- TEST INFRASTRUCTURE ONLY (CPU oracle, never shipped, never on the product path).
  *
- * What can be said about exact per-pixel face ids WITHOUT the reference's VTK/OpenGL stack
- * (geograypher/meshes/meshes.py:1776-1836 renders through vtk==9.2.6; neither VTK nor a GL driver exists in this image).
+ * What can be said about exact per-pixel face ids WITHOUT the reference's VTK stack
+ * (geograypher/meshes/meshes.py:1776-1836 renders through vtk==9.2.6, which is not in this image.  Two GL implementations
+ * are -- Mesa llvmpipe, GL_SUBPIXEL_BITS = 8, and SwiftShader, GL_SUBPIXEL_BITS = 4 -- and tests/test_gl_pin.py holds this
+ * file's classification against renders of both: 0 disagreements on the pixels it calls implementation-independent when
+ * `delta` is set for the implementation's own grid, 2^-bits + 2e-3.  With the 8-bit default, SwiftShader's 4-bit grid
+ * disagrees on thousands of "independent" pixels: the default claims nothing about implementations coarser than 8 bits.)
  * OpenGL 4.6 (14.6.1, 13.7) fixes what a rasterizer must do only up to three implementation choices: how window
- * coordinates are snapped to the sub-pixel grid, which of two triangles owns a sample that lies exactly on their shared
- * edge, and the precision of the depth comparison.  Every conforming implementation -- VTK on any driver, the HIP kernels
- * of this repository, oracle_raster.c -- must therefore produce the SAME face id at a pixel whenever none of the three
+ * coordinates are snapped to the sub-pixel grid (and how fine that grid is: at least 4 bits), which of two triangles owns
+ * a sample that lies exactly on their shared edge, and the precision of the depth comparison.  Every conforming
+ * implementation WITH AT LEAST THE SUB-PIXEL RESOLUTION `delta` STANDS FOR -- VTK on such a driver, the HIP kernels of
+ * this repository, oracle_raster.c -- must therefore produce the SAME face id at a pixel whenever none of the three
  * choices can matter there.  This file provides
  *
  *   orc_envelope      the classification: a pixel is IMPLEMENTATION-INDEPENDENT when, evaluated in float64 without any

@@ -8,15 +8,22 @@
  *
  * The arithmetic of that stage lives in a third-party dependency that is absent from /root/reference and
  * from this image: vtk==9.2.6 driven through pyvista==0.42.2 (poetry.lock:3361-3362, 2342-2343), i.e. an
- * OpenGL polygon rasterizer.  What is restated here is the *published* algorithm of that stage (OpenGL 4.6
+ * OpenGL polygon rasterizer (whichever GL implementation the host provides; Mesa's in the reference's Dockerfile).  What is restated here is the *published* algorithm of that stage (OpenGL 4.6
  * core spec 14.6.1 "Basic Polygon Rasterization": point sampling at pixel centres, a consistent
  * shared-edge fill rule, nearest-depth-wins with window-space-linear depth) as the fixed rule-set R0-R7 of
  * DESIGN.md.  The HIP kernels implement the same rule-set independently; tests require bit equality.
  *
- * PARITY STATUS: pinned to the reference's own known-answer tests for this stage
- * (tests/test_derived_meshes.py:23-76 pixel colours; tests/test_derived_cameras.py:339-415 shape/dtype/range
- * properties), restated in tests/test_reference_kats.py.  Exact per-pixel face ids versus a real VTK/OpenGL
- * stack are PARITY UNPINNED: the reference holds no golden pix2face array and VTK cannot run here.
+ * PARITY STATUS: pinned twice.
+ *  (1) To the reference's own known-answer tests for this stage (tests/test_derived_meshes.py:23-76 pixel colours;
+ *      tests/test_derived_cameras.py:339-415 shape/dtype/range properties), restated in tests/test_reference_kats.py.
+ *  (2) To two REAL third-party OpenGL rasterizers found in the build image -- Mesa 23.2.1 llvmpipe (8 sub-pixel bits; the
+ *      software GL family the reference's Dockerfile:6-13 installs) and Google SwiftShader 4.1 (ES 3.0, 4 sub-pixel bits) --
+ *      which rendered the id image the way meshes.py:1776-1836 does (tests/golden/make_golden_gl.py -> reference_gl_*.npz;
+ *      tests/test_gl_pin.py): identical on EVERY pixel that oracle_envelope.c calls implementation-independent at
+ *      delta = 2^-bits + 2e-3 px, identical on 99.996-99.998 % of ALL pixels of full-size C2 / C5 views against llvmpipe
+ *      (profiles/r05_gl_pin.log), every differing pixel an edge pixel.
+ *  What stays unpinned is VTK ITSELF (its shaders and matrices on top of the GL implementation): vtk==9.2.6 is not in the
+ *  image and the reference holds no golden pix2face array.
  *
  * Two entry points compute the same function:
  *   orc_raster_spec  -- literal rule-set, every pixel of the bounding box evaluated from the closed forms.

@@ -2,8 +2,9 @@
 """tools/compare_with_reference.py [--scale S] -- per-pixel agreement of this library's pix2face with the REAL reference
 (geograypher + pyvista/VTK) on the C1 scene (9 800 faces, 8 views 640 x 480).
 
-The reference's rasterizer is VTK/OpenGL, which cannot run in the image this repository is built in (no pyvista, no GL):
-exact per-pixel parity with a VTK stack is the one thing DESIGN.md marks "unpinned".  This script is the harness that pins
+The reference's rasterizer is VTK on top of the host's OpenGL.  VTK / pyvista are not in the image this repository is built
+in; two GL implementations are (Mesa llvmpipe and SwiftShader) and tests/test_gl_pin.py pins the oracle and the HIP kernels to
+renders of both (tests/golden/make_golden_gl.py).  Parity with VTK ITSELF is the one thing DESIGN.md still marks "unpinned".  This script is the harness that pins
 it on a machine that has both: `pip install geograypher` (or a checkout on PYTHONPATH) next to this repository and an
 MI355X (or any gfx9 GPU the library was built for).  It prints, per view, the fraction of pixels with identical ids,
 the fraction whose two ids are faces sharing an edge or vertex (a one-pixel disagreement along a shared edge: sub-pixel
