@@ -148,6 +148,21 @@ __global__ __launch_bounds__(256) void k_cull_blocks(const float *__restrict__ c
   }
 }
 
+struct FaceForm {
+  int Xf, Yf, dxf, dyf, tf, rf;   // FIRST edge (a = -dy > 0: it bounds a span from the left): origin vertex, direction,
+  int Xm, Ym, dxm, dym, tm, rm;   //   top-left bias (0 / -1), reach = (TW/2)|a| + (TH/2)|b|;  MIDDLE edge;
+  int Xl, Yl, dxl, dyl, tl, rl;   //   LAST edge (a < 0: from the right)
+  int X0, Y0;                     // vertex 0: the anchor of the 1/z plane, whatever the edge order
+  int w3, w4, w5;                 // slope words (16- or 24-bit packing)
+  int ywf;                        // flag bits of the Yw word: bit 31 = 24-bit slopes, bit 30 = the span solver must correct its floor
+  bool fast;                      // snapped bounding box below GR_FAST_EXT: 24-bit products, int32 everywhere
+  int jmin, jmax, imin, imax;     // pixel bounding box (R2), clamped to the image
+  int iz0, A, B, nface;           // 1/z at vertex 0 and its gradients (float bits), ~face
+};
+
+__device__ __forceinline__ FaceForm face_form(const int4 p0, const int4 p1, const int4 p2, int TW, int TH);
+__device__ __forceinline__ bool tile_entry(const FaceForm &ff, int px0, int py0, int TW, int TH, int4 &e0, int4 &e1, int4 &e2,
+                                           int &rows);
 __device__ __forceinline__ bool compile_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
                                               uint8_t *__restrict__ nr8, int64_t idx, const int4 p0, const int4 p1,
                                               const int4 p2, int px0, int py0, int TW, int TH);
@@ -161,14 +176,8 @@ __device__ __forceinline__ void store_entry(const BinArgs &a, uint32_t *__restri
 // range of tiles its pixel bounding box touches.  Returns false for faces that draw nothing in this view; clip_me: the face
 // straddles the near plane or the guard band (R7).  Used by K1 and, for faces over more than 2 x 2 tiles, by k_bin_big:
 // same code, same bits.
-__device__ __forceinline__ bool face_setup(const BinArgs &a, const float *__restrict__ cam, int64_t f, int4 &r0, int4 &r1,
-                                           int4 &r2, int &tx0, int &tx1, int &ty0, int &ty1, bool &clip_me) {
-  // the face's three vertices sit side by side in the soup: one coalesced 36-byte read per lane instead of an index
-  // load followed by three dependent 12-byte gathers (one dependent memory round trip less per wave)
-  const float *sp = a.soup + 9 * f;
-  Vtx v0 = project_vertex(sp, cam);
-  Vtx v1 = project_vertex(sp + 3, cam);
-  Vtx v2 = project_vertex(sp + 6, cam);
+__device__ __forceinline__ bool face_setup_tail(const BinArgs &a, int face_id, Vtx v0, Vtx v1, Vtx v2, int4 &r0, int4 &r1,
+                                                int4 &r2, int &tx0, int &tx1, int &ty0, int &ty1, bool &clip_me) {
   clip_me = !(v0.valid && v1.valid && v2.valid) && (v0.front || v1.front || v2.front) && v0.finite && v1.finite && v2.finite;
   if (!(v0.valid && v1.valid && v2.valid)) return false;
   long long area2 = (long long)(v1.X - v0.X) * (long long)(v2.Y - v0.Y) - (long long)(v2.X - v0.X) * (long long)(v1.Y - v0.Y);
@@ -197,11 +206,33 @@ __device__ __forceinline__ bool face_setup(const BinArgs &a, const float *__rest
     B = (float)((n1 - n2) / a2);
   }
   r0 = make_int4(v0.X, v0.Y, v1.X, v1.Y);
-  r1 = make_int4(v2.X, v2.Y, __float_as_int(v0.iz), a.orig[f]);
+  r1 = make_int4(v2.X, v2.Y, __float_as_int(v0.iz), face_id);
   r2 = make_int4(__float_as_int(A), __float_as_int(B), jmin | (jmax << 16), imin | (imax << 16));
   tx0 = jmin >> a.twl; tx1 = jmax >> a.twl;
   ty0 = imin >> a.thl; ty1 = imax >> a.thl;
   return true;
+}
+
+__device__ __forceinline__ bool face_setup(const BinArgs &a, const float *__restrict__ cam, int64_t f, int4 &r0, int4 &r1,
+                                           int4 &r2, int &tx0, int &tx1, int &ty0, int &ty1, bool &clip_me) {
+  // the face's three vertices sit side by side in the soup: one coalesced 36-byte read per lane (k_bin_big: rare faces; K1
+  // takes the block's DISTINCT vertices instead, each transformed once -- same function, same bits)
+  const float *sp = a.soup + 9 * f;
+  const Vtx v0 = project_vertex(sp, cam);
+  const Vtx v1 = project_vertex(sp + 3, cam);
+  const Vtx v2 = project_vertex(sp + 6, cam);
+  return face_setup_tail(a, a.orig[f], v0, v1, v2, r0, r1, r2, tx0, tx1, ty0, ty1, clip_me);
+}
+
+// a transformed vertex as the waves of K1 keep it in LDS: {X, Y, 1/z, valid | front << 1 | finite << 2}
+__device__ __forceinline__ int4 pack_vtx(const Vtx &v) {
+  return make_int4(v.X, v.Y, __float_as_int(v.iz), (v.valid ? 1 : 0) | (v.front ? 2 : 0) | (v.finite ? 4 : 0));
+}
+__device__ __forceinline__ Vtx unpack_vtx(const int4 q) {
+  Vtx v;
+  v.X = q.x; v.Y = q.y; v.iz = __int_as_float(q.z);
+  v.valid = (q.w & 1) != 0; v.front = (q.w & 2) != 0; v.finite = (q.w & 4) != 0;
+  return v;
 }
 
 // Single-pass binning of the wave's faces that reach over more than 2 x 2 tiles (`big`: this lane holds one, records r0 .. r2,
@@ -255,30 +286,146 @@ __device__ __forceinline__ void bin_big_pairs(const BinArgs &a, uint32_t *__rest
   }
 }
 
+// Diagnostic build only (-DGR_STAMPS, tools/setup_phases.py): where a wave of K1 spends its life.  A stamp first waits for the
+// wave's outstanding memory operations (vmcnt / lgkmcnt 0), so that a latency is charged to the phase that waited for it.
+//   0 the block's loads (vertex list, positions)   1 transform + LDS exchange + face set-up (incl. the face-id load)
+//   2 clip list + tile groups   3 counter atomics (issue + return)   4 entries of small faces   5 big faces, exact-path records
+#ifdef GR_STAMPS
+#define GR_SSTAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                          sacc[k] += t_ - st_; st_ = t_; } while (0)
+#else
+#define GR_SSTAMP(k) do { } while (0)
+#endif
+
 // DIRECT = true: single-pass binning.  Every tile owns a fixed segment of a.cap_tile entries; the list position
 // returned by the (wave-aggregated) tile counter is final, so the compiled entry is written straight from here and
 // the record planes, k_scan_tiles and k_fill_compile are skipped.  A tile that receives more than cap_tile entries
 // raises the view's overflow word; the caller then repeats the call with the exact two-pass path (DIRECT = false).
 template <bool DIRECT>
-__global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ cams, BinArgs a) {
+__global__ __launch_bounds__(256)
+#if GR_EXP & 16  // boundness probe: at most 3 waves per SIMD
+__attribute__((amdgpu_waves_per_eu(1, 3)))
+#elif GR_EXP & 256  // A/B build: six waves per SIMD (80 VGPRs, 44 bytes of scratch)
+__attribute__((amdgpu_waves_per_eu(6, 6)))
+#else
+__attribute__((amdgpu_waves_per_eu(5, 5)))  // at most 96 VGPRs: five waves per SIMD (three: +14.5 %, the kernel lives on latency hiding)
+#endif
+void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
+  const int lane = threadIdx.x & 63;
+  uint32_t n_rec = 0;                    // single-pass binning: the wave's record count (a statistic), added when the wave leaves a view
+#ifdef GR_STAMPS
+  unsigned long long sacc[6] = {0, 0, 0, 0, 0, 0}, st_ = __builtin_amdgcn_s_memtime(), siter = 0;
+  const unsigned long long st0_ = st_, sr0_ = __builtin_amdgcn_s_memrealtime();
+#endif
+  __shared__ int4 vt_s[4][GR_BLOCK_VERTS];  // the block's transformed vertices, one set of rows per wave (12 KiB per workgroup)
+  int4 *const vt = vt_s[threadIdx.x >> 6];
+#if !(GR_EXP & 32)  // the grid of rounds 1-4 -- (workgroups, views), every wave strides over ITS view's list (A/B bit 32: the joint list below)
   const int slot = blockIdx.y;
   const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
   uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
   const uint32_t *work = a.work + (int64_t)slot * a.work_stride;
   // every wave takes its own 64-face block from the view's work list (wave-uniform control flow, no workgroup barrier)
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), wstep = gridDim.x * 4;
-  uint32_t blk_next = work[wave0];       // read alongside the count (any slot of the list is valid memory)
+  const uint32_t wave0 = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wstep = gridDim.x * 4;
   const uint32_t n_work = ctrl[3];       // (a) blocks that passed k_cull_blocks for this view
-  uint32_t n_rec = 0;                    // single-pass binning: the wave's record count (a statistic), added once at the end
+  if (wave0 >= n_work) return;
+  // (block indices through readfirstlane: loaded with a uniform address, but into a vector register -- every address derived
+  // from them would be 64-bit VALU arithmetic instead of a scalar base.  The same for the wave's index above: the compiler
+  // cannot see that threadIdx.x >> 6 is wave-uniform, and the loop's control flow and the work-list loads were vector code:
+  // round 5, set-up stage 5.14 -> 4.78 us per C2 view together with the face-id load moved up beside the other two.)
+  // (readfirstlane where the index is USED: applied to the load itself it would make the wave wait for the next block's index
+  // at the top of every iteration instead of leaving the load in flight for the whole of it: +5 %)
+  uint32_t blk_next = work[wave0];
   for (uint32_t wi = wave0; wi < n_work; wi += wstep) {
-  const int64_t f = (int64_t)blk_next * GR_BLOCK + lane;
+  const uint32_t blk_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk_next);
+  const int64_t f = (int64_t)blk_cur * GR_BLOCK + lane;
   if (wi + wstep < n_work) blk_next = work[wi + wstep];
+#else
+  // (a) ONE work list for the launch group: the views' lists of surviving blocks (k_cull_blocks) laid end to end.  A survey
+  //     view over the edge of the mesh keeps half as many blocks as one over its middle; with a (workgroups, views) grid the
+  //     waves of the heavy views ran twice as long and the launch ended in a tail (13-16 of 20 possible waves resident per CU
+  //     on average, tools/setup_phases.py).  Now the grid is ONE generation of workgroups (what the chip holds, bin_batch) and
+  //     every wave takes the same number of consecutive items of the joint list, +-1: lane v holds the count of view v, a
+  //     wave prefix sum gives the views' ranges, a wave crosses a view boundary at most a few times in its life (the camera
+  //     and the view's pointers are reloaded there).
+  // (the wave's index through readfirstlane: the compiler cannot see that threadIdx.x >> 6 is wave-uniform, and everything below
+  // -- the item range, the view, the camera pointer -- would be treated as divergent: vector loads of the camera, masked branches)
+  const uint32_t wave_id = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), n_waves = gridDim.x * 4;
+  const uint32_t vcnt = lane < nb ? a.ctrl[(int64_t)lane * a.ctrl_stride + 3] : 0u;
+  const uint32_t vincl = (uint32_t)wave_incl_scan((int)vcnt);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)vincl, 63);
+#if GR_EXP & 64  // A/B build: items dealt round-robin (the waves in flight share a window of the joint list, like the old grid)
+  const uint32_t g0 = wave_id, g1 = total, gstep = n_waves;
+#else
+  const uint32_t per = (total + n_waves - 1) / n_waves;
+  const uint32_t g0 = wave_id * per, g1 = min(g0 + per, total), gstep = 1;
+#endif
+  if (g0 >= g1) return;                  // wave-uniform; the kernel has no workgroup barrier
+  int slot = 0;
+  uint32_t v_beg = 0, v_end = 0, blk_next = 0;
+  const float *cam = cams;
+  uint32_t *ctrl = a.ctrl;
+  const uint32_t *work = a.work;
+  for (uint32_t g = g0; g < g1; g += gstep) {
+  if (g >= v_end) {                      // the view item g lies in: the first whose inclusive prefix exceeds g
+    if (DIRECT && lane == 0 && n_rec) atomicAdd(&ctrl[0], n_rec);
+    n_rec = 0;
+    slot = __popcll(__ballot(vincl <= g));
+    v_end = (uint32_t)__builtin_amdgcn_readlane((int)vincl, slot);
+    v_beg = v_end - (uint32_t)__builtin_amdgcn_readlane((int)vcnt, slot);
+    cam = cams + (int64_t)slot * GR_CAM_FLOATS;
+    ctrl = a.ctrl + slot * a.ctrl_stride;
+    work = a.work + (int64_t)slot * a.work_stride;
+    blk_next = work[g - v_beg];
+  }
+  const uint32_t blk_cur = blk_next;
+  const int64_t f = (int64_t)blk_cur * GR_BLOCK + lane;
+  if (g + gstep < v_end) blk_next = work[g + gstep - v_beg];
+#endif
 
   bool keep = false, clip_me = false;
   int4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0};
   int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+#if GR_EXP & 8  // boundness probe: 100 dependent-free slow-class VALU instructions (410 SIMD cycles) per block, results unused
+  {
+    int d0 = lane, d1 = lane + 1, d2 = lane + 2, d3 = lane + 3;
+#pragma unroll
+    for (int i = 0; i < 25; ++i)
+      asm volatile("v_max_i32 %0, %0, %1\n\tv_max_i32 %1, %1, %2\n\tv_max_i32 %2, %2, %3\n\tv_max_i32 %3, %3, %0" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+  }
+#endif
+#ifdef GR_STAMPS
+  st_ = __builtin_amdgcn_s_memtime(); ++siter;
+#endif
+#if GR_EXP & 2  // A/B build: three transforms per face from the soup (rounds 1-4)
   if (f < a.F) keep = face_setup(a, cam, f, r0, r1, r2, tx0, tx1, ty0, ty1, clip_me);
+  (void)vt;
+#else
+  {
+    // (b) R1 once per DISTINCT vertex of the block (k_block_vertices: about 48 for the 192 corners of a manifold patch, one
+    //     round of the wave; a face soup takes three), results through the wave's own LDS rows -- LDS operations of one wave
+    //     complete in order, so the reads below need no barrier --, then every face picks its three by position
+    // everything the block needs from memory is requested here, together: the face's vertex-position word and id, this lane's
+    // vertex of the block's list (every slot of the list is valid memory).  (Requesting them one block AHEAD -- a software
+    // pipeline, 5 more live VGPRs: the fifth wave per SIMD or 12 bytes of scratch -- measured no better: 4.75 vs 4.78 us.)
+    const uint32_t bi = f < a.F ? a.bidx[f] : 0u;
+    const int face_id = f < a.F ? a.orig[f] : 0;
+    const float *bv0 = a.bvert + ((int64_t)blk_cur * GR_BLOCK_VERTS + lane) * 3;
+    const float vx = bv0[0], vy = bv0[1], vz = bv0[2];
+    const int nv = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)bi) >> 24) + 1;  // lane 0 of a listed block is a face
+    const float *bv = a.bvert + (int64_t)blk_cur * (3 * GR_BLOCK_VERTS);
+#ifdef GR_STAMPS
+    GR_SSTAMP(0);
+#endif
+    {
+      const float p0[3] = {vx, vy, vz};
+      if (lane < nv) vt[lane] = pack_vtx(project_vertex(p0, cam));
+    }
+    for (int i = lane + 64; i < nv; i += 64) vt[i] = pack_vtx(project_vertex(bv + 3 * i, cam));  // a face soup: two more rounds
+    const int4 q0 = vt[bi & 255u], q1 = vt[(bi >> 8) & 255u], q2 = vt[(bi >> 16) & 255u];
+    if (f < a.F) keep = face_setup_tail(a, face_id, unpack_vtx(q0), unpack_vtx(q1), unpack_vtx(q2), r0, r1, r2, tx0, tx1, ty0, ty1, clip_me);
+  }
+#endif
+  GR_SSTAMP(1);
   // R7: faces that straddle the near plane or the guard band go to the view's clip list (k_clip_faces)
   const unsigned long long mc = __ballot(clip_me);
   if (mc) {
@@ -309,6 +456,7 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ca
   if (__ballot(t01 >= 0)) wave_group(t01, lane, l1, k1, n1);
   if (__ballot(t10 >= 0)) wave_group(t10, lane, l2, k2, n2);
   if (__ballot(t11 >= 0)) wave_group(t11, lane, l3, k3, n3);
+  GR_SSTAMP(2);
   uint32_t base = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
   // record count: a list position for the exact path; a statistic otherwise, kept in a register until the wave is done (one
   // atomic per block on the view's one address made every wave of the view queue there: same-address atomics are served
@@ -325,16 +473,19 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ca
   r3.y = (int)(__shfl(b1, l1) + (uint32_t)k1);
   r3.z = (int)(__shfl(b2, l2) + (uint32_t)k2);
   r3.w = (int)(__shfl(b3, l3) + (uint32_t)k3);
+  GR_SSTAMP(3);
   if (DIRECT) {
     // faces over at most 2x2 tiles: positions came from the wave-aggregated counters; the lanes of a group hold
-    // consecutive positions of the same tile segment, so their 48-byte entries are written side by side.  Every such face has
-    // a FIRST tile: one dense round of entry compilation.  Second to fourth tiles are the exception (0.5 per face): instead of
-    // three more rounds in which most lanes wait (the set-up kernel of a forest scene is VALU-bound: SQ counters in
-    // profiles/), those (face, tile) pairs are dealt to the lanes -- prefix sum of the extra tiles per face, 6-step search for
-    // the owning lane, records pulled from its registers (ds_bpermute) -- and take one round together.
+    // consecutive positions of the same tile segment, so their entries are written side by side.  The tile-independent half
+    // of an entry (face_form) is computed once per face; every such face has a FIRST tile -- one dense round of tile_entry --,
+    // second to fourth tiles are the exception (0.5 per face) and take three more rounds in the face's OWN lane, most lanes
+    // idle but each round a quarter of a whole build_entry.  (Rounds 2-4 compacted those (face, tile) pairs instead -- prefix
+    // sum, 6-step search for the owning lane, 15 ds_bpermute to pull its records, all of build_entry again: 338 static VALU
+    // instructions for the one compacted round against 3 x ~70 here.)
     int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
     uint8_t *nr8 = a.nrow8 + slot * a.ent_cap;
     const int TW = 1 << a.twl, TH = 1 << a.thl;
+#if !(GR_EXP & 4)  // the compacted extra-tile round of rounds 2-4 (A/B bit 4: own-lane rounds from one FaceForm, measured +4 %)
     if (small_fp && !(GR_DBG(a) & 32)) {
       if ((uint32_t)r3.x < (uint32_t)a.cap_tile) {
         const int64_t idx = (int64_t)t00 * a.cap_tile + (uint32_t)r3.x;
@@ -369,7 +520,29 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ca
         } else atomicOr(&ctrl[2], 1u);
       }
     }
+#else
+    if (__ballot(small_fp) && !(GR_DBG(a) & 32)) {
+      const FaceForm ff = face_form(r0, r1, r2, TW, TH);
+      const int shape = small_fp ? ((tx1 > tx0 ? 1 : 0) | (ty1 > ty0 ? 2 : 0)) : 0;  // which neighbours exist: 1 right, 2 below
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool has = small_fp && (shape & k) == k;       // tile slot k: 0 first, 1 right, 2 below, 3 below right
+        if (k > 0 && (!__ballot(has) || (GR_DBG(a) & 64))) continue;
+        if (has) {
+          const uint32_t pos = (uint32_t)(k == 0 ? r3.x : k == 1 ? r3.y : k == 2 ? r3.z : r3.w);
+          const int tx = tx0 + (k & 1), ty = ty0 + (k >> 1);
+          if (pos < (uint32_t)a.cap_tile) {
+            int4 e0, e1, e2;
+            int rows;
+            tile_entry(ff, tx << a.twl, ty << a.thl, TW, TH, e0, e1, e2, rows);
+            store_entry(a, ctrl, comp, nr8, (int64_t)(ty * a.TX + tx) * a.cap_tile + pos, e0, e1, e2, rows);
+          } else atomicOr(&ctrl[2], 1u);
+        }
+      }
+    }
+#endif
   }
+  GR_SSTAMP(4);
   if (DIRECT) {
     // faces over more than 2 x 2 tiles: the wave expands their (face, tile) pairs right here, from the records it holds
     // (bin_big_pairs).  Variant bit 64: they go to the view's big list instead (the back of the clip buffer, ctrl[5] = count)
@@ -399,8 +572,19 @@ __global__ __launch_bounds__(256) void k_setup_cull(const float *__restrict__ ca
       for (int ty = ty0; ty <= ty1; ++ty)
         for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&cntB[ty * a.TX + tx], 1u);
   }
+  GR_SSTAMP(5);
   }  // work list loop
   if (DIRECT && lane == 0 && n_rec) atomicAdd(&ctrl[0], n_rec);
+#ifdef GR_STAMPS
+  if (lane == 0 && a.stamps) {  // the second half of the stamp buffer: 1024 slots of 16 words
+    unsigned long long *sd = a.stamps + 16 * 1024 + 16 * ((blockIdx.x * 4 + (threadIdx.x >> 6) + blockIdx.y * 977) & 1023);
+    for (int k = 0; k < 6; ++k) atomicAdd(&sd[k], sacc[k]);
+    atomicAdd(&sd[12], __builtin_amdgcn_s_memtime() - st0_);
+    atomicAdd(&sd[13], __builtin_amdgcn_s_memrealtime() - sr0_);
+    atomicAdd(&sd[14], siter);
+    atomicAdd(&sd[15], 1ull);
+  }
+#endif
 }
 
 // K2d  (single-pass binning) per view: totals of the per-tile counters for gr_raster_status.  grid (views), 1024 threads
@@ -514,20 +698,67 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(BinArgs a) {
 #define GR_FAST_EXT 24000
 #define GR_FLOOR_NOCORR_MAX 16000  // largest slope magnitude for which edge_floor<false> is exact (see there)
 __device__ __forceinline__ int pack16(int lo, int hi) { return (lo & 0xFFFF) | (hi << 16); }
-__device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const int4 p2, int px0, int py0, int TW, int TH,
-                                            int4 &e0, int4 &e1, int4 &e2, int &rows) {
+
+// build_entry in two halves.  face_form: everything about an entry that does not depend on the tile -- the three edges in the
+// order the tile kernel wants them (each with its origin vertex, direction, fill-rule bias and "reach"), the slope words, the
+// flag bits, the plane of 1/z -- computed ONCE per face; tile_entry: the part that does -- the three edge constants at the
+// tile's centre pixel, the rows of the entry, the anchors of the row / column words -- about a quarter of the whole.  K1
+// compiles the first and the second-to-fourth tiles of a small face in the face's own lane from one FaceForm (round 5;
+// rounds 2-4 dealt the extra (face, tile) pairs to lanes through 15 ds_bpermute per pair and ran all of build_entry again).
+__device__ __forceinline__ FaceForm face_form(const int4 p0, const int4 p1, const int4 p2, int TW, int TH) {
+  FaceForm ff;
   const int X0 = p0.x, Y0 = p0.y, X1 = p0.z, Y1 = p0.w, X2 = p1.x, Y2 = p1.y;
-  const int Pxo = px0 * 256 + 128, Pyo = py0 * 256 + 128;  // centre of the tile's first pixel
-  const int jlo = max((p2.z & 0xFFFF) - px0, 0), jhi = min((int)((uint32_t)p2.z >> 16) - px0, TW - 1);
-  const int ilo = max((p2.w & 0xFFFF) - py0, 0), ihi = min((int)((uint32_t)p2.w >> 16) - py0, TH - 1);
   const int dx0 = X1 - X0, dy0 = Y1 - Y0, dx1 = X2 - X1, dy1 = Y2 - Y1, dx2 = X0 - X2, dy2 = Y0 - Y2;
   const int t0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;  // R3 top-left rule as a bias
   const int t1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
   const int t2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
   const int ext = max(imax3(X0, X1, X2) - imin3(X0, X1, X2), imax3(Y0, Y1, Y2) - imin3(Y0, Y1, Y2));
+  ff.fast = ext < GR_FAST_EXT;
+  const int a0 = -dy0, a1 = -dy1, a2 = -dy2;
+  // The edges are stored in an order the tile kernel relies on: FIRST an edge with a > 0 (it bounds the span from the left),
+  // LAST one with a < 0 (from the right), the remaining one in between -- a triangle of non-zero area has both kinds (the a_k
+  // sum to zero; so do the b_k: the last edge's slopes are not stored).
+  const int kf = a0 > 0 ? 0 : (a1 > 0 ? 1 : 2);   // first: a > 0
+  const int kl = a0 < 0 ? 0 : (a1 < 0 ? 1 : 2);   // last: a < 0
+  const int km = 3 - kf - kl;
+  auto pick = [](int k, int v0, int v1, int v2) { return k == 0 ? v0 : (k == 1 ? v1 : v2); };
+  ff.Xf = pick(kf, X0, X1, X2); ff.Yf = pick(kf, Y0, Y1, Y2); ff.dxf = pick(kf, dx0, dx1, dx2); ff.dyf = pick(kf, dy0, dy1, dy2);
+  ff.Xm = pick(km, X0, X1, X2); ff.Ym = pick(km, Y0, Y1, Y2); ff.dxm = pick(km, dx0, dx1, dx2); ff.dym = pick(km, dy0, dy1, dy2);
+  ff.Xl = pick(kl, X0, X1, X2); ff.Yl = pick(kl, Y0, Y1, Y2); ff.dxl = pick(kl, dx0, dx1, dx2); ff.dyl = pick(kl, dy0, dy1, dy2);
+  ff.tf = pick(kf, t0, t1, t2); ff.tm = pick(km, t0, t1, t2); ff.tl = pick(kl, t0, t1, t2);
+  ff.rf = (TW / 2) * abs(ff.dyf) + (TH / 2) * abs(ff.dxf);
+  ff.rm = (TW / 2) * abs(ff.dym) + (TH / 2) * abs(ff.dxm);
+  ff.rl = (TW / 2) * abs(ff.dyl) + (TH / 2) * abs(ff.dxl);
+  const int af = -ff.dyf, am = -ff.dym, bf = ff.dxf, bm = ff.dxm;
+  // slopes: four values (the last edge's are -(first + middle)).  Two packings: 16 bits each when every slope of the face
+  // fits (faces below 128 pixels: nearly all of them), else 24 bits each, flagged in bit 31 of the Yw word
+  const bool narrow = max(max(abs(a0), abs(a1)), max(abs(a2), max(abs(dx0), max(abs(dx1), abs(dx2))))) <= 32767;
+  if (narrow) {
+    ff.w3 = pack16(af, am); ff.w4 = pack16(bf, bm);
+    ff.w5 = ff.fast ? 0 : 1;  // never read for 16-bit slopes; non-zero tells store_entry that the short form does not fit
+  } else {
+    ff.w3 = (af & 0xFFFFFF) | (am << 24);
+    ff.w4 = ((am >> 8) & 0xFFFF) | (bf << 16);
+    ff.w5 = ((bf >> 16) & 0xFF) | (bm << 8);
+  }
+  // bit 31: 24-bit slopes; bit 30: some slope magnitude beyond GR_FLOOR_NOCORR_MAX (the span solver must correct its floor)
+  const bool corr = !narrow || max(abs(a0), max(abs(a1), abs(a2))) > GR_FLOOR_NOCORR_MAX;
+  ff.ywf = (narrow ? 0 : (int)0x80000000) | (corr ? 0x40000000 : 0);
+  ff.X0 = X0; ff.Y0 = Y0;
+  ff.jmin = p2.z & 0xFFFF; ff.jmax = (int)((uint32_t)p2.z >> 16);
+  ff.imin = p2.w & 0xFFFF; ff.imax = (int)((uint32_t)p2.w >> 16);
+  ff.iz0 = p1.z; ff.A = p2.x; ff.B = p2.y; ff.nface = (int)~(uint32_t)p1.w;
+  return ff;
+}
+
+__device__ __forceinline__ bool tile_entry(const FaceForm &ff, int px0, int py0, int TW, int TH, int4 &e0, int4 &e1, int4 &e2,
+                                           int &rows) {
+  const int Pxo = px0 * 256 + 128, Pyo = py0 * 256 + 128;  // centre of the tile's first pixel
+  const int jlo = max(ff.jmin - px0, 0), jhi = min(ff.jmax - px0, TW - 1);
+  const int ilo = max(ff.imin - py0, 0), ihi = min(ff.imax - py0, TH - 1);
   // row word, CENTRED like everything else the tile kernel reads: float(P_y - Y0) of centred row y_c = y - TH/2 is
   // float(256 y_c + Yw); the entry's first row as y_c (6 bits, signed).  |Pyo - Y0| + 8192 < 2^23 inside the guard band
-  const int yw = ((Pyo - Y0 + (TH / 2) * 256) & 0xFFFFFF) | (((ilo - TH / 2) & 0x3F) << 24);
+  const int yw = ((Pyo - ff.Y0 + (TH / 2) * 256) & 0xFFFFFF) | (((ilo - TH / 2) & 0x3F) << 24);
   int nr = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;         // rows of the entry in this tile (<= 64)
   // ONE form for every face, however large: the three edge functions in units of 256 around the tile CENTRE,
   //   E'_k(x_c, y_c) = C'_k + a_k x_c + b_k y_c,   x_c = x - TW/2, y_c = y - TH/2,   a_k = -dy_k, b_k = dx_k (|.| < 2^23),
@@ -536,64 +767,44 @@ __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const 
   // C'_k can be as large as 2^39 for a face that spans the guard band, but inside the tile (|x_c| <= TW/2 + 2 with the
   // solver's reach, |y_c| <= TH/2) the sum a x_c + b y_c stays within M_k = (TW/2 + 2)|a_k| + (TH/2)|b_k|: a C'_k beyond
   // +-M_k cannot change sign in the tile, so it is CLAMPED to +-(M_k + 1) -- same coverage, and every value the tile
-  // kernel forms fits int32 (M_k < 2^29.1).  The edges are stored in an order the tile kernel relies on: FIRST an edge
-  // with a > 0 (it bounds the span from the left), LAST one with a < 0 (from the right), the remaining one in between
-  // -- a triangle of non-zero area has both kinds (the a_k sum to zero; so do the b_k: the last edge's slopes are not
-  // stored).  The plane of 1/z refers to vertex 0 whatever the edge order.
+  // kernel forms fits int32 (M_k < 2^29.1).  The plane of 1/z refers to vertex 0 whatever the edge order.
   const int Pxc = Pxo + (TW / 2) * 256, Pyc = Pyo + (TH / 2) * 256;  // centre of the tile's centre pixel
-  int c0, c1, c2;
-  if (ext < GR_FAST_EXT) {  // every product has 24-bit factors and every value fits int32: no 64-bit arithmetic, no clamp
-    c0 = (__mul24(dx0, Pyc - Y0) - __mul24(dy0, Pxc - X0) + t0) >> 8;
-    c1 = (__mul24(dx1, Pyc - Y1) - __mul24(dy1, Pxc - X1) + t1) >> 8;
-    c2 = (__mul24(dx2, Pyc - Y2) - __mul24(dy2, Pxc - X2) + t2) >> 8;
+  int cf, cm, cl;
+  if (ff.fast) {  // every product has 24-bit factors and every value fits int32: no 64-bit arithmetic, no clamp
+    cf = (__mul24(ff.dxf, Pyc - ff.Yf) - __mul24(ff.dyf, Pxc - ff.Xf) + ff.tf) >> 8;
+    cm = (__mul24(ff.dxm, Pyc - ff.Ym) - __mul24(ff.dym, Pxc - ff.Xm) + ff.tm) >> 8;
+    cl = (__mul24(ff.dxl, Pyc - ff.Yl) - __mul24(ff.dyl, Pxc - ff.Xl) + ff.tl) >> 8;
   } else {
-    const long long C0 = ((long long)dx0 * (Pyc - Y0) - (long long)dy0 * (Pxc - X0) + (long long)t0) >> 8;
-    const long long C1 = ((long long)dx1 * (Pyc - Y1) - (long long)dy1 * (Pxc - X1) + (long long)t1) >> 8;
-    const long long C2 = ((long long)dx2 * (Pyc - Y2) - (long long)dy2 * (Pxc - X2) + (long long)t2) >> 8;
+    const long long Cf = ((long long)ff.dxf * (Pyc - ff.Yf) - (long long)ff.dyf * (Pxc - ff.Xf) + (long long)ff.tf) >> 8;
+    const long long Cm = ((long long)ff.dxm * (Pyc - ff.Ym) - (long long)ff.dym * (Pxc - ff.Xm) + (long long)ff.tm) >> 8;
+    const long long Cl = ((long long)ff.dxl * (Pyc - ff.Yl) - (long long)ff.dyl * (Pxc - ff.Xl) + (long long)ff.tl) >> 8;
     const long long hx = TW / 2 + 2, hy = TH / 2;
-    const long long M0 = hx * abs(dy0) + hy * abs(dx0) + 1, M1 = hx * abs(dy1) + hy * abs(dx1) + 1,
-                    M2 = hx * abs(dy2) + hy * abs(dx2) + 1;
-    c0 = (int)min(max(C0, -M0), M0);
-    c1 = (int)min(max(C1, -M1), M1);
-    c2 = (int)min(max(C2, -M2), M2);
+    const long long Mf = hx * abs(ff.dyf) + hy * abs(ff.dxf) + 1, Mm = hx * abs(ff.dym) + hy * abs(ff.dxm) + 1,
+                    Ml = hx * abs(ff.dyl) + hy * abs(ff.dxl) + 1;
+    cf = (int)min(max(Cf, -Mf), Mf);
+    cm = (int)min(max(Cm, -Mm), Mm);
+    cl = (int)min(max(Cl, -Ml), Ml);
   }
-  const int a0 = -dy0, a1 = -dy1, a2 = -dy2;
   // The bounding box reaches this tile; the triangle itself may not (the far corner of a diagonal face).  An edge whose
   // value is negative even at the tile corner most in its favour, C' + (TW/2)|a| + (TH/2)|b| < 0, excludes every pixel of
   // the tile: the entry is DEAD (0 rows: the tile kernel never looks at it); k_bin_big asks before it takes a list slot.
-  const bool touches = nr > 0 && c0 + (TW / 2) * abs(a0) + (TH / 2) * abs(dx0) >= 0 &&
-                       c1 + (TW / 2) * abs(a1) + (TH / 2) * abs(dx1) >= 0 && c2 + (TW / 2) * abs(a2) + (TH / 2) * abs(dx2) >= 0;
+  const bool touches = nr > 0 && cf + ff.rf >= 0 && cm + ff.rm >= 0 && cl + ff.rl >= 0;
   if (!touches) nr = 0;
   rows = nr;
   // float(P_x - X0) of the pixel with CENTRED column x_c = x - TW/2 is float(256 x_c + Xw)
-  const int xw = ((Pxo - X0 + (TW / 2) * 256) & 0xFFFFFF) | (nr << 24);
-  const int kf = a0 > 0 ? 0 : (a1 > 0 ? 1 : 2);   // first: a > 0
-  const int kl = a0 < 0 ? 0 : (a1 < 0 ? 1 : 2);   // last: a < 0
-  const int km = 3 - kf - kl;
-  auto pick = [](int k, int v0, int v1, int v2) { return k == 0 ? v0 : (k == 1 ? v1 : v2); };
-  const int cf = pick(kf, c0, c1, c2), cm = pick(km, c0, c1, c2), cl = pick(kl, c0, c1, c2);
-  const int af = pick(kf, a0, a1, a2), am = pick(km, a0, a1, a2);
-  const int bf = pick(kf, dx0, dx1, dx2), bm = pick(km, dx0, dx1, dx2);
-  // slopes: four values (the last edge's are -(first + middle)).  Two packings: 16 bits each when every slope of the face
-  // fits (faces below 128 pixels: nearly all of them), else 24 bits each, flagged in bit 31 of the Yw word
-  const bool narrow = max(max(abs(a0), abs(a1)), max(abs(a2), max(abs(dx0), max(abs(dx1), abs(dx2))))) <= 32767;
-  int w3, w4, w5;
-  if (narrow) {
-    w3 = pack16(af, am); w4 = pack16(bf, bm);
-    w5 = ext < GR_FAST_EXT ? 0 : 1;  // never read for 16-bit slopes; non-zero tells store_entry that the short form does not fit
-  } else {
-    w3 = (af & 0xFFFFFF) | (am << 24);
-    w4 = ((am >> 8) & 0xFFFF) | (bf << 16);
-    w5 = ((bf >> 16) & 0xFF) | (bm << 8);
-  }
-  e0 = make_int4(cf, cm, cl, w3);
-  e1 = make_int4(w4, w5, p1.z, p2.x);
-  // bit 31: 24-bit slopes; bit 30: some slope magnitude beyond GR_FLOOR_NOCORR_MAX (the span solver must correct its floor)
-  const bool corr = !narrow || max(abs(a0), max(abs(a1), abs(a2))) > GR_FLOOR_NOCORR_MAX;
+  const int xw = ((Pxo - ff.X0 + (TW / 2) * 256) & 0xFFFFFF) | (nr << 24);
+  e0 = make_int4(cf, cm, cl, ff.w3);
+  e1 = make_int4(ff.w4, ff.w5, ff.iz0, ff.A);
   // ~face sits in an EVEN word: the tile kernel forms the 64-bit key (depth << 32 | ~face) in the register pair the entry
   // was read into, without a move
-  e2 = make_int4(p2.y, xw, (int)~(uint32_t)p1.w, yw | (narrow ? 0 : (int)0x80000000) | (corr ? 0x40000000 : 0));
+  e2 = make_int4(ff.B, xw, ff.nface, yw | ff.ywf);
   return touches;
+}
+
+__device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const int4 p2, int px0, int py0, int TW, int TH,
+                                            int4 &e0, int4 &e1, int4 &e2, int &rows) {
+  const FaceForm ff = face_form(p0, p1, p2, TW, TH);
+  return tile_entry(ff, px0, py0, TW, TH, e0, e1, e2, rows);
 }
 
 // The SHORT form of an entry, 40 bytes (single-pass binning, a.ent40): what a face whose snapped bounding box stays below
@@ -881,18 +1092,33 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int
     const int nblk = (int)ceil_div(c->F, GR_BLOCK);
     hipLaunchKernelGGL(k_cull_blocks, dim3((unsigned)ceil_div(nblk, 256), nb), dim3(256), a.touched ? sizeof(uint32_t) * a.tw : 0, s,
                        cams, a, nblk);
-    // k_setup_cull: a wave per surviving 64-face block would mostly pay for starting waves (a survey view keeps a tenth of
-    // the blocks: C2 7.5 -> 6.1 us per view with an eighth of the workgroups): about nblk / 32 waves per view take a few
-    // blocks each -- but never fewer than 16 k waves per launch, so that a call with a few views still fills the machine.
-    // (Requesting the next block's soup one iteration ahead was measured on top of this: 100 VGPRs, no gain.)
+#if !(GR_EXP & 32)
+    // about nblk / 32 waves per view take a few blocks each -- but never fewer than 16 k waves per launch, so that a call with
+    // a few views still fills the machine.
     const int gmax = std::min((nblk + 3) / 4, 1024);
-    const unsigned gsetup = (unsigned)std::max(1, std::min(gmax, std::max(nblk / 128, 4096 / std::max(nb, 1))));
+    const dim3 gsetup((unsigned)std::max(1, std::min(gmax, std::max(nblk / 128, 4096 / std::max(nb, 1)))), nb);
+#else
+    // A/B build (measured, round 5: C5 -17 %, C2 +16 %, not the default) -- k_setup_cull: ONE generation of workgroups -- as many as the chip holds at the kernel's register count (asked of the
+    // runtime once per context) --, every wave an equal share of the launch group's joint work list; fewer when the group is
+    // small (at least four blocks per wave if nothing were culled).  A wave per surviving block would mostly pay for starting
+    // waves (rounds 1-4: C2 7.5 -> 6.1 us per view with an eighth of the workgroups).
+    if (c->setup_wgs[0] == 0) {
+      int per_cu[2] = {0, 0}, cus = 0;
+      GR_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[0], k_setup_cull<true>, 256, 0));
+      GR_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[1], k_setup_cull<false>, 256, 0));
+      GR_HIP(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+      c->setup_wgs[0] = std::max(1, per_cu[0] * cus);
+      c->setup_wgs[1] = std::max(1, per_cu[1] * cus);
+    }
+    const int64_t cap_wgs = c->setup_wgs[a.cap_tile > 0 ? 0 : 1];
+    const dim3 gsetup((unsigned)std::max<int64_t>(1, std::min<int64_t>(cap_wgs, ceil_div((int64_t)nb * nblk, 16))));
+#endif
     if (a.cap_tile > 0) {
-      hipLaunchKernelGGL(k_setup_cull<true>, dim3(gsetup, nb), dim3(256), 0, s, cams, a);
+      hipLaunchKernelGGL(k_setup_cull<true>, gsetup, dim3(256), 0, s, cams, a, nb);
       if (a.var & 64) hipLaunchKernelGGL(k_bin_big, dim3(256, nb), dim3(256), 0, s, cams, a);
       hipLaunchKernelGGL(k_clip_faces<true>, dim3(8, nb), dim3(64), 0, s, cams, a);
     } else {
-      hipLaunchKernelGGL(k_setup_cull<false>, dim3(gsetup, nb), dim3(256), 0, s, cams, a);
+      hipLaunchKernelGGL(k_setup_cull<false>, gsetup, dim3(256), 0, s, cams, a, nb);
       hipLaunchKernelGGL(k_clip_faces<false>, dim3(8, nb), dim3(64), 0, s, cams, a);
     }
   }

@@ -246,7 +246,7 @@ int gr_ctx_create(int device, gr_ctx **out) {
   }
   (void)hipMemset(c->stats, 0, sizeof(unsigned long long) * 8);
 #ifdef GR_STAMPS
-  if (hipMalloc(&c->stamps, sizeof(unsigned long long) * 16 * 1024) == hipSuccess) (void)hipMemset(c->stamps, 0, sizeof(unsigned long long) * 16 * 1024);
+  if (hipMalloc(&c->stamps, sizeof(unsigned long long) * 32 * 1024) == hipSuccess) (void)hipMemset(c->stamps, 0, sizeof(unsigned long long) * 32 * 1024);
 #endif
   *out = c;
   return GR_OK;
@@ -276,6 +276,8 @@ int gr_ctx_destroy(gr_ctx *c) {
   if (c->blk_chunks) (void)hipFree(c->blk_chunks);
   if (c->touched) (void)hipFree(c->touched);
   if (c->soup) (void)hipFree(c->soup);
+  if (c->bvert) (void)hipFree(c->bvert);
+  if (c->bidx) (void)hipFree(c->bidx);
   if (c->orig) (void)hipFree(c->orig);
   if (c->stats) (void)hipFree(c->stats);
   if (c->flag) (void)hipFree(c->flag);
@@ -348,6 +350,20 @@ int gr_debug_read_stamps(gr_ctx *c, unsigned long long *out16_h) {
   std::vector<unsigned long long> all(16 * 1024);
   GR_HIP(c, hipMemcpy(all.data(), c->stamps, sizeof(unsigned long long) * all.size(), hipMemcpyDeviceToHost));
   GR_HIP(c, hipMemset(c->stamps, 0, sizeof(unsigned long long) * all.size()));
+  for (int k = 0; k < 16; ++k) out16_h[k] = 0;
+  for (size_t i = 0; i < all.size(); ++i) out16_h[i & 15] += all[i];
+  return GR_OK;
+}
+#endif
+
+#ifdef GR_STAMPS
+// diagnostic build only (tools/setup_phases.py): the set-up kernel's phase-cycle sums (the second half of the stamp buffer)
+int gr_debug_read_setup_stamps(gr_ctx *c, unsigned long long *out16_h) {
+  if (!c || !out16_h || !c->stamps) return GR_EINVAL;
+  GR_HIP(c, hipDeviceSynchronize());
+  std::vector<unsigned long long> all(16 * 1024);
+  GR_HIP(c, hipMemcpy(all.data(), c->stamps + 16 * 1024, sizeof(unsigned long long) * all.size(), hipMemcpyDeviceToHost));
+  GR_HIP(c, hipMemset(c->stamps + 16 * 1024, 0, sizeof(unsigned long long) * all.size()));
   for (int k = 0; k < 16; ++k) out16_h[k] = 0;
   for (size_t i = 0; i < all.size(); ++i) out16_h[i & 15] += all[i];
   return GR_OK;

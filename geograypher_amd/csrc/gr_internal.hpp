@@ -30,6 +30,7 @@
 #define GR_CTRL_HDR 8       // ctrl words before the tile arrays: rec_count, total_entries, overflow, work_count, clip_count, big_count
 #define GR_MAX_DIM 16384    // h, w limit (guard band and 16-bit bbox packing)
 #define GR_BLOCK 64         // faces per block of the Morton-ordered soup: one wave, one bounding sphere
+#define GR_BLOCK_VERTS 192  // distinct vertices a block can have (3 per face); a patch of a manifold mesh has about 48
 #define GR_CHUNK_LIST 16
 // The timing-only ablation masks (GR_OPT_DEBUG: skip the scanline loop, the epilogue, the triangles, ...) exist in the
 // DIAGNOSTIC build only (-DGR_ABLATE: tools/ab_kernel.py builds and loads it when a variant asks for a mask): the product's
@@ -40,6 +41,10 @@
 #define GR_DBG(a) 0
 #endif    // chunks of 256 caller face ids listed per block (k_block_chunks)
 
+#ifndef GR_EXP
+#define GR_EXP 0   // experiment bits of A/B builds (geograypher_amd.build.build_variant, tools/ab_libs.py); 0 in the product
+#endif
+
 namespace grimpl {
 
 struct BinArgs {
@@ -49,6 +54,8 @@ struct BinArgs {
   int4 *rec;             // [slot][4][F]  plane0 {X0,Y0,X1,Y1} plane1 {X2,Y2,iz0,face} plane2 {A,B,jmin|jmax<<16,imin|imax<<16}
                          //               plane3 {list position in up to 4 tiles}
   const float *soup;     // [F][9] the three vertex positions of every face, in Morton order (built once per upload)
+  const float *bvert;    // [ceil(F/64)][GR_BLOCK_VERTS][3] the DISTINCT vertices of every 64-face block, in order of first use
+  const uint32_t *bidx;  // [F] positions of the face's three vertices in its block's list (8 bits each) | (distinct vertices - 1) << 24
   const int32_t *orig;   // [F] soup position -> face id of the caller's mesh
   const float4 *blk;     // [ceil(F/64)] bounding sphere (centre, radius) of each block of GR_BLOCK faces, local frame
   const uint32_t *blk_chunks;  // [ceil(F/64)][17] count (or ~0: more than 16) + the 256-face chunks of CALLER ids the block's faces lie in
@@ -116,6 +123,8 @@ struct gr_ctx {
   int cur_tw = 0;
   int64_t blk_cap = 0;
   float *soup = nullptr;
+  float *bvert = nullptr;    // distinct vertices per 64-face block (k_block_vertices)
+  uint32_t *bidx = nullptr;  // per soup face: its vertices' positions in the block's list
   int32_t *orig = nullptr;   // soup position -> caller's face id (Morton order)
   int64_t soup_cap = 0;
   unsigned long long *stats = nullptr;
@@ -148,6 +157,7 @@ struct gr_ctx {
   int last_n_views = 0;
   bool direct_ok = true;     // cleared when a tile overflowed its slots: later calls take the exact path
   bool last_direct = false;
+  int64_t setup_wgs[2] = {0, 0};  // workgroups of k_setup_cull<true / false> the device holds at once (one generation: bin_batch)
   // winner scratch
   void *winner = nullptr;
   size_t winner_bytes = 0;
@@ -257,7 +267,7 @@ inline BinArgs make_args(gr_ctx *c, int h, int w, int slot0) {
   a.ctrl = c->ctrl + slot0 * a.ctrl_stride; a.rec = c->rec + slot0 * a.rec_stride;
   a.comp = c->comp + slot0 * a.ent_cap * GR_ENT_Q; a.work = c->work + slot0 * a.work_stride;
   a.nrow8 = c->nrow8 + slot0 * a.ent_cap;
-  a.stats = c->stats; a.blk = c->blk; a.soup = c->soup; a.orig = c->orig;
+  a.stats = c->stats; a.blk = c->blk; a.soup = c->soup; a.orig = c->orig; a.bvert = c->bvert; a.bidx = c->bidx;
   a.blk_chunks = c->blk_chunks; a.touched = c->cur_touched; a.tw = c->cur_tw;
   a.clip = c->clip + slot0 * c->F;
   a.twl = GR_TILE_LOG2; a.thl = c->opt_thl;

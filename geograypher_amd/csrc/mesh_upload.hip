@@ -130,7 +130,61 @@ __global__ __launch_bounds__(256) void k_block_chunks(const int32_t *__restrict_
   if (lane == 0) out[b * (GR_CHUNK_LIST + 1)] = rem ? 0xFFFFFFFFu : (uint32_t)n;
 }
 
-// K0b  per view: sphere-vs-frustum test of every 64-face block (one thread per block); survivors are appended to the
+// K0c  (once per upload) the DISTINCT vertices of every block of 64 soup faces.  The set-up kernel transforms a vertex once
+//      per block and view instead of once per face corner: a patch of a manifold mesh has about 48 distinct vertices for its
+//      192 corners (a face soup has 192: no worse than before).  One wave per block: the 192 corner indices go to LDS, every
+//      corner finds the first corner with the same mesh index (192 broadcast reads), first corners are numbered in order
+//      (prefix sum over the wave), and
+//        bvert[block][n]  = coordinates of the block's n-th distinct vertex
+//        bidx[face]       = n(corner 0) | n(corner 1) << 8 | n(corner 2) << 16 | (distinct vertices of the block - 1) << 24
+__global__ __launch_bounds__(256) void k_block_vertices(const float *__restrict__ verts, const int32_t *__restrict__ faces,
+                                                        const int32_t *__restrict__ orig, int64_t F, float *__restrict__ bvert,
+                                                        uint32_t *__restrict__ bidx) {
+  __shared__ int gi_s[4][GR_BLOCK_VERTS];
+  __shared__ int lid_s[4][GR_BLOCK_VERTS];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int *gi = gi_s[wv], *lid = lid_s[wv];
+  const int64_t b = (int64_t)blockIdx.x * 4 + wv;
+  if (b * GR_BLOCK >= F) return;   // wave-uniform
+  const int64_t f = b * GR_BLOCK + lane;
+  const bool live = f < F;
+  int g[3] = {-1, -1, -1};
+  if (live) {
+    const int64_t o = orig[f];
+    g[0] = faces[3 * o]; g[1] = faces[3 * o + 1]; g[2] = faces[3 * o + 2];
+  }
+  for (int k = 0; k < 3; ++k) gi[3 * lane + k] = g[k];
+  __builtin_amdgcn_wave_barrier();
+  int first[3] = {3 * lane, 3 * lane + 1, 3 * lane + 2};
+  for (int s = GR_BLOCK_VERTS - 1; s >= 0; --s) {  // descending: the smallest matching corner is kept
+    const int v = gi[s];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (v == g[k] && s < first[k]) first[k] = s;
+  }
+  int mine = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) mine += (live && first[k] == 3 * lane + k) ? 1 : 0;
+  int incl = mine;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  const int total = __shfl(incl, 63);
+  int n = incl - mine;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (live && first[k] == 3 * lane + k) {
+      lid[3 * lane + k] = n;
+      const float *p = verts + 3 * (int64_t)g[k];
+      float *d = bvert + ((int64_t)b * GR_BLOCK_VERTS + n) * 3;
+      d[0] = p[0]; d[1] = p[1]; d[2] = p[2];
+      ++n;
+    }
+  __builtin_amdgcn_wave_barrier();
+  if (live)
+    bidx[f] = (uint32_t)lid[first[0]] | ((uint32_t)lid[first[1]] << 8) | ((uint32_t)lid[first[2]] << 16) | ((uint32_t)(total - 1) << 24);
+}
 
 __global__ __launch_bounds__(256) void k_validate_faces(const int32_t *__restrict__ faces, int64_t n, int64_t V,
                                                         int *__restrict__ bad) {
@@ -199,8 +253,14 @@ int gr_mesh_upload(gr_ctx *c, const float *verts, const int32_t *faces, int64_t 
     if (c->soup) (void)hipFree(c->soup);
     if (c->orig) (void)hipFree(c->orig);
     c->soup = nullptr; c->orig = nullptr; c->soup_cap = 0;
+    if (c->bvert) (void)hipFree(c->bvert);
+    if (c->bidx) (void)hipFree(c->bidx);
+    c->bvert = nullptr; c->bidx = nullptr;
     if (hipMalloc(&c->soup, sizeof(float) * 9 * F) != hipSuccess) return fail(c, GR_ENOMEM, "face soup allocation failed");
     if (hipMalloc(&c->orig, sizeof(int32_t) * F) != hipSuccess) return fail(c, GR_ENOMEM, "face order allocation failed");
+    if (hipMalloc(&c->bvert, sizeof(float) * 3 * GR_BLOCK_VERTS * ceil_div(F, GR_BLOCK)) != hipSuccess)
+      return fail(c, GR_ENOMEM, "block vertex allocation failed");
+    if (hipMalloc(&c->bidx, sizeof(uint32_t) * F) != hipSuccess) return fail(c, GR_ENOMEM, "block index allocation failed");
     c->soup_cap = F;
   }
   // Morton codes -> stable radix sort of (code, face) pairs (rocPRIM through hipcub) -> orig[]
@@ -227,6 +287,7 @@ int gr_mesh_upload(gr_ctx *c, const float *verts, const int32_t *faces, int64_t 
   hipLaunchKernelGGL(k_build_soup, dim3((unsigned)ceil_div(3 * F, 256)), dim3(256), 0, s, verts, faces, c->orig, F, c->soup);
   hipLaunchKernelGGL(k_block_bounds, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s, c->soup, F, c->blk);
   hipLaunchKernelGGL(k_block_chunks, dim3((unsigned)ceil_div(nblk, 4)), dim3(256), 0, s, c->orig, F, c->blk_chunks);
+  hipLaunchKernelGGL(k_block_vertices, dim3((unsigned)ceil_div(nblk, 4)), dim3(256), 0, s, verts, faces, c->orig, F, c->bvert, c->bidx);
   GR_HIP(c, hipGetLastError());
   c->verts = verts; c->faces = faces; c->V = V; c->F = F;
   return GR_OK;

@@ -29,7 +29,9 @@ from geograypher_amd.utils import synthetic
 
 H, W, C = 3000, 4000, 4
 DEFAULT = ["base:0", "xcd:64"]
-WORKLOAD = os.environ.get("AB_WORKLOAD", "c2")  # c2: 1.2 M faces, 4000 x 3000; c5: 5 M faces, 6000 x 4000 (20 views)
+# c2: 1.2 M faces, 4000 x 3000; c5: 5 M faces, 6000 x 4000 (20 views); c2q: c2 at render_img_scale 0.25 (1000 x 750);
+# forest / forestq: the hostile workload (terrain + 20 000 trees, 20 oblique views) at scale 1 / 0.25
+WORKLOAD = os.environ.get("AB_WORKLOAD", "c2")
 
 
 def main():
@@ -46,10 +48,17 @@ def main():
     if WORKLOAD == "c5":
         H, W = 4000, 6000
         (points, faces), cams = synthetic.config5_scene(n_views=max(nv, 1))
+    elif WORKLOAD in ("forest", "forestq"):
+        points, faces = synthetic.forest_scene()
+        cams = synthetic.oblique_cameras(20)
+        nv = min(nv, 20)
     else:
         points, faces = synthetic.terrain_mesh()
         cams = synthetic.config2_cameras(50)
-    recs = torch.from_numpy(cams.get_raster_records(1.0, near=1.0)[:nv]).cuda()
+    scale = 0.25 if WORKLOAD.endswith("q") else 1.0
+    if scale != 1.0:
+        H, W = cams[0].get_image_size(scale)
+    recs = torch.from_numpy(cams.get_raster_records(scale, near=1.0)[:nv]).cuda()
     hip = HipRaster(0)
     hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
     ids = torch.empty((nv, H, W), dtype=torch.int32, device="cuda")

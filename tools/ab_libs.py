@@ -37,9 +37,9 @@ def main():
     sums = {}
     for r in range(rounds):
         for w in workloads:
-            for tag, path, var in libs:
+            for tag, path, var in libs[r % len(libs):] + libs[:r % len(libs)]:   # rotate the order: no build is always first
                 env = dict(os.environ, GEOGRAYPHER_AMD_LIB=str(path), AB_WORKLOAD=w, AB_CHECKSUM="1")
-                nv, reps = ("20", "4") if w == "c5" else ("50", "5")
+                nv, reps = ("20", "4") if w in ("c5", "forest", "forestq") else ("50", "5")
                 res = subprocess.run([sys.executable, str(ROOT / "tools" / "ab_kernel.py"), nv, reps, f"x:{var}"], env=env,
                                      capture_output=True, text=True)
                 lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
@@ -63,7 +63,8 @@ def main():
                 continue
             med = lambda k1, k2: statistics.median(r[k1][k2] for r in runs)
             print(json.dumps({"workload": w, "build": tag, "setup": med("plain", "setup_ms"), "plain": med("plain", "raster_ms"),
-                              "fused": med("fused", "raster_ms"), "vote": med("fused", "vote_ms"), "runs": len(runs)}))
+                              "fused": med("fused", "raster_ms"), "vote": med("fused", "vote_ms"), "runs": len(runs),
+                              "setup_runs": [r["plain"]["setup_ms"] for r in runs], "plain_runs": [r["plain"]["raster_ms"] for r in runs]}))
 
 
 if __name__ == "__main__":
