@@ -695,6 +695,22 @@ def run(args, rig=None) -> int:
             cpu_baseline["affinity_cores"] = None
 
     if rank == 0:
+        # The driver keeps the `roofline` object whole and only the NAMES of the side legs: the scalars a reader needs from them
+        # are repeated here.  binding_resource: what binds the dominant kernel (VALU issue) -- "bound": "hbm"
+        # above names the roofline BASELINE.json asks the fraction of.
+        roofline["binding_resource"] = "valu"
+        roofline["valu_frac"] = (roofline.get("valu") or {}).get("frac")
+        roofline["setup_us_per_view"] = round(stage_ms_per_view["setup_ms"] * 1e3, 3)
+        roofline["raster_us_per_view"] = round(stage_ms_per_view["raster_ms"] * 1e3, 3)
+        if c5:
+            roofline["c5_kernel_frac"] = c5.get("raster_kernel_frac_of_hbm_peak")
+            roofline["c5_raster_views_per_s"] = c5.get("raster_views_per_s")
+        if aggregate:
+            roofline["c3_views_per_s"] = aggregate.get("views_per_s")
+        if workload_2:
+            roofline["hostile_gpix_scale_1"] = round(workload_2["scale_1"]["mpix_per_s"] / 1e3, 2)
+            roofline["hostile_gpix_scale_0.25"] = round(workload_2["scale_0.25"]["mpix_per_s"] / 1e3, 2)
+            roofline["hostile_overflow_retries_cold"] = workload_2["scale_1"].get("overflow_retries_cold")
         line = {
             "metric": "Mpix/s rasterized (face-ID pix2face), 1.2M-face mesh @ 4000x3000",
             "value": round(mpix_per_s, 1),
@@ -881,7 +897,9 @@ def leg_workload2(rig, local_rank, dev):
     from geograypher_amd import _hip
 
     cache_dir = tempfile.mkdtemp(prefix="geograster_cache_")
-    _hip.load_library().gr_learned_cache_file(str(Path(cache_dir, "geograster_learned.txt")).encode())
+    lib = _hip.load_library()
+    lib.gr_learned_cache_clear()   # whatever earlier legs (or an earlier run's file in the user's cache folder) taught the process
+    lib.gr_learned_cache_file(str(Path(cache_dir, "geograster_learned.txt")).encode())
     hip_cold = rig.make_raster(local_rank)
     hip_cold.upload_mesh(fpts.astype(np.float32), ffaces.astype(np.int32))
     for scale in (1.0, 0.25):
@@ -954,6 +972,13 @@ def leg_workload2(rig, local_rank, dev):
         assert same, f"workload_2 scale {scale}: GPU ids differ from the CPU oracle"
         del out2
     del hip2
+    # the leg's cache file goes away with the leg: the process-wide table points back at where the binding attached it (or
+    # nowhere), and the temporary directory is removed
+    import shutil
+
+    lib.gr_learned_cache_file(None)
+    _hip._attach_learned_cache(lib)
+    shutil.rmtree(cache_dir, ignore_errors=True)
     return out
 
 

@@ -8,6 +8,7 @@ only `tensor.data_ptr()` and the raw `hipStream_t` of the current torch stream.
 from __future__ import annotations
 
 import ctypes
+import threading
 from pathlib import Path
 from typing import Optional
 
@@ -34,6 +35,7 @@ EXPORTED_SYMBOLS = (
     "gr_set_profiling",
     "gr_set_option",
     "gr_learned_cache_file",
+    "gr_learned_cache_clear",
     "gr_get_stage_times",
     "gr_mesh_upload",
     "gr_raster_face_ids",
@@ -157,6 +159,8 @@ def load_library() -> ctypes.CDLL:
     lib.gr_resize_image_f64.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     lib.gr_learned_cache_file.restype = i32
     lib.gr_learned_cache_file.argtypes = [ctypes.c_char_p]
+    lib.gr_learned_cache_clear.restype = i32
+    lib.gr_learned_cache_clear.argtypes = []
     lib.gr_finalize_votes.restype = i32
     lib.gr_finalize_votes.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp]
     lib.gr_finalize_sums_f64.restype = i32
@@ -313,20 +317,25 @@ class PairAccumulator:
 
 
 _default_backends = {}
+_default_backends_lock = threading.Lock()
 
 
 def default_backend(device: Optional[int] = None):
-    """One shared `HipRaster` per device for callers that are not handed a backend (camera-set warps)."""
+    """One shared `HipRaster` per (device, host thread) for callers that are not handed a backend (camera-set warps, the
+    down-scale of `get_image`).  A libgeograster context is not thread safe (include/geograster.h: one context per device and
+    host thread): a loader thread that resizes photos while the caller's thread rasterizes gets a context of its own."""
     torch = _torch()
     if not torch.cuda.is_available():
         raise RuntimeError(
             "geograypher_amd: no ROCm GPU visible (torch.cuda.is_available() is False). "
             "The projection path runs on MI355X only; there is no CPU fallback."
         )
-    key = torch.cuda.current_device() if device is None else int(device)
-    if key not in _default_backends:
-        _default_backends[key] = HipRaster(key)
-    return _default_backends[key]
+    dev = torch.cuda.current_device() if device is None else int(device)
+    key = (dev, threading.get_ident())
+    with _default_backends_lock:
+        if key not in _default_backends:
+            _default_backends[key] = HipRaster(dev)
+        return _default_backends[key]
 
 
 class HipRaster:

@@ -159,12 +159,17 @@ class PhotogrammetryCamera:
         """reference: cameras.py:154-174 -- uint8 images are returned as float in [0, 1]; `image_scale != 1` resizes with
         scikit-image's `resize` defaults (anti-aliasing Gaussian + order 1).  The resize runs on the device
         (`gr_resize_image_f64`, pinned to the real scikit-image's output in tests/test_photo_resize.py); there is no CPU
-        resizer in the product: without a GPU a scaled image raises RuntimeError."""
+        resizer in the product: without a GPU a scaled image raises RuntimeError.  The scaled image is float64 whatever the
+        file's dtype (scikit-image >= 0.19, the reference's pinned 0.21, returns float32 for a float32 FILE; photos are uint8
+        and come back float64 there too): documented, values within float32 rounding of that."""
         if self.image is None:
             native = self.get_image_native()
             image = native / 255.0 if native.dtype == np.uint8 else native
-            if self.cache_image:
-                self.image = image
+            # `cache_image` keeps ONE copy per photo: the file's own array (a uint8 photo: an eighth of its float image, and
+            # what the device paths upload; `/ 255.0` is redone per call) -- the reference caches the float image
+            if self.cache_image and native.dtype != np.uint8:
+                self.image = image             # the file's array itself
+                self._image_native = None
         else:
             native = None
             image = self.image
@@ -375,8 +380,10 @@ class PhotogrammetryCameraSet:
     def get_image_by_index(self, index: int, image_scale: float = 1.0) -> np.ndarray:
         return self[index].get_image(image_scale=image_scale)
 
-    # file reads are independent: the view loop of the mesh class may prefetch them on a loader thread
-    thread_safe_lookup = True
+    # May `get_image_by_index` of this set run on the mesh class's loader thread while the caller's thread rasterizes?  False
+    # by default: a subclass (a segmentor set around a stateful or GPU segmentor, a user's own look-up) must say so itself.
+    # The plain file-backed set needs no flag: the mesh class recognises it by its un-overridden methods and decodes ahead.
+    thread_safe_lookup = False
 
     def get_native_image_by_index(self, index: int) -> np.ndarray:
         """The image of camera `index` in its file dtype, for the device input pipeline of project_images /

@@ -41,13 +41,38 @@ gr_ctx::Learned g_learned[64];
 int g_n_learned = 0;
 char g_learned_path[1024] = {0};
 
+// cap == GR_LEARNED_EXACT: the image's tiles need more slots than one view's entry memory may take -- it bins exactly
+#define GR_LEARNED_EXACT (-1)
+#define GR_LEARNED_MAX_CAP 65536   // what GR_OPT_DIRECT_CAP accepts
+
+inline int merge_cap(int a, int b) { return (a == GR_LEARNED_EXACT || b == GR_LEARNED_EXACT) ? GR_LEARNED_EXACT : std::max(a, b); }
+
+void put_global_locked(const gr_ctx::Learned &v);
+
+bool parse_learned_line(const char *line, gr_ctx::Learned &v) {
+  unsigned long long m; int T, cap, full;
+  if (line[0] == '#' || sscanf(line, "%llx %d %d %d", &m, &T, &cap, &full) != 4) return false;
+  if (T <= 0 || cap < GR_LEARNED_EXACT || cap > GR_LEARNED_MAX_CAP) return false;
+  v = {(uint64_t)m, T, cap, full != 0};
+  return true;
+}
+
 void save_learned_locked() {
   if (!g_learned_path[0]) return;
+  // several processes (the ranks of one job) share the file: what the others wrote since this process read it is merged
+  // in before the rewrite (entry-wise maximum), so that no rank's lesson is lost to another's rename
+  if (FILE *f = fopen(g_learned_path, "r")) {
+    char line[256];
+    gr_ctx::Learned v;
+    while (fgets(line, sizeof(line), f))
+      if (parse_learned_line(line, v)) put_global_locked(v);
+    fclose(f);
+  }
   char tmp[1100];
   snprintf(tmp, sizeof(tmp), "%s.tmp.%d", g_learned_path, (int)getpid());
   FILE *f = fopen(tmp, "w");
   if (!f) return;
-  fprintf(f, "# libgeograster: slots per tile / entry form learned per (mesh signature, tile count)\n");
+  fprintf(f, "# libgeograster: slots per tile (-1: exact binning) / entry form learned per (mesh signature, tile count)\n");
   for (int i = 0; i < std::min(g_n_learned, 64); ++i)
     fprintf(f, "%016llx %d %d %d\n", (unsigned long long)g_learned[i].mesh, g_learned[i].T, g_learned[i].cap, g_learned[i].full ? 1 : 0);
   fclose(f);
@@ -58,10 +83,13 @@ void put_global_locked(const gr_ctx::Learned &v) {
   int j = 0;
   for (; j < std::min(g_n_learned, 64); ++j)
     if (g_learned[j].mesh == v.mesh && g_learned[j].T == v.T) break;
-  if (j == std::min(g_n_learned, 64)) { j = g_n_learned % 64; g_n_learned += 1; }
-  else if (g_learned[j].cap >= v.cap && (g_learned[j].full || !v.full)) return;  // nothing new
-  g_learned[j].mesh = v.mesh; g_learned[j].T = v.T;
-  g_learned[j].cap = std::max(g_learned[j].cap, v.cap); g_learned[j].full = g_learned[j].full || v.full;
+  if (j == std::min(g_n_learned, 64)) {
+    j = g_n_learned % 64; g_n_learned += 1;
+    g_learned[j] = v;
+    return;
+  }
+  g_learned[j].cap = merge_cap(g_learned[j].cap, v.cap);
+  g_learned[j].full = g_learned[j].full || v.full;
 }
 
 // what is known about images of T tiles of the current mesh: slots per tile (0: nothing learned) and the entry form
@@ -86,6 +114,7 @@ void resolve_binning(gr_ctx *c, int T) {
   c->cur_cap = 0; c->cur_ent40 = false;
   if (c->opt_direct_cap <= 0 || !c->direct_ok) return;
   lookup_learned(c, T, cap, full);
+  if (cap == GR_LEARNED_EXACT) return;  // this (mesh, image size) bins exactly: one view's segments would not fit the budget
   c->cur_cap = std::max(cap, c->opt_direct_cap);
   c->cur_ent40 = !(c->cur_cap & 63) && !(c->opt_var & 128) && !full;
 }
@@ -94,7 +123,7 @@ void resolve_binning(gr_ctx *c, int T) {
 void learn(gr_ctx *c, int T, int cap, bool full) {
   int old_cap; bool old_full;
   lookup_learned(c, T, old_cap, old_full);
-  const gr_ctx::Learned v = {c->mesh_sig, T, std::max(cap, old_cap), full || old_full};
+  const gr_ctx::Learned v = {c->mesh_sig, T, merge_cap(cap, old_cap), full || old_full};
   int i = 0;
   for (; i < std::min(c->n_learned, 8); ++i)
     if (c->learned[i].mesh == c->mesh_sig && c->learned[i].T == T) break;
@@ -332,13 +361,17 @@ int gr_learned_cache_file(const char *path_h) {
   FILE *f = fopen(path_h, "r");
   if (!f) return GR_OK;  // nothing learned yet: the file appears with the first overflow
   char line[256];
-  while (fgets(line, sizeof(line), f)) {
-    unsigned long long m; int T, cap, full;
-    if (line[0] == '#' || sscanf(line, "%llx %d %d %d", &m, &T, &cap, &full) != 4) continue;
-    if (T <= 0 || cap < 0 || cap > 16384) continue;
-    put_global_locked({(uint64_t)m, T, cap, full != 0});
-  }
+  gr_ctx::Learned v;
+  while (fgets(line, sizeof(line), f))
+    if (parse_learned_line(line, v)) put_global_locked(v);
   fclose(f);
+  return GR_OK;
+}
+
+int gr_learned_cache_clear(void) {
+  std::lock_guard<std::mutex> lk(g_learned_mu);
+  g_n_learned = 0;
+  memset(g_learned, 0, sizeof(g_learned));
   return GR_OK;
 }
 
@@ -414,10 +447,12 @@ int gr_raster_status(gr_ctx *c, gr_raster_stats *o) {
     const bool grow = (int64_t)st[2] > used;
     if (st[5] != 0) learn(c, c->last_T, 0, true);
     if (grow) {
+      // (priced for ONE view: raster_views shrinks the launch group until the segments fit the budget -- round 4 priced the
+      // failed call's whole group and switched single-pass binning off for the CONTEXT, every image size, for good)
       const int64_t need = ((int64_t)st[2] + (int64_t)st[2] / 8 + 16 + 63) / 64 * 64;
-      const int64_t bytes = need * (16 * GR_ENT_Q) * (int64_t)c->last_T * (int64_t)std::max(c->last_B, 1);
-      if (need <= 16384 && bytes <= (c->opt_budget_mb << 20)) learn(c, c->last_T, (int)need, false);
-      else c->direct_ok = false;
+      const int64_t bytes_one_view = need * (16 * GR_ENT_Q) * (int64_t)c->last_T;
+      if (need <= GR_LEARNED_MAX_CAP && bytes_one_view <= (c->opt_budget_mb << 20)) learn(c, c->last_T, (int)need, false);
+      else learn(c, c->last_T, GR_LEARNED_EXACT, false);   // this (mesh, image size) bins exactly from now on
       return fail(c, GR_EOVERFLOW, "single-pass binning overflow: a tile received %llu entries (slots per tile %d); "
                   "retry the call", st[2], used);
     }

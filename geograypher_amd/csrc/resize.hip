@@ -132,7 +132,7 @@ int gr_resize_image_f64(gr_ctx *c, const void *src, int dtype, int h_in, int w_i
                         int w_out, double *out, void *stream) {
   if (!c) return GR_EINVAL;
   if (!src || !out || h_in <= 0 || w_in <= 0 || C <= 0 || h_out <= 0 || w_out <= 0 || (int64_t)w_in * C > 0x7FFFFFFFll ||
-      (int64_t)w_out * C > 0x7FFFFFFFll || h_in > (1 << 24) || w_in > (1 << 24) || h_out > 32767 /* grid.y = 2 h_out */)
+      (int64_t)w_out * C > 0x7FFFFFFFll || h_in > (1 << 24) || w_in > (1 << 24))
     return fail(c, GR_EINVAL, "bad resize args %dx%dx%d -> %dx%d", h_in, w_in, C, h_out, w_out);
   if (dtype != GR_DTYPE_U8 && dtype != GR_DTYPE_F32 && dtype != GR_DTYPE_F64) return fail(c, GR_EINVAL, "unknown image dtype %d", dtype);
   hipStream_t s = (hipStream_t)stream;
@@ -147,6 +147,8 @@ int gr_resize_image_f64(gr_ctx *c, const void *src, int dtype, int h_in, int w_i
     GR_HIP(c, hipGetLastError());
     return GR_OK;
   }
+  // (only the resize proper has this limit -- grid.y = 2 h_out --: the conversion of a tall image above has none)
+  if (h_out > 32767) return fail(c, GR_EINVAL, "resize to %d rows: at most 32767", h_out);
   const double fr = (double)h_in / (double)h_out, fc = (double)w_in / (double)w_out;
   const double sr = std::max(0.0, (fr - 1.0) / 2.0), sc = std::max(0.0, (fc - 1.0) / 2.0);
   const int rr = sr > 1e-15 ? (int)(4.0 * sr + 0.5) : 0, rc = sc > 1e-15 ? (int)(4.0 * sc + 0.5) : 0;  // scipy: truncate = 4.0

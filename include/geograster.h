@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GR_VERSION 120 /* 0.2.0: gr_resize_image_f64, gr_learned_cache_file, mesh-signature keyed learned table */
+#define GR_VERSION 121 /* 0.2.1: gr_learned_cache_clear; 0.2.0: gr_resize_image_f64, gr_learned_cache_file, mesh-signature keyed learned table */
 
 enum {
   GR_OK = 0,
@@ -124,7 +124,8 @@ enum {
   GR_OPT_DIRECT_BUDGET_MB = 9, /* entry memory one launch group may take, MiB (default 24576).  Scratch of the single-pass
                                binning = views per launch group (<= 64) x tiles x slots per tile x 48 B -- 9.3 GB for 64
                                views of 4000 x 3000 at the default 512 slots --; a launch group shrinks until it fits, and
-                               an image whose learned slots would not fit even one view bins exactly instead            */
+                               an image whose learned slots would not fit even ONE view bins exactly instead (remembered
+                               per mesh and image size like the slots themselves; other image sizes are not affected)   */
   GR_OPT_DEBUG_LDS = 98,    /* extra dynamic LDS bytes per tile workgroup: lowers occupancy (timing experiments)     */
   GR_OPT_DEBUG = 99         /* timing-only ablation mask for tools/ab_kernel.py: OUTPUTS BECOME WRONG          */
 };
@@ -137,6 +138,10 @@ int gr_set_option(gr_ctx *ctx, int key, int value);
  * The reference keeps its caches under CACHE_FOLDER (constants.py:18; pix2face's cache_folder argument, meshes.py:1683):
  * the Python binding points this at CACHE_FOLDER/geograster_learned.txt. */
 int gr_learned_cache_file(const char *path_h);
+/* Forget everything the PROCESS-WIDE table holds (contexts keep what they learned themselves; the file is not touched and the
+ * file name stays set).  For callers that need a cold start -- a benchmark's "first process that ever sees the scene" leg, a
+ * hermetic test -- after which gr_learned_cache_file(path) reads a file's entries into the empty table. */
+int gr_learned_cache_clear(void);
 int gr_get_stage_times(gr_ctx *ctx, gr_stage_times *out_h);
 
 /* mesh -- replaces the per-view mesh + colour upload of meshes.py:1776-1817 (plotter.clear/add_mesh) and the
@@ -175,7 +180,13 @@ int gr_project_labels_u8(gr_ctx *ctx, const int32_t *ids, const uint8_t *labels,
  * sums[f*C+c] = nz(sums[f*C+c]) + nz(value) view by view, nz(NaN) = 0 -- np.nansum([summed, projection], axis=0) of
  * meshes.py:2060-2062 to the letter: a running sum that went NaN (+inf met -inf) counts as 0 at the next view of the call
  * or of the next call on the same buffers, whether that view shows the face or not; counts[f] += any(isfinite(row))
- * (2064-2067). */
+ * (2064-2067).
+ * CONTRACT WHEN VIEWS ARE SHARDED over processes (geograypher_amd/distributed.py: rank r accumulates views r, r + N, ... into
+ * its own buffers, the buffers are added with one all-reduce): counts are exact for any N; sums of FINITE inputs equal the
+ * serial result within 1e-12 relative (addition order); for inputs with +-inf the recurrence above runs per rank over that
+ * rank's views and the per-rank sums are then added, so a face that met +inf and -inf in views of DIFFERENT ranks ends NaN
+ * where the serial reference -- which drops the NaN at the following view -- ends finite
+ * (tests/test_distributed_gloo.py::test_float_aggregation_contract_for_non_finite_inputs_at_world_two). */
 int gr_project_values_f64(gr_ctx *ctx, const int32_t *ids, const double *img, int n_views, int h, int w, int C,
                           double *sums, uint32_t *counts, int flags, void *stream);
 

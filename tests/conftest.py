@@ -10,6 +10,10 @@ if str(ROOT) not in sys.path:
 
 GOLDEN = ROOT / "tests" / "golden"
 
+# hermetic: the library's learned-binning table is not read from / written to the user's cache folder by the suite (a test
+# that wants persistence points gr_learned_cache_file at its own tmp_path)
+os.environ.setdefault("GEOGRAYPHER_AMD_CACHE", "off")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")

@@ -159,3 +159,81 @@ def test_pytorch3d_plugin_focal_length_switch():
     assert rec[12] == 750.0 and rec[13] == 500.0 + 3.0 and rec[14] == 375.0 - 1.75
     with pytest.raises(ValueError):
         cam.get_raster_record(focal_scaling="half")
+
+
+# ---- round-4 advice: which thread a camera set's images are fetched on ------------------------------------------------------
+def _thread_probe_set(flag):
+    import threading
+
+    from geograypher_amd.cameras.cameras import PhotogrammetryCameraSet
+    from geograypher_amd.utils import synthetic
+
+    (points, faces), cams = synthetic.config1_scene()
+    cams = cams[0:3]
+    for c in cams.cameras:
+        c.image_width, c.image_height, c.image_size, c.f = 64, 48, (48, 64), 50.0
+    seen = []
+
+    class ProbeSet(PhotogrammetryCameraSet):
+        def get_image_by_index(self, index, image_scale=1.0):
+            seen.append(threading.get_ident())
+            return np.full((48, 64, 1), float(index))
+
+    if flag is not None:
+        ProbeSet.thread_safe_lookup = flag
+    return (points, faces), ProbeSet(cams.cameras, local_to_epsg_4978_transform=np.eye(4)), seen
+
+
+def test_a_camera_set_without_the_flag_is_staged_on_the_callers_thread():
+    """`thread_safe_lookup` was True on the BASE camera set, so every subclass -- a segmentor set around a
+    stateful or GPU segmentor included -- had its look-ups run on the mesh class's loader thread.  The default is False now:
+    only a set (or segmentor) that says so, and the plain file-backed set, are fetched ahead on another thread."""
+    import threading
+
+    from geograypher_amd.cameras.cameras import PhotogrammetryCameraSet
+    from geograypher_amd.meshes import TexturedPhotogrammetryMesh
+    from tests.oracle_backend import OracleBackend
+
+    assert PhotogrammetryCameraSet.thread_safe_lookup is False
+    me = threading.get_ident()
+    for flag, on_caller in ((None, True), (False, True), (True, False)):
+        (points, faces), cam_set, seen = _thread_probe_set(flag)
+        mesh = TexturedPhotogrammetryMesh((points, faces), log_level="ERROR", backend=OracleBackend())
+        avg, info = mesh.aggregate_projected_images(cam_set, apply_distortion=False)
+        assert len(seen) >= 3 and np.isfinite(avg).any()
+        assert all((t == me) == on_caller for t in seen), (flag, seen, me)
+
+
+def test_default_backend_is_per_thread(monkeypatch):
+    """A libgeograster context serves one host thread (include/geograster.h): `default_backend()` hands every thread its own."""
+    import threading
+
+    from geograypher_amd import _hip
+
+    made = []
+
+    class FakeRaster:
+        def __init__(self, dev):
+            made.append((dev, threading.get_ident()))
+
+    class FakeCuda:
+        @staticmethod
+        def is_available():
+            return True
+
+        @staticmethod
+        def current_device():
+            return 0
+
+    class FakeTorch:
+        cuda = FakeCuda
+
+    monkeypatch.setattr(_hip, "HipRaster", FakeRaster)
+    monkeypatch.setattr(_hip, "_torch", lambda: FakeTorch)
+    monkeypatch.setattr(_hip, "_default_backends", {})
+    a = _hip.default_backend()
+    assert _hip.default_backend() is a
+    other = []
+    t = threading.Thread(target=lambda: other.append(_hip.default_backend()))
+    t.start(); t.join()
+    assert other[0] is not a and len(made) == 2 and made[0][1] != made[1][1]

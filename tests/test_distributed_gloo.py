@@ -172,3 +172,119 @@ def test_float_image_aggregation_distributed_equals_single_process(tmp_path):
         np.testing.assert_array_equal(np.load(tmp_path / f"fcnt_{r}.npy"), want_cnt)
         np.testing.assert_allclose(np.load(tmp_path / f"fsum_{r}.npy"), want_sum, rtol=1e-12, atol=0, equal_nan=True)
         np.testing.assert_allclose(np.load(tmp_path / f"favg_{r}.npy"), want_avg, rtol=1e-12, atol=0, equal_nan=True)  # north star: 1e-5
+
+
+# ---- the float contract at N > 1 (stated in include/geograster.h) -------------------------------------
+# value per (view, special face): what the view's image holds on every pixel that shows the face; None: NaN (= the view does not
+# observe the face: an all-NaN projection row, which nansum skips and the counts ignore).  The table of
+# tests/test_hip_parity.py::test_running_nan_of_the_float_sums_is_dropped_like_numpy_nansum.
+_INF = float("inf")
+_VAL = [[_INF, _INF, _INF, 1.0, _INF, None],
+        [-_INF, -_INF, 2.0, -_INF, None, 3.0],
+        [5.0, None, -_INF, _INF, None, None],
+        [None, None, None, None, -_INF, None],
+        [None, None, 7.0, None, None, _INF],
+        [None, None, None, None, None, -_INF]]
+
+
+def _nonfinite_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from geograypher_amd.cameras.cameras import PhotogrammetryCameraSet
+        from geograypher_amd.meshes import TexturedPhotogrammetryMesh
+        from geograypher_amd.utils import synthetic
+        from tests.oracle_backend import OracleBackend
+
+        (points, faces), cams = synthetic.config1_scene()
+        cams = cams[0:6]
+        for c in cams.cameras:
+            c.image_width, c.image_height, c.image_size, c.f = 96, 72, (72, 96), 75.0
+        mesh = TexturedPhotogrammetryMesh((points, faces), log_level="ERROR", backend=OracleBackend())
+        ids = np.asarray(mesh.pix2face(cams, apply_distortion=False))
+        seen_by_all = set(np.unique(ids[0][ids[0] >= 0]).tolist())
+        for v in range(1, 6):
+            seen_by_all &= set(np.unique(ids[v]).tolist())
+        special = sorted(seen_by_all)[:6]      # six faces every view shows (and not the last face: -1 aliases it)
+        assert len(special) == 6 and special[-1] < faces.shape[0] - 1
+        images = []
+        for v in range(6):
+            rng = np.random.default_rng(500 + v)
+            img = rng.random((72, 96, 2))
+            for k, face in enumerate(special):
+                x = _VAL[v][k]
+                # channel 0 carries the value, channel 1 a finite 1.0 wherever the view observes the face (the row then counts:
+                # a row of +-inf alone is not "finite" for meshes.py:2064-2066)
+                img[ids[v] == face] = (np.nan, np.nan) if x is None else (x, 1.0)
+            images.append(img)
+
+        class ImageSet(PhotogrammetryCameraSet):
+            def get_image_by_index(self, index, image_scale=1.0):
+                return images[[c.image_filename for c in cams.cameras].index(self.cameras[index].image_filename)]
+
+        img_set = ImageSet(cams.cameras, local_to_epsg_4978_transform=np.eye(4))
+        avg, info = mesh.aggregate_projected_images(img_set, distributed=True, apply_distortion=False)
+        np.save(os.path.join(out_dir, f"nsum_{rank}.npy"), info["summed_projections"])
+        np.save(os.path.join(out_dir, f"ncnt_{rank}.npy"), info["projection_counts"])
+        if rank == 0:
+            _, info1 = mesh.aggregate_projected_images(img_set, distributed=False, apply_distortion=False)
+            np.save(os.path.join(out_dir, "nsum_single.npy"), info1["summed_projections"])
+            np.save(os.path.join(out_dir, "ncnt_single.npy"), info1["projection_counts"])
+            np.save(os.path.join(out_dir, "special.npy"), np.array(special))
+    finally:
+        dist.destroy_process_group()
+
+
+def _serial_recurrence(values):
+    """meshes.py:2057-2062 for one face and one channel: the first projection as it is, then nansum([running, next])."""
+    run = None
+    for x in values:
+        p = np.nan if x is None else x
+        if run is None:
+            run = p
+        else:
+            with np.errstate(invalid="ignore"):
+                run = np.nansum([run, p])
+    return run
+
+
+@pytest.mark.timeout(300)
+def test_float_aggregation_contract_for_non_finite_inputs_at_world_two(tmp_path):
+    """THE CONTRACT.  Finite inputs: the distributed result equals the serial one within 1e-12 (north star: 1e-5).  Non-finite
+    inputs (+-inf, NaN): every rank runs the reference's recurrence -- np.nansum([running, projection]) drops a NaN of the running
+    sum at the NEXT view -- over ITS OWN views in view order, then the per-rank sums are ADDED (one all-reduce): a face that saw
+    +inf and -inf in views of different ranks ends NaN where the serial run, which met them in consecutive views and dropped
+    the NaN at the view after, ends finite.  Counts are integers and agree exactly.  A documented deviation, asserted here so
+    that it cannot change silently."""
+    world = 2
+    mp.spawn(_nonfinite_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want_sum, want_cnt = np.load(tmp_path / "nsum_single.npy"), np.load(tmp_path / "ncnt_single.npy")
+    special = np.load(tmp_path / "special.npy")
+    ordinary = np.ones(want_sum.shape[0], dtype=bool)
+    ordinary[special] = False
+    # the rule, per special face: rank r's recurrence over views r, r + 2, r + 4, then IEEE addition of the two results
+    # (finalize_sums turns the NaN of a rank-local running sum into 0 only where a later LOCAL view followed: the recurrence)
+    expect = []
+    for k in range(6):
+        col = [_VAL[v][k] for v in range(6)]
+        parts = []
+        for r in range(world):
+            mine = col[r::world]
+            part = _serial_recurrence(mine)
+            # a rank whose views never observed the face contributes 0 (its sums start at zero)
+            parts.append(0.0 if all(x is None for x in mine) else part)
+        with np.errstate(invalid="ignore"):
+            expect.append(parts[0] + parts[1])
+    serial = [_serial_recurrence([_VAL[v][k] for v in range(6)]) for k in range(6)]
+    for r in range(world):
+        got_sum, got_cnt = np.load(tmp_path / f"nsum_{r}.npy"), np.load(tmp_path / f"ncnt_{r}.npy")
+        np.testing.assert_array_equal(got_cnt, want_cnt)                                  # integers: exact everywhere
+        np.testing.assert_allclose(got_sum[ordinary], want_sum[ordinary], rtol=1e-12, atol=0, equal_nan=True)
+        np.testing.assert_array_equal(want_sum[special, 0], np.array(serial))             # the serial run IS the reference's recurrence
+        got = got_sum[special, 0]
+        for k in range(6):
+            e = expect[k]
+            assert (np.isnan(got[k]) and np.isnan(e)) or got[k] == e, (k, got[k], e, serial[k])
+    # and the deviation is real: at least one special face differs from the serial reference (face 1: serial 0.0, sharded NaN)
+    assert any(not ((np.isnan(e) and np.isnan(s)) or e == s) for e, s in zip(expect, serial))

@@ -199,6 +199,7 @@ def test_second_context_and_new_process_start_sized(hip, tmp_path):
 
     lib = load_library()
     cache = tmp_path / "learned.txt"
+    assert lib.gr_learned_cache_clear() == 0   # hermetic: nothing an earlier test (or an earlier run's file) taught the process
     assert lib.gr_learned_cache_file(str(cache).encode()) == 0
     try:
         (points, faces), cams = synthetic.config1_scene()
@@ -250,6 +251,7 @@ def test_second_context_and_new_process_start_sized(hip, tmp_path):
         assert "RETRIES 0" in res.stdout, res.stdout
     finally:
         lib.gr_learned_cache_file(None)
+        lib.gr_learned_cache_clear()
 
 
 def test_entry_memory_budget_option_shrinks_the_launch_group(hip):
