@@ -1093,6 +1093,11 @@ def leg_api(points, faces, wl, n_views=16):
                 mesh.aggregate_projected_images(fcams, aggregate_img_scale=scale)
                 _, dt = timed(lambda: mesh.aggregate_projected_images(fcams, aggregate_img_scale=scale))
                 out[f"aggregate_uint8_photo_files_{tag}_views_per_s"] = round(nf / dt, 1)
+            # with the opt-in decoded-input cache: the first pass stores the decoded photos, later passes memory-map them
+            cache_dir = Path(d) / "decoded_cache"
+            mesh.aggregate_projected_images(fcams, aggregate_img_scale=0.25, decoded_cache=cache_dir)
+            _, dt = timed(lambda: mesh.aggregate_projected_images(fcams, aggregate_img_scale=0.25, decoded_cache=cache_dir))
+            out["aggregate_uint8_photo_files_scale_0.25_decoded_cache_later_pass_views_per_s"] = round(nf / dt, 1)
             # the resize alone, photo resident on the device
             dev_img = torch.from_numpy(np.asarray(Image.open(files[0]))).cuda()
             mesh.backend.resize_image(dev_img, (wl.H // 4, wl.W // 4))
@@ -1171,6 +1176,17 @@ def leg_io(points, faces, wl, n_views=64):
             mesh.aggregate_projected_images(seg, aggregate_img_scale=scale, loader_threads=threads)   # warm-up (scratch, pinned buffers)
             _, dt = timed(lambda: mesh.aggregate_projected_images(seg, aggregate_img_scale=scale, loader_threads=threads))
             labels_in[f"{tag}_views_per_s"] = round(n / dt, 1)
+        # the opt-in decoded-input cache (aggregate_projected_images(decoded_cache=...)): the first pass decodes and stores
+        # uncompressed .npy entries, later passes memory-map them
+        cache_dir = Path(d) / "decoded_cache"
+        for tag, scale in (("scale_1", 1.0), ("scale_0.25", 0.25)):
+            _, dt_first = timed(lambda: mesh.aggregate_projected_images(seg, aggregate_img_scale=scale, loader_threads=threads,
+                                                                         decoded_cache=cache_dir))
+            _, dt_cached = timed(lambda: mesh.aggregate_projected_images(seg, aggregate_img_scale=scale, loader_threads=threads,
+                                                                          decoded_cache=cache_dir))
+            labels_in[f"{tag}_decoded_cache_first_pass_views_per_s"] = round(n / dt_first, 1)
+            labels_in[f"{tag}_decoded_cache_later_pass_views_per_s"] = round(n / dt_cached, 1)
+        labels_in["decoded_cache_MB"] = round(sum(f.stat().st_size for f in cache_dir.glob("*.npy")) / 1e6, 1)
         labels_in["binds"] = ("PNG decode on the host threads (zlib inflate, one file per thread): the aggregate rate follows the "
                               "decode-alone rate; the link and the kernels are 5-30x faster") \
             if labels_in["scale_1_views_per_s"] < 2.0 * labels_in["png_decode_alone_views_per_s"] else "link / kernels"

@@ -150,7 +150,12 @@ class PhotogrammetryCamera:
         down-scaled there (`HipRaster.resize_image`)."""
         native = getattr(self, "_image_native", None)
         if native is None:
-            native = _imread(self.image_filename)
+            from geograypher_amd.utils.decoded_cache import cached_decode
+
+            # decoded_cache (set by the camera set / aggregate_projected_images(decoded_cache=...)): the decoded photo as an
+            # uncompressed .npy keyed by (path, mtime, size), memory-mapped by later passes; None: decode every time
+            native = cached_decode(self.image_filename, getattr(self, "decoded_cache", None),
+                                   lambda: _imread(self.image_filename), "photo-native")
             if self.cache_image:
                 self._image_native = native
         return native
@@ -384,6 +389,13 @@ class PhotogrammetryCameraSet:
     # by default: a subclass (a segmentor set around a stateful or GPU segmentor, a user's own look-up) must say so itself.
     # The plain file-backed set needs no flag: the mesh class recognises it by its un-overridden methods and decodes ahead.
     thread_safe_lookup = False
+
+    def set_decoded_cache(self, spec) -> None:
+        """Opt in to (or, with None, out of) the decoded-input cache for this set's photos (utils/decoded_cache.py): True --
+        `CACHE_FOLDER/decoded`, the reference's cache root (constants.py:18) --, or a folder.  Passes after the first
+        memory-map the decoded photos instead of decoding them again."""
+        for cam in self.cameras:
+            cam.decoded_cache = spec
 
     def get_native_image_by_index(self, index: int) -> np.ndarray:
         """The image of camera `index` in its file dtype, for the device input pipeline of project_images /

@@ -17,6 +17,7 @@ from __future__ import annotations
 import hashlib
 import logging
 import sys
+import contextlib
 import typing
 from pathlib import Path
 
@@ -519,6 +520,8 @@ class TexturedPhotogrammetryMesh:
             tdtype = native.get(flat.dtype.name)
             if tdtype is None:  # anything else takes the reference's route: float64 on the host
                 flat, tdtype = flat.astype(np.float64), torch.float64
+            if not flat.flags.writeable:  # a memory-mapped cache entry: torch wants a writable array
+                flat = np.array(flat)
             if not on_gpu:
                 return torch.from_numpy(np.ascontiguousarray(flat)), n_channels, resize_to
             if slot_free[k] is not None:
@@ -604,8 +607,52 @@ class TexturedPhotogrammetryMesh:
             else:
                 yield _to_host(self.backend.project_view(ids, img, neg1_is_last_face=self.neg1_is_last_face))
 
+    @staticmethod
+    @contextlib.contextmanager
+    def _decoded_cache_scope(cameras, spec):
+        """`decoded_cache=` of project_images / aggregate_projected_images: for the duration of the call the camera set's photos
+        and its segmentor's label files go through the decoded-input cache (utils/decoded_cache.py); None changes nothing."""
+        if spec is None:
+            yield
+            return
+        segmentor = getattr(cameras, "segmentor", None)
+        base = getattr(cameras, "base_camera_set", cameras)
+        before_seg = getattr(segmentor, "decoded_cache", None) if hasattr(segmentor, "decoded_cache") else None
+        before_cams = [getattr(cam, "decoded_cache", None) for cam in getattr(base, "cameras", [])]
+        try:
+            if hasattr(segmentor, "decoded_cache"):
+                segmentor.decoded_cache = spec
+            for cam in getattr(base, "cameras", []):
+                cam.decoded_cache = spec
+            yield
+        finally:
+            if hasattr(segmentor, "decoded_cache"):
+                segmentor.decoded_cache = before_seg
+            for cam, old in zip(getattr(base, "cameras", []), before_cams):
+                cam.decoded_cache = old
+
     # -- aggregate_projected_images ------------------------------------------------------------------------------
     def aggregate_projected_images(
+        self,
+        cameras: typing.Union[PhotogrammetryCamera, PhotogrammetryCameraSet],
+        batch_size: int = 1,
+        aggregate_img_scale: float = 1,
+        return_all: bool = False,
+        distributed: bool = False,
+        decoded_cache=None,
+        **kwargs,
+    ):
+        """`_aggregate_projected_images` (below: the reference's method) with one more opt-in keyword, `decoded_cache`: None
+        (default) -- every pass decodes the label PNGs / photos it reads, like the reference --; True or a folder -- decoded
+        inputs are kept as uncompressed `.npy` files keyed by (path, mtime, size, scale) under `CACHE_FOLDER/decoded` (the
+        reference's cache root, constants.py:18; its own `save_to_cache` precedent: meshes.py:1759-1770, 1838-1840) or the
+        folder, and the second and later passes memory-map them: the host side of a pass is bound by PNG / JPEG inflate
+        otherwise (bench `io`)."""
+        with self._decoded_cache_scope(cameras, decoded_cache):
+            return self._aggregate_projected_images(cameras, batch_size=batch_size, aggregate_img_scale=aggregate_img_scale,
+                                                    return_all=return_all, distributed=distributed, **kwargs)
+
+    def _aggregate_projected_images(
         self,
         cameras: typing.Union[PhotogrammetryCamera, PhotogrammetryCameraSet],
         batch_size: int = 1,

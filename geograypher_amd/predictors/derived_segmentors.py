@@ -48,24 +48,35 @@ class LookUpSegmentor(Segmentor):
 
     thread_safe_lookup = True  # stateless file look-ups: the aggregation input pipeline may decode several at once
 
-    def __init__(self, base_folder, lookup_folder, num_classes=10, reference_float_rescale: bool = False):
+    def __init__(self, base_folder, lookup_folder, num_classes=10, reference_float_rescale: bool = False, decoded_cache=None):
         self.base_folder = Path(base_folder)
         self.lookup_folder = lookup_folder
         self.num_classes = num_classes
         self.reference_float_rescale = reference_float_rescale
+        # None: every look-up decodes its PNG (the reference's behaviour).  True / a folder: the decoded -- and, at
+        # image_scale != 1, resized -- index image is kept as an uncompressed .npy keyed by (path, mtime, size, scale) and later
+        # passes memory-map it (utils/decoded_cache.py)
+        self.decoded_cache = decoded_cache
 
     def segment_image_indices(self, image: np.ndarray, filename: PATH_TYPE, image_scale: float):
-        from PIL import Image
+        from geograypher_amd.utils.decoded_cache import cached_decode
 
         relative_path = Path(filename).relative_to(self.base_folder)
         lookup_path = Path(self.lookup_folder, relative_path).with_suffix(".png")
-        with Image.open(lookup_path) as im:
-            inds = np.asarray(im)
-        if image_scale != 1:
-            inds = _nearest_resize(inds, (int(inds.shape[0] * image_scale), int(inds.shape[1] * image_scale)))
-            if self.reference_float_rescale:
-                inds = _float_rescaled_indices(inds)
-        return inds
+
+        def decode():
+            from PIL import Image
+
+            with Image.open(lookup_path) as im:
+                inds = np.asarray(im)
+            if image_scale != 1:
+                inds = _nearest_resize(inds, (int(inds.shape[0] * image_scale), int(inds.shape[1] * image_scale)))
+                if self.reference_float_rescale:
+                    inds = _float_rescaled_indices(inds)
+            return inds
+
+        tag = f"label-indices|scale={float(image_scale):.8f}|float_rescale={int(bool(self.reference_float_rescale))}"
+        return cached_decode(lookup_path, self.decoded_cache, decode, tag)
 
     def segment_image(self, image: np.ndarray, filename: PATH_TYPE, image_scale: float):
         if self.reference_float_rescale and image_scale != 1:
