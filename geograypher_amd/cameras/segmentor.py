@@ -6,7 +6,7 @@ the aggregation fast path the (h, w) uint8 class-index image the one-hot was mad
 4000x3000 view), which is what the HIP vote kernel consumes.
 """
 import typing
-from copy import deepcopy
+from copy import copy
 
 import numpy as np
 
@@ -55,22 +55,30 @@ class SegmentorPhotogrammetryCameraSet(PhotogrammetryCameraSet):
         return self.base_camera_set.get_image_by_index(index=index, image_scale=image_scale)
 
     def get_subset_cameras(self, inds: typing.List[int]):
-        """reference: segmentor.py:49-55"""
-        subset_camera_set = deepcopy(self)
-        subset_camera_set.cameras = [subset_camera_set.cameras[i] for i in inds]
-        subset_camera_set.base_camera_set = subset_camera_set.base_camera_set.get_subset_cameras(inds)
-        return subset_camera_set
+        """The set restricted to views `inds` (reference: segmentor.py:49-55, which deep-copies the whole wrapper -- segmentor
+        included -- once per call).  Here: a shallow copy of the wrapper around the BASE set's own subset (cameras copied there,
+        as the reference's base class does) with the SAME segmentor object -- look-up configuration or a model, neither of
+        which a view subset should duplicate -- and the same distortion-map caches (keyed by the lens parameters: a map built
+        for a subset serves the whole set)."""
+        subset = copy(self)
+        subset.base_camera_set = self.base_camera_set.get_subset_cameras(inds)
+        subset.cameras = subset.base_camera_set.cameras
+        return subset
 
     def n_image_channels(self) -> int:
         return self.segmentor.num_classes
 
     def get_subset_with_valid_segmentation(self) -> "SegmentorPhotogrammetryCameraSet":
-        """reference: segmentor.py:60-76"""
-        valid_inds = []
-        for i in range(len(self)):
+        """The views whose segmentation can be produced (reference: segmentor.py:60-76: whatever the segmentor raises for a
+        view -- typically a missing prediction file -- drops that view).  The class-index image is asked for where the segmentor
+        has one (a quarter of the one-hot image's bytes, no per-class loop)."""
+        probe = self.get_label_index_image if hasattr(self.segmentor, "segment_image_indices") else self.get_image_by_index
+
+        def produces_a_segmentation(i: int) -> bool:
             try:
-                self.get_image_by_index(i)
-                valid_inds.append(i)
+                probe(i)
             except Exception:
-                pass
-        return self.get_subset_cameras(valid_inds)
+                return False
+            return True
+
+        return self.get_subset_cameras([i for i in range(len(self)) if produces_a_segmentation(i)])

@@ -320,6 +320,7 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
   __shared__ int4 vt_s[4][GR_BLOCK_VERTS];  // the block's transformed vertices, one set of rows per wave (12 KiB per workgroup)
   int4 *const vt = vt_s[threadIdx.x >> 6];
 #if !(GR_EXP & 32)  // the grid of rounds 1-4 -- (workgroups, views), every wave strides over ITS view's list (A/B bit 32: the joint list below)
+  (void)nb;
   const int slot = blockIdx.y;
   const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
   uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;

@@ -364,7 +364,9 @@ template <int TWL, int TH, int NT, int PAD, bool EDGE>
 __device__ __forceinline__ void fused_winners(const unsigned long long *keys, const BinArgs &a, uint32_t *__restrict__ win,
                                               int te, int px0, int py0, int dbg) {
   static_assert(TWL == 6 && NT == 256 && TH % 32 == 0, "16 lanes x 4 pixels per tile row, 16 row pairs per pass");
+#if GR_EXP & 1
   const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
+#endif
   const int c4 = (te & 15) * 4, rp = te >> 4;  // row pair 0 .. 15 of a pass
 #pragma unroll
   for (int pass = 0; pass < TH / 32; ++pass) {
