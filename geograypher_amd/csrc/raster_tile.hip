@@ -24,6 +24,9 @@ using namespace grimpl;
 #ifndef GR_NUM_SGPR
 #define GR_NUM_SGPR 80
 #endif
+#ifndef GR_ROLL_KT
+#define GR_ROLL_KT 16   // tiles per workgroup of the rolling-chain kernel
+#endif
 #ifndef GR_EXP
 #define GR_EXP 0   // experiment bits of A/B builds (geograypher_amd.build.build_variant, tools/ab_libs.py); 0 in the product
 #endif
@@ -488,9 +491,13 @@ __device__ __forceinline__ bool short_piece_needed(uint32_t q, uint32_t n) {
 // (a chain), or here behind the fill of the key tile (WAIT: one tile per workgroup -- the request's latency overlaps the fill).
 // PLAIN: the ids-only kernel of the usual call -- ids to an image whose rows take 16-byte stores, no depth image: the epilogue's
 // other forms (depth, one pixel per lane) are not in the kernel at all (the cold paths cost the hot one registers and schedule)
-template <int TWL, int THL, int NT, bool FUSE, int PAD, bool SHORT, bool WAIT, bool PLAIN>
+// The four first-chunk requests a rolling chain keeps in flight (k_raster_tile_roll): whole 16-byte tuples + the row counts.
+struct ChunkRing { v4i e0; uint32_t n0; };
+
+template <int TWL, int THL, int NT, bool FUSE, int PAD, bool SHORT, bool WAIT, bool PLAIN, bool ROLL = false>
 __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOut &out, unsigned long long *keys, const int slot,
-                                                const int tile, uint32_t cnt, const int64_t beg, uint32_t nr_first, v4i ex GR_STAMP_ARG) {
+                                                const int tile, uint32_t cnt, const int64_t beg, uint32_t nr_first, v4i ex GR_STAMP_ARG,
+                                                ChunkRing *ring = nullptr) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   constexpr int NKEYS = (TW + PAD) * TH;
   constexpr int NW = NT / 64;
@@ -512,6 +519,9 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
   const uint8_t *nr8 = a.nrow8 + slot * a.ent_cap + beg;
 
   if (!FUSE && cnt == 0) {  // empty tile (a view that overhangs the mesh): background, without the LDS round trip
+    // (a rolling chain waits for its ring here as well, before the stores: a path that left the function with a request in
+    // flight made the compiler wait for EVERYTHING -- the previous tile's stores included -- at the next tile's first request)
+    if (ROLL) asm volatile("" : "+v"(ring->e0), "+v"(ring->n0));
     if (PLAIN) {  // 16-byte stores: a lane owns 4 consecutive pixels of a row, 16 rows per pass
       const int gx4 = px0 + (tid & 15) * 4;
       if (gx4 < a.w && !(GR_DBG(a) & 2))
@@ -546,7 +556,7 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
   {  // first chunk: in registers already, complete (k_raster_tile waits for every request of the chain before its first
      // tile: a wait on the memory counter here would wait for the previous tile's stores)
     if (WAIT) asm volatile("" : "+v"(ex), "+v"(nr_first));
-    if (lane < EL) ent_st[wv * EL + lane] = ex;
+    if (!ROLL && lane < EL) ent_st[wv * EL + lane] = ex;   // a rolling chain staged it before it re-used the registers
     GR_STAMP(1);
     __syncthreads();  // keys filled, chunk visible
     GR_STAMP(2);
@@ -577,6 +587,10 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
   int te = tid;
   asm volatile("" : "+v"(te));  // the epilogue's addresses are derived here, not hoisted above the scanline phase
   GR_PRIO_MEM();
+  // a rolling chain: the request for the NEXT tile (issued at this tile's start, an items phase ago) is waited for HERE,
+  // before this tile's id stores are issued -- loads and stores share one in-order counter, and behind the stores the wait
+  // would be a wait for them.  Named as whole register tuples: behind this statement nothing of the ring is in flight.
+  if (ROLL) asm volatile("" : "+v"(ring->e0), "+v"(ring->n0));
   __syncthreads();              // keys complete
   if (GR_PRIO_E != GR_PRIO_M) __builtin_amdgcn_s_setprio(GR_PRIO_E);
   GR_STAMP(5);
@@ -709,6 +723,24 @@ __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile(BinArgs a, Rast
   // memory counter has nothing left to wait for in the loop over tiles 1 .. 3 -- where a wait means waiting for the
   // previous tile's id stores (tests/test_isa_waits.py)
   if (KT > 1) asm volatile("" : "+v"(ex0), "+v"(ex1), "+v"(ex2), "+v"(ex3), "+v"(nr0), "+v"(nr1), "+v"(nr2), "+v"(nr3));
+#if GR_EXP & 1024
+  // Upper-bound probe for "hide the chain prologue" (round 5): the prologue's two dependent round trips are paid TWICE -- the
+  // counters and the four first chunks are loaded again, each behind a full wait, results folded into the ones in use (same
+  // values) -- so that what a prefetch could at best remove is measured as what doubling it costs.
+  if (KT > 1 && a.cap_tile > 0) {
+    const volatile uint32_t *vc = ctrl + GR_CTRL_HDR + tile0;
+    uint32_t again = vc[0];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(again));
+    again = min(again, (uint32_t)a.cap_tile) ^ cnt0;   // 0
+    v4i e0b = ex0, e1b = ex1, e2b = ex2, e3b = ex3;
+    if ((lane < EL) & needed(q, cnt0 + again)) e0b = __builtin_nontemporal_load(pieces(beg0) + q);
+    if ((lane < EL) & needed(q, cnt1 + again)) e1b = __builtin_nontemporal_load(pieces(beg1) + q);
+    if ((lane < EL) & needed(q, cnt2 + again)) e2b = __builtin_nontemporal_load(pieces(beg2) + q);
+    if ((lane < EL) & needed(q, cnt3 + again)) e3b = __builtin_nontemporal_load(pieces(beg3) + q);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(e0b), "+v"(e1b), "+v"(e2b), "+v"(e3b));
+    ex0 = e0b; ex1 = e1b; ex2 = e2b; ex3 = e3b;
+  }
+#endif
   GR_STAMP(0);
   static_assert(!(FUSE && PLAIN), "the plain kernel writes ids only");
   raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, KT == 1, PLAIN>(a, out, keys, slot, tile0, cnt0, beg0, nr0, ex0 GR_STAMP_PASS);
@@ -730,6 +762,96 @@ __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile(BinArgs a, Rast
     atomicAdd(&st[13], __builtin_amdgcn_s_memrealtime() - sa.r0);  // ... and in 10 ns ticks: their ratio x 100 MHz is the clock under load
     atomicAdd(&st[15], 1ull);                 // waves
     atomicAdd(&st[14], (unsigned long long)n_tiles);  // tile visits x waves
+  }
+#endif
+}
+
+// K3r  ROLLING chains (round 5).  A chain of four pays its prologue -- two dependent round trips: the tiles' counters, then
+//      their first chunks -- once per four tiles, and doubling that prologue costs C2 3.9 % and C5 7.0 % of the kernel
+//      (profiles/r05_ab/tile_prologue_doubled.log): that is what hiding it can buy.  Here a workgroup takes KTL consecutive
+//      tiles and keeps ONE first-chunk request in flight all the time (five live registers; a chain of four holds fifteen
+//      through its first tile): the prologue asks for tile 0; every tile copies its chunk from the request registers to LDS
+//      and at once re-uses them for the NEXT tile's request (all the chain's counters were read in the prologue), which has
+//      the tile's whole items phase to arrive and is waited for before the tile's id stores go out (raster_one_tile<ROLL>).
+//      The exposed prologue is paid once per KTL tiles.  Single-pass binning only (the counters of consecutive tiles sit side
+//      by side).
+template <int TWL, int THL, int NT, bool FUSE, int PAD, bool SHORT, bool PLAIN, int KTL>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(THL == 5 ? GR_WPE : (FUSE ? 1 : 4), 8)))
+__attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile_roll(BinArgs a, RasterOut out) {
+  constexpr int TW = 1 << TWL, TH = 1 << THL;
+  constexpr int NKEYS = (TW + PAD) * TH;
+  constexpr int NW = NT / 64;
+  constexpr int NMAIL = NW * 16;
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[NKEYS + NMAIL + 64 * (SHORT ? 5 : 6)];
+  static_assert(NT == 256 && KTL >= 2 && KTL <= 63, "one lane per counter, one more reads as zero");
+  const int slot = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#ifdef GR_STAMPS
+  StampAcc sa;
+  for (int k = 0; k < 9; ++k) sa.acc[k] = 0;
+  sa.t = sa.t0 = __builtin_amdgcn_s_memtime();
+  sa.r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  const int tile0 = KTL * (int)blockIdx.x;
+  const int n_tiles = min(KTL, a.T - tile0);
+  constexpr int EL = SHORT ? 40 : 48;
+  const uint32_t q = wv * EL + lane;
+  const v4i *base = reinterpret_cast<const v4i *>(a.comp + (int64_t)slot * a.ent_cap * GR_ENT_Q);
+  auto pieces = [&](int64_t first) {
+    return SHORT ? reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(base) + first * 40) : base + first * GR_ENT_Q;
+  };
+  auto needed = [](uint32_t qq, uint32_t n) { return SHORT ? short_piece_needed(qq, min(n, 64u)) : qq < n * GR_ENT_Q; };
+  const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
+  if (FUSE && ctrl[2] != 0u) return;
+  const uint32_t cap = (uint32_t)a.cap_tile;
+  const int64_t sbase = slot * a.ent_cap;
+  // the chain's counters: lane k holds tile k's (ONE vector register for the whole chain, read with v_readlane: no counter is
+  // loaded inside the tile loop, where a load is a wait)
+  const uint32_t *cntp = ctrl + GR_CTRL_HDR + tile0;
+  uint32_t cvec = lane < n_tiles ? min(cntp[lane], cap) : 0u;
+  asm volatile("" : "+v"(cvec));
+  auto count_at = [&](int tt) { return (uint32_t)__builtin_amdgcn_readlane((int)cvec, tt); };   // tt < 64; lanes >= n_tiles hold 0
+  ChunkRing r;
+  r.n0 = 0u;
+  typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+  auto request = [&](uint32_t cnt, int64_t beg, v4i &e, uint32_t &n) {
+    // The lane's row count as the low byte of an (unaligned) DWORD load, unconditionally (the bytes read lie in the tile's
+    // segment or the 64 bytes of padding behind the array; entries beyond the count are never looked at).  Nothing may touch
+    // the loaded register before the request is waited for: a byte load is followed by its zero extension at once, a register
+    // that is zeroed and then loaded under a mask by a wait for every store in flight -- each a full wait at the tile's start.
+    n = *reinterpret_cast<const u32_unaligned *>(a.nrow8 + sbase + beg + lane);
+    const char *seg = reinterpret_cast<const char *>(base) + beg * (SHORT ? 40 : 48);
+    if ((lane < EL) & needed(q, cnt)) e = *reinterpret_cast<const v4i *>(seg + (q << 4));
+  };
+  const int64_t beg0 = (int64_t)tile0 * a.cap_tile;
+  request(count_at(0), beg0, r.e0, r.n0);
+  asm volatile("" : "+v"(r.e0), "+v"(r.n0));
+  GR_STAMP(0);
+  v4i *ent_st = reinterpret_cast<v4i *>(keys + NKEYS + NMAIL);
+#pragma unroll 1
+  for (int t = 0; t < n_tiles; ++t) {
+    if (t > 0) {
+      __syncthreads();                   // every wave has read the previous tile's keys (and is done with its last chunk)
+      GR_STAMP(7);
+    }
+    // stage the tile's first chunk from the request registers and re-use them at once for the NEXT tile's request
+    const uint32_t cnt = count_at(t), cnt1 = count_at(t + 1);
+    const int64_t beg = (int64_t)(tile0 + t) * a.cap_tile;
+    if (lane < EL) ent_st[wv * EL + lane] = r.e0;
+    const uint32_t nr_first = r.n0 & 0xFFu;
+    request(cnt1, beg + a.cap_tile, r.e0, r.n0);
+    // (the by-value chunk argument is the later chunks' temporary: NOT the request register, which is in flight again)
+    raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, false, PLAIN, true>(a, out, keys, slot, tile0 + t, cnt, beg, nr_first, v4i{0, 0, 0, 0} GR_STAMP_PASS, &r);
+  }
+#ifdef GR_STAMPS
+  if (lane == 0 && a.stamps) {
+    unsigned long long *st = a.stamps + 16 * ((blockIdx.x * 4 + wv + blockIdx.y * 977) & 1023);
+    for (int kk = 0; kk < 9; ++kk) atomicAdd(&st[kk], sa.acc[kk]);
+    atomicAdd(&st[12], __builtin_amdgcn_s_memtime() - sa.t0);
+    atomicAdd(&st[13], __builtin_amdgcn_s_memrealtime() - sa.r0);
+    atomicAdd(&st[15], 1ull);
+    atomicAdd(&st[14], (unsigned long long)n_tiles);
   }
 #endif
 }
@@ -761,11 +883,21 @@ int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStr
     // with heavy tiles: chains of them make a few workgroups very long; hostile workload 57.9 vs 30.4 us per view at
     // 1000x750) or the launch has too few tiles to keep every CU busy with chains.
     const bool chain = (a.var & 1) == 0 && ((a.var & 16) != 0 || (a.cap_tile > 0 && a.cap_tile <= 512 && (int64_t)a.T * nb >= 16384));
-    const dim3 grid(chain ? (unsigned)((a.T + 3) >> 2) : (unsigned)a.T, nb), block(256);
+    // Rolling chains of GR_ROLL_KT tiles (k_raster_tile_roll) where a chain of four would run -- for the FUSED kernel, whose
+    // epilogue stores nothing: C2 15.07 -> 14.22 us per view, C5 29.99 -> 28.67 (profiles/r05_ab/rolling_chains.log).  The ids
+    // kernel loses with them (C2 13.21 -> 13.94, C5 28.5 -> 33.3): the wait for the next tile's request, placed before the
+    // tile's id stores, is also a wait for the PREVIOUS tile's stores (one in-order counter), so a wave never has more than
+    // one tile's stores in flight -- a chain of four has up to four.  Variant bit 1024: rolling chains for the ids kernels as
+    // well (A/B); bit 2048: none at all.
+    const bool roll = chain && a.cap_tile > 0 && a.thl == 5 && !(a.var & 2048) && (out.winner != nullptr || (a.var & 1024) != 0);
+    const dim3 grid(roll ? (unsigned)((a.T + GR_ROLL_KT - 1) / GR_ROLL_KT) : chain ? (unsigned)((a.T + 3) >> 2) : (unsigned)a.T, nb), block(256);
     const size_t pad = (size_t)c->opt_lds_pad;
 #define GR_LAUNCH_TILE(THL_, FUSE_, PLAIN_)                                                                           \
   do {                                                                                                                \
-    if (a.ent40) {                                                                                                    \
+    if (roll && THL_ == 5) {                                                                                          \
+      if (a.ent40) hipLaunchKernelGGL((k_raster_tile_roll<6, 5, 256, FUSE_, GR_LDS_PAD, true, PLAIN_, GR_ROLL_KT>), grid, block, pad, s, a, out);  \
+      else hipLaunchKernelGGL((k_raster_tile_roll<6, 5, 256, FUSE_, GR_LDS_PAD48, false, PLAIN_, GR_ROLL_KT>), grid, block, pad, s, a, out);        \
+    } else if (a.ent40) {                                                                                             \
       if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD, true, PLAIN_>), grid, block, pad, s, a, out);  \
       else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD, true, PLAIN_>), grid, block, pad, s, a, out);        \
     } else if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD48, false, PLAIN_>), grid, block, pad, s, a, out);  \

@@ -117,7 +117,9 @@ enum {
                                the single-pass binning writes 40-byte entries and falls back to 48 bytes -- one
                                GR_EOVERFLOW retry, remembered like the slots per tile -- for images with faces of
                                93 pixels and more); 512 = the general ids kernel (depth output, any width) also for calls
-                               the plain one would take (ids only, rows of whole 16-byte pieces)                        */
+                               the plain one would take (ids only, rows of whole 16-byte pieces); 1024 = rolling chains of
+                               16 tiles (the next tile's first chunk requested while the current one is rasterized) for the
+                               ids kernels too (default: the fused kernel only); 2048 = no rolling chains               */
   GR_OPT_SHARE_LEARNED = 8, /* 1 (default): consult and feed the process-wide table of learned slots per tile / entry forms
                                (and its file, gr_learned_cache_file); 0: this context learns for itself only.  Setting
                                GR_OPT_DIRECT_CAP by hand switches it off; this option switches it back on            */

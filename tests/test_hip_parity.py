@@ -22,7 +22,11 @@ VARIANTS = {"tile32_chain": (5, 512, 16), "tile64_single_full": (6, 512, 129), "
             "tile64_exact_chain": (6, 0, 16), "tile32_single_nospec_full": (5, 512, 141), "tile32_chain_nospec_nobitmap": (5, 512, 56),
             "tile32_chain_biglist": (5, 512, 80), "tile64_single": (6, 512, 1),
             # 512: the general ids kernel (depth / odd widths) also where the plain one (16-byte id stores only) would run
-            "tile32_chain_general_ids": (5, 512, 528), "tile64_single_general_ids": (6, 512, 513)}
+            "tile32_chain_general_ids": (5, 512, 528), "tile64_single_general_ids": (6, 512, 513),
+            # 1024: rolling chains of 16 tiles (k_raster_tile_roll) for the ids kernels too (the fused kernel's default wherever a
+            # chain of four would run); 2048: none
+            "tile32_roll": (5, 512, 1040), "tile32_roll_full_general": (5, 512, 1040 + 128 + 512),
+            "tile32_chain_no_roll": (5, 512, 16 + 2048)}
 
 
 @pytest.fixture(params=list(VARIANTS), autouse=True)
