@@ -561,11 +561,48 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
     __syncthreads();  // keys filled, chunk visible
     GR_STAMP(2);
     GR_PRIO_ITEMS();
+#if !(GR_EXP & 2048)
+    // LATER CHUNKS ARE REQUESTED ONE CHUNK AHEAD (round 5).  A tile with more than 64 entries -- every tile of a down-scaled
+    // or a hostile view: 3-6 chunks at 1000 x 750 on the terrain, dozens under the forest -- used to load each later chunk and
+    // its row counts right where it staged them, behind the barrier that frees the chunk buffer: two exposed round trips
+    // per chunk, 80 % (terrain at quarter scale) to 94 % (forest) of a wave's life (tools/tile_phases.py).  Now the request
+    // for chunk c + 1 goes out before chunk c's items are walked and has that whole phase to arrive.  The row counts come as
+    // the low byte of an unaligned dword load: a byte load is zero-extended at once, i.e. waited for at once.
+    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+    auto request_chunk = [&](uint32_t c0, v4i &exn, uint32_t &nrn) {
+      if (c0 >= cnt) return;
+      nrn = *reinterpret_cast<const u32_unaligned *>(nr8 + c0 + lane);   // bytes behind the tile's entries: its segment / padding
+      if (lane < EL) {
+        const uint32_t qc = wv * EL + lane;  // piece of the chunk
+        const uint32_t q = (SHORT ? (c0 >> 1) * 5 : c0 * GR_ENT_Q) + qc;
+        if (SHORT ? short_piece_needed(qc, min(cnt - c0, 64u)) : q < cnt * GR_ENT_Q) exn = reinterpret_cast<const v4i *>(comp)[q];
+      }
+    };
+    uint32_t nrn = 0u;
+    request_chunk(64u, ex, nrn);
+#endif
     const int nrows = (uint32_t)lane < cnt ? (int)nr_first : 0;
     const int nb = raster_chunk_gather<TWL, TH, NW, PAD, SHORT>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot, GR_DBG(a));
     rot = (rot - nb) & (NW - 1);
     GR_STAMP(3);
+#if !(GR_EXP & 2048)
+#pragma unroll 1
+    for (uint32_t c0 = 64; c0 < cnt; c0 += 64) {
+      GR_PRIO_MEM();
+      __syncthreads();  // every wave is done with the previous chunk before it is overwritten
+      if (lane < EL) ent_st[wv * EL + lane] = ex;
+      const uint32_t e = c0 + (uint32_t)lane;
+      const int nrows_c = e < cnt ? (int)(nrn & 0xFFu) : 0;
+      request_chunk(c0 + 64u, ex, nrn);   // into the registers just staged: in flight through this chunk's items
+      __syncthreads();
+      GR_PRIO_ITEMS();
+      const int nbc = raster_chunk_gather<TWL, TH, NW, PAD, SHORT>(keys, tab_base, tab_self, gen, ent_lds, nrows_c, lane, rot, GR_DBG(a));
+      rot = (rot - nbc) & (NW - 1);
+      GR_STAMP(4);
+    }
+#endif
   }
+#if GR_EXP & 2048  // A/B build: every later chunk loaded where it is staged (rounds 1-4)
 #pragma unroll 1
   for (uint32_t c0 = 64; c0 < cnt; c0 += 64) {
     GR_PRIO_MEM();
@@ -584,6 +621,7 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
     rot = (rot - nb) & (NW - 1);
     GR_STAMP(4);
   }
+#endif
   int te = tid;
   asm volatile("" : "+v"(te));  // the epilogue's addresses are derived here, not hoisted above the scanline phase
   GR_PRIO_MEM();

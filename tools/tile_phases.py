@@ -46,6 +46,7 @@ def main():
     else:
         points, faces = synthetic.terrain_mesh()
         cams = synthetic.config2_cameras(50)
+        scale = 0.25 if wl.endswith("q") else 1.0   # c2q: config 2 at render_img_scale 0.25
     H, W = cams[0].get_image_size(scale)
     recs = torch.from_numpy(cams.get_raster_records(scale, near=1.0)[:nv]).cuda()
     hip = HipRaster(0)
