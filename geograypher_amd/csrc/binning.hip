@@ -162,15 +162,15 @@ struct FaceForm {
 
 __device__ __forceinline__ FaceForm face_form(const int4 p0, const int4 p1, const int4 p2, int TW, int TH);
 __device__ __forceinline__ bool tile_entry(const FaceForm &ff, int px0, int py0, int TW, int TH, int4 &e0, int4 &e1, int4 &e2,
-                                           int &rows);
+                                           int &rows, int *xinfo = nullptr);
 __device__ __forceinline__ bool compile_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
                                               uint8_t *__restrict__ nr8, int64_t idx, const int4 p0, const int4 p1,
-                                              const int4 p2, int px0, int py0, int TW, int TH);
+                                              const int4 p2, int px0, int py0, int TW, int TH, bool micro = false);
 __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const int4 p2, int px0, int py0, int TW, int TH,
-                                            int4 &e0, int4 &e1, int4 &e2, int &rows);
+                                            int4 &e0, int4 &e1, int4 &e2, int &rows, int *xinfo = nullptr);
 __device__ __forceinline__ void store_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
                                             uint8_t *__restrict__ nr8, int64_t idx, const int4 e0, const int4 e1, const int4 e2,
-                                            int rows);
+                                            int rows, int xinfo = -1);
 
 // R1 / R2 / R4 for one face of the soup: the record (three int4) that compile_entry turns into per-tile entries, and the
 // range of tiles its pixel bounding box touches.  Returns false for faces that draw nothing in this view; clip_me: the face
@@ -313,6 +313,7 @@ __attribute__((amdgpu_waves_per_eu(5, 5)))  // at most 96 VGPRs: five waves per 
 void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
   const int lane = threadIdx.x & 63;
   uint32_t n_rec = 0;                    // single-pass binning: the wave's record count (a statistic), added when the wave leaves a view
+  uint32_t n_mic = 0;                    // ... and its count of micro faces (pixel box at most 4 x 4)
 #ifdef GR_STAMPS
   unsigned long long sacc[6] = {0, 0, 0, 0, 0, 0}, st_ = __builtin_amdgcn_s_memtime(), siter = 0;
   const unsigned long long st0_ = st_, sr0_ = __builtin_amdgcn_s_memrealtime();
@@ -369,7 +370,8 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
   for (uint32_t g = g0; g < g1; g += gstep) {
   if (g >= v_end) {                      // the view item g lies in: the first whose inclusive prefix exceeds g
     if (DIRECT && lane == 0 && n_rec) atomicAdd(&ctrl[0], n_rec);
-    n_rec = 0;
+    if (DIRECT && lane == 0 && n_mic) atomicAdd(&ctrl[6], n_mic);
+    n_rec = 0; n_mic = 0;
     slot = __popcll(__ballot(vincl <= g));
     v_end = (uint32_t)__builtin_amdgcn_readlane((int)vincl, slot);
     v_beg = v_end - (uint32_t)__builtin_amdgcn_readlane((int)vcnt, slot);
@@ -448,10 +450,37 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
   const bool small_fp = keep && (tx1 - tx0 <= 1) && (ty1 - ty0 <= 1);
   uint32_t *cntS = ctrl + GR_CTRL_HDR;
   uint32_t *cntB = cntS + a.Tcap;
-  const int t00 = small_fp ? ty0 * a.TX + tx0 : -1;
-  const int t01 = (small_fp && tx1 > tx0) ? ty0 * a.TX + tx1 : -1;
-  const int t10 = (small_fp && ty1 > ty0) ? ty1 * a.TX + tx0 : -1;
-  const int t11 = (small_fp && tx1 > tx0 && ty1 > ty0) ? ty1 * a.TX + tx1 : -1;
+  // MICRO entries (round 5; single-pass binning with 40-byte entries): the (face, tile) pairs of a face whose pixel bounding
+  // box is at most 4 x 4 pixels -- nearly every face of a survey mesh at render_img_scale 0.25, the reference's operating
+  // point -- go to a SECOND list of their tile, filled from the back of the tile's segment and
+  // counted in the otherwise unused cntB array; the tile kernel takes it one lane per FACE (sixteen point-sampled pixels, no
+  // span solver, no mailboxes, no staging barriers: raster_tile.hip).  Bit 30 of a tile id marks the class, so that
+  // wave_group keeps the two lists' positions apart.
+  constexpr int GR_MICRO_BIT = 1 << 30;
+  int mcls = 0;  // bit k: tile slot k (0 first, 1 right, 2 below, 3 below right) is a micro entry
+  if (DIRECT) {
+    const int jmin = r2.z & 0xFFFF, jmax = (int)((uint32_t)r2.z >> 16), imin = r2.w & 0xFFFF, imax = (int)((uint32_t)r2.w >> 16);
+    // how many faces of the view are micro faces (whole box at most 4 x 4): the statistic that switches micro lists on for
+    // the NEXT call on this mesh and image size (gr_raster_status).  At full size only the clipped corners of ordinary faces
+    // would qualify (2 % of the pairs) and give nearly every tile a list of a handful of entries -- a whole extra phase per
+    // tile: ids kernel +7 % on C2 and C5 (profiles/r05_ab/micro_lists_per_tile_part.log) -- so the lists exist only where
+    // micro FACES are the rule; there every pair is classed by its own part of the box in its tile.
+    n_mic += (uint32_t)__popcll(__ballot(small_fp && jmax - jmin < 4 && imax - imin < 4));
+    if (a.micro && small_fp) {
+      const int xb = (tx0 + 1) << a.twl, yb = (ty0 + 1) << a.thl;   // first column / row of the right / lower tiles
+      const bool wl = min(jmax, xb - 1) - jmin < 4, wr = jmax - xb < 4, ht = min(imax, yb - 1) - imin < 4, hb = imax - yb < 4;
+      mcls = (wl && ht ? 1 : 0) | (wr && ht ? 2 : 0) | (wl && hb ? 4 : 0) | (wr && hb ? 8 : 0);
+    }
+  }
+  const int t00 = small_fp ? (ty0 * a.TX + tx0) | ((mcls & 1) ? GR_MICRO_BIT : 0) : -1;
+  const int t01 = (small_fp && tx1 > tx0) ? (ty0 * a.TX + tx1) | ((mcls & 2) ? GR_MICRO_BIT : 0) : -1;
+  const int t10 = (small_fp && ty1 > ty0) ? (ty1 * a.TX + tx0) | ((mcls & 4) ? GR_MICRO_BIT : 0) : -1;
+  const int t11 = (small_fp && tx1 > tx0 && ty1 > ty0) ? (ty1 * a.TX + tx1) | ((mcls & 8) ? GR_MICRO_BIT : 0) : -1;
+  // a tile's counter: cntS, or cntB for its micro list; an entry's slot: from the front of the segment, or from its back
+  auto counter_of = [&](int t) { return (t & GR_MICRO_BIT) ? &cntB[t & ~GR_MICRO_BIT] : &cntS[t]; };
+  auto slot_of = [&](int t, uint32_t pos) {
+    return (t & GR_MICRO_BIT) ? (int64_t)(t & ~GR_MICRO_BIT) * a.cap_tile + ((uint32_t)a.cap_tile - 1u - pos) : (int64_t)t * a.cap_tile + pos;
+  };
   int l0, k0, n0, l1 = lane, k1 = 0, n1 = 0, l2 = lane, k2 = 0, n2 = 0, l3 = lane, k3 = 0, n3 = 0;
   wave_group(t00, lane, l0, k0, n0);
   if (__ballot(t01 >= 0)) wave_group(t01, lane, l1, k1, n1);
@@ -464,10 +493,10 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
   // one after the other, tools/ubench/atomic_rate.hip)
   if (DIRECT) n_rec += (uint32_t)n;
   else if (lane == leader) base = atomicAdd(&ctrl[0], (uint32_t)n);
-  if (t00 >= 0 && lane == l0) b0 = atomicAdd(&cntS[t00], (uint32_t)n0);
-  if (t01 >= 0 && lane == l1) b1 = atomicAdd(&cntS[t01], (uint32_t)n1);
-  if (t10 >= 0 && lane == l2) b2 = atomicAdd(&cntS[t10], (uint32_t)n2);
-  if (t11 >= 0 && lane == l3) b3 = atomicAdd(&cntS[t11], (uint32_t)n3);
+  if (t00 >= 0 && lane == l0) b0 = atomicAdd(counter_of(t00), (uint32_t)n0);
+  if (t01 >= 0 && lane == l1) b1 = atomicAdd(counter_of(t01), (uint32_t)n1);
+  if (t10 >= 0 && lane == l2) b2 = atomicAdd(counter_of(t10), (uint32_t)n2);
+  if (t11 >= 0 && lane == l3) b3 = atomicAdd(counter_of(t11), (uint32_t)n3);
   if (!DIRECT) base = __shfl(base, leader);
   int4 r3;
   r3.x = (int)(__shfl(b0, l0) + (uint32_t)k0);
@@ -489,15 +518,14 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
 #if !(GR_EXP & 4)  // the compacted extra-tile round of rounds 2-4 (A/B bit 4: own-lane rounds from one FaceForm, measured +4 %)
     if (small_fp && !(GR_DBG(a) & 32)) {
       if ((uint32_t)r3.x < (uint32_t)a.cap_tile) {
-        const int64_t idx = (int64_t)t00 * a.cap_tile + (uint32_t)r3.x;
-        compile_entry(a, ctrl, comp, nr8, idx, r0, r1, r2, tx0 << a.twl, ty0 << a.thl, TW, TH);
+        compile_entry(a, ctrl, comp, nr8, slot_of(t00, (uint32_t)r3.x), r0, r1, r2, tx0 << a.twl, ty0 << a.thl, TW, TH, (mcls & 1) != 0);
       } else atomicOr(&ctrl[2], 1u);
     }
     const int shape = small_fp ? ((tx1 > tx0 ? 1 : 0) | (ty1 > ty0 ? 2 : 0)) : 0;  // which neighbours exist: 1 right, 2 below
     const int ne = shape == 3 ? 3 : (shape ? 1 : 0);
     const int incl_e = wave_incl_scan(ne);
     const int total_e = (GR_DBG(a) & (32 | 64)) ? 0 : __builtin_amdgcn_readlane(incl_e, 63);
-    const int geo = tx0 | (ty0 << 12) | (shape << 24);
+    const int geo = tx0 | (ty0 << 12) | (shape << 24) | (mcls << 26);
     for (int k0 = 0; k0 < total_e; k0 += 64) {
       const int q = k0 + lane;
       int t = 0;  // the face of pair q: the first lane whose inclusive sum exceeds q
@@ -515,9 +543,10 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
       if (q < total_e) {
         const uint32_t pos = (uint32_t)(k == 1 ? py : k == 2 ? pz : pw);
         const int tx = (g & 0xFFF) + (k & 1), ty = ((g >> 12) & 0xFFF) + (k >> 1);
+        const bool mic = ((g >> (26 + k)) & 1) != 0;
         if (pos < (uint32_t)a.cap_tile) {
-          const int64_t idx = (int64_t)(ty * a.TX + tx) * a.cap_tile + pos;
-          compile_entry(a, ctrl, comp, nr8, idx, p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH);
+          const int64_t idx = slot_of((ty * a.TX + tx) | (mic ? GR_MICRO_BIT : 0), pos);
+          compile_entry(a, ctrl, comp, nr8, idx, p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH, mic);
         } else atomicOr(&ctrl[2], 1u);
       }
     }
@@ -535,8 +564,10 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
           if (pos < (uint32_t)a.cap_tile) {
             int4 e0, e1, e2;
             int rows;
-            tile_entry(ff, tx << a.twl, ty << a.thl, TW, TH, e0, e1, e2, rows);
-            store_entry(a, ctrl, comp, nr8, (int64_t)(ty * a.TX + tx) * a.cap_tile + pos, e0, e1, e2, rows);
+            int xinfo = -1;
+            const bool mic = ((mcls >> k) & 1) != 0;
+            tile_entry(ff, tx << a.twl, ty << a.thl, TW, TH, e0, e1, e2, rows, &xinfo);
+            store_entry(a, ctrl, comp, nr8, slot_of((ty * a.TX + tx) | (mic ? GR_MICRO_BIT : 0), pos), e0, e1, e2, rows, mic ? xinfo : -1);
           } else atomicOr(&ctrl[2], 1u);
         }
       }
@@ -576,6 +607,7 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
   GR_SSTAMP(5);
   }  // work list loop
   if (DIRECT && lane == 0 && n_rec) atomicAdd(&ctrl[0], n_rec);
+  if (DIRECT && lane == 0 && n_mic) atomicAdd(&ctrl[6], n_mic);
 #ifdef GR_STAMPS
   if (lane == 0 && a.stamps) {  // the second half of the stamp buffer: 1024 slots of 16 words
     unsigned long long *sd = a.stamps + 16 * 1024 + 16 * ((blockIdx.x * 4 + (threadIdx.x >> 6) + blockIdx.y * 977) & 1023);
@@ -597,7 +629,8 @@ __global__ __launch_bounds__(1024) void k_bin_stats(BinArgs a) {
   const uint32_t *cnt = ctrl + GR_CTRL_HDR;
   unsigned long long sum = 0;
   uint32_t mx = 0;
-  for (int t = threadIdx.x; t < a.T; t += 1024) { const uint32_t c = cnt[t]; sum += c; mx = max(mx, c); }
+  // (with micro lists a tile's segment holds both lists, one from each end: the two counts together must fit)
+  for (int t = threadIdx.x; t < a.T; t += 1024) { const uint32_t c = cnt[t] + (a.micro ? cnt[a.Tcap + t] : 0u); sum += c; mx = max(mx, c); }
   for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); }
   if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = sum; pmax[threadIdx.x >> 6] = mx; }
   __syncthreads();
@@ -627,6 +660,7 @@ __global__ __launch_bounds__(1024) void k_bin_stats(BinArgs a) {
     const bool ovf = m > (uint32_t)a.cap_tile || ctrl[2] != 0;
     atomicAdd(&a.stats[0], (unsigned long long)ctrl[0]);
     atomicAdd(&a.stats[1], total);
+    atomicAdd(&a.stats[8], (unsigned long long)ctrl[6]);  // micro faces (pixel box at most 4 x 4)
     atomicMax(&a.stats[2], (unsigned long long)m);  // direct mode: the largest per-tile count
     if (ovf) { atomicMax(&a.stats[3], 1ull); atomicMin(&a.stats[4], (unsigned long long)a.group); }
     if (ctrl[2] & 2u) atomicMax(&a.stats[5], 1ull);  // a face the 40-byte entry form cannot hold
@@ -753,7 +787,7 @@ __device__ __forceinline__ FaceForm face_form(const int4 p0, const int4 p1, cons
 }
 
 __device__ __forceinline__ bool tile_entry(const FaceForm &ff, int px0, int py0, int TW, int TH, int4 &e0, int4 &e1, int4 &e2,
-                                           int &rows) {
+                                           int &rows, int *xinfo) {
   const int Pxo = px0 * 256 + 128, Pyo = py0 * 256 + 128;  // centre of the tile's first pixel
   const int jlo = max(ff.jmin - px0, 0), jhi = min(ff.jmax - px0, TW - 1);
   const int ilo = max(ff.imin - py0, 0), ihi = min(ff.imax - py0, TH - 1);
@@ -792,6 +826,9 @@ __device__ __forceinline__ bool tile_entry(const FaceForm &ff, int px0, int py0,
   const bool touches = nr > 0 && cf + ff.rf >= 0 && cm + ff.rm >= 0 && cl + ff.rl >= 0;
   if (!touches) nr = 0;
   rows = nr;
+  // a MICRO entry (clipped bounding box of at most 4 x 4 pixels, K1) also says where its columns are: first column in the
+  // tile (6 bits) | columns - 1 (2 bits)
+  if (xinfo) *xinfo = (jlo & 63) | ((min(max(jhi - jlo, 0), 3)) << 6);
   // float(P_x - X0) of the pixel with CENTRED column x_c = x - TW/2 is float(256 x_c + Xw)
   const int xw = ((Pxo - ff.X0 + (TW / 2) * 256) & 0xFFFFFF) | (nr << 24);
   e0 = make_int4(cf, cm, cl, ff.w3);
@@ -803,9 +840,9 @@ __device__ __forceinline__ bool tile_entry(const FaceForm &ff, int px0, int py0,
 }
 
 __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const int4 p2, int px0, int py0, int TW, int TH,
-                                            int4 &e0, int4 &e1, int4 &e2, int &rows) {
+                                            int4 &e0, int4 &e1, int4 &e2, int &rows, int *xinfo) {
   const FaceForm ff = face_form(p0, p1, p2, TW, TH);
-  return tile_entry(ff, px0, py0, TW, TH, e0, e1, e2, rows);
+  return tile_entry(ff, px0, py0, TW, TH, e0, e1, e2, rows, xinfo);
 }
 
 // The SHORT form of an entry, 40 bytes (single-pass binning, a.ent40): what a face whose snapped bounding box stays below
@@ -821,7 +858,7 @@ __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const 
 // for a tile that outgrew its segment, remembers that this (mesh, image) needs 48-byte entries, and the caller repeats.
 __device__ __forceinline__ void store_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
                                             uint8_t *__restrict__ nr8, int64_t idx, const int4 e0, const int4 e1, const int4 e2,
-                                            int rows) {
+                                            int rows, int xinfo) {
   if (a.ent40) {
     // e1.y (the third slope word) is zero for 16-bit slopes; bit 0 of it is build_entry's "too large for the short form"
     // (the slot was handed out already: it must not keep stale bytes -- an older view's entry, or 48-byte data read as a
@@ -832,7 +869,10 @@ __device__ __forceinline__ void store_entry(const BinArgs &a, uint32_t *__restri
     char *chunk = reinterpret_cast<char *>(comp) + (idx >> 6) * 2560;
     const int t = (int)(idx & 63);
     int4 *d4 = reinterpret_cast<int4 *>(chunk) + t * 2;
-    d4[0] = make_int4(e0.x, e0.y, (int)(((uint32_t)e0.z & 0xFFFFFFu) | ((uint32_t)e2.w & 0x3F000000u) | (((uint32_t)e2.w << 1) & 0x80000000u)),
+    // a micro entry (xinfo >= 0; short form only, K1 hands such entries to the tile's SECOND list) carries its column range in
+    // the top byte of c_mid, whose value needs 24 bits there (|c| < 2^23 for a face of a few pixels)
+    const int cmid = xinfo >= 0 ? (int)(((uint32_t)e0.y & 0xFFFFFFu) | ((uint32_t)xinfo << 24)) : e0.y;
+    d4[0] = make_int4(e0.x, cmid, (int)(((uint32_t)e0.z & 0xFFFFFFu) | ((uint32_t)e2.w & 0x3F000000u) | (((uint32_t)e2.w << 1) & 0x80000000u)),
                       (int)(((uint32_t)e2.y & 0xFFFFu) | ((uint32_t)e2.w << 16)));
     d4[1] = make_int4(e0.w, e1.x, e1.z, e1.w);
     reinterpret_cast<uint2 *>(chunk + 2048)[t] = make_uint2((uint32_t)e2.z, (uint32_t)e2.x);
@@ -845,11 +885,11 @@ __device__ __forceinline__ void store_entry(const BinArgs &a, uint32_t *__restri
 
 __device__ __forceinline__ bool compile_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
                                               uint8_t *__restrict__ nr8, int64_t idx, const int4 p0, const int4 p1,
-                                              const int4 p2, int px0, int py0, int TW, int TH) {
+                                              const int4 p2, int px0, int py0, int TW, int TH, bool micro) {
   int4 e0, e1, e2;
-  int rows;
-  const bool touches = build_entry(p0, p1, p2, px0, py0, TW, TH, e0, e1, e2, rows);
-  store_entry(a, ctrl, comp, nr8, idx, e0, e1, e2, rows);
+  int rows, xinfo = -1;
+  const bool touches = build_entry(p0, p1, p2, px0, py0, TW, TH, e0, e1, e2, rows, &xinfo);
+  store_entry(a, ctrl, comp, nr8, idx, e0, e1, e2, rows, micro ? xinfo : -1);
   return touches;
 }
 

@@ -50,10 +50,10 @@ inline int merge_cap(int a, int b) { return (a == GR_LEARNED_EXACT || b == GR_LE
 void put_global_locked(const gr_ctx::Learned &v);
 
 bool parse_learned_line(const char *line, gr_ctx::Learned &v) {
-  unsigned long long m; int T, cap, full;
-  if (line[0] == '#' || sscanf(line, "%llx %d %d %d", &m, &T, &cap, &full) != 4) return false;
+  unsigned long long m; int T, cap, full, micro = 0;
+  if (line[0] == '#' || sscanf(line, "%llx %d %d %d %d", &m, &T, &cap, &full, &micro) < 4) return false;   // the fifth field came with 0.2.2
   if (T <= 0 || cap < GR_LEARNED_EXACT || cap > GR_LEARNED_MAX_CAP) return false;
-  v = {(uint64_t)m, T, cap, full != 0};
+  v = {(uint64_t)m, T, cap, full != 0, micro != 0};
   return true;
 }
 
@@ -72,9 +72,10 @@ void save_learned_locked() {
   snprintf(tmp, sizeof(tmp), "%s.tmp.%d", g_learned_path, (int)getpid());
   FILE *f = fopen(tmp, "w");
   if (!f) return;
-  fprintf(f, "# libgeograster: slots per tile (-1: exact binning) / entry form learned per (mesh signature, tile count)\n");
+  fprintf(f, "# libgeograster: slots per tile (-1: exact binning) / 48-byte entries / micro lists learned per (mesh signature, tile count)\n");
   for (int i = 0; i < std::min(g_n_learned, 64); ++i)
-    fprintf(f, "%016llx %d %d %d\n", (unsigned long long)g_learned[i].mesh, g_learned[i].T, g_learned[i].cap, g_learned[i].full ? 1 : 0);
+    fprintf(f, "%016llx %d %d %d %d\n", (unsigned long long)g_learned[i].mesh, g_learned[i].T, g_learned[i].cap, g_learned[i].full ? 1 : 0,
+            g_learned[i].micro ? 1 : 0);
   fclose(f);
   if (rename(tmp, g_learned_path) != 0) (void)remove(tmp);
 }
@@ -90,17 +91,27 @@ void put_global_locked(const gr_ctx::Learned &v) {
   }
   g_learned[j].cap = merge_cap(g_learned[j].cap, v.cap);
   g_learned[j].full = g_learned[j].full || v.full;
+  g_learned[j].micro = g_learned[j].micro || v.micro;
 }
 
 // what is known about images of T tiles of the current mesh: slots per tile (0: nothing learned) and the entry form
-void lookup_learned(const gr_ctx *c, int T, int &cap, bool &full) {
+void lookup_learned(const gr_ctx *c, int T, int &cap, bool &full, bool *micro = nullptr) {
   cap = 0; full = false;
+  if (micro) *micro = false;
   for (int i = 0; i < std::min(c->n_learned, 8); ++i)
-    if (c->learned[i].mesh == c->mesh_sig && c->learned[i].T == T) { cap = c->learned[i].cap; full = c->learned[i].full; return; }
+    if (c->learned[i].mesh == c->mesh_sig && c->learned[i].T == T) {
+      cap = c->learned[i].cap; full = c->learned[i].full;
+      if (micro) *micro = c->learned[i].micro;
+      return;
+    }
   if (c->share_learned) {
     std::lock_guard<std::mutex> lk(g_learned_mu);
     for (int i = 0; i < std::min(g_n_learned, 64); ++i)
-      if (g_learned[i].mesh == c->mesh_sig && g_learned[i].T == T) { cap = g_learned[i].cap; full = g_learned[i].full; return; }
+      if (g_learned[i].mesh == c->mesh_sig && g_learned[i].T == T) {
+        cap = g_learned[i].cap; full = g_learned[i].full;
+        if (micro) *micro = g_learned[i].micro;
+        return;
+      }
   }
 }
 
@@ -110,20 +121,23 @@ void lookup_learned(const gr_ctx *c, int T, int &cap, bool &full) {
 // laid out in chunks of 64 entries (store_entry): a tile's segment must be a whole number of chunks -- slots per tile set by
 // hand to anything else: 48 bytes.
 void resolve_binning(gr_ctx *c, int T) {
-  int cap = 0; bool full = false;
-  c->cur_cap = 0; c->cur_ent40 = false;
+  int cap = 0; bool full = false, micro = false;
+  c->cur_cap = 0; c->cur_ent40 = false; c->cur_micro = false;
   if (c->opt_direct_cap <= 0 || !c->direct_ok) return;
-  lookup_learned(c, T, cap, full);
+  lookup_learned(c, T, cap, full, &micro);
   if (cap == GR_LEARNED_EXACT) return;  // this (mesh, image size) bins exactly: one view's segments would not fit the budget
   c->cur_cap = std::max(cap, c->opt_direct_cap);
   c->cur_ent40 = !(c->cur_cap & 63) && !(c->opt_var & 128) && !full;
+  // micro lists: where an earlier call found most faces of the image at most 4 x 4 pixels (gr_raster_status; remembered like
+  // the slots per tile), with 40-byte entries.  Variant bits: 8192 = always, 4096 = never.
+  c->cur_micro = c->cur_ent40 && !(c->opt_var & 4096) && (micro || (c->opt_var & 8192));
 }
 
 // cap > 0: the slots per tile the image needs; full: it needs 48-byte entries (both are kept once learned)
-void learn(gr_ctx *c, int T, int cap, bool full) {
-  int old_cap; bool old_full;
-  lookup_learned(c, T, old_cap, old_full);
-  const gr_ctx::Learned v = {c->mesh_sig, T, merge_cap(cap, old_cap), full || old_full};
+void learn(gr_ctx *c, int T, int cap, bool full, bool micro = false) {
+  int old_cap; bool old_full, old_micro;
+  lookup_learned(c, T, old_cap, old_full, &old_micro);
+  const gr_ctx::Learned v = {c->mesh_sig, T, merge_cap(cap, old_cap), full || old_full, micro || old_micro};
   int i = 0;
   for (; i < std::min(c->n_learned, 8); ++i)
     if (c->learned[i].mesh == c->mesh_sig && c->learned[i].T == T) break;
@@ -207,7 +221,7 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   note_stream(c, s);
   GR_HIP(c, hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 4, s));
   GR_HIP(c, hipMemsetAsync(c->stats + 4, 0xFF, sizeof(unsigned long long), s));  // first overflowed group: none
-  GR_HIP(c, hipMemsetAsync(c->stats + 5, 0, sizeof(unsigned long long) * 3, s)); // short-form miss: none; blocks, chunk visits
+  GR_HIP(c, hipMemsetAsync(c->stats + 5, 0, sizeof(unsigned long long) * 4, s)); // short-form miss: none; blocks, chunk visits, micro faces
   c->last_n_views = n_views;
   int g = 0;
   for (int v0 = 0; v0 < n_views; v0 += B, ++g) {
@@ -268,12 +282,12 @@ int gr_ctx_create(int device, gr_ctx **out) {
   gr_ctx *c = new (std::nothrow) gr_ctx();
   if (!c) return GR_ENOMEM;
   c->device = device;
-  if (hipMalloc(&c->stats, sizeof(unsigned long long) * 8) != hipSuccess ||
+  if (hipMalloc(&c->stats, sizeof(unsigned long long) * 16) != hipSuccess ||
       hipMalloc(&c->flag, sizeof(int) * 8) != hipSuccess) {  // flag word + upload scratch (vertex bounds)
     delete c;
     return GR_ENOMEM;
   }
-  (void)hipMemset(c->stats, 0, sizeof(unsigned long long) * 8);
+  (void)hipMemset(c->stats, 0, sizeof(unsigned long long) * 16);
 #ifdef GR_STAMPS
   if (hipMalloc(&c->stamps, sizeof(unsigned long long) * 32 * 1024) == hipSuccess) (void)hipMemset(c->stamps, 0, sizeof(unsigned long long) * 32 * 1024);
 #endif
@@ -429,7 +443,7 @@ int gr_raster_face_ids(gr_ctx *c, const float *cams, int n_views, int h, int w, 
 
 int gr_raster_status(gr_ctx *c, gr_raster_stats *o) {
   if (!c || !o) return GR_EINVAL;
-  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   GR_HIP(c, hipMemcpyAsync(st, c->stats, sizeof(st), hipMemcpyDeviceToHost, c->last_stream));
   GR_HIP(c, hipStreamSynchronize(c->last_stream));
   o->records = (int64_t)st[0]; o->entries = (int64_t)st[1]; o->max_entries = (int64_t)st[2];
@@ -459,6 +473,10 @@ int gr_raster_status(gr_ctx *c, gr_raster_stats *o) {
     return fail(c, GR_EOVERFLOW, "single-pass binning: a face does not fit the 40-byte entry form; retry the call "
                 "(48-byte entries from now on)");
   }
+  // Most of the image's faces are at most 4 x 4 pixels (K1 counts them; a survey mesh rendered at a quarter of its photos'
+  // resolution: 85-95 %): the next call for this mesh and image size keeps micro lists (no retry: this call's result stands)
+  if (!st[3] && c->last_direct && c->cur_ent40 && !c->cur_micro && !(c->opt_var & 4096) && st[0] > 0 && 5 * st[8] > 2 * st[0])
+    learn(c, c->last_T, 0, false, true);
   if (st[3]) {
     // grow on the next call: exact need is known
     c->ent_cap_request = (int64_t)st[2] + (int64_t)st[2] / 8 + 65536;

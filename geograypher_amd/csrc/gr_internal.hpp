@@ -80,6 +80,7 @@ struct BinArgs {
   int twl, thl;          // log2 of the tile width / height in pixels
   int cap_tile;          // > 0: single-pass binning, every tile owns cap_tile entry slots (list base = tile * cap_tile)
   int ent40;             // 1: entries are written in the SHORT form (40 bytes, store_entry below); single-pass binning only
+  int micro;             // 1: (face, tile) pairs of at most 4 x 4 pixels go to the tile's second list (K1 / raster_one_tile); needs ent40
   int var;               // variant bits (GR_OPT_VARIANT): 1 = one tile per workgroup instead of four, 4 = votes on the caller's stream, 8 = no speculative first chunk, 16 = chains of four whatever the launch looks like, 32 = votes without chunk bitmaps
 #ifdef GR_STAMPS
   unsigned long long *stamps;  // diagnostic build: [16] cycles per tile-kernel phase, summed over waves (raster_tile.hip)
@@ -140,7 +141,7 @@ struct gr_ctx {
   int opt_var = 0;
   int opt_lds_pad = 0;   // extra dynamic LDS bytes per tile workgroup (occupancy experiments, GR_OPT_DEBUG_LDS)
   int opt_direct_cap = 512;  // single-pass binning: entry slots per tile (0 = always use the exact two-pass path)
-  struct Learned { uint64_t mesh; int T, cap; bool full; };
+  struct Learned { uint64_t mesh; int T, cap; bool full; bool micro = false; };
   Learned learned[8] = {};             // slots per tile learned from overflows -- and whether the image has faces the 40-byte entry
                                        // form cannot hold --, per (mesh signature, tile count); [n_learned % 8] is replaced next
   int n_learned = 0;
@@ -152,6 +153,7 @@ struct gr_ctx {
   // of every launch group must agree on the slots per tile and on the entry form.
   int cur_cap = 0;                     // single-pass binning: slots per tile (0: exact two-pass binning)
   bool cur_ent40 = false;              // 40-byte entries
+  bool cur_micro = false;              // micro lists (faces of at most 4 x 4 pixels on a second list per tile) for this call
   int64_t opt_budget_mb = 24 << 10;    // entry memory of one launch group (GR_OPT_DIRECT_BUDGET_MB)
   int last_T = 0, last_B = 0;          // tile count and launch-group size of the last raster call
   int last_n_views = 0;
@@ -275,6 +277,7 @@ inline BinArgs make_args(gr_ctx *c, int h, int w, int slot0) {
   a.h = h; a.w = w; a.dbg = c->opt_dbg; a.var = c->opt_var;
   a.cap_tile = c->cur_cap;          // the call's snapshot: every launch group, bin pass and tile pass alike
   a.ent40 = c->cur_ent40 ? 1 : 0;
+  a.micro = c->cur_micro ? 1 : 0;   // resolved once per call (resolve_binning)
   a.group = 0;
 #ifdef GR_STAMPS
   a.stamps = c->stamps;

@@ -237,6 +237,56 @@ __device__ __forceinline__ void raster_item(unsigned long long *keys, const Entr
   }
 }
 
+// MICRO entries (round 5): one lane = one FACE.  K1 sends a (face, tile) pair whose part of the pixel bounding box in the tile
+// is at most 4 x 4 pixels to the tile's second list (binning.hip); such a face is not worth scanline items -- three rows of
+// two pixels at render_img_scale 0.25, each paying the span solver's three reciprocals, the mailbox look-up and its share of
+// two barriers per chunk.  Here the lane point-samples the (at most) sixteen pixel centres of the box with the entry's own
+// edge functions E'_k = C'_k + a_k x_c + b_k y_c >= 0 (three adds per pixel) and the same 1/z expression as raster_item, op
+// for op (R4): identical coverage and identical depth bits, whichever list a face was put in.  The entry is the 40-byte form
+// as it stands plus the box's first column and width in the top byte of c_mid (store_entry).  nrows: rows of the box (0: a
+// lane without an entry).  Rows and columns outside the tile can only come from a torn entry of an overflowed pass (the view
+// is repeated): they are masked, never written.
+template <int TWL, int TH, int PAD>
+__device__ __forceinline__ void micro_item(unsigned long long *keys, const int4 ea, const int4 eb, const uint2 s89, const int nrows) {
+  constexpr int TW = 1 << TWL;
+  const int c0 = ea.x, c1 = __builtin_amdgcn_sbfe(ea.y, 0, 24), c2 = __builtin_amdgcn_sbfe(ea.z, 0, 24);
+  const int xinfo = (int)((uint32_t)ea.y >> 24);
+  const int y_first = __builtin_amdgcn_sbfe(ea.z, 24, 6);
+  const int X0rel = __builtin_amdgcn_sbfe(ea.w, 0, 16), Y0rel = ea.w >> 16;
+  const int a0 = __builtin_amdgcn_sbfe(eb.x, 0, 16), a1 = eb.x >> 16, b0 = __builtin_amdgcn_sbfe(eb.y, 0, 16), b1 = eb.y >> 16;
+  const int a2 = -(a0 + a1), b2 = -(b0 + b1);                 // the last edge's slopes are not stored (they sum to zero)
+  const float iz0 = __int_as_float(eb.z), A = __int_as_float(eb.w), B = __uint_as_float(s89.y);
+  const uint32_t key = s89.x;
+  const int xc0 = (xinfo & 63) - TW / 2;                      // centred first column
+  const int last_col = xinfo >> 6;                            // columns - 1
+  const float fx0 = (float)(xc0 * 256 + X0rel);
+#pragma unroll 1   // (unrolled, the sixteen pixels' temporaries cost the chain kernels their 64-register budget)
+  for (int r = 0; r < 4; ++r) {
+    const bool rl = r < nrows;
+    if (!__ballot(rl)) break;
+    const int yc = y_first + r;
+    int e0 = c0 + __mul24(b0, yc) + __mul24(a0, xc0);
+    int e1 = c1 + __mul24(b1, yc) + __mul24(a1, xc0);
+    int e2 = c2 + __mul24(b2, yc) + __mul24(a2, xc0);
+    // a fourth "edge": columns left in the box (negative beyond it, and for a row this lane does not have or that lies outside the tile)
+    int e3 = (rl && (uint32_t)(yc + TH / 2) < (uint32_t)TH) ? last_col : -1;
+    const float m1 = B * (float)(yc * 256 + Y0rel);
+    unsigned long long *row = keys + (__mul24(yc + TH / 2, TW + PAD) + xc0 + TW / 2);
+    float fx = fx0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool in = ((e0 | e1) | (e2 | e3)) >= 0;
+      float t = A * fx;
+      t = m1 + t;
+      const float z = iz0 + t;
+      const int zb = max(__float_as_int(z), 1);
+      if (in) atomicMax(row + j, ((unsigned long long)(uint32_t)zb << 32) | key);
+      e0 += a0; e1 += a1; e2 += a2; e3 -= 1;
+      fx += 256.0f;
+    }
+  }
+}
+
 // Phases 2-3 for one CHUNK of up to 64 entries staged in LDS (`ent`, 48 bytes each).  Every wave of the workgroup scans
 // the same 64 row counts; batch b of the chunk belongs to wave (b + rot) % NW.  tab: the wave's 64 mailbox words in LDS,
 // gen: the wave's batch counter (mailbox generation).  Returns the number of batches of the chunk.
@@ -494,10 +544,10 @@ __device__ __forceinline__ bool short_piece_needed(uint32_t q, uint32_t n) {
 // The four first-chunk requests a rolling chain keeps in flight (k_raster_tile_roll): whole 16-byte tuples + the row counts.
 struct ChunkRing { v4i e0; uint32_t n0; };
 
-template <int TWL, int THL, int NT, bool FUSE, int PAD, bool SHORT, bool WAIT, bool PLAIN, bool ROLL = false>
+template <int TWL, int THL, int NT, bool FUSE, int PAD, bool SHORT, bool WAIT, bool PLAIN, bool ROLL = false, bool MICRO = false>
 __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOut &out, unsigned long long *keys, const int slot,
                                                 const int tile, uint32_t cnt, const int64_t beg, uint32_t nr_first, v4i ex GR_STAMP_ARG,
-                                                ChunkRing *ring = nullptr) {
+                                                ChunkRing *ring = nullptr, uint32_t cntm = 0u) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
   constexpr int NKEYS = (TW + PAD) * TH;
   constexpr int NW = NT / 64;
@@ -518,7 +568,14 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
                            : a.comp + (slot * a.ent_cap + beg) * GR_ENT_Q;
   const uint8_t *nr8 = a.nrow8 + slot * a.ent_cap + beg;
 
-  if (!FUSE && cnt == 0) {  // empty tile (a view that overhangs the mesh): background, without the LDS round trip
+  // the tile's MICRO list (single-pass binning with 40-byte entries): cntm entries from the back of the segment; the scanline
+  // list must not reach into it (the two can only collide in a pass whose tile outgrew its segment: the view is repeated)
+  if (!(SHORT && MICRO)) cntm = 0u;
+  if (SHORT && MICRO) {
+    cntm = min(cntm, (uint32_t)a.cap_tile);
+    cnt = min(cnt, (uint32_t)a.cap_tile - cntm);
+  }
+  if (!FUSE && cnt == 0 && cntm == 0) {  // empty tile (a view that overhangs the mesh): background, without the LDS round trip
     // (a rolling chain waits for its ring here as well, before the stores: a path that left the function with a request in
     // flight made the compiler wait for EVERYTHING -- the previous tile's stores included -- at the next tile's first request)
     if (ROLL) asm volatile("" : "+v"(ring->e0), "+v"(ring->n0));
@@ -622,6 +679,23 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
     GR_STAMP(4);
   }
 #endif
+  if (SHORT && MICRO && cntm > 0) {
+    // micro entries: every wave reads ITS chunks of 64 straight from the segment (no staging, no barrier), one face per lane.
+    // Entry k of the list sits in slot cap - 1 - k: block (slot / 64) of 2560 bytes, 32 + 8 bytes at position slot % 64.
+    const char *segb = reinterpret_cast<const char *>(comp);
+    const uint32_t top = (uint32_t)a.cap_tile - 1u;
+#pragma unroll 1
+    for (uint32_t c = (uint32_t)wv; c * 64u < cntm; c += NW) {
+      const uint32_t k = c * 64u + (uint32_t)lane;
+      const uint32_t sl = top - min(k, top);
+      const char *blk = segb + (sl >> 6) * 2560u;
+      const uint32_t tp = sl & 63u;
+      const int4 ea = *reinterpret_cast<const int4 *>(blk + tp * 32u), eb = *reinterpret_cast<const int4 *>(blk + tp * 32u + 16u);
+      const uint2 s89 = *reinterpret_cast<const uint2 *>(blk + 2048u + tp * 8u);
+      const int nrows = k < cntm ? min((int)nr8[sl], 4) : 0;
+      micro_item<TWL, TH, PAD>(keys, ea, eb, s89, nrows);
+    }
+  }
   int te = tid;
   asm volatile("" : "+v"(te));  // the epilogue's addresses are derived here, not hoisted above the scanline phase
   GR_PRIO_MEM();
@@ -673,7 +747,10 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
 // fused kernel is not (left at the default).  Work items of two consecutive rows (look-up, unpack and the reciprocals paid
 // once per two rows: -16 % VALU instructions) were measured as well: 74 VGPRs and half as many batches per tile for four
 // waves -- 15.6 vs 16.0 without the hint, 16.3 vs 15.3 with it, fused 18.3 vs 17.2 -- dropped.
-template <int TWL, int THL, int NT, bool FUSE, int KT, int PAD, bool SHORT, bool PLAIN = false>
+// MICRO: the kernels of a call that keeps micro lists (binning.hip; chosen per mesh and image size, gr_raster_status) -- a build of
+// their own: the second list's counters and phase cost the ordinary kernels 6 of their 64 registers and 1-2.6 % on C2 even
+// when every micro list is empty (profiles/r05_ab/micro_lists_whole_face.log).
+template <int TWL, int THL, int NT, bool FUSE, int KT, int PAD, bool SHORT, bool PLAIN = false, bool MICRO = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(THL == 5 ? GR_WPE : (FUSE ? 1 : 4), 8)))
 __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile(BinArgs a, RasterOut out) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
@@ -723,7 +800,14 @@ __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile(BinArgs a, Rast
   // not walked at all (one scalar load beside the counters')
   if (FUSE && ctrl[2] != 0u) return;
   uint32_t cnt0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
+  uint32_t cm0 = 0, cm1 = 0, cm2 = 0, cm3 = 0;   // the tiles' micro lists (counted in the cntB array: binning.hip)
   int64_t beg0, beg1 = 0, beg2 = 0, beg3 = 0;
+  if (SHORT && MICRO) {
+    if (KT == 4) {
+      const uint4 m4 = *reinterpret_cast<const uint4 *>(ctrl + GR_CTRL_HDR + a.Tcap + tile0);
+      cm0 = m4.x; cm1 = n_tiles > 1 ? m4.y : 0u; cm2 = n_tiles > 2 ? m4.z : 0u; cm3 = n_tiles > 3 ? m4.w : 0u;
+    } else cm0 = ctrl[GR_CTRL_HDR + a.Tcap + tile0];
+  }
   if (KT == 4 && a.cap_tile > 0) {
     // single-pass binning: the chain's four counters sit side by side, 16-byte aligned -- ONE scalar load instead of four
     // dependent ones, each behind its own wait (words behind the last tile's belong to the next counter array: valid memory)
@@ -742,7 +826,7 @@ __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile(BinArgs a, Rast
       if (n_tiles > 3) tile_list(a, ctrl, tile0 + 3, cnt3, beg3);
     }
   }
-  if (GR_DBG(a) & 4) cnt0 = cnt1 = cnt2 = cnt3 = 0;
+  if (GR_DBG(a) & 4) cnt0 = cnt1 = cnt2 = cnt3 = cm0 = cm1 = cm2 = cm3 = 0;
   const int64_t sbase = slot * a.ent_cap;
   if (!spec) {  // exact binning (or segments under 64 slots): the first chunk can only be requested now
     if ((uint32_t)lane < cnt0) nr0 = a.nrow8[sbase + beg0 + lane];
@@ -781,14 +865,14 @@ __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile(BinArgs a, Rast
 #endif
   GR_STAMP(0);
   static_assert(!(FUSE && PLAIN), "the plain kernel writes ids only");
-  raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, KT == 1, PLAIN>(a, out, keys, slot, tile0, cnt0, beg0, nr0, ex0 GR_STAMP_PASS);
+  raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, KT == 1, PLAIN, false, MICRO>(a, out, keys, slot, tile0, cnt0, beg0, nr0, ex0 GR_STAMP_PASS, nullptr, cm0);
   if (KT > 1) {
 #pragma unroll 1
     for (int k = 1; k < n_tiles; ++k) {  // ONE copy of the tile code for tiles 1 .. 3: the chunks rotate through ex1
       __syncthreads();                   // every wave has read the previous tile's keys
       GR_STAMP(7);
-      raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, false, PLAIN>(a, out, keys, slot, tile0 + k, cnt1, beg1, nr1, ex1 GR_STAMP_PASS);
-      cnt1 = cnt2; cnt2 = cnt3; beg1 = beg2; beg2 = beg3;
+      raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, false, PLAIN, false, MICRO>(a, out, keys, slot, tile0 + k, cnt1, beg1, nr1, ex1 GR_STAMP_PASS, nullptr, cm1);
+      cnt1 = cnt2; cnt2 = cnt3; beg1 = beg2; beg2 = beg3; cm1 = cm2; cm2 = cm3;
       nr1 = nr2; nr2 = nr3; ex1 = ex2; ex2 = ex3;
     }
   }
@@ -813,7 +897,7 @@ __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile(BinArgs a, Rast
 //      the tile's whole items phase to arrive and is waited for before the tile's id stores go out (raster_one_tile<ROLL>).
 //      The exposed prologue is paid once per KTL tiles.  Single-pass binning only (the counters of consecutive tiles sit side
 //      by side).
-template <int TWL, int THL, int NT, bool FUSE, int PAD, bool SHORT, bool PLAIN, int KTL>
+template <int TWL, int THL, int NT, bool FUSE, int PAD, bool SHORT, bool PLAIN, int KTL, bool MICRO = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(THL == 5 ? GR_WPE : (FUSE ? 1 : 4), 8)))
 __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile_roll(BinArgs a, RasterOut out) {
   constexpr int TW = 1 << TWL, TH = 1 << THL;
@@ -848,7 +932,8 @@ __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile_roll(BinArgs a,
   // loaded inside the tile loop, where a load is a wait)
   const uint32_t *cntp = ctrl + GR_CTRL_HDR + tile0;
   uint32_t cvec = lane < n_tiles ? min(cntp[lane], cap) : 0u;
-  asm volatile("" : "+v"(cvec));
+  uint32_t mvec = (SHORT && MICRO && lane < n_tiles) ? cntp[a.Tcap + lane] : 0u;   // the tiles' micro lists (cntB array)
+  asm volatile("" : "+v"(cvec), "+v"(mvec));
   auto count_at = [&](int tt) { return (uint32_t)__builtin_amdgcn_readlane((int)cvec, tt); };   // tt < 64; lanes >= n_tiles hold 0
   ChunkRing r;
   r.n0 = 0u;
@@ -880,7 +965,8 @@ __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile_roll(BinArgs a,
     const uint32_t nr_first = r.n0 & 0xFFu;
     request(cnt1, beg + a.cap_tile, r.e0, r.n0);
     // (the by-value chunk argument is the later chunks' temporary: NOT the request register, which is in flight again)
-    raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, false, PLAIN, true>(a, out, keys, slot, tile0 + t, cnt, beg, nr_first, v4i{0, 0, 0, 0} GR_STAMP_PASS, &r);
+    raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, false, PLAIN, true, MICRO>(a, out, keys, slot, tile0 + t, cnt, beg, nr_first, v4i{0, 0, 0, 0} GR_STAMP_PASS, &r,
+                                                                                 (uint32_t)__builtin_amdgcn_readlane((int)mvec, t));
   }
 #ifdef GR_STAMPS
   if (lane == 0 && a.stamps) {
@@ -930,16 +1016,21 @@ int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStr
     const bool roll = chain && a.cap_tile > 0 && a.thl == 5 && !(a.var & 2048) && (out.winner != nullptr || (a.var & 1024) != 0);
     const dim3 grid(roll ? (unsigned)((a.T + GR_ROLL_KT - 1) / GR_ROLL_KT) : chain ? (unsigned)((a.T + 3) >> 2) : (unsigned)a.T, nb), block(256);
     const size_t pad = (size_t)c->opt_lds_pad;
-#define GR_LAUNCH_TILE(THL_, FUSE_, PLAIN_)                                                                           \
+#define GR_LAUNCH_TILE_M(THL_, FUSE_, PLAIN_, MICRO_)                                                                 \
   do {                                                                                                                \
     if (roll && THL_ == 5) {                                                                                          \
-      if (a.ent40) hipLaunchKernelGGL((k_raster_tile_roll<6, 5, 256, FUSE_, GR_LDS_PAD, true, PLAIN_, GR_ROLL_KT>), grid, block, pad, s, a, out);  \
-      else hipLaunchKernelGGL((k_raster_tile_roll<6, 5, 256, FUSE_, GR_LDS_PAD48, false, PLAIN_, GR_ROLL_KT>), grid, block, pad, s, a, out);        \
+      if (a.ent40) hipLaunchKernelGGL((k_raster_tile_roll<6, 5, 256, FUSE_, GR_LDS_PAD, true, PLAIN_, GR_ROLL_KT, MICRO_>), grid, block, pad, s, a, out);  \
+      else hipLaunchKernelGGL((k_raster_tile_roll<6, 5, 256, FUSE_, GR_LDS_PAD48, false, PLAIN_, GR_ROLL_KT, false>), grid, block, pad, s, a, out);        \
     } else if (a.ent40) {                                                                                             \
-      if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD, true, PLAIN_>), grid, block, pad, s, a, out);  \
-      else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD, true, PLAIN_>), grid, block, pad, s, a, out);        \
-    } else if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD48, false, PLAIN_>), grid, block, pad, s, a, out);  \
-    else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD48, false, PLAIN_>), grid, block, pad, s, a, out);        \
+      if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD, true, PLAIN_, MICRO_>), grid, block, pad, s, a, out);  \
+      else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD, true, PLAIN_, MICRO_>), grid, block, pad, s, a, out);        \
+    } else if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD48, false, PLAIN_, false>), grid, block, pad, s, a, out);  \
+    else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD48, false, PLAIN_, false>), grid, block, pad, s, a, out);        \
+  } while (0)
+#define GR_LAUNCH_TILE(THL_, FUSE_, PLAIN_)                                                                           \
+  do {                                                                                                                \
+    if (a.micro) GR_LAUNCH_TILE_M(THL_, FUSE_, PLAIN_, true);                                                         \
+    else GR_LAUNCH_TILE_M(THL_, FUSE_, PLAIN_, false);                                                                \
   } while (0)
     // the usual ids-only call: rows of whole 16-byte pieces, every view's plane 16-byte aligned, no depth image
     const bool plain = !out.winner && out.ids && !out.depth && (w & 3) == 0 && (reinterpret_cast<uintptr_t>(out.ids) & 15) == 0 &&
@@ -953,6 +1044,7 @@ int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStr
     } else if (a.thl == 6) GR_LAUNCH_TILE(6, false, false);
     else GR_LAUNCH_TILE(5, false, false);
 #undef GR_LAUNCH_TILE
+#undef GR_LAUNCH_TILE_M
     c->prof_raster_launches += 1;
   }
   c->prof_views += nb;

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GR_VERSION 121 /* 0.2.1: gr_learned_cache_clear; 0.2.0: gr_resize_image_f64, gr_learned_cache_file, mesh-signature keyed learned table */
+#define GR_VERSION 122 /* 0.2.2: micro lists (a fifth field in the learned-table file); 0.2.1: gr_learned_cache_clear; 0.2.0: gr_resize_image_f64, gr_learned_cache_file, mesh-signature keyed learned table */
 
 enum {
   GR_OK = 0,
@@ -119,7 +119,11 @@ enum {
                                93 pixels and more); 512 = the general ids kernel (depth output, any width) also for calls
                                the plain one would take (ids only, rows of whole 16-byte pieces); 1024 = rolling chains of
                                16 tiles (the next tile's first chunk requested while the current one is rasterized) for the
-                               ids kernels too (default: the fused kernel only); 2048 = no rolling chains               */
+                               ids kernels too (default: the fused kernel only); 2048 = no rolling chains; 8192 = micro
+                               lists always, 4096 = never (default: a call whose views show mostly faces of at most 4 x 4
+                               pixels -- a mesh rendered at a fraction of its photos' resolution -- teaches the library to
+                               keep, for that mesh and image size, a second list per tile for such faces, which the tile
+                               kernel point-samples one face per lane; remembered like the slots per tile)              */
   GR_OPT_SHARE_LEARNED = 8, /* 1 (default): consult and feed the process-wide table of learned slots per tile / entry forms
                                (and its file, gr_learned_cache_file); 0: this context learns for itself only.  Setting
                                GR_OPT_DIRECT_CAP by hand switches it off; this option switches it back on            */

@@ -26,7 +26,11 @@ VARIANTS = {"tile32_chain": (5, 512, 16), "tile64_single_full": (6, 512, 129), "
             # 1024: rolling chains of 16 tiles (k_raster_tile_roll) for the ids kernels too (the fused kernel's default wherever a
             # chain of four would run); 2048: none
             "tile32_roll": (5, 512, 1040), "tile32_roll_full_general": (5, 512, 1040 + 128 + 512),
-            "tile32_chain_no_roll": (5, 512, 16 + 2048)}
+            "tile32_chain_no_roll": (5, 512, 16 + 2048),
+            # 8192: micro lists always (faces of at most 4 x 4 pixels on a second list per tile, one face per lane); the default
+            # keeps them only where an earlier call found such faces to be the rule
+            "tile32_micro_chain": (5, 512, 16 + 8192), "tile32_micro_single": (5, 512, 1 + 8192), "tile64_micro": (6, 512, 8192),
+            "tile32_micro_roll_ids": (5, 512, 16 + 1024 + 8192)}
 
 
 @pytest.fixture(params=list(VARIANTS), autouse=True)
