@@ -610,8 +610,10 @@ def run(args, rig=None) -> int:
 
     # ---- hostile workload (N == 1): terrain + 20 000 trees, cameras tilted 30-45 degrees; full and quarter resolution -------
     workload_2 = None
+    quarter = None
     if rank == 0 and world == 1 and not args.no_workload2 and rig.side_legs():
         workload_2 = leg_workload2(rig, local_rank, dev)
+        quarter = leg_quarter_scale(rig, local_rank, dev, points, faces, wl)
 
     # ---- PCIe-inclusive rates of the reference-shaped numpy API (N == 1) -------------------------------------------------------
     api = None
@@ -711,6 +713,9 @@ def run(args, rig=None) -> int:
             roofline["hostile_gpix_scale_1"] = round(workload_2["scale_1"]["mpix_per_s"] / 1e3, 2)
             roofline["hostile_gpix_scale_0.25"] = round(workload_2["scale_0.25"]["mpix_per_s"] / 1e3, 2)
             roofline["hostile_overflow_retries_cold"] = workload_2["scale_1"].get("overflow_retries_cold")
+        if quarter:
+            roofline["c2_quarter_scale_gpix"] = round(quarter["mpix_per_s"] / 1e3, 2)
+            roofline["c2_quarter_scale_views_per_s"] = quarter["views_per_s"]
         line = {
             "metric": "Mpix/s rasterized (face-ID pix2face), 1.2M-face mesh @ 4000x3000",
             "value": round(mpix_per_s, 1),
@@ -749,6 +754,7 @@ def run(args, rig=None) -> int:
             "c4": c4,
             "c5": c5,
             "workload_2": workload_2,
+            "quarter_scale": quarter,
             "api": api,
             "io": io,
         }
@@ -874,6 +880,55 @@ def leg_c5(rig, wl, rank, world, local_rank, dev, distributed, barrier, max_over
         assert ok_ids and ok_votes, "config 5 differs from the CPU oracle"
     del labels5, votes5, counts5, hip5
     return out
+
+
+def leg_quarter_scale(rig, local_rank, dev, points, faces, wl):
+    """BASELINE config 2's mesh and cameras at render_img_scale = 0.25 (1000 x 750): the reference's documented operating point
+    for aggregation (AGGREGATE_IMAGE_SCALE = 0.25, examples/aggregate_predictions.ipynb:60-61).  A face is about 3 pixels wide
+    there: the first call teaches the library to keep micro lists for this mesh and image size (one face per lane in the tile
+    kernel), the timed calls use them.  One view against the CPU oracle."""
+    import torch
+
+    from geograypher_amd.utils import synthetic
+
+    oracle_c = rig.checker()
+    cams = synthetic.survey_cameras(10, 5, 40.0, 60.0, seed=3, **wl.cam_kw())
+    h, w = cams[0].get_image_size(0.25)
+    recs_np = cams.get_raster_records(0.25, near=1.0)
+    recs = torch.from_numpy(recs_np).to(dev)
+    hip = rig.make_raster(local_rank)
+    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+    out = torch.empty((recs.shape[0], h, w), dtype=torch.int32, device=dev)
+    hip.raster_face_ids(recs, h, w, out=out, check=True)       # sizes the segments; counts the micro faces
+    hip.raster_face_ids(recs, h, w, out=out, check=True)       # micro lists from here on
+    for _ in range(3):
+        hip.raster_face_ids(recs, h, w, out=out, check=False)
+    hip.set_profiling(True)
+    rig.synchronize(dev)
+    t0 = time.perf_counter()
+    n_rep = 40
+    for _ in range(n_rep):
+        hip.raster_face_ids(recs, h, w, out=out, check=False)
+    rig.synchronize(dev)
+    dt = time.perf_counter() - t0
+    stg = hip.stage_times()
+    hip.set_profiling(False)
+    st = hip.raster_status()
+    want = oracle_c.raster(points, faces, recs_np[7], h, w)
+    same = bool(np.array_equal(out[7].cpu().numpy(), want))
+    assert same, "quarter-scale leg: GPU ids differ from the CPU oracle"
+    res = {
+        "workload": f"BASELINE config 2 at render_img_scale 0.25: {faces.shape[0]} faces, {recs.shape[0]} views {w}x{h}",
+        "views_per_s": round(n_rep * recs.shape[0] / dt, 1),
+        "mpix_per_s": round(n_rep * recs.shape[0] * h * w / dt / 1e6, 1),
+        "us_per_view": {"setup": round(stg["setup_ms"] / max(stg["views"], 1) * 1e3, 2),
+                        "raster": round(stg["raster_ms"] / max(stg["views"], 1) * 1e3, 2)},
+        "entries_per_view": round(st["entries"] / recs.shape[0], 1),
+        "max_entries_per_tile": int(st["max_entries"]),
+        "oracle_parity_view_7": same,
+    }
+    del out, hip
+    return res
 
 
 def leg_workload2(rig, local_rank, dev):
