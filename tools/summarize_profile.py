@@ -84,10 +84,11 @@ def key_of(kernel):
     """traffic.json / valu.json key: the kernel's name without template arguments; the fused tile kernel gets its own."""
     name = kernel.replace("void ", "").strip()
     base = name.split("<")[0].strip()
-    if base == "k_raster_tile" and "<" in name:
+    if base in ("k_raster_tile", "k_raster_tile_roll") and "<" in name:   # the fused kernel runs rolling chains since round 5
         args = [a.strip() for a in name.split("<", 1)[1].rstrip(">").split(",")]
         if len(args) > 3 and args[3] == "true":
             return "k_raster_tile_fused"
+        return "k_raster_tile"
     return base
 
 
