@@ -713,6 +713,7 @@ def run(args, rig=None) -> int:
             roofline["hostile_gpix_scale_1"] = round(workload_2["scale_1"]["mpix_per_s"] / 1e3, 2)
             roofline["hostile_gpix_scale_0.25"] = round(workload_2["scale_0.25"]["mpix_per_s"] / 1e3, 2)
             roofline["hostile_overflow_retries_cold"] = workload_2["scale_1"].get("overflow_retries_cold")
+            roofline["hostile_first_group_rebinned_cold"] = workload_2["scale_1"].get("first_group_rebinned_cold")
         if quarter:
             roofline["c2_quarter_scale_gpix"] = round(quarter["mpix_per_s"] / 1e3, 2)
             roofline["c2_quarter_scale_views_per_s"] = quarter["views_per_s"]
@@ -933,8 +934,10 @@ def leg_quarter_scale(rig, local_rank, dev, points, faces, wl):
 
 def leg_workload2(rig, local_rank, dev):
     """Terrain + 20 000 trees seen obliquely, full and quarter resolution.  The slots per tile such images need are learned
-    from the overflow of the very first call in this process (`overflow_retries_cold`); a second, fresh context -- the one
-    that is timed -- starts with what the process has learned (`overflow_retries_first_call`)."""
+    by the very first call in this process: the library reads the counts of that call's first launch group before the group's
+    tile kernel runs and bins it again with segments that fit (`first_group_rebinned_cold`; rounds 1-4 finished the overflowed
+    call and the caller repeated it: `overflow_retries_cold`); a second, fresh context -- the one that is timed -- starts with
+    what the process has learned (`overflow_retries_first_call`)."""
     import torch
 
     from geograypher_amd.utils import synthetic
@@ -961,8 +964,13 @@ def leg_workload2(rig, local_rank, dev):
         h2, w2 = fcams[0].get_image_size(scale)
         r2 = torch.from_numpy(fcams.get_raster_records(scale, near=1.0)).to(dev)
         o2 = torch.empty((len(fcams), h2, w2), dtype=torch.int32, device=dev)
+        rig.synchronize(dev)
+        t0 = time.perf_counter()
         hip_cold.raster_face_ids(r2, h2, w2, out=o2, check=True)
-        cold[scale] = int(hip_cold.last_retries)
+        # (GR_EOVERFLOW retries of the call, times the library binned the call's first launch group again after its look at the
+        # group's counts -- gr_raster_stats.rebinned_groups: what replaced the retry in round 5 --, wall time of the call incl.
+        # the allocation of the entry memory)
+        cold[scale] = (int(hip_cold.last_retries), int(hip_cold.last_stats.get("rebinned_groups", 0)), round((time.perf_counter() - t0) * 1e3, 2))
         del o2
     del hip_cold
     new_process = {}
@@ -1019,7 +1027,9 @@ def leg_workload2(rig, local_rank, dev):
             "entries_per_view": round(st2["entries"] / len(fcams), 1),
             "max_entries_per_tile": int(st2["max_entries"]),
             "overflow_retries_first_call": int(retries),
-            "overflow_retries_cold": cold[scale],
+            "overflow_retries_cold": cold[scale][0],
+            "first_group_rebinned_cold": cold[scale][1],
+            "cold_call_ms": cold[scale][2],
             "overflow_retries_new_process": new_process.get(f"{scale:g}" if f"{scale:g}" in new_process else str(scale), new_process.get("failed")),
             "oracle_parity_view_3": same,
             "covered_fraction": round(float((want >= 0).mean()), 4),

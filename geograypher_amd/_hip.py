@@ -85,6 +85,7 @@ class RasterStats(ctypes.Structure):
         ("views_done", ctypes.c_int32),
         ("blocks", ctypes.c_int64),
         ("chunk_visits", ctypes.c_int64),
+        ("rebinned_groups", ctypes.c_int64),
     ]
 
     def as_dict(self):
@@ -208,6 +209,7 @@ class _StatsAccumulator:
         self.chunk_visits = 0.0
         self.max_entries = 0
         self.views = 0
+        self.rebinned = 0
         self.last = None
 
     def add(self, st: "RasterStats", n_views: int, partial: bool):
@@ -219,12 +221,14 @@ class _StatsAccumulator:
         self.chunk_visits += st.chunk_visits * share
         self.max_entries = max(self.max_entries, int(st.max_entries))
         self.views += done
+        self.rebinned += int(st.rebinned_groups)
         self.last = st
 
     def result(self) -> dict:
         d = self.last.as_dict()
         d.update(records=int(round(self.records)), entries=int(round(self.entries)), max_entries=self.max_entries,
-                 views_done=self.views, blocks=int(round(self.blocks)), chunk_visits=int(round(self.chunk_visits)))
+                 views_done=self.views, blocks=int(round(self.blocks)), chunk_visits=int(round(self.chunk_visits)),
+                 rebinned_groups=self.rebinned)
         return d
 
 

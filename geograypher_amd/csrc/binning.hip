@@ -242,7 +242,11 @@ __device__ __forceinline__ Vtx unpack_vtx(const int4 q) {
 // time, a pair finds its face by a 6-step search over the prefix sums and pulls the record out of the owning lane's
 // registers (ds_bpermute).  A tile the triangle does not touch takes no list slot.  The pairs of a step that name the same
 // tile (neighbouring faces of one tree do) share ONE returning counter atomic (wave_group_capped: at most 16 groups are
-// looked for, left-over pairs stand alone); all atomics of a step are in flight together.
+// looked for, left-over pairs stand alone; 8 or 32 measure the same, 4: forest set-up +14 % -- setup_big_pairs_group_cap.log);
+// all atomics of a step are in flight together.  (Round 5: the steps software-pipelined -- a step's positions and stores after
+// the NEXT step's build_entry, built entries parked in LDS -- hide the atomics' round trip from the wave: forest set-up 39.6 ->
+// 38.5 us per view, C2 +1.3 %: the other four waves of the SIMD hide it already.  Log and patch:
+// profiles/r05_ab/setup_big_pairs_pipelined.*)
 __device__ __forceinline__ void bin_big_pairs(const BinArgs &a, uint32_t *__restrict__ ctrl, const int slot, const int lane,
                                               const bool big, const int4 r0, const int4 r1, const int4 r2, const int tx0,
                                               const int tx1, const int ty0, const int ty1) {
@@ -415,7 +419,6 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
     const float *bv0 = a.bvert + ((int64_t)blk_cur * GR_BLOCK_VERTS + lane) * 3;
     const float vx = bv0[0], vy = bv0[1], vz = bv0[2];
     const int nv = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)bi) >> 24) + 1;  // lane 0 of a listed block is a face
-    const float *bv = a.bvert + (int64_t)blk_cur * (3 * GR_BLOCK_VERTS);
 #ifdef GR_STAMPS
     GR_SSTAMP(0);
 #endif
@@ -423,7 +426,16 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
       const float p0[3] = {vx, vy, vz};
       if (lane < nv) vt[lane] = pack_vtx(project_vertex(p0, cam));
     }
-    for (int i = lane + 64; i < nv; i += 64) vt[i] = pack_vtx(project_vertex(bv + 3 * i, cam));  // a face soup: two more rounds
+    if (nv > 64) {  // a face soup: two more rounds
+      // the address is made from an opaque copy of the lane number: left to itself the compiler keeps `a.bvert + 12 * (lane + 64)`
+      // as a loop invariant of the kernel's block loop and, at the 96 registers of five waves per SIMD, in SCRATCH -- a scratch
+      // reload per block in front of these loads (tests/test_isa_waits.py holds the kernels to no scratch; C2 set-up 4.89 ->
+      // 4.80 us per view, profiles/r05_ab/setup_scratch_fix.log)
+      uint32_t l = lane;
+      asm volatile("" : "+v"(l));
+      const float *bvi = a.bvert + ((int64_t)blk_cur * GR_BLOCK_VERTS + l) * 3;
+      for (int i = lane + 64; i < nv; i += 64) vt[i] = pack_vtx(project_vertex(bvi += 3 * 64, cam));
+    }
     const int4 q0 = vt[bi & 255u], q1 = vt[(bi >> 8) & 255u], q2 = vt[(bi >> 16) & 255u];
     if (f < a.F) keep = face_setup_tail(a, face_id, unpack_vtx(q0), unpack_vtx(q1), unpack_vtx(q2), r0, r1, r2, tx0, tx1, ty0, ty1, clip_me);
   }

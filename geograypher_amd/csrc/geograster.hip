@@ -122,10 +122,13 @@ void lookup_learned(const gr_ctx *c, int T, int &cap, bool &full, bool *micro = 
 // hand to anything else: 48 bytes.
 void resolve_binning(gr_ctx *c, int T) {
   int cap = 0; bool full = false, micro = false;
-  c->cur_cap = 0; c->cur_ent40 = false; c->cur_micro = false;
+  c->cur_cap = 0; c->cur_ent40 = false; c->cur_micro = false; c->cur_look = false;
   if (c->opt_direct_cap <= 0 || !c->direct_ok) return;
   lookup_learned(c, T, cap, full, &micro);
   if (cap == GR_LEARNED_EXACT) return;  // this (mesh, image size) bins exactly: one view's segments would not fit the budget
+  // nothing is known about the slots this mesh and image size need: the call looks at the counts of its first launch group
+  // before that group's tile kernel runs (raster_views).  Variant bit 16384: never (rounds 1-4: gr_raster_status reports it)
+  c->cur_look = cap == 0 && !(c->opt_var & 16384);
   c->cur_cap = std::max(cap, c->opt_direct_cap);
   c->cur_ent40 = !(c->cur_cap & 63) && !(c->opt_var & 128) && !full;
   // micro lists: where an earlier call found most faces of the image at most 4 x 4 pixels (gr_raster_status; remembered like
@@ -147,6 +150,17 @@ void learn(gr_ctx *c, int T, int cap, bool full, bool micro = false) {
   std::lock_guard<std::mutex> lk(g_learned_mu);
   put_global_locked(v);
   save_learned_locked();
+}
+
+// What the counters of an overflowed single-pass bin pass teach (they kept counting, so the need is known): segments of that
+// size if ONE view's entry memory stays within budget -- raster_views shrinks the launch group until the segments fit; round 4
+// priced the failed call's whole group and switched single-pass binning off for the CONTEXT, every image size, for good --,
+// exact binning (count, scan, fill) otherwise.  max_tile: the largest count a tile reached.
+void learn_slots(gr_ctx *c, int T, int64_t max_tile, bool full, bool micro) {
+  const int64_t need = (max_tile + max_tile / 8 + 16 + 63) / 64 * 64;
+  const int64_t bytes_one_view = need * (16 * GR_ENT_Q) * (int64_t)T;
+  if (need <= GR_LEARNED_MAX_CAP && bytes_one_view <= (c->opt_budget_mb << 20)) learn(c, T, (int)need, full, micro);
+  else learn(c, T, GR_LEARNED_EXACT, full, micro);   // this (mesh, image size) bins exactly from now on
 }
 
 int ensure_bins(gr_ctx *c, int n_slots, int T) {
@@ -175,9 +189,10 @@ int ensure_bins(gr_ctx *c, int n_slots, int T) {
 // pix2face for n_views cameras, optionally fused with the label projection (labels != nullptr): per launch group the
 // tile kernel's epilogue feeds the per-face winners straight from LDS and k_vote_labels folds them into votes/counts.
 int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_t *ids, float *depth,
-                 const uint8_t *labels, int C, uint32_t *votes, uint32_t *counts, int flags, hipStream_t s) {
+                 const uint8_t *labels, int C, uint32_t *votes, uint32_t *counts, int flags, hipStream_t s, int again = 0) {
   int rc = check_common(c, n_views, h, w);
   if (rc) return rc;
+  c->rebinned = again;
   if (!c->verts) return fail(c, GR_ENOMESH, "gr_mesh_upload has not been called");
   if (!cams) return fail(c, GR_EINVAL, "null cams");
   if (n_views == 0) return GR_OK;
@@ -238,6 +253,23 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
     rc = bin_batch(c, cams + (int64_t)v0 * GR_CAM_FLOATS, nb, h, w, 0, v0 / B, s);
     c->cur_touched = nullptr;
     if (rc) return rc;
+    if (c->cur_look && g == 0 && again < 2) {
+      // The first launch group of a (mesh, image size) nothing has been learned about: its counts are read HERE, before its
+      // tile kernel runs -- one host round trip per mesh and image size in the life of the learned table.  A tile that outgrew
+      // its slots, a face the 40-byte entries cannot hold, a view of mostly micro faces: the lesson is taken and the call
+      // starts over (nothing has been written yet; this group's bin pass -- a quarter of its time -- is what the lesson
+      // costs, where rounds 1-4 paid the whole call once more after gr_raster_status).  Otherwise the slots in use are noted as
+      // sufficient and no call looks again.  Later groups of the call, and later calls with more crowded views, keep the
+      // GR_EOVERFLOW protocol.
+      unsigned long long st[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      GR_HIP(c, hipMemcpyAsync(st, c->stats, sizeof(st), hipMemcpyDeviceToHost, s));
+      GR_HIP(c, hipStreamSynchronize(s));
+      const bool grow = st[3] && (int64_t)st[2] > c->cur_cap, miss = st[3] && st[5] != 0;
+      const bool micro = !c->cur_micro && !(c->opt_var & (128 | 4096)) && !miss && st[0] > 0 && 5 * st[8] > 2 * st[0];
+      if (grow) learn_slots(c, T, (int64_t)st[2], miss, micro);
+      else learn(c, T, c->cur_cap, miss, micro);
+      if (grow || miss || micro) return raster_views(c, cams, n_views, h, w, ids, depth, labels, C, votes, counts, flags, s, again + 1);
+    }
     uint32_t *win = labels ? (uint32_t *)c->winner + (int64_t)buf * F * B : nullptr;
     RasterOut out;
     out.ids = ids ? ids + v0 * P : nullptr;
@@ -449,6 +481,7 @@ int gr_raster_status(gr_ctx *c, gr_raster_stats *o) {
   o->records = (int64_t)st[0]; o->entries = (int64_t)st[1]; o->max_entries = (int64_t)st[2];
   o->entry_cap = c->ent_cap; o->overflow = (int32_t)st[3];
   o->blocks = (int64_t)st[6]; o->chunk_visits = (int64_t)st[7];
+  o->rebinned_groups = c->rebinned;
   // views of the last call whose results are complete: every launch group in front of the first one that overflowed
   o->views_done = st[3] ? (int32_t)std::min<unsigned long long>(st[4] * (unsigned long long)std::max(c->last_B, 1),
                                                                 (unsigned long long)c->last_n_views)
@@ -461,12 +494,7 @@ int gr_raster_status(gr_ctx *c, gr_raster_stats *o) {
     const bool grow = (int64_t)st[2] > used;
     if (st[5] != 0) learn(c, c->last_T, 0, true);
     if (grow) {
-      // (priced for ONE view: raster_views shrinks the launch group until the segments fit the budget -- round 4 priced the
-      // failed call's whole group and switched single-pass binning off for the CONTEXT, every image size, for good)
-      const int64_t need = ((int64_t)st[2] + (int64_t)st[2] / 8 + 16 + 63) / 64 * 64;
-      const int64_t bytes_one_view = need * (16 * GR_ENT_Q) * (int64_t)c->last_T;
-      if (need <= GR_LEARNED_MAX_CAP && bytes_one_view <= (c->opt_budget_mb << 20)) learn(c, c->last_T, (int)need, false);
-      else learn(c, c->last_T, GR_LEARNED_EXACT, false);   // this (mesh, image size) bins exactly from now on
+      learn_slots(c, c->last_T, (int64_t)st[2], false, false);
       return fail(c, GR_EOVERFLOW, "single-pass binning overflow: a tile received %llu entries (slots per tile %d); "
                   "retry the call", st[2], used);
     }

@@ -154,6 +154,9 @@ struct gr_ctx {
   int cur_cap = 0;                     // single-pass binning: slots per tile (0: exact two-pass binning)
   bool cur_ent40 = false;              // 40-byte entries
   bool cur_micro = false;              // micro lists (faces of at most 4 x 4 pixels on a second list per tile) for this call
+  bool cur_look = false;               // nothing learned about this (mesh, image size): the first launch group's counts are read
+                                       // before its tile kernel runs (raster_views)
+  int rebinned = 0;                    // times the last raster call started over after that look
   int64_t opt_budget_mb = 24 << 10;    // entry memory of one launch group (GR_OPT_DIRECT_BUDGET_MB)
   int last_T = 0, last_B = 0;          // tile count and launch-group size of the last raster call
   int last_n_views = 0;

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GR_VERSION 122 /* 0.2.2: micro lists (a fifth field in the learned-table file); 0.2.1: gr_learned_cache_clear; 0.2.0: gr_resize_image_f64, gr_learned_cache_file, mesh-signature keyed learned table */
+#define GR_VERSION 123 /* 0.2.3: the first launch group of an unknown (mesh, image size) is looked at before its tile kernel runs (gr_raster_stats.rebinned_groups); 0.2.2: micro lists (a fifth field in the learned-table file); 0.2.1: gr_learned_cache_clear; 0.2.0: gr_resize_image_f64, gr_learned_cache_file, mesh-signature keyed learned table */
 
 enum {
   GR_OK = 0,
@@ -83,6 +83,10 @@ typedef struct gr_raster_stats {
                            what a culled pass has to read of the mesh is blocks x 64 x 36 B + 16 B per block tested   */
   int64_t chunk_visits; /* fused aggregation: 256-face chunks of caller ids the vote pass visits, summed over views
                            (each visit reads and resets 256 winners: 256 x 8 B of k_vote_labels' algorithmic bytes)   */
+  int64_t rebinned_groups; /* times the last call binned its FIRST launch group again: a call for a mesh and image size the
+                           library has learned nothing about reads that group's counts before its tile kernel runs (one host
+                           round trip, once per mesh and image size) and, if a tile outgrew its slots, a face needs 48-byte
+                           entries or micro lists pay, starts over with what it learned -- instead of a GR_EOVERFLOW retry  */
 } gr_raster_stats;
 
 int gr_version(void);
@@ -101,12 +105,15 @@ enum {
   GR_OPT_TILE_H_LOG2 = 2,   /* tile height: 5 (64x32, default) or 6 (64x64)                                  */
   GR_OPT_BATCH = 3,         /* views per launch group, 1..64 (default 64)                                    */
   GR_OPT_DIRECT_CAP = 6,    /* single-pass binning: entry slots per tile (default 512); 0 = always bin exactly
-                               (count, scan, fill).  A tile that outgrows its slots is reported by
+                               (count, scan, fill).  A call for a mesh and image size nothing is known about reads the
+                               counts of its FIRST launch group before that group's tile kernel runs and starts over by
+                               itself if they say so (gr_raster_stats.rebinned_groups); in any later group, or any later
+                               call with more crowded views, a tile that outgrows its slots is reported by
                                gr_raster_status (GR_EOVERFLOW); the retry uses segments of the size that image needs
                                (remembered per mesh size and tile count, in the context and -- unless this option was
                                set by hand -- process-wide, so that another context for the same mesh and image size
-                               starts with segments that fit) or, beyond 16384 slots / 24 GB of entry memory per
-                               launch group, bins exactly.  Setting the option forgets what the context learned     */
+                               starts with segments that fit) or, beyond 65536 slots, or 24 GB of entry memory for ONE
+                               view, bins exactly.  Setting the option forgets what the context learned          */
   GR_OPT_VARIANT = 7,       /* variant bits for A/B runs (results identical): 1 = one tile per workgroup instead of a
                                chain of four; 4 = fused votes on the caller's stream instead of a side stream; 8 = no
                                first chunk requested ahead of the tile's count; 16 = chains of four tiles whatever the
@@ -123,7 +130,8 @@ enum {
                                lists always, 4096 = never (default: a call whose views show mostly faces of at most 4 x 4
                                pixels -- a mesh rendered at a fraction of its photos' resolution -- teaches the library to
                                keep, for that mesh and image size, a second list per tile for such faces, which the tile
-                               kernel point-samples one face per lane; remembered like the slots per tile)              */
+                               kernel point-samples one face per lane; remembered like the slots per tile); 16384 = no
+                               look at the first launch group's counts (every overflow goes through gr_raster_status)  */
   GR_OPT_SHARE_LEARNED = 8, /* 1 (default): consult and feed the process-wide table of learned slots per tile / entry forms
                                (and its file, gr_learned_cache_file); 0: this context learns for itself only.  Setting
                                GR_OPT_DIRECT_CAP by hand switches it off; this option switches it back on            */

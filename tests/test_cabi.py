@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_symbols():
         assert hasattr(lib, name), f"libgeograster.so does not export {name}"
     lib.gr_version.restype = ctypes.c_int
-    assert lib.gr_version() == 122
+    assert lib.gr_version() == 123
 
 
 def test_no_gpu_fails_loudly():

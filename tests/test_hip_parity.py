@@ -30,7 +30,10 @@ VARIANTS = {"tile32_chain": (5, 512, 16), "tile64_single_full": (6, 512, 129), "
             # 8192: micro lists always (faces of at most 4 x 4 pixels on a second list per tile, one face per lane); the default
             # keeps them only where an earlier call found such faces to be the rule
             "tile32_micro_chain": (5, 512, 16 + 8192), "tile32_micro_single": (5, 512, 1 + 8192), "tile64_micro": (6, 512, 8192),
-            "tile32_micro_roll_ids": (5, 512, 16 + 1024 + 8192)}
+            "tile32_micro_roll_ids": (5, 512, 16 + 1024 + 8192),
+            # 16384: no look at the first launch group's counts (a call for a mesh / image size nothing has been learned about
+            # reads them before the group's tile kernel runs and starts over by itself): every overflow through gr_raster_status
+            "tile32_chain_no_look": (5, 512, 16 + 16384), "tile64_single_no_look": (6, 512, 1 + 16384)}
 
 
 @pytest.fixture(params=list(VARIANTS), autouse=True)

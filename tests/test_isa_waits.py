@@ -12,10 +12,16 @@ import pytest
 
 from geograypher_amd import build as gbuild
 
-# (fused, short entries) -> s_waitcnt vmcnt instructions of k_raster_tile<6, 5, 256, fused, 4, 5, short, plain>: ONE wait for all
-# requests of the chain before its first tile, and the waits for later chunks and their row counts inside a tile (2 per copy
-# of the tile code, 2 copies) -- none for the empty-tile path, none between or inside the tiles of the chain
-KNOWN_GOOD = {(False, False): 5, (False, True): 5, (True, False): 5, (True, True): 5}
+# The kernels of the usual calls at 64x32 tiles (round 5) -> their number of `s_waitcnt vmcnt` instructions:
+#   "ids"   k_raster_tile<6, 5, 256, false, 4, PAD, short, PLAIN, micro>: chains of 4 tiles -- ONE wait for all requests of the
+#           chain before its first tile, and the waits for later chunks and their row counts inside a tile (2 per copy of the
+#           tile code, 2 copies); none for the empty-tile path, none between or inside the tiles of the chain;
+#   "fused" k_raster_tile_roll<6, 5, 256, true, PAD, short, false, 16, micro>: rolling chains of 16 tiles -- the counters of
+#           the chain, the first tile's request, the chunk-ahead wait and the wait in front of the epilogue of ONE inlined tile
+#           body (the request of the next tile stays in flight over the epilogue: that is the point of the kernel).
+#   With micro lists (the MICRO builds, used only for meshes the learned table marks) a wave also reads its own micro chunks.
+KNOWN_GOOD = {("ids", False, False): 5, ("ids", True, False): 5, ("fused", False, False): 5, ("fused", True, False): 5,
+              ("ids", True, True): 11, ("fused", True, True): 9}
 
 
 def _device_asm(src, out):
@@ -32,11 +38,14 @@ def device_asm(tmp_path_factory):
     return _device_asm(gbuild.SRC, tmp_path_factory.mktemp("isa") / "raster_tile.s")
 
 
-def _kernel_body(lines, fused, short):
-    # the kernels of the usual calls: fused aggregation, and the PLAIN ids kernel (last template flag)
-    name = "_ZN12_GLOBAL__N_113k_raster_tileILi6ELi5ELi256ELb%dELi4ELi%dELb%dELb%dEEEvN6grimpl7BinArgsENS1_9RasterOutE:" % (
-        int(fused), _lds_pad(short), int(short), int(not fused))
-    start = [i for i, l in enumerate(lines) if l.startswith(name)]
+def _kernel_body(lines, kind, short, micro):
+    tail = "EEvN6grimpl7BinArgsENS1_9RasterOutE:"
+    if kind == "ids":
+        name = "_ZN12_GLOBAL__N_113k_raster_tileILi6ELi5ELi256ELb0ELi4ELi%dELb%dELb1ELb%dE" % (_lds_pad(short), int(short), int(micro))
+    else:
+        name = "_ZN12_GLOBAL__N_118k_raster_tile_rollILi6ELi5ELi256ELb1ELi%dELb%dELb0ELi%dELb%dE" % (
+            _lds_pad(short), int(short), _roll_kt(), int(micro))
+    start = [i for i, l in enumerate(lines) if l.startswith(name + tail)]
     assert len(start) == 1, f"kernel symbol not found: {name}"
     end = next(i for i in range(start[0], len(lines)) if lines[i].startswith(".Lfunc_end"))
     return lines[start[0]:end]
@@ -47,17 +56,22 @@ def _lds_pad(short=True):
     return int(m.group(1))
 
 
-@pytest.mark.parametrize("fused,short", sorted(KNOWN_GOOD))
-def test_tile_kernel_has_no_new_memory_waits(device_asm, fused, short):
-    body = _kernel_body(device_asm, fused, short)
+def _roll_kt():
+    return int(re.search(r"#define GR_ROLL_KT (\d+)", gbuild.SRC.read_text()).group(1))
+
+
+@pytest.mark.parametrize("kind,short,micro", sorted(KNOWN_GOOD))
+def test_tile_kernel_has_no_new_memory_waits(device_asm, kind, short, micro):
+    body = _kernel_body(device_asm, kind, short, micro)
     waits = [(i, l.strip()) for i, l in enumerate(body) if "s_waitcnt" in l and "vmcnt" in l]
-    assert len(waits) <= KNOWN_GOOD[(fused, short)], (
-        f"k_raster_tile<fused={fused}, short={short}> has {len(waits)} vmcnt waits, known-good build has "
-        f"{KNOWN_GOOD[(fused, short)]}: {waits} -- check that none of them sits in the loop over the chain's tiles")
-    # the chain's four chunk requests are issued back to back: no wait between the first and the last of them
-    loads = [i for i, l in enumerate(body) if "global_load_dwordx4" in l]
-    assert len(loads) >= 4
-    assert waits[0][0] > loads[3], (waits[:3], loads[:5])
+    assert len(waits) <= KNOWN_GOOD[(kind, short, micro)], (
+        f"{kind} kernel (short={short}, micro={micro}) has {len(waits)} vmcnt waits, known-good build has "
+        f"{KNOWN_GOOD[(kind, short, micro)]}: {waits} -- check that none of them sits in the loop over the chain's tiles")
+    if kind == "ids":
+        # the chain's four chunk requests are issued back to back: no wait between the first and the last of them
+        loads = [i for i, l in enumerate(body) if "global_load_dwordx4" in l]
+        assert len(loads) >= 4
+        assert waits[0][0] > loads[3], (waits[:3], loads[:5])
 
 
 @pytest.mark.parametrize("unit", [p.name for p in gbuild.SOURCES])

@@ -15,6 +15,15 @@ def _records(cams, scale=1.0, near=0.05):
     return cams.get_raster_records(scale, near=near)
 
 
+NO_LOOK = 16384  # variant bit: no look at the first launch group's counts -- every overflow goes through gr_raster_status
+
+
+def _lessons(h):
+    """Times the last checked call was taught something: GR_EOVERFLOW retries (gr_raster_status) + times its first launch
+    group was binned again after the look at its counts (an unknown mesh / image size; gr_raster_stats.rebinned_groups)."""
+    return h.last_retries + h.last_stats["rebinned_groups"]
+
+
 @pytest.fixture(autouse=True)
 def _default_options(hip):
     hip.set_option(2, 5)
@@ -126,20 +135,25 @@ def test_short_entries_fall_back_when_a_later_group_has_a_large_face(hip):
     assert hip.last_retries == 0 and torch.equal(got, want)              # remembered
 
 
-def test_slots_per_tile_set_by_hand_to_an_odd_size(hip):
+@pytest.mark.parametrize("look", [True, False])
+def test_slots_per_tile_set_by_hand_to_an_odd_size(hip, look):
     """80 slots per tile: not a whole number of 64-entry chunks, so the call starts with 48-byte entries; the C1 views put
     more than 80 entries into a tile, the call overflows, learns a segment size (a multiple of 64: 40-byte entries from then
-    on) and finishes -- ids equal the oracle's either way."""
+    on) and finishes -- ids equal the oracle's either way.  The overflow is in the call's first launch group: by default the
+    library sees it before the tile kernel runs and bins the group again itself; with variant bit 16384 gr_raster_status
+    reports it and the caller retries."""
     (points, faces), cams = synthetic.config1_scene()
     recs = _records(cams)
     hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+    hip.set_option(7, 0 if look else NO_LOOK)
     hip.set_option(6, 80)
     ids = hip.raster_face_ids(recs, 480, 640)
-    assert hip.last_retries >= 1 and hip.last_stats["max_entries"] > 80
+    assert hip.last_stats["max_entries"] > 80
+    assert (hip.last_retries, hip.last_stats["rebinned_groups"]) == ((0, 1) if look else (1, 0))
     for v in (0, 5):
         np.testing.assert_array_equal(ids[v].cpu().numpy(), oracle_c.raster(points, faces, recs[v], 480, 640))
     again = hip.raster_face_ids(recs, 480, 640)
-    assert hip.last_retries == 0 and torch.equal(again, ids)
+    assert _lessons(hip) == 0 and torch.equal(again, ids)
 
 
 def _big_face_scene():
@@ -150,13 +164,16 @@ def _big_face_scene():
     return points, faces, cams, _records(cams)
 
 
-def test_short_form_miss_leaves_no_stale_entry(hip):
+@pytest.mark.parametrize("look", [False, True])
+def test_short_form_miss_leaves_no_stale_entry(hip, look):
     """Round-3 advisor finding: a face the 40-byte entry form cannot hold took a list slot and wrote nothing -- the slot kept
     whatever an earlier call had left there, the fused tile kernel rasterized it and issued winner atomics with a garbage face
     id.  Debug bit 512 poisons every entry slot and row count with 0xFF before each launch group is binned: with the miss in
     the FIRST group of a fused call the result must still be the unfused projection's (the missed slot is a null entry, the
     view's tiles are not walked by the fused kernel, the retry takes 48-byte entries), and the winner scratch must be clean
-    for the calls that follow."""
+    for the calls that follow.  (look=False: variant bit 16384, the protocol of rounds 1-4 in which the tile kernel runs on the
+    group with the missed face; look=True, the default: the library reads the first group's counts, sees the miss before any
+    tile kernel runs and starts over with 48-byte entries by itself.)"""
     points, faces, cams, recs = _big_face_scene()
     C = 3
     hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
@@ -167,17 +184,18 @@ def test_short_form_miss_leaves_no_stale_entry(hip):
     want_v, want_c = hip.new_vote_buffers(C)
     hip.project_labels(want, labels, C, want_v, want_c)
     try:
-        hip.set_option(7, 0)
+        hip.set_option(7, 0 if look else NO_LOOK)
         hip.set_option(6, 512)      # forgets the entry form: the call starts with 40-byte entries
         hip.set_option(99, 512)     # poisoned scratch
         v2, c2 = hip.new_vote_buffers(C)
         hip.raster_project_labels(recs, labels, C, v2, c2)
-        assert hip.last_retries == 1 and hip.last_stats["views_done"] == len(cams)
+        assert (hip.last_retries, hip.last_stats["rebinned_groups"]) == ((0, 1) if look else (1, 0))
+        assert hip.last_stats["views_done"] == len(cams)
         assert torch.equal(v2, want_v) and torch.equal(c2, want_c)
         # nothing stale is left in the winner scratch: the same call again (no retry now) gives the same votes once more
         v3, c3 = hip.new_vote_buffers(C)
         hip.raster_project_labels(recs, labels, C, v3, c3)
-        assert hip.last_retries == 0
+        assert _lessons(hip) == 0
         assert torch.equal(v3, want_v) and torch.equal(c3, want_c)
         got = hip.raster_face_ids(recs, 480, 640)
         assert torch.equal(got, want)
@@ -209,26 +227,26 @@ def test_second_context_and_new_process_start_sized(hip, tmp_path):
         a = HipRaster(0)   # fresh contexts: sharing is on (the session fixture has set options by hand)
         a.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
         ids_a = a.raster_face_ids(recs, 480, 640)
-        assert a.last_retries >= 1 and a.last_stats["max_entries"] > 512      # the whole mesh in a few tiles
+        assert _lessons(a) == 1 and a.last_stats["max_entries"] > 512      # the whole mesh in a few tiles
         np.testing.assert_array_equal(ids_a[1].cpu().numpy(), oracle_c.raster(points, faces, recs[1], 480, 640))
         assert cache.is_file() and len([l for l in cache.read_text().splitlines() if not l.startswith("#")]) >= 1
         b = HipRaster(0)
         b.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
         ids_b = b.raster_face_ids(recs, 480, 640)
-        assert b.last_retries == 0 and torch.equal(ids_a, ids_b)
+        assert _lessons(b) == 0 and torch.equal(ids_a, ids_b)
         # another mesh with the same number of faces (vertices moved): nothing inherited -> it overflows by itself
         c = HipRaster(0)
         moved = points.copy()
         moved[:, 0] += 0.125
         c.upload_mesh(moved.astype(np.float32), faces.astype(np.int32))
         c.raster_face_ids(recs, 480, 640)
-        assert c.last_retries >= 1
+        assert _lessons(c) == 1
         # a context that opted out learns for itself only
         d = HipRaster(0)
         d.set_option(8, 0)
         d.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
         d.raster_face_ids(recs, 480, 640)
-        assert d.last_retries >= 1
+        assert _lessons(d) == 1
         for ctx in (a, b, c, d):
             ctx.close()
         # a NEW PROCESS with the same cache file starts sized
@@ -242,7 +260,7 @@ def test_second_context_and_new_process_start_sized(hip, tmp_path):
             "h = HipRaster(0)\n"
             "h.upload_mesh(points.astype(np.float32), faces.astype(np.int32))\n"
             "h.raster_face_ids(far.get_raster_records(1.0, near=0.05), 480, 640)\n"
-            "print('RETRIES', h.last_retries)\n"
+            "print('RETRIES', h.last_retries + h.last_stats['rebinned_groups'])\n"
         )
         env = dict(os.environ, GEOGRAYPHER_AMD_CACHE=str(tmp_path))
         (tmp_path / "geograster_learned.txt").write_text(cache.read_text())
