@@ -607,11 +607,11 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
   }
   if (keep && !DIRECT) {
     int4 *rec = a.rec + slot * a.rec_stride;
-    const int64_t s = (int64_t)base + prefix;
+    const int64_t s = (int64_t)base + prefix, RP = a.rec_stride >> 2;  // four planes of RP >= F records per slot
     rec[s] = r0;
-    rec[a.F + s] = r1;
-    rec[2 * a.F + s] = r2;
-    rec[3 * a.F + s] = r3;
+    rec[RP + s] = r1;
+    rec[2 * RP + s] = r2;
+    rec[3 * RP + s] = r3;
     if (!small_fp)
       for (int ty = ty0; ty <= ty1; ++ty)
         for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&cntB[ty * a.TX + tx], 1u);
@@ -720,6 +720,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(BinArgs a) {
     atomicAdd(&a.stats[0], (unsigned long long)ctrl[0]);
     atomicAdd(&a.stats[1], (unsigned long long)total);
     atomicMax(&a.stats[2], (unsigned long long)total);
+    atomicMax(&a.stats[9], (unsigned long long)ctrl[0]);   // records the view needs (clipped faces: several each)
     if (ovf) { atomicMax(&a.stats[3], 1ull); atomicMin(&a.stats[4], (unsigned long long)a.group); }
   }
 }
@@ -908,7 +909,8 @@ __device__ __forceinline__ bool compile_entry(const BinArgs &a, uint32_t *__rest
 __global__ __launch_bounds__(256) void k_fill_compile(BinArgs a) {
   const int slot = blockIdx.y;
   uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
-  const uint32_t n_rec = ctrl[0];
+  const int64_t RP = a.rec_stride >> 2;                                  // records per plane
+  const uint32_t n_rec = (uint32_t)min((int64_t)ctrl[0], RP);            // (the counter keeps counting past the planes: the call is repeated)
   const uint32_t *cntS = ctrl + GR_CTRL_HDR;
   const uint32_t *off = ctrl + GR_CTRL_HDR + 2 * a.Tcap;
   uint32_t *cur = ctrl + GR_CTRL_HDR + 3 * a.Tcap;
@@ -917,12 +919,12 @@ __global__ __launch_bounds__(256) void k_fill_compile(BinArgs a) {
   uint8_t *nr8 = a.nrow8 + slot * a.ent_cap;
   const int TW = 1 << a.twl, TH = 1 << a.thl;
   for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n_rec; r += gridDim.x * 256) {
-    const int4 p0 = rec0[r], p1 = rec0[a.F + r], p2 = rec0[2 * a.F + r];
+    const int4 p0 = rec0[r], p1 = rec0[RP + r], p2 = rec0[2 * RP + r];
     const int tx0 = (p2.z & 0xFFFF) >> a.twl, tx1 = (int)((uint32_t)p2.z >> 16) >> a.twl;
     const int ty0 = (p2.w & 0xFFFF) >> a.thl, ty1 = (int)((uint32_t)p2.w >> 16) >> a.thl;
     const bool small_fp = (tx1 - tx0 <= 1) && (ty1 - ty0 <= 1);
     int4 pos = {0, 0, 0, 0};
-    if (small_fp) pos = rec0[3 * a.F + r];
+    if (small_fp) pos = rec0[3 * RP + r];
 #pragma unroll 1
     for (int ty = ty0; ty <= ty1; ++ty) {
 #pragma unroll 1
@@ -1001,8 +1003,12 @@ __device__ void emit_triangle(const BinArgs &a, int slot, uint32_t *ctrl, Vtx v0
         } else atomicOr(&ctrl[2], 1u);
       }
   } else {
+    // a clipped face becomes up to six triangles, each a record: more records than the planes hold (F, unless an earlier call
+    // asked for more) -> the view is reported like any overflow; the counter keeps counting, so the retry knows the need
+    // (k_scan_tiles: stats[9]; found by tools/fuzz_parity.py seed 934669: 18 faces around the camera, exact binning)
     const uint32_t s = atomicAdd(&ctrl[0], 1u);
-    if ((int64_t)s >= a.F) { atomicMax(&a.stats[3], 1ull); atomicMin(&a.stats[4], (unsigned long long)a.group); return; }  // more records than faces: the call is rejected
+    const int64_t RP = a.rec_stride >> 2;
+    if ((int64_t)s >= RP) { atomicMax(&a.stats[3], 1ull); atomicMin(&a.stats[4], (unsigned long long)a.group); return; }
     const bool small_fp = (tx1 - tx0 <= 1) && (ty1 - ty0 <= 1);
     int4 r3 = {0, 0, 0, 0};
     if (small_fp) {
@@ -1015,7 +1021,7 @@ __device__ void emit_triangle(const BinArgs &a, int slot, uint32_t *ctrl, Vtx v0
         for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&cntB[ty * a.TX + tx], 1u);
     }
     int4 *rec = a.rec + slot * a.rec_stride;
-    rec[s] = r0; rec[a.F + s] = r1; rec[2 * a.F + s] = r2; rec[3 * a.F + s] = r3;
+    rec[s] = r0; rec[RP + s] = r1; rec[2 * RP + s] = r2; rec[3 * RP + s] = r3;
   }
 }
 

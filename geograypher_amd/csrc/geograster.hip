@@ -179,10 +179,11 @@ int ensure_bins(gr_ctx *c, int n_slots, int T) {
   if (!rc) rc = grow(c, c->nrow8, c->nrow_have, cap * n_slots + 64, "entry row counts");
   if (!rc) rc = grow(c, c->work, c->work_have, work_stride * n_slots, "work list");
   if (!rc) rc = grow(c, c->clip, c->clip_have, F * n_slots, "clip list");
-  if (!rc && !direct) rc = grow(c, c->rec, c->rec_have, 4 * F * n_slots, "record planes");  // exact path only
+  const int64_t RF = std::max<int64_t>(F, c->rec_cap_request);  // records per view: a face each, a clipped face up to six
+  if (!rc && !direct) rc = grow(c, c->rec, c->rec_have, 4 * RF * n_slots, "record planes");  // exact path only
   if (rc) return rc;
   c->slots = n_slots; c->Tcap = Tcap; c->ent_cap = cap; c->ctrl_stride = ctrl_stride; c->work_stride = work_stride;
-  c->rec_F = F; c->rec_stride = 4 * F;
+  c->rec_F = RF; c->rec_stride = 4 * RF;
   return GR_OK;
 }
 
@@ -236,7 +237,7 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   note_stream(c, s);
   GR_HIP(c, hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 4, s));
   GR_HIP(c, hipMemsetAsync(c->stats + 4, 0xFF, sizeof(unsigned long long), s));  // first overflowed group: none
-  GR_HIP(c, hipMemsetAsync(c->stats + 5, 0, sizeof(unsigned long long) * 4, s)); // short-form miss: none; blocks, chunk visits, micro faces
+  GR_HIP(c, hipMemsetAsync(c->stats + 5, 0, sizeof(unsigned long long) * 5, s)); // short-form miss: none; blocks, chunk visits, micro faces, records of a view
   c->last_n_views = n_views;
   int g = 0;
   for (int v0 = 0; v0 < n_views; v0 += B, ++g) {
@@ -475,7 +476,7 @@ int gr_raster_face_ids(gr_ctx *c, const float *cams, int n_views, int h, int w, 
 
 int gr_raster_status(gr_ctx *c, gr_raster_stats *o) {
   if (!c || !o) return GR_EINVAL;
-  unsigned long long st[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   GR_HIP(c, hipMemcpyAsync(st, c->stats, sizeof(st), hipMemcpyDeviceToHost, c->last_stream));
   GR_HIP(c, hipStreamSynchronize(c->last_stream));
   o->records = (int64_t)st[0]; o->entries = (int64_t)st[1]; o->max_entries = (int64_t)st[2];
@@ -505,6 +506,14 @@ int gr_raster_status(gr_ctx *c, gr_raster_stats *o) {
   // resolution: 85-95 %): the next call for this mesh and image size keeps micro lists (no retry: this call's result stands)
   if (!st[3] && c->last_direct && c->cur_ent40 && !c->cur_micro && !(c->opt_var & 4096) && st[0] > 0 && 5 * st[8] > 2 * st[0])
     learn(c, c->last_T, 0, false, true);
+  if (st[3] && (int64_t)st[9] > c->rec_F) {
+    // exact binning: the clipped faces of a view became more triangles than the record planes hold (one record per face
+    // unless a call asked for more): the planes grow on the next call, the need is known
+    c->rec_cap_request = (int64_t)st[9] + (int64_t)st[9] / 8 + 64;
+    if ((int64_t)st[2] > c->ent_cap) c->ent_cap_request = (int64_t)st[2] + (int64_t)st[2] / 8 + 65536;
+    return fail(c, GR_EOVERFLOW, "record list overflow: a view needs %llu records (a clipped face becomes several triangles), "
+                "capacity %lld; retry the call", st[9], (long long)c->rec_F);
+  }
   if (st[3]) {
     // grow on the next call: exact need is known
     c->ent_cap_request = (int64_t)st[2] + (int64_t)st[2] / 8 + 65536;

@@ -72,7 +72,7 @@ struct BinArgs {
                               //     short-form miss (a face the 40-byte entry cannot hold: the caller repeats with 48 bytes)
   int group;             // index of this launch group inside the call
   int64_t ctrl_stride;   // words per slot
-  int64_t rec_stride;    // int4 per slot (= 3*F)
+  int64_t rec_stride;    // int4 per slot: four planes of rec_stride / 4 >= F records
   int64_t ent_cap;       // entries per slot
   int64_t F;
   int T, TX, TY, Tcap;
@@ -133,7 +133,8 @@ struct gr_ctx {
   int64_t ctrl_stride = 0, rec_stride = 0, ent_cap = 0, ent_cap_request = 0;
   int64_t ctrl_have = 0, comp_have = 0, work_have = 0, rec_have = 0;  // allocated element counts
   int Tcap = 0, slots = 0;
-  int64_t rec_F = 0;
+  int64_t rec_F = 0;                   // records per plane and slot of the exact path (>= F)
+  int64_t rec_cap_request = 0;         // ... asked for by a call whose clipped faces outgrew F records (gr_raster_status)
   // tuning knobs (gr_set_option)
   int opt_thl = 5;      // log2 tile height (5 or 6); width is 64.  64x32 tiles: 16 KiB of LDS, 8 workgroups per CU
   int opt_batch = GR_MAX_BATCH;

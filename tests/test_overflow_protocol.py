@@ -319,3 +319,29 @@ def test_argmax_uses_the_shared_context(hip):
     finally:
         _hip.HipRaster.__init__ = orig
     assert not created and _hip.default_backend() is shared
+
+
+def test_clipped_faces_outgrow_the_record_planes_of_exact_binning(hip):
+    """Exact binning (slots per tile 0) keeps one record per face -- but a face that straddles the near plane or the guard band
+    is clipped into up to six triangles, a record each: a small mesh AROUND the camera needs more records than it has faces.
+    Found by tools/fuzz_parity.py (seed 934669: 18 faces, the call failed after four identical retries); the status call now
+    reports the need, the planes grow, the retry finishes -- ids equal the oracle's."""
+    # six nearly horizontal triangles at different heights, each with two vertices 400 m to the sides in front of the camera
+    # (far outside the guard band) and one behind it: near plane + both side planes cut every one of them
+    zs = np.linspace(-1.5, 1.0, 6)
+    c = np.concatenate([np.array([[-400.0, 1.0, z], [400.0, 1.0, z], [0.0, -5.0, z + 0.2]]) for z in zs])
+    faces = np.arange(18, dtype=np.int64).reshape(6, 3)
+    poses = [synthetic.look_at((0.0, 0.0, 0.0), (0.0, 10.0, 0.0), up_hint=(0, 0, 1)),
+             synthetic.look_at((0.3, -0.2, 0.1), (1.0, 10.0, -0.5), up_hint=(0, 0, 1))]
+    cams = synthetic.camera_set_from_poses(poses, f=150.0, width=320, height=240)
+    recs = _records(cams, near=0.05)
+    hip.upload_mesh(c.astype(np.float32), faces.astype(np.int32))
+    hip.set_option(6, 0)
+    ids = hip.raster_face_ids(recs, 240, 320)
+    assert hip.last_retries == 1, hip.last_stats
+    for v in range(len(cams)):
+        want = oracle_c.raster(c, faces, recs[v], 240, 320)
+        assert (want >= 0).mean() > 0.5
+        np.testing.assert_array_equal(ids[v].cpu().numpy(), want)
+    again = hip.raster_face_ids(recs, 240, 320)
+    assert hip.last_retries == 0 and torch.equal(again, ids)

@@ -25,7 +25,9 @@ from geograypher_amd._hip import HipRaster
 from geograypher_amd.utils import synthetic
 from oracle import oracle_c
 
-VARIANT_BITS = [1, 4, 8, 16, 32, 64, 128, 512]
+# round 5: 1024 / 2048 rolling chains for the ids kernels / never, 4096 / 8192 micro lists never / always, 16384 no look at the first
+# launch group's counts (the overflow protocol of rounds 1-4)
+VARIANT_BITS = [1, 4, 8, 16, 32, 64, 128, 512, 1024, 2048, 4096, 8192, 16384]
 
 
 BIG = False
@@ -123,6 +125,7 @@ def one(hip, seed):
             "var": var, "batch": batch}
     hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
     ids, dep = hip.raster_face_ids(recs, h, w, want_depth=True)
+    info["lessons"] = (int(hip.last_retries), int(hip.last_stats.get("rebinned_groups", 0)))
     ids2 = hip.raster_face_ids(recs, h, w)  # the ids-only kernels
     ids_np, dep_np = ids.cpu().numpy(), dep.cpu().numpy()
     bad = []
@@ -157,7 +160,7 @@ def main():
     BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
     hip = HipRaster(0)
     t0 = time.time()
-    n = views = pixels = faces = 0
+    n = views = pixels = faces = retried = rebinned = 0
     failures = []
     while time.time() - t0 < budget:
         try:
@@ -169,8 +172,10 @@ def main():
             print("FAIL", json.dumps(failures[-1]), flush=True)
         n += 1
         views += info.get("views", 0); pixels += info.get("pixels", 0); faces += info.get("faces", 0)
+        retried += 1 if info.get("lessons", (0, 0))[0] else 0; rebinned += 1 if info.get("lessons", (0, 0))[1] else 0
         seed += 1
-    print(json.dumps({"scenes": n, "views": views, "pixels": pixels, "faces": faces, "failures": len(failures),
+    print(json.dumps({"scenes": n, "views": views, "pixels": pixels, "faces": faces, "failures": len(failures), "first_calls_retried": retried,
+                      "first_calls_with_a_rebinned_first_group": rebinned,
                       "first_seed": seed - n, "seconds": round(time.time() - t0, 1)}))
     return 1 if failures else 0
 
