@@ -1113,6 +1113,17 @@ __global__ __launch_bounds__(64) void k_clip_faces(const float *__restrict__ cam
   }
 }
 
+// K0i  the zeroes a launch group's bin pass starts from (bin_batch); stats != null: the call's first group
+__global__ __launch_bounds__(256) void k_bin_init(uint4 *__restrict__ ctrl16, int64_t n16, uint32_t *__restrict__ touched, int64_t nt,
+                                                  unsigned long long *__restrict__ stats) {
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, step = (int64_t)gridDim.x * 256;
+  for (int64_t i = i0; i < n16; i += step) ctrl16[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (int64_t i = i0; i < nt; i += step) touched[i] = 0u;
+  // [0..3] records, entries, largest count, overflow; [4] first overflowed launch group: none; [5..9] short-form miss, blocks,
+  // chunk visits, micro faces, records of a view (gr_raster_status)
+  if (stats && i0 < 10) stats[i0] = i0 == 4 ? ~0ull : 0ull;
+}
+
 // K1b  (variant bit 64 only: the default expands big faces inside K1) single-pass binning of the view's big list: a wave takes
 //      64 big faces, one per lane (records recomputed from the soup: same code as K1, same bits) and expands their
 //      (face, tile) pairs with bin_big_pairs.
@@ -1141,7 +1152,20 @@ namespace grimpl {
 int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int group, hipStream_t s) {
   BinArgs a = make_args(c, h, w, slot0);
   a.group = group;
-  GR_HIP(c, hipMemsetAsync(a.ctrl, 0, sizeof(uint32_t) * c->ctrl_stride * nb, s));
+  {
+    // ONE kernel zeroes what the group's bin pass counts in -- the control words of its views, the fused path's chunk bitmaps
+    // and, in the call's first group, the call's statistics -- where rounds 1-5 issued four to five fills: a fill of 40 bytes
+    // costs as much as a kernel launch (4.9 us each in the rocprof trace of a C2 step of 940 us; the step: -1.8 %,
+    // profiles/r05_ab/step_init_kernel_vs_fills.log).  (Folding k_bin_stats into the last k_clip_faces block of each view, to
+    // save that launch too, measured no gain: one wave adding up a view's counters takes as long as the launch it saves --
+    // step_clip_stats_merged*.)
+    const int64_t n16 = c->ctrl_stride * nb / 4;   // ctrl_stride is a multiple of 64 words
+    const int64_t nt = a.touched ? (int64_t)nb * a.tw : 0;
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(std::max(n16, nt), 256), 2048));
+    hipLaunchKernelGGL(k_bin_init, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4 *>(a.ctrl), n16, a.touched, nt,
+                       c->stats_pending ? c->stats : nullptr);
+    c->stats_pending = false;
+  }
   if (a.dbg & 512) {  // test hook: every entry slot and row count starts as garbage (0xFF), like scratch that an earlier call left behind
     GR_HIP(c, hipMemsetAsync(a.comp, 0xFF, sizeof(int4) * GR_ENT_Q * (size_t)c->ent_cap * nb, s));
     GR_HIP(c, hipMemsetAsync(a.nrow8, 0xFF, (size_t)c->ent_cap * nb, s));

@@ -235,9 +235,7 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   }
   c->last_stream = s;
   note_stream(c, s);
-  GR_HIP(c, hipMemsetAsync(c->stats, 0, sizeof(unsigned long long) * 4, s));
-  GR_HIP(c, hipMemsetAsync(c->stats + 4, 0xFF, sizeof(unsigned long long), s));  // first overflowed group: none
-  GR_HIP(c, hipMemsetAsync(c->stats + 5, 0, sizeof(unsigned long long) * 5, s)); // short-form miss: none; blocks, chunk visits, micro faces, records of a view
+  c->stats_pending = true;   // the call's statistics are reset by the first launch group's init kernel (bin_batch: k_bin_init)
   c->last_n_views = n_views;
   int g = 0;
   for (int v0 = 0; v0 < n_views; v0 += B, ++g) {
@@ -248,7 +246,7 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
       // (the votes of group g - 2, which read this bitmap, are waited for below, before the tile kernel -- but the bitmap
       // is rewritten here already: wait now)
       if (overlap && g >= 2) GR_HIP(c, hipStreamWaitEvent(s, c->ev_vote[buf], 0));
-      GR_HIP(c, hipMemsetAsync(tch, 0, sizeof(uint32_t) * (size_t)nb * tw, s));
+      // (zeroed by the group's init kernel: bin_batch)
     }
     c->cur_touched = tch; c->cur_tw = tw;
     rc = bin_batch(c, cams + (int64_t)v0 * GR_CAM_FLOATS, nb, h, w, 0, v0 / B, s);

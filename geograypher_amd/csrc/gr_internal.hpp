@@ -158,6 +158,7 @@ struct gr_ctx {
   bool cur_look = false;               // nothing learned about this (mesh, image size): the first launch group's counts are read
                                        // before its tile kernel runs (raster_views)
   int rebinned = 0;                    // times the last raster call started over after that look
+  bool stats_pending = false;          // the call's statistics have not been reset yet (the first launch group's init kernel does)
   int64_t opt_budget_mb = 24 << 10;    // entry memory of one launch group (GR_OPT_DIRECT_BUDGET_MB)
   int last_T = 0, last_B = 0;          // tile count and launch-group size of the last raster call
   int last_n_views = 0;
