@@ -1155,8 +1155,8 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int
   {
     // ONE kernel zeroes what the group's bin pass counts in -- the control words of its views, the fused path's chunk bitmaps
     // and, in the call's first group, the call's statistics -- where rounds 1-5 issued four to five fills: a fill of 40 bytes
-    // costs as much as a kernel launch (4.9 us each in the rocprof trace of a C2 step of 940 us; the step: -1.8 %,
-    // profiles/r05_ab/step_init_kernel_vs_fills.log).  (Folding k_bin_stats into the last k_clip_faces block of each view, to
+    // costs as much as a kernel launch (4.9 us each in the rocprof trace of a C2 step of 940 us; the step: -0.9 %, at quarter
+    // scale -2 %: profiles/r05_ab/step_deferred_stats_vs_init_kernel_vs_fills.log, builds in rotated order).  (Folding k_bin_stats into the last k_clip_faces block of each view, to
     // save that launch too, measured no gain: one wave adding up a view's counters takes as long as the launch it saves --
     // step_clip_stats_merged*.)
     const int64_t n16 = c->ctrl_stride * nb / 4;   // ctrl_stride is a multiple of 64 words
@@ -1207,8 +1207,17 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int
   }
   c->last_direct = a.cap_tile > 0;
   if (a.cap_tile > 0) {
-    Timed t(c, s, ST_SCAN);
-    hipLaunchKernelGGL(k_bin_stats, dim3(nb), dim3(1024), 0, s, a);
+    // the view totals behind gr_raster_status.  Nothing on the device waits for them unless the call is fused (the vote kernel
+    // skips overflowed groups), has more launch groups to come (they reuse the counters) or looks at its first group:
+    // otherwise they are added up when -- if -- the status call asks (bin_stats_deferred), and a caller that runs unchecked
+    // calls back to back (check=False: bench.py's timed loops) does not pay a launch per call for numbers nobody reads (the C2
+    // step -1.5 %, at quarter scale -3.5 %: same log)
+    if (c->defer_stats) {
+      c->stats_deferred = true; c->deferred_args = a; c->deferred_nb = nb;   // (the arguments as they are: options may change before the status call)
+    } else {
+      Timed t(c, s, ST_SCAN);
+      hipLaunchKernelGGL(k_bin_stats, dim3(nb), dim3(1024), 0, s, a);
+    }
   } else {
     {
       Timed t(c, s, ST_SCAN);
@@ -1220,6 +1229,15 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int
       hipLaunchKernelGGL(k_fill_compile, dim3(g, nb), dim3(256), 0, s, a);
     }
   }
+  GR_HIP(c, hipGetLastError());
+  return GR_OK;
+}
+
+// the deferred k_bin_stats of the last raster call (see bin_batch), on the stream of that call
+int bin_stats_deferred(gr_ctx *c, hipStream_t s) {
+  if (!c->stats_deferred) return GR_OK;
+  c->stats_deferred = false;
+  hipLaunchKernelGGL(k_bin_stats, dim3(c->deferred_nb), dim3(1024), 0, s, c->deferred_args);
   GR_HIP(c, hipGetLastError());
   return GR_OK;
 }

@@ -236,6 +236,9 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   c->last_stream = s;
   note_stream(c, s);
   c->stats_pending = true;   // the call's statistics are reset by the first launch group's init kernel (bin_batch: k_bin_init)
+  c->stats_deferred = false;
+  // (variant bit 32768: never deferred -- A/B and tests of the eager form)
+  c->defer_stats = !labels && n_views <= B && !(c->cur_look && again < 2) && !(c->opt_var & 32768);
   c->last_n_views = n_views;
   int g = 0;
   for (int v0 = 0; v0 < n_views; v0 += B, ++g) {
@@ -475,6 +478,10 @@ int gr_raster_face_ids(gr_ctx *c, const float *cams, int n_views, int h, int w, 
 int gr_raster_status(gr_ctx *c, gr_raster_stats *o) {
   if (!c || !o) return GR_EINVAL;
   unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  {
+    const int rc = bin_stats_deferred(c, c->last_stream);   // the view totals of a call that left them for now
+    if (rc) return rc;
+  }
   GR_HIP(c, hipMemcpyAsync(st, c->stats, sizeof(st), hipMemcpyDeviceToHost, c->last_stream));
   GR_HIP(c, hipStreamSynchronize(c->last_stream));
   o->records = (int64_t)st[0]; o->entries = (int64_t)st[1]; o->max_entries = (int64_t)st[2];

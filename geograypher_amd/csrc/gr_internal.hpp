@@ -159,6 +159,10 @@ struct gr_ctx {
                                        // before its tile kernel runs (raster_views)
   int rebinned = 0;                    // times the last raster call started over after that look
   bool stats_pending = false;          // the call's statistics have not been reset yet (the first launch group's init kernel does)
+  bool defer_stats = false;            // this call's view totals (k_bin_stats) wait for gr_raster_status: one launch group, not fused, no look
+  bool stats_deferred = false;         // ... and have not been added up yet
+  grimpl::BinArgs deferred_args;               // ... with these arguments, for deferred_nb views
+  int deferred_nb = 0;
   int64_t opt_budget_mb = 24 << 10;    // entry memory of one launch group (GR_OPT_DIRECT_BUDGET_MB)
   int last_T = 0, last_B = 0;          // tile count and launch-group size of the last raster call
   int last_n_views = 0;
@@ -300,6 +304,7 @@ inline int check_common(gr_ctx *c, int n_views, int h, int w) {
 // launchers that live in other translation units
 int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int group, hipStream_t s);   // binning.hip
 int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStream_t s);                 // raster_tile.hip
+int bin_stats_deferred(gr_ctx *c, hipStream_t s);                                                         // binning.hip
 int project_labels(gr_ctx *c, const int32_t *ids, const uint8_t *labels, int n_views, int h, int w, int C, uint32_t *votes,
                    uint32_t *counts, int flags, hipStream_t s);                                           // project.hip
 void launch_vote_labels(gr_ctx *c, hipStream_t vs, uint32_t *win, const uint8_t *labels, int nb, int64_t F, int64_t P, int C,

@@ -290,6 +290,7 @@ int gr_mesh_upload(gr_ctx *c, const float *verts, const int32_t *faces, int64_t 
   hipLaunchKernelGGL(k_block_vertices, dim3((unsigned)ceil_div(nblk, 4)), dim3(256), 0, s, verts, faces, c->orig, F, c->bvert, c->bidx);
   GR_HIP(c, hipGetLastError());
   c->verts = verts; c->faces = faces; c->V = V; c->F = F;
+  c->stats_deferred = false;   // (view totals a raster call on the old mesh left for the status call: void)
   return GR_OK;
 }
 

@@ -131,7 +131,9 @@ enum {
                                pixels -- a mesh rendered at a fraction of its photos' resolution -- teaches the library to
                                keep, for that mesh and image size, a second list per tile for such faces, which the tile
                                kernel point-samples one face per lane; remembered like the slots per tile); 16384 = no
-                               look at the first launch group's counts (every overflow goes through gr_raster_status)  */
+                               look at the first launch group's counts (every overflow goes through gr_raster_status);
+                               32768 = the view totals behind gr_raster_status are added up inside every call (default: a
+                               call of one launch group that is not fused leaves them to the status call)              */
   GR_OPT_SHARE_LEARNED = 8, /* 1 (default): consult and feed the process-wide table of learned slots per tile / entry forms
                                (and its file, gr_learned_cache_file); 0: this context learns for itself only.  Setting
                                GR_OPT_DIRECT_CAP by hand switches it off; this option switches it back on            */
@@ -170,7 +172,8 @@ int gr_mesh_upload(gr_ctx *ctx, const float *verts, const int32_t *faces, int64_
  * fp32 camera-space depth of the visible face, +inf for background.  Rule-set: DESIGN.md R0-R7. */
 int gr_raster_face_ids(gr_ctx *ctx, const float *cams, int n_views, int h, int w, int32_t *ids, float *depth,
                        void *stream);
-/* Outcome of the last raster call (synchronises its stream).  GR_EOVERFLOW: the single-pass binning could not finish a launch
+/* Outcome of the last raster call (synchronises its stream; a call of one launch group that is not fused leaves its view totals
+ * to be added up here, by one small kernel on that stream, instead of paying for them in every call).  GR_EOVERFLOW: the single-pass binning could not finish a launch
  * group -- a tile received more entries than its segment holds, or a face is too large (93 px and more) for the 40-byte
  * entries the call started with.  The first `views_done` views are final; the context (and the process-wide table, see
  * GR_OPT_DIRECT_CAP) now knows the segment size / entry form this mesh and image size need: call again for the remaining

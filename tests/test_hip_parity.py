@@ -33,7 +33,10 @@ VARIANTS = {"tile32_chain": (5, 512, 16), "tile64_single_full": (6, 512, 129), "
             "tile32_micro_roll_ids": (5, 512, 16 + 1024 + 8192),
             # 16384: no look at the first launch group's counts (a call for a mesh / image size nothing has been learned about
             # reads them before the group's tile kernel runs and starts over by itself): every overflow through gr_raster_status
-            "tile32_chain_no_look": (5, 512, 16 + 16384), "tile64_single_no_look": (6, 512, 1 + 16384)}
+            "tile32_chain_no_look": (5, 512, 16 + 16384), "tile64_single_no_look": (6, 512, 1 + 16384),
+            # 32768: the view totals behind gr_raster_status added up inside every call (default: left to the status call when
+            # nothing on the device waits for them)
+            "tile32_chain_eager_stats": (5, 512, 16 + 32768)}
 
 
 @pytest.fixture(params=list(VARIANTS), autouse=True)

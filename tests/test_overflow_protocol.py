@@ -345,3 +345,35 @@ def test_clipped_faces_outgrow_the_record_planes_of_exact_binning(hip):
         np.testing.assert_array_equal(ids[v].cpu().numpy(), want)
     again = hip.raster_face_ids(recs, 240, 320)
     assert hip.last_retries == 0 and torch.equal(again, ids)
+
+
+def test_view_totals_left_to_the_status_call(hip):
+    """A call of one launch group that is not fused does not add up its view totals itself (nothing on the device waits for
+    them): gr_raster_status does, when asked.  The numbers must be those of the eager form (variant bit 32768), also when other
+    work ran on the stream in between, and an overflow must still be reported -- by the status call of an unchecked call too."""
+    EAGER = 32768
+    (points, faces), cams = synthetic.config1_scene()
+    recs = _records(cams)
+    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+    keys = ("records", "entries", "max_entries", "overflow", "views_done", "blocks")
+    hip.set_option(7, EAGER)
+    hip.set_option(6, 512)
+    want_ids = hip.raster_face_ids(recs, 480, 640)
+    want = {k: hip.last_stats[k] for k in keys}
+    hip.set_option(7, 0)
+    hip.set_option(6, 512)
+    hip.raster_face_ids(recs, 480, 640)                       # learns (the look): the next call is an ordinary one
+    ids = hip.raster_face_ids(recs, 480, 640, check=False)
+    assert hip.last_stats == {"unchecked": True}
+    _ = hip.gather_texture(ids[0], np.zeros((faces.shape[0], 2)))   # other work of the context on the stream
+    got = hip.raster_status()
+    assert {k: got[k] for k in keys} == want and torch.equal(ids, want_ids)
+    assert {k: hip.raster_status()[k] for k in keys} == want        # asking twice does not count twice
+    # an overflow of an unchecked call (no look: the slots are known to be too few only to us)
+    hip.set_option(7, NO_LOOK)
+    hip.set_option(6, 64)
+    hip.raster_face_ids(recs, 480, 640, check=False)
+    with pytest.raises(RuntimeError, match="overflow"):
+        hip.raster_status()
+    fixed = hip.raster_face_ids(recs, 480, 640)
+    assert torch.equal(fixed, want_ids)
