@@ -305,6 +305,9 @@ __device__ __forceinline__ void bin_big_pairs(const BinArgs &a, uint32_t *__rest
 // returned by the (wave-aggregated) tile counter is final, so the compiled entry is written straight from here and
 // the record planes, k_scan_tiles and k_fill_compile are skipped.  A tile that receives more than cap_tile entries
 // raises the view's overflow word; the caller then repeats the call with the exact two-pass path (DIRECT = false).
+#ifndef GR_SETUP_BPW
+#define GR_SETUP_BPW 4u   // surviving blocks per wave of k_setup_cull, at least
+#endif
 template <bool DIRECT>
 __global__ __launch_bounds__(256)
 #if GR_EXP & 16  // boundness probe: at most 3 waves per SIMD
@@ -331,9 +334,16 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
   uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
   const uint32_t *work = a.work + (int64_t)slot * a.work_stride;
   // every wave takes its own 64-face block from the view's work list (wave-uniform control flow, no workgroup barrier)
-  const uint32_t wave0 = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wstep = gridDim.x * 4;
+  const uint32_t wave0 = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t n_work = ctrl[3];       // (a) blocks that passed k_cull_blocks for this view
   if (wave0 >= n_work) return;
+  // The grid is sized by the MESH (bin_batch: a workgroup per 128 blocks before culling); how many blocks of the view survive
+  // the cull is only known here.  The view's list goes to its first ceil(n_work / GR_SETUP_BPW) waves -- at least that many
+  // blocks per wave -- and the other waves leave: a view that sees 5 % of a 5 M-face mesh (config 5: 1.6 surviving blocks per
+  // wave of the grid) no longer pays 2440 wave start-ups for 4000 blocks (set-up 10.7 -> 8.x us per view,
+  // profiles/r05_ab/setup_grid_*.log: a grid sized per launch instead -- 6144 workgroups -- helps config 5 as much but costs C2 2 %); a view that keeps its waves busy anyway (C2: 4.2 blocks per wave) is not touched.
+  const uint32_t wstep = min(gridDim.x * 4u, (n_work + GR_SETUP_BPW - 1u) / GR_SETUP_BPW);
+  if (wave0 >= wstep) return;
   // (block indices through readfirstlane: loaded with a uniform address, but into a vector register -- every address derived
   // from them would be 64-bit VALU arithmetic instead of a scalar base.  The same for the wave's index above: the compiler
   // cannot see that threadIdx.x >> 6 is wave-uniform, and the loop's control flow and the work-list loads were vector code:
