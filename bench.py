@@ -400,7 +400,9 @@ def run(args, rig=None) -> int:
         step()
     for _ in range(args.warmup):
         step()
-    # the library's HIP events (one pair per kernel group, recorded on the stream the kernels run on) stay ON through the
+    # the library's HIP events (on the stream the kernels run on; for the two stages of a raster call they ride on the kernel
+    # launches themselves -- hipExtLaunchKernelGGL stop events, a stage = [end of the kernel before it, end of its last kernel]
+    # -- so that timing the kernels does not slow them: recorded events cost the step 1.65 %) stay ON through the
     # timed windows: the per-kernel durations of the roofline object are those of exactly the timed steps
     hip.set_profiling(True)
     # windows of EXACTLY --steps steps; at least --windows of them, and as many more as it takes to put --min-timed-s of GPU
@@ -452,7 +454,7 @@ def run(args, rig=None) -> int:
         roofline["pipeline_traffic_over_culled_algorithmic"] = round(sum(moved) / culled_bytes, 4)
     rooflines = {
         "k_setup_cull": hbm_roofline(
-            "set-up stage of pix2face: k_cull_blocks + k_setup_cull + k_clip_faces (one HIP-event pair around the three)",
+            "set-up stage of pix2face: k_cull_blocks + k_setup_cull + k_clip_faces (HIP events: end of k_bin_init -> end of k_clip_faces)",
             (12.0 * V + 12.0 * F) * views_per_launch, setup_ms_per_launch, views_per_launch, "k_setup_cull",
             note="12 V + 12 F per view: the mesh read of B_r (SURVEY 8d)"),
     }

@@ -1172,8 +1172,8 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int
     const int64_t n16 = c->ctrl_stride * nb / 4;   // ctrl_stride is a multiple of 64 words
     const int64_t nt = a.touched ? (int64_t)nb * a.tw : 0;
     const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(std::max(n16, nt), 256), 2048));
-    hipLaunchKernelGGL(k_bin_init, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4 *>(a.ctrl), n16, a.touched, nt,
-                       c->stats_pending ? c->stats : nullptr);
+    unsigned long long *const st = c->stats_pending ? c->stats : nullptr;
+    GR_LAUNCH_EV((hipEvent_t) nullptr, chain_begin(c), k_bin_init, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4 *>(a.ctrl), n16, a.touched, nt, st);
     c->stats_pending = false;
   }
   if (a.dbg & 512) {  // test hook: every entry slot and row count starts as garbage (0xFF), like scratch that an earlier call left behind
@@ -1181,7 +1181,7 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int
     GR_HIP(c, hipMemsetAsync(a.nrow8, 0xFF, (size_t)c->ent_cap * nb, s));
   }
   {
-    Timed t(c, s, ST_SETUP);
+    // (the stage's span: from the end of k_bin_init to the end of k_clip_faces -- chain_stop)
     const int nblk = (int)ceil_div(c->F, GR_BLOCK);
     hipLaunchKernelGGL(k_cull_blocks, dim3((unsigned)ceil_div(nblk, 256), nb), dim3(256), a.touched ? sizeof(uint32_t) * a.tw : 0, s,
                        cams, a, nblk);
@@ -1209,10 +1209,10 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int
     if (a.cap_tile > 0) {
       hipLaunchKernelGGL(k_setup_cull<true>, gsetup, dim3(256), 0, s, cams, a, nb);
       if (a.var & 64) hipLaunchKernelGGL(k_bin_big, dim3(256, nb), dim3(256), 0, s, cams, a);
-      hipLaunchKernelGGL(k_clip_faces<true>, dim3(8, nb), dim3(64), 0, s, cams, a);
+      GR_LAUNCH_EV((hipEvent_t) nullptr, chain_stop(c, ST_SETUP), k_clip_faces<true>, dim3(8, nb), dim3(64), 0, s, cams, a);
     } else {
       hipLaunchKernelGGL(k_setup_cull<false>, gsetup, dim3(256), 0, s, cams, a, nb);
-      hipLaunchKernelGGL(k_clip_faces<false>, dim3(8, nb), dim3(64), 0, s, cams, a);
+      GR_LAUNCH_EV((hipEvent_t) nullptr, chain_stop(c, ST_SETUP), k_clip_faces<false>, dim3(8, nb), dim3(64), 0, s, cams, a);
     }
   }
   c->last_direct = a.cap_tile > 0;
@@ -1225,18 +1225,13 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int
     if (c->defer_stats) {
       c->stats_deferred = true; c->deferred_args = a; c->deferred_nb = nb;   // (the arguments as they are: options may change before the status call)
     } else {
-      Timed t(c, s, ST_SCAN);
-      hipLaunchKernelGGL(k_bin_stats, dim3(nb), dim3(1024), 0, s, a);
+      GR_LAUNCH_EV((hipEvent_t) nullptr, chain_stop(c, ST_SCAN), k_bin_stats, dim3(nb), dim3(1024), 0, s, a);
     }
   } else {
+    GR_LAUNCH_EV((hipEvent_t) nullptr, chain_stop(c, ST_SCAN), k_scan_tiles, dim3(nb), dim3(1024), 0, s, a);
     {
-      Timed t(c, s, ST_SCAN);
-      hipLaunchKernelGGL(k_scan_tiles, dim3(nb), dim3(1024), 0, s, a);
-    }
-    {
-      Timed t(c, s, ST_FILL);
       const unsigned g = (unsigned)std::min<int64_t>(ceil_div(c->F, 256), 1024);
-      hipLaunchKernelGGL(k_fill_compile, dim3(g, nb), dim3(256), 0, s, a);
+      GR_LAUNCH_EV((hipEvent_t) nullptr, chain_stop(c, ST_FILL), k_fill_compile, dim3(g, nb), dim3(256), 0, s, a);
     }
   }
   GR_HIP(c, hipGetLastError());

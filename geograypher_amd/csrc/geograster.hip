@@ -333,7 +333,7 @@ int gr_ctx_destroy(gr_ctx *c) {
   if (!c) return GR_OK;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  for (auto &sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+  for (auto &sp : c->spans) { if (sp.own_a) (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   for (auto e : c->pool) (void)hipEventDestroy(e);
   if (c->ctrl) (void)hipFree(c->ctrl);
   if (c->rec) (void)hipFree(c->rec);
@@ -367,8 +367,7 @@ const char *gr_last_error(const gr_ctx *c) { return c ? c->err : "null context";
 int gr_set_profiling(gr_ctx *c, int enabled) {
   if (!c) return GR_EINVAL;
   c->profiling = enabled != 0;
-  for (auto &sp : c->spans) { c->pool.push_back(sp.a); c->pool.push_back(sp.b); }
-  c->spans.clear();
+  release_spans(c);
   c->prof_views = 0; c->prof_raster_launches = 0;
   return GR_OK;
 }
@@ -463,8 +462,7 @@ int gr_get_stage_times(gr_ctx *c, gr_stage_times *o) {
   o->setup_ms = acc[ST_SETUP]; o->scan_ms = acc[ST_SCAN]; o->fill_ms = acc[ST_FILL]; o->raster_ms = acc[ST_RASTER];
   o->project_ms = acc[ST_PROJECT]; o->vote_ms = acc[ST_VOTE]; o->gather_ms = acc[ST_GATHER];
   o->raster_launches = c->prof_raster_launches; o->views = c->prof_views;
-  for (auto &sp : c->spans) { c->pool.push_back(sp.a); c->pool.push_back(sp.b); }
-  c->spans.clear();
+  release_spans(c);
   c->prof_views = 0; c->prof_raster_launches = 0;
   return GR_OK;
 }

@@ -9,6 +9,7 @@
 //   warp.hip         distortion warp, lens inversion (row f1)
 //   resize.hip       photo down-scale of get_image (anti-aliased resize)
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -186,7 +187,9 @@ struct gr_ctx {
   std::vector<hipStream_t> used_streams;  // streams that work touching context scratch was enqueued on since the last quiesce
   // profiling
   bool profiling = false;
-  struct Span { hipEvent_t a, b; int stage; };
+  struct Span { hipEvent_t a, b; int stage; bool own_a = true; };   // own_a false: `a` is the `b` of the span before (a chain of launch-attached stop events)
+  hipEvent_t chain_ev = nullptr;       // the stop event of the latest instrumented launch of the running raster call (chain_stop)
+  bool chain_first = false;
   std::vector<Span> spans;
   std::vector<hipEvent_t> pool;
   int prof_views = 0, prof_raster_launches = 0;
@@ -223,12 +226,46 @@ inline hipEvent_t take_event(gr_ctx *c) {
 struct Timed {  // RAII span around a kernel group when profiling is on
   gr_ctx *c; hipStream_t s; int stage; hipEvent_t a = nullptr, b = nullptr;
   Timed(gr_ctx *c_, hipStream_t s_, int st) : c(c_), s(s_), stage(st) {
-    if (c->profiling) { a = take_event(c); b = take_event(c); if (a) (void)hipEventRecord(a, s); }
+    if (c->profiling && st >= 0) { a = take_event(c); b = take_event(c); if (a) (void)hipEventRecord(a, s); }   // (st < 0: no span)
   }
   ~Timed() {
-    if (c->profiling && a && b) { (void)hipEventRecord(b, s); c->spans.push_back({a, b, stage}); }
+    if (c->profiling && a && b) { (void)hipEventRecord(b, s); gr_ctx::Span sp; sp.a = a; sp.b = b; sp.stage = stage; c->spans.push_back(sp); }
   }
 };
+
+// Spans whose events ride on kernel LAUNCHES (hipExtLaunchKernelGGL's stop event: the END of that kernel) instead of being
+// recorded between kernels: an event record is a packet of its own on the stream and costs the kernels behind it 3.8 us -- four
+// of them 1.65 % of a C2 step, 4.3 % of a quarter-scale one (tools/event_cost.py).  (The launch's START event is no use: it is
+// stamped when the packet is taken up, while the kernel before it still runs.)  So the stages of a raster call are timed as a
+// CHAIN of ends: chain_begin -> the end of the kernel in front of the first stage (k_bin_init); chain_stop(stage) -> the end of
+// the stage's last kernel, the span [previous end, this end] -- the launch gap in front of a kernel is part of its span.
+inline hipEvent_t chain_begin(gr_ctx *c) {
+  c->chain_ev = c->profiling ? take_event(c) : nullptr;
+  c->chain_first = true;
+  return c->chain_ev;
+}
+inline hipEvent_t chain_stop(gr_ctx *c, int stage) {
+  if (!c->profiling || !c->chain_ev) return nullptr;
+  hipEvent_t e = take_event(c);
+  if (!e) return nullptr;
+  gr_ctx::Span sp; sp.a = c->chain_ev; sp.b = e; sp.stage = stage; sp.own_a = c->chain_first;
+  c->spans.push_back(sp);
+  c->chain_first = false;
+  c->chain_ev = e;
+  return e;
+}
+inline void release_spans(gr_ctx *c) {   // events back to the pool
+  c->chain_ev = nullptr;
+  for (auto &sp : c->spans) { if (sp.own_a) c->pool.push_back(sp.a); c->pool.push_back(sp.b); }
+  c->spans.clear();
+}
+// launch KERNEL with (optional) start / stop events attached
+#define GR_LAUNCH_EV(EVA, EVB, KERNEL, GRID, BLOCK, SHMEM, STREAM, ...)                                        \
+  do {                                                                                                         \
+    const hipEvent_t eva_ = (EVA), evb_ = (EVB);   /* evaluated ONCE: chain_stop takes an event and pushes a span */ \
+    if (eva_ || evb_) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, STREAM, eva_, evb_, 0, __VA_ARGS__);   \
+    else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, STREAM, __VA_ARGS__);                                  \
+  } while (0)
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -1002,7 +1002,11 @@ namespace grimpl {
 int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStream_t s) {
   BinArgs a = make_args(c, h, w, slot0);
   {
-    Timed t(c, s, ST_RASTER);
+    // the kernel's span: from the end of the kernel in front of it (the chain of launch-attached stop events bin_batch began)
+    // to its own end; a call whose bin pass left no chain: recorded events
+    hipEvent_t ev_stop = chain_stop(c, ST_RASTER);
+    Timed t(c, s, ev_stop ? -1 : ST_RASTER);
+    const hipEvent_t ev_none = nullptr;
     // Four consecutive tiles per workgroup -- unless the image needed more than the default 512 slots per tile (a scene
     // with heavy tiles: chains of them make a few workgroups very long; hostile workload 57.9 vs 30.4 us per view at
     // 1000x750) or the launch has too few tiles to keep every CU busy with chains.
@@ -1019,13 +1023,13 @@ int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStr
 #define GR_LAUNCH_TILE_M(THL_, FUSE_, PLAIN_, MICRO_)                                                                 \
   do {                                                                                                                \
     if (roll && THL_ == 5) {                                                                                          \
-      if (a.ent40) hipLaunchKernelGGL((k_raster_tile_roll<6, 5, 256, FUSE_, GR_LDS_PAD, true, PLAIN_, GR_ROLL_KT, MICRO_>), grid, block, pad, s, a, out);  \
-      else hipLaunchKernelGGL((k_raster_tile_roll<6, 5, 256, FUSE_, GR_LDS_PAD48, false, PLAIN_, GR_ROLL_KT, false>), grid, block, pad, s, a, out);        \
+      if (a.ent40) GR_LAUNCH_EV(ev_none, ev_stop, (k_raster_tile_roll<6, 5, 256, FUSE_, GR_LDS_PAD, true, PLAIN_, GR_ROLL_KT, MICRO_>), grid, block, pad, s, a, out);  \
+      else GR_LAUNCH_EV(ev_none, ev_stop, (k_raster_tile_roll<6, 5, 256, FUSE_, GR_LDS_PAD48, false, PLAIN_, GR_ROLL_KT, false>), grid, block, pad, s, a, out);        \
     } else if (a.ent40) {                                                                                             \
-      if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD, true, PLAIN_, MICRO_>), grid, block, pad, s, a, out);  \
-      else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD, true, PLAIN_, MICRO_>), grid, block, pad, s, a, out);        \
-    } else if (chain) hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD48, false, PLAIN_, false>), grid, block, pad, s, a, out);  \
-    else hipLaunchKernelGGL((k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD48, false, PLAIN_, false>), grid, block, pad, s, a, out);        \
+      if (chain) GR_LAUNCH_EV(ev_none, ev_stop, (k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD, true, PLAIN_, MICRO_>), grid, block, pad, s, a, out);  \
+      else GR_LAUNCH_EV(ev_none, ev_stop, (k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD, true, PLAIN_, MICRO_>), grid, block, pad, s, a, out);        \
+    } else if (chain) GR_LAUNCH_EV(ev_none, ev_stop, (k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD48, false, PLAIN_, false>), grid, block, pad, s, a, out);  \
+    else GR_LAUNCH_EV(ev_none, ev_stop, (k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD48, false, PLAIN_, false>), grid, block, pad, s, a, out);        \
   } while (0)
 #define GR_LAUNCH_TILE(THL_, FUSE_, PLAIN_)                                                                           \
   do {                                                                                                                \
@@ -1045,6 +1049,7 @@ int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStr
     else GR_LAUNCH_TILE(5, false, false);
 #undef GR_LAUNCH_TILE
 #undef GR_LAUNCH_TILE_M
+    c->chain_ev = nullptr;
     c->prof_raster_launches += 1;
   }
   c->prof_views += nb;

@@ -96,8 +96,11 @@ int gr_ctx_create(int device, gr_ctx **out);
 int gr_ctx_destroy(gr_ctx *ctx);
 const char *gr_last_error(const gr_ctx *ctx);
 
-/* Turn per-stage hipEvent timing on (1) or off (0).  When on, events are recorded on `stream` around every
- * kernel group; gr_get_stage_times synchronises on them. */
+/* Turn per-stage hipEvent timing on (1) or off (0).  When on, HIP events on `stream` delimit every kernel group;
+ * gr_get_stage_times synchronises on them.  The stages of a raster call (set-up, tile kernel; scan / fill of the exact
+ * binning) are delimited by stop events attached to the kernel launches themselves (hipExtLaunchKernelGGL): a stage runs
+ * from the end of the kernel in front of it to the end of its last kernel, the launch gap in front of a kernel included --
+ * timing costs the call 0.2 % this way, where events recorded between the kernels cost it 1.65 % (4.3 % on small images). */
 int gr_set_profiling(gr_ctx *ctx, int enabled);
 
 /* Tuning knobs (results never depend on them; tests run every setting against the oracle). */
