@@ -240,6 +240,7 @@ struct Timed {  // RAII span around a kernel group when profiling is on
 // CHAIN of ends: chain_begin -> the end of the kernel in front of the first stage (k_bin_init); chain_stop(stage) -> the end of
 // the stage's last kernel, the span [previous end, this end] -- the launch gap in front of a kernel is part of its span.
 inline hipEvent_t chain_begin(gr_ctx *c) {
+  if (c->chain_ev && c->chain_first) c->pool.push_back(c->chain_ev);   // a chain that was begun and never continued
   c->chain_ev = c->profiling ? take_event(c) : nullptr;
   c->chain_first = true;
   return c->chain_ev;
@@ -255,7 +256,8 @@ inline hipEvent_t chain_stop(gr_ctx *c, int stage) {
   return e;
 }
 inline void release_spans(gr_ctx *c) {   // events back to the pool
-  c->chain_ev = nullptr;
+  if (c->chain_ev && c->chain_first) c->pool.push_back(c->chain_ev);
+  c->chain_ev = nullptr; c->chain_first = false;
   for (auto &sp : c->spans) { if (sp.own_a) c->pool.push_back(sp.a); c->pool.push_back(sp.b); }
   c->spans.clear();
 }
