@@ -7,6 +7,10 @@ OUT=$REPO/gpurun_out/r5_final
 mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -q > $OUT/gpu_tests.log 2>&1
 tail -3 $OUT/gpu_tests.log
+bash tools/profile.sh r05 > $OUT/profile.log 2>&1
+grep -E "k_raster_tile|k_setup_cull|k_vote|k_cull" gpurun_out/prof_r05/summary_r05.txt | cut -c1-170
+# the counter files of THIS tree in place before the bench line is taken, so that the line carries `traffic` / `valu`
+cp gpurun_out/prof_r05/traffic.json gpurun_out/prof_r05/valu.json profiles/
 ( time timeout 900 python bench.py ) > $OUT/bench.json 2> $OUT/bench.err
 tail -4 $OUT/bench.err
 python -c "
@@ -19,8 +23,6 @@ print(d['quarter_scale'])
 print({k: v for k, v in d['io']['aggregate_from_label_png_files'].items() if 'views_per_s' in k})
 print({k: v for k, v in d['api'].items() if 'photo' in k})
 "
-bash tools/profile.sh r05 > $OUT/profile.log 2>&1
-grep -E "k_raster_tile|k_setup_cull|k_vote|k_cull" gpurun_out/prof_r05/summary_r05.txt | cut -c1-170
 cd /tmp && export TMPDIR=/tmp
 # kernel-trace statistics of config 5 (ids kernel, 20 views per launch) and of the hostile forest (20 oblique views, both scales)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_r05/trace_c5 -o t -- python3 $REPO/tools/prof_c5.py 20 6 > $OUT/trace_c5.log 2>&1
