@@ -342,7 +342,13 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
   // blocks per wave -- and the other waves leave: a view that sees 5 % of a 5 M-face mesh (config 5: 1.6 surviving blocks per
   // wave of the grid) no longer pays 2440 wave start-ups for 4000 blocks (set-up 10.7 -> 8.x us per view,
   // profiles/r05_ab/setup_grid_*.log: a grid sized per launch instead -- 6144 workgroups -- helps config 5 as much but costs C2 2 %); a view that keeps its waves busy anyway (C2: 4.2 blocks per wave) is not touched.
-  const uint32_t wstep = min(gridDim.x * 4u, (n_work + GR_SETUP_BPW - 1u) / GR_SETUP_BPW);
+  // ... at least GR_SETUP_BPW = 4, and as many more as the view has surviving blocks per TILE (up to 16): where the blocks
+  // outnumber the tiles -- a mesh rendered at a quarter of its photos' size: the hostile forest at 1000 x 750 has 25 blocks per
+  // tile, C2 at that size 6.5 -- every tile counter is hit from many blocks at once and fewer waves in flight get through
+  // faster (forest at 1000 x 750: 27.5 -> 24.5 us per view at 16 blocks per wave, C2 at 1000 x 750 3.84 -> 3.76 at 6; the
+  // full-size images, under 2 blocks per tile, lose 5-9 % at 12-16: setup_grid_blocks_per_wave_small_images.log)
+  const uint32_t bpw = min(16u, max((uint32_t)GR_SETUP_BPW, n_work / (uint32_t)max(a.T, 1)));
+  const uint32_t wstep = min(gridDim.x * 4u, (n_work + bpw - 1u) / bpw);
   if (wave0 >= wstep) return;
   // (block indices through readfirstlane: loaded with a uniform address, but into a vector register -- every address derived
   // from them would be 64-bit VALU arithmetic instead of a scalar base.  The same for the wave's index above: the compiler
