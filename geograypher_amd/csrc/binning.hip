@@ -280,7 +280,7 @@ __device__ __forceinline__ void bin_big_pairs(const BinArgs &a, uint32_t *__rest
     int ld, rk, sz;
     wave_group_capped(tile, lane, ld, rk, sz, 16);
     uint32_t base = 0;
-    if (tile >= 0 && lane == ld) base = atomicAdd(&cntS[tile], (uint32_t)sz);
+    if (tile >= 0 && lane == ld) base = atomicAdd(&cntS[(int64_t)tile << a.csl], (uint32_t)sz);
     const uint32_t pos = __shfl(base, ld) + (uint32_t)rk;
     if (tile >= 0) {
       if (pos < (uint32_t)a.cap_tile) {
@@ -307,6 +307,9 @@ __device__ __forceinline__ void bin_big_pairs(const BinArgs &a, uint32_t *__rest
 // raises the view's overflow word; the caller then repeats the call with the exact two-pass path (DIRECT = false).
 #ifndef GR_SETUP_BPW
 #define GR_SETUP_BPW 4u   // surviving blocks per wave of k_setup_cull, at least
+#endif
+#ifndef GR_SETUP_BPW_MAX
+#define GR_SETUP_BPW_MAX 8u   // ... and at most (where the blocks outnumber the tiles)
 #endif
 template <bool DIRECT>
 __global__ __launch_bounds__(256)
@@ -342,12 +345,14 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
   // blocks per wave -- and the other waves leave: a view that sees 5 % of a 5 M-face mesh (config 5: 1.6 surviving blocks per
   // wave of the grid) no longer pays 2440 wave start-ups for 4000 blocks (set-up 10.7 -> 8.x us per view,
   // profiles/r05_ab/setup_grid_*.log: a grid sized per launch instead -- 6144 workgroups -- helps config 5 as much but costs C2 2 %); a view that keeps its waves busy anyway (C2: 4.2 blocks per wave) is not touched.
-  // ... at least GR_SETUP_BPW = 4, and as many more as the view has surviving blocks per TILE (up to 16): where the blocks
+  // ... at least GR_SETUP_BPW = 4, and as many more as the view has surviving blocks per TILE, up to 8: where the blocks
   // outnumber the tiles -- a mesh rendered at a quarter of its photos' size: the hostile forest at 1000 x 750 has 25 blocks per
   // tile, C2 at that size 6.5 -- every tile counter is hit from many blocks at once and fewer waves in flight get through
-  // faster (forest at 1000 x 750: 27.5 -> 24.5 us per view at 16 blocks per wave, C2 at 1000 x 750 3.84 -> 3.76 at 6; the
-  // full-size images, under 2 blocks per tile, lose 5-9 % at 12-16: setup_grid_blocks_per_wave_small_images.log)
-  const uint32_t bpw = min(16u, max((uint32_t)GR_SETUP_BPW, n_work / (uint32_t)max(a.T, 1)));
+  // faster.  (Measured with the counters of such an image packed into twelve 128-byte lines: forest at 1000 x 750 27.5 -> 24.5 us
+  // per view at 16 blocks per wave, C2 at 1000 x 750 3.84 -> 3.76 at 6, full-size images -- under 2 blocks per tile -- 5-9 %
+  // slower at 12-16.  With ONE counter per line for small images (ensure_bins; forest 24.9 -> 20.3 us) the forest's optimum is
+  // back at 4-8 -- 19.5 us -- and 16 costs it 5 %: setup_grid_blocks_per_wave_*.log, setup_counter_per_line_small_images.log.)
+  const uint32_t bpw = min((uint32_t)GR_SETUP_BPW_MAX, max((uint32_t)GR_SETUP_BPW, n_work / (uint32_t)max(a.T, 1)));
   const uint32_t wstep = min(gridDim.x * 4u, (n_work + bpw - 1u) / bpw);
   if (wave0 >= wstep) return;
   // (block indices through readfirstlane: loaded with a uniform address, but into a vector register -- every address derived
@@ -505,7 +510,7 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
   const int t10 = (small_fp && ty1 > ty0) ? (ty1 * a.TX + tx0) | ((mcls & 4) ? GR_MICRO_BIT : 0) : -1;
   const int t11 = (small_fp && tx1 > tx0 && ty1 > ty0) ? (ty1 * a.TX + tx1) | ((mcls & 8) ? GR_MICRO_BIT : 0) : -1;
   // a tile's counter: cntS, or cntB for its micro list; an entry's slot: from the front of the segment, or from its back
-  auto counter_of = [&](int t) { return (t & GR_MICRO_BIT) ? &cntB[t & ~GR_MICRO_BIT] : &cntS[t]; };
+  auto counter_of = [&](int t) { return (t & GR_MICRO_BIT) ? &cntB[(int64_t)(t & ~GR_MICRO_BIT) << a.csl] : &cntS[(int64_t)t << a.csl]; };
   auto slot_of = [&](int t, uint32_t pos) {
     return (t & GR_MICRO_BIT) ? (int64_t)(t & ~GR_MICRO_BIT) * a.cap_tile + ((uint32_t)a.cap_tile - 1u - pos) : (int64_t)t * a.cap_tile + pos;
   };
@@ -658,7 +663,7 @@ __global__ __launch_bounds__(1024) void k_bin_stats(BinArgs a) {
   unsigned long long sum = 0;
   uint32_t mx = 0;
   // (with micro lists a tile's segment holds both lists, one from each end: the two counts together must fit)
-  for (int t = threadIdx.x; t < a.T; t += 1024) { const uint32_t c = cnt[t] + (a.micro ? cnt[a.Tcap + t] : 0u); sum += c; mx = max(mx, c); }
+  for (int t = threadIdx.x; t < a.T; t += 1024) { const int64_t i = (int64_t)t << a.csl; const uint32_t c = cnt[i] + (a.micro ? cnt[a.Tcap + i] : 0u); sum += c; mx = max(mx, c); }
   for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); }
   if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = sum; pmax[threadIdx.x >> 6] = mx; }
   __syncthreads();
@@ -1012,7 +1017,7 @@ __device__ void emit_triangle(const BinArgs &a, int slot, uint32_t *ctrl, Vtx v0
     for (int ty = ty0; ty <= ty1; ++ty)
       for (int tx = tx0; tx <= tx1; ++tx) {
         const int t = ty * a.TX + tx;
-        const uint32_t pos = atomicAdd(&cntS[t], 1u);
+        const uint32_t pos = atomicAdd(&cntS[(int64_t)t << a.csl], 1u);
         if (pos < (uint32_t)a.cap_tile) {
           const int64_t idx = (int64_t)t * a.cap_tile + pos;
           compile_entry(a, ctrl, comp, nr8, idx, r0, r1, r2, tx << a.twl, ty << a.thl, 1 << a.twl, 1 << a.thl);

@@ -171,8 +171,14 @@ int ensure_bins(gr_ctx *c, int n_slots, int T) {
   if (direct) cap = std::max<int64_t>(cap, (int64_t)T * dcap);
   // The layout (strides) is that of THIS call; a buffer is re-allocated only when the call needs more elements than the
   // buffer has (a huge image with a small launch group and a small image with a full one share the same memory).
-  const int Tcap = (T + 3) & ~3;  // the per-tile counter arrays start 16-byte aligned (a chain reads four counters at once)
-  const int64_t ctrl_stride = ((GR_CTRL_HDR + 4 * (int64_t)Tcap) + 63) / 64 * 64;
+  // Small images: ONE tile counter per 128-byte line.  Atomics on the same line are served one after the other whatever their
+  // addresses (32 counters in one line: 5.9 ns per atomic chip-wide, one per line: 0.37 -- profiles/r03_ubench_atomic_rate.txt),
+  // and an image of 1000 x 750 has all its 384 counters in twelve lines, hit by every wave that bins the view.  (Images of
+  // thousands of tiles spread their atomics over hundreds of lines anyway, and padding them would cost the init kernel 32 x the
+  // bytes.)  Single-pass binning only; variant bit 131072: packed counters everywhere.
+  const int csl = (direct && T <= 1024 && !(c->opt_var & 131072)) ? 5 : 0;
+  const int Tcap = ((T + 3) & ~3) << csl;  // words per counter array; the arrays start 16-byte aligned (a chain reads four counters at once)
+  const int64_t ctrl_stride = ((GR_CTRL_HDR + (direct ? 2 : 4) * (int64_t)Tcap) + 63) / 64 * 64;   // (exact binning: + offsets and cursors)
   const int64_t work_stride = ceil_div(F, GR_BLOCK) + 4;
   int rc = grow(c, c->ctrl, c->ctrl_have, ctrl_stride * n_slots, "bin control");
   if (!rc) rc = grow(c, c->comp, c->comp_have, GR_ENT_Q * cap * n_slots, "entry list");
@@ -182,7 +188,7 @@ int ensure_bins(gr_ctx *c, int n_slots, int T) {
   const int64_t RF = std::max<int64_t>(F, c->rec_cap_request);  // records per view: a face each, a clipped face up to six
   if (!rc && !direct) rc = grow(c, c->rec, c->rec_have, 4 * RF * n_slots, "record planes");  // exact path only
   if (rc) return rc;
-  c->slots = n_slots; c->Tcap = Tcap; c->ent_cap = cap; c->ctrl_stride = ctrl_stride; c->work_stride = work_stride;
+  c->slots = n_slots; c->Tcap = Tcap; c->csl = csl; c->ent_cap = cap; c->ctrl_stride = ctrl_stride; c->work_stride = work_stride;
   c->rec_F = RF; c->rec_stride = 4 * RF;
   return GR_OK;
 }

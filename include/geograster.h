@@ -136,7 +136,9 @@ enum {
                                kernel point-samples one face per lane; remembered like the slots per tile); 16384 = no
                                look at the first launch group's counts (every overflow goes through gr_raster_status);
                                32768 = the view totals behind gr_raster_status are added up inside every call (default: a
-                               call of one launch group that is not fused leaves them to the status call)              */
+                               call of one launch group that is not fused leaves them to the status call); 131072 = tile
+                               counters packed side by side whatever the image size (default: images of at most 1024 tiles
+                               keep one counter per 128-byte line -- atomics on one line are served one after the other) */
   GR_OPT_SHARE_LEARNED = 8, /* 1 (default): consult and feed the process-wide table of learned slots per tile / entry forms
                                (and its file, gr_learned_cache_file); 0: this context learns for itself only.  Setting
                                GR_OPT_DIRECT_CAP by hand switches it off; this option switches it back on            */

@@ -36,7 +36,10 @@ VARIANTS = {"tile32_chain": (5, 512, 16), "tile64_single_full": (6, 512, 129), "
             "tile32_chain_no_look": (5, 512, 16 + 16384), "tile64_single_no_look": (6, 512, 1 + 16384),
             # 32768: the view totals behind gr_raster_status added up inside every call (default: left to the status call when
             # nothing on the device waits for them)
-            "tile32_chain_eager_stats": (5, 512, 16 + 32768)}
+            "tile32_chain_eager_stats": (5, 512, 16 + 32768),
+            # 131072: tile counters packed side by side (default for images of at most 1024 tiles -- every image of this file but
+            # the full-size ones: one counter per 128-byte line)
+            "tile32_chain_packed_counters": (5, 512, 16 + 131072), "tile64_single_packed_counters": (6, 512, 1 + 131072)}
 
 
 @pytest.fixture(params=list(VARIANTS), autouse=True)

@@ -27,7 +27,7 @@ from oracle import oracle_c
 
 # round 5: 1024 / 2048 rolling chains for the ids kernels / never, 4096 / 8192 micro lists never / always, 16384 no look at the first
 # launch group's counts (the overflow protocol of rounds 1-4)
-VARIANT_BITS = [1, 4, 8, 16, 32, 64, 128, 512, 1024, 2048, 4096, 8192, 16384]
+VARIANT_BITS = [1, 4, 8, 16, 32, 64, 128, 512, 1024, 2048, 4096, 8192, 16384, 32768, 131072]
 
 
 BIG = False
