@@ -280,7 +280,7 @@ __device__ __forceinline__ void bin_big_pairs(const BinArgs &a, uint32_t *__rest
     int ld, rk, sz;
     wave_group_capped(tile, lane, ld, rk, sz, 16);
     uint32_t base = 0;
-    if (tile >= 0 && lane == ld) base = atomicAdd(&cntS[(int64_t)tile << a.csl], (uint32_t)sz);
+    if (tile >= 0 && lane == ld) base = atomicAdd(&cntS[cidx(a, tile)], (uint32_t)sz);
     const uint32_t pos = __shfl(base, ld) + (uint32_t)rk;
     if (tile >= 0) {
       if (pos < (uint32_t)a.cap_tile) {
@@ -510,7 +510,7 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
   const int t10 = (small_fp && ty1 > ty0) ? (ty1 * a.TX + tx0) | ((mcls & 4) ? GR_MICRO_BIT : 0) : -1;
   const int t11 = (small_fp && tx1 > tx0 && ty1 > ty0) ? (ty1 * a.TX + tx1) | ((mcls & 8) ? GR_MICRO_BIT : 0) : -1;
   // a tile's counter: cntS, or cntB for its micro list; an entry's slot: from the front of the segment, or from its back
-  auto counter_of = [&](int t) { return (t & GR_MICRO_BIT) ? &cntB[(int64_t)(t & ~GR_MICRO_BIT) << a.csl] : &cntS[(int64_t)t << a.csl]; };
+  auto counter_of = [&](int t) { return (t & GR_MICRO_BIT) ? &cntB[cidx(a, t & ~GR_MICRO_BIT)] : &cntS[cidx(a, t)]; };
   auto slot_of = [&](int t, uint32_t pos) {
     return (t & GR_MICRO_BIT) ? (int64_t)(t & ~GR_MICRO_BIT) * a.cap_tile + ((uint32_t)a.cap_tile - 1u - pos) : (int64_t)t * a.cap_tile + pos;
   };
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(1024) void k_bin_stats(BinArgs a) {
   unsigned long long sum = 0;
   uint32_t mx = 0;
   // (with micro lists a tile's segment holds both lists, one from each end: the two counts together must fit)
-  for (int t = threadIdx.x; t < a.T; t += 1024) { const int64_t i = (int64_t)t << a.csl; const uint32_t c = cnt[i] + (a.micro ? cnt[a.Tcap + i] : 0u); sum += c; mx = max(mx, c); }
+  for (int t = threadIdx.x; t < a.T; t += 1024) { const int64_t i = cidx(a, t); const uint32_t c = cnt[i] + (a.micro ? cnt[a.Tcap + i] : 0u); sum += c; mx = max(mx, c); }
   for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); }
   if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = sum; pmax[threadIdx.x >> 6] = mx; }
   __syncthreads();
@@ -1017,7 +1017,7 @@ __device__ void emit_triangle(const BinArgs &a, int slot, uint32_t *ctrl, Vtx v0
     for (int ty = ty0; ty <= ty1; ++ty)
       for (int tx = tx0; tx <= tx1; ++tx) {
         const int t = ty * a.TX + tx;
-        const uint32_t pos = atomicAdd(&cntS[(int64_t)t << a.csl], 1u);
+        const uint32_t pos = atomicAdd(&cntS[cidx(a, t)], 1u);
         if (pos < (uint32_t)a.cap_tile) {
           const int64_t idx = (int64_t)t * a.cap_tile + pos;
           compile_entry(a, ctrl, comp, nr8, idx, r0, r1, r2, tx << a.twl, ty << a.thl, 1 << a.twl, 1 << a.thl);

@@ -163,6 +163,9 @@ void learn_slots(gr_ctx *c, int T, int64_t max_tile, bool full, bool micro) {
   else learn(c, T, GR_LEARNED_EXACT, full, micro);   // this (mesh, image size) bins exactly from now on
 }
 
+#ifndef GR_CPERM_LARGE
+#define GR_CPERM_LARGE 0
+#endif
 int ensure_bins(gr_ctx *c, int n_slots, int T) {
   const int64_t F = c->F > 0 ? c->F : 1;
   const int dcap = c->cur_cap;  // resolved once per call (resolve_binning)
@@ -176,8 +179,14 @@ int ensure_bins(gr_ctx *c, int n_slots, int T) {
   // and an image of 1000 x 750 has all its 384 counters in twelve lines, hit by every wave that bins the view.  (Images of
   // thousands of tiles spread their atomics over hundreds of lines anyway, and padding them would cost the init kernel 32 x the
   // bytes.)  Single-pass binning only; variant bit 131072: packed counters everywhere.
-  const int csl = (direct && T <= 1024 && !(c->opt_var & 131072)) ? 5 : 0;
-  const int Tcap = ((T + 3) & ~3) << csl;  // words per counter array; the arrays start 16-byte aligned (a chain reads four counters at once)
+  int clg = -1;
+  if (direct && !(c->opt_var & 131072)) {
+    if (T <= 1024) { clg = 0; while ((1 << clg) < T + 3) ++clg; }          // a line per tile
+#if GR_CPERM_LARGE
+    else { clg = 0; while ((32 << clg) < T + 3) ++clg; }                   // A/B: neighbouring tiles in different lines, no more lines than needed
+#endif
+  }
+  const int Tcap = clg < 0 ? ((T + 3) & ~3) : (32 << clg);  // words per counter array; the arrays start 16-byte aligned (a chain reads four counters at once)
   const int64_t ctrl_stride = ((GR_CTRL_HDR + (direct ? 2 : 4) * (int64_t)Tcap) + 63) / 64 * 64;   // (exact binning: + offsets and cursors)
   const int64_t work_stride = ceil_div(F, GR_BLOCK) + 4;
   int rc = grow(c, c->ctrl, c->ctrl_have, ctrl_stride * n_slots, "bin control");
@@ -188,7 +197,7 @@ int ensure_bins(gr_ctx *c, int n_slots, int T) {
   const int64_t RF = std::max<int64_t>(F, c->rec_cap_request);  // records per view: a face each, a clipped face up to six
   if (!rc && !direct) rc = grow(c, c->rec, c->rec_have, 4 * RF * n_slots, "record planes");  // exact path only
   if (rc) return rc;
-  c->slots = n_slots; c->Tcap = Tcap; c->csl = csl; c->ent_cap = cap; c->ctrl_stride = ctrl_stride; c->work_stride = work_stride;
+  c->slots = n_slots; c->Tcap = Tcap; c->clg = clg; c->ent_cap = cap; c->ctrl_stride = ctrl_stride; c->work_stride = work_stride;
   c->rec_F = RF; c->rec_stride = 4 * RF;
   return GR_OK;
 }

@@ -77,7 +77,8 @@ struct BinArgs {
   int64_t ent_cap;       // entries per slot
   int64_t F;
   int T, TX, TY, Tcap;   // Tcap: WORDS per counter array (the tile count rounded up to 4, times the counter stride)
-  int csl;               // log2 of the counter stride in words: tile t's counters are cntS[t << csl], cntB[t << csl] (0, or 5 for small images)
+  int clg;               // tile t's counters are cntS[cidx(a, t)], cntB[cidx(a, t)]: -1 = packed side by side; >= 0 = spread over 2^clg lines of
+                         // 128 bytes, tile t in line t mod 2^clg at word t div 2^clg (2^clg >= T: every tile a line of its own)
   int h, w;
   int twl, thl;          // log2 of the tile width / height in pixels
   int cap_tile;          // > 0: single-pass binning, every tile owns cap_tile entry slots (list base = tile * cap_tile)
@@ -92,6 +93,11 @@ struct BinArgs {
                          // second-to-fourth tiles of small faces, 256 no depth gradients; 512 (a TEST hook, results stay right):
                          // entry slots and row counts are poisoned with 0xFF before every launch group is binned
 };
+
+// word of tile t's counter inside a counter array (BinArgs::clg)
+__device__ __forceinline__ int64_t cidx(const BinArgs &a, int t) {
+  return a.clg < 0 ? (int64_t)t : (int64_t)((((uint32_t)t & ((1u << a.clg) - 1u)) << 5) | ((uint32_t)t >> a.clg));
+}
 
 struct RasterOut {
   int32_t *ids;      // [slot][h][w] or null
@@ -134,7 +140,7 @@ struct gr_ctx {
   int *flag = nullptr;
   int64_t ctrl_stride = 0, rec_stride = 0, ent_cap = 0, ent_cap_request = 0;
   int64_t ctrl_have = 0, comp_have = 0, work_have = 0, rec_have = 0;  // allocated element counts
-  int Tcap = 0, slots = 0, csl = 0;
+  int Tcap = 0, slots = 0, clg = -1;
   int64_t rec_F = 0;                   // records per plane and slot of the exact path (>= F)
   int64_t rec_cap_request = 0;         // ... asked for by a call whose clipped faces outgrew F records (gr_raster_status)
   // tuning knobs (gr_set_option)
@@ -322,7 +328,7 @@ inline BinArgs make_args(gr_ctx *c, int h, int w, int slot0) {
   a.blk_chunks = c->blk_chunks; a.touched = c->cur_touched; a.tw = c->cur_tw;
   a.clip = c->clip + slot0 * c->F;
   a.twl = GR_TILE_LOG2; a.thl = c->opt_thl;
-  a.TX = (w + (1 << a.twl) - 1) >> a.twl; a.TY = (h + (1 << a.thl) - 1) >> a.thl; a.T = a.TX * a.TY; a.Tcap = c->Tcap; a.csl = c->csl;
+  a.TX = (w + (1 << a.twl) - 1) >> a.twl; a.TY = (h + (1 << a.thl) - 1) >> a.thl; a.T = a.TX * a.TY; a.Tcap = c->Tcap; a.clg = c->clg;
   a.h = h; a.w = w; a.dbg = c->opt_dbg; a.var = c->opt_var;
   a.cap_tile = c->cur_cap;          // the call's snapshot: every launch group, bin pass and tile pass alike
   a.ent40 = c->cur_ent40 ? 1 : 0;

@@ -486,7 +486,7 @@ __device__ __forceinline__ void fused_winners(const unsigned long long *keys, co
 // the tile's entry list: count and first slot (single-pass binning: the tile's fixed segment; exact binning: the scan's offset)
 __device__ __forceinline__ void tile_list(const BinArgs &a, const uint32_t *__restrict__ ctrl, int tile, uint32_t &cnt, int64_t &beg) {
   if (a.cap_tile > 0) {
-    cnt = min(ctrl[GR_CTRL_HDR + ((int64_t)tile << a.csl)], (uint32_t)a.cap_tile);
+    cnt = min(ctrl[GR_CTRL_HDR + cidx(a, tile)], (uint32_t)a.cap_tile);
     beg = (int64_t)tile * a.cap_tile;
   } else {
     cnt = ctrl[GR_CTRL_HDR + tile] + ctrl[GR_CTRL_HDR + a.Tcap + tile];
@@ -805,22 +805,22 @@ __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile(BinArgs a, Rast
   if (SHORT && MICRO) {
     if (KT == 4) {
       uint4 m4;
-      if (a.csl == 0) m4 = *reinterpret_cast<const uint4 *>(ctrl + GR_CTRL_HDR + a.Tcap + tile0);
-      else {   // small images: a counter per 128-byte line (ensure_bins); the three words behind the last tile's are valid memory
-        const uint32_t *m = ctrl + GR_CTRL_HDR + a.Tcap + ((int64_t)tile0 << a.csl);
-        m4 = make_uint4(m[0], m[(int64_t)1 << a.csl], m[(int64_t)2 << a.csl], m[(int64_t)3 << a.csl]);
+      if (a.clg < 0) m4 = *reinterpret_cast<const uint4 *>(ctrl + GR_CTRL_HDR + a.Tcap + tile0);
+      else {   // counters spread over lines (ensure_bins); the three tiles behind the image's last have counters too (zero)
+        const uint32_t *m = ctrl + GR_CTRL_HDR + a.Tcap;
+        m4 = make_uint4(m[cidx(a, tile0)], m[cidx(a, tile0 + 1)], m[cidx(a, tile0 + 2)], m[cidx(a, tile0 + 3)]);
       }
       cm0 = m4.x; cm1 = n_tiles > 1 ? m4.y : 0u; cm2 = n_tiles > 2 ? m4.z : 0u; cm3 = n_tiles > 3 ? m4.w : 0u;
-    } else cm0 = ctrl[GR_CTRL_HDR + a.Tcap + ((int64_t)tile0 << a.csl)];
+    } else cm0 = ctrl[GR_CTRL_HDR + a.Tcap + cidx(a, tile0)];
   }
   if (KT == 4 && a.cap_tile > 0) {
     // single-pass binning: the chain's four counters sit side by side, 16-byte aligned -- ONE scalar load instead of four
     // dependent ones, each behind its own wait (words behind the last tile's belong to the next counter array: valid memory)
     uint4 c4;
-    if (a.csl == 0) c4 = *reinterpret_cast<const uint4 *>(ctrl + GR_CTRL_HDR + tile0);
+    if (a.clg < 0) c4 = *reinterpret_cast<const uint4 *>(ctrl + GR_CTRL_HDR + tile0);
     else {
-      const uint32_t *cp = ctrl + GR_CTRL_HDR + ((int64_t)tile0 << a.csl);
-      c4 = make_uint4(cp[0], cp[(int64_t)1 << a.csl], cp[(int64_t)2 << a.csl], cp[(int64_t)3 << a.csl]);
+      const uint32_t *cp = ctrl + GR_CTRL_HDR;
+      c4 = make_uint4(cp[cidx(a, tile0)], cp[cidx(a, tile0 + 1)], cp[cidx(a, tile0 + 2)], cp[cidx(a, tile0 + 3)]);
     }
     const uint32_t cap = (uint32_t)a.cap_tile;
     cnt0 = min(c4.x, cap);
@@ -940,9 +940,9 @@ __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile_roll(BinArgs a,
   const int64_t sbase = slot * a.ent_cap;
   // the chain's counters: lane k holds tile k's (ONE vector register for the whole chain, read with v_readlane: no counter is
   // loaded inside the tile loop, where a load is a wait)
-  const uint32_t *cntp = ctrl + GR_CTRL_HDR + ((int64_t)tile0 << a.csl);
-  uint32_t cvec = lane < n_tiles ? min(cntp[(int64_t)lane << a.csl], cap) : 0u;
-  uint32_t mvec = (SHORT && MICRO && lane < n_tiles) ? cntp[a.Tcap + ((int64_t)lane << a.csl)] : 0u;   // the tiles' micro lists (cntB array)
+  const uint32_t *cntp = ctrl + GR_CTRL_HDR;
+  uint32_t cvec = lane < n_tiles ? min(cntp[cidx(a, tile0 + lane)], cap) : 0u;
+  uint32_t mvec = (SHORT && MICRO && lane < n_tiles) ? cntp[a.Tcap + cidx(a, tile0 + lane)] : 0u;   // the tiles' micro lists (cntB array)
   asm volatile("" : "+v"(cvec), "+v"(mvec));
   auto count_at = [&](int tt) { return (uint32_t)__builtin_amdgcn_readlane((int)cvec, tt); };   // tt < 64; lanes >= n_tiles hold 0
   ChunkRing r;
