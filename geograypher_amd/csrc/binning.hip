@@ -491,14 +491,18 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
   // wave_group keeps the two lists' positions apart.
   constexpr int GR_MICRO_BIT = 1 << 30;
   int mcls = 0;  // bit k: tile slot k (0 first, 1 right, 2 below, 3 below right) is a micro entry
-  if (DIRECT) {
+  if (DIRECT && (a.count_micro | a.micro)) {   // (wave-uniform: a call that neither counts micro faces nor keeps micro lists skips all of it)
     const int jmin = r2.z & 0xFFFF, jmax = (int)((uint32_t)r2.z >> 16), imin = r2.w & 0xFFFF, imax = (int)((uint32_t)r2.w >> 16);
     // how many faces of the view are micro faces (whole box at most 4 x 4): the statistic that switches micro lists on for
     // the NEXT call on this mesh and image size (gr_raster_status).  At full size only the clipped corners of ordinary faces
     // would qualify (2 % of the pairs) and give nearly every tile a list of a handful of entries -- a whole extra phase per
     // tile: ids kernel +7 % on C2 and C5 (profiles/r05_ab/micro_lists_per_tile_part.log) -- so the lists exist only where
     // micro FACES are the rule; there every pair is classed by its own part of the box in its tile.
-    n_mic += (uint32_t)__popcll(__ballot(small_fp && jmax - jmin < 4 && imax - imin < 4));
+    // Counted only by the calls that can still learn from it (BinArgs::count_micro: the call that looks at its first launch group
+    // -- the first for this mesh and image size --, or every call under the status-call protocol of variant bit 16384; not with
+    // 48-byte entries, not once the lists are on): four compares, a ballot and a population count per block were 2 % of the
+    // set-up stage on C2, 5 % at 1000 x 750, for a number nobody read.
+    if (a.count_micro) n_mic += (uint32_t)__popcll(__ballot(small_fp && jmax - jmin < 4 && imax - imin < 4));
     if (a.micro && small_fp) {
       const int xb = (tx0 + 1) << a.twl, yb = (ty0 + 1) << a.thl;   // first column / row of the right / lower tiles
       const bool wl = min(jmax, xb - 1) - jmin < 4, wr = jmax - xb < 4, ht = min(imax, yb - 1) - imin < 4, hb = imax - yb < 4;

@@ -122,7 +122,7 @@ void lookup_learned(const gr_ctx *c, int T, int &cap, bool &full, bool *micro = 
 // hand to anything else: 48 bytes.
 void resolve_binning(gr_ctx *c, int T) {
   int cap = 0; bool full = false, micro = false;
-  c->cur_cap = 0; c->cur_ent40 = false; c->cur_micro = false; c->cur_look = false;
+  c->cur_cap = 0; c->cur_ent40 = false; c->cur_micro = false; c->cur_look = false; c->cur_count_micro = false;
   if (c->opt_direct_cap <= 0 || !c->direct_ok) return;
   lookup_learned(c, T, cap, full, &micro);
   if (cap == GR_LEARNED_EXACT) return;  // this (mesh, image size) bins exactly: one view's segments would not fit the budget
@@ -134,6 +134,9 @@ void resolve_binning(gr_ctx *c, int T) {
   // micro lists: where an earlier call found most faces of the image at most 4 x 4 pixels (gr_raster_status; remembered like
   // the slots per tile), with 40-byte entries.  Variant bits: 8192 = always, 4096 = never.
   c->cur_micro = c->cur_ent40 && !(c->opt_var & 4096) && (micro || (c->opt_var & 8192));
+  // micro faces are counted where the count can still switch the lists on: by the call that looks at its first launch group, and
+  // by every call of the status-call protocol (variant bit 16384)
+  c->cur_count_micro = c->cur_ent40 && !c->cur_micro && !(c->opt_var & 4096) && (c->cur_look || (c->opt_var & 16384));
 }
 
 // cap > 0: the slots per tile the image needs; full: it needs 48-byte entries (both are kept once learned)

@@ -83,6 +83,7 @@ struct BinArgs {
   int twl, thl;          // log2 of the tile width / height in pixels
   int cap_tile;          // > 0: single-pass binning, every tile owns cap_tile entry slots (list base = tile * cap_tile)
   int ent40;             // 1: entries are written in the SHORT form (40 bytes, store_entry below); single-pass binning only
+  int count_micro;       // 1: K1 counts the view's micro faces (pixel box at most 4 x 4) for gr_raster_stats: calls that can still learn micro lists
   int micro;             // 1: (face, tile) pairs of at most 4 x 4 pixels go to the tile's second list (K1 / raster_one_tile); needs ent40
   int var;               // variant bits (GR_OPT_VARIANT): 1 = one tile per workgroup instead of four, 4 = votes on the caller's stream, 8 = no speculative first chunk, 16 = chains of four whatever the launch looks like, 32 = votes without chunk bitmaps
 #ifdef GR_STAMPS
@@ -163,6 +164,7 @@ struct gr_ctx {
   int cur_cap = 0;                     // single-pass binning: slots per tile (0: exact two-pass binning)
   bool cur_ent40 = false;              // 40-byte entries
   bool cur_micro = false;              // micro lists (faces of at most 4 x 4 pixels on a second list per tile) for this call
+  bool cur_count_micro = false;        // ... and whether this call counts micro faces (it can still learn the lists)
   bool cur_look = false;               // nothing learned about this (mesh, image size): the first launch group's counts are read
                                        // before its tile kernel runs (raster_views)
   int rebinned = 0;                    // times the last raster call started over after that look
@@ -333,6 +335,7 @@ inline BinArgs make_args(gr_ctx *c, int h, int w, int slot0) {
   a.cap_tile = c->cur_cap;          // the call's snapshot: every launch group, bin pass and tile pass alike
   a.ent40 = c->cur_ent40 ? 1 : 0;
   a.micro = c->cur_micro ? 1 : 0;   // resolved once per call (resolve_binning)
+  a.count_micro = c->cur_count_micro ? 1 : 0;
   a.group = 0;
 #ifdef GR_STAMPS
   a.stamps = c->stamps;
