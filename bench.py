@@ -616,6 +616,8 @@ def run(args, rig=None) -> int:
     if rank == 0 and world == 1 and not args.no_workload2 and rig.side_legs():
         workload_2 = leg_workload2(rig, local_rank, dev)
         quarter = leg_quarter_scale(rig, local_rank, dev, points, faces, wl)
+        if not args.no_aggregate:
+            quarter["fused"] = leg_quarter_scale_fused(rig, local_rank, dev, points, faces, wl)
 
     # ---- PCIe-inclusive rates of the reference-shaped numpy API (N == 1) -------------------------------------------------------
     api = None
@@ -719,6 +721,10 @@ def run(args, rig=None) -> int:
         if quarter:
             roofline["c2_quarter_scale_gpix"] = round(quarter["mpix_per_s"] / 1e3, 2)
             roofline["c2_quarter_scale_views_per_s"] = quarter["views_per_s"]
+            roofline["c2_quarter_scale_us_per_view"] = quarter["us_per_view"]
+            if quarter.get("fused"):
+                roofline["c3_quarter_scale_fused_views_per_s"] = quarter["fused"]["views_per_s"]
+                roofline["c3_quarter_scale_fused_us_per_view"] = quarter["fused"]["us_per_view"]
         line = {
             "metric": "Mpix/s rasterized (face-ID pix2face), 1.2M-face mesh @ 4000x3000",
             "value": round(mpix_per_s, 1),
@@ -931,6 +937,82 @@ def leg_quarter_scale(rig, local_rank, dev, points, faces, wl):
         "oracle_parity_view_7": same,
     }
     del out, hip
+    return res
+
+
+def leg_quarter_scale_fused(rig, local_rank, dev, points, faces, wl):
+    """BASELINE config 3 at the reference's operating point: the 500-view camera grid of the C2 mesh through the FUSED
+    aggregation (`raster_project_labels`: raster + last-writer-wins projection + votes, ids never leave the chip) at
+    aggregate_img_scale = 0.25 (1000 x 750; AGGREGATE_IMAGE_SCALE of examples/aggregate_predictions.ipynb:61, consumed at
+    meshes.py:1959, 1987-2002), 4 classes.  Set-up / tile kernel / vote microseconds per view from the library's HIP events; the
+    votes of one view against the CPU oracle."""
+    import torch
+
+    from geograypher_amd.utils import synthetic
+
+    oracle_c = rig.checker()
+    C = wl.n_classes
+    cams = synthetic.config3_cameras(wl.c3_views, **wl.cam_kw())
+    n = len(cams)
+    h, w = cams[0].get_image_size(0.25)
+    recs_np = cams.get_raster_records(0.25, near=1.0)
+    recs = torch.from_numpy(recs_np).to(dev)
+    hip = rig.make_raster(local_rank)
+    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+    F = faces.shape[0]
+    labels = torch.empty((n, h, w), dtype=torch.uint8, device=dev)
+    step_views = 50
+    ids = torch.empty((step_views, h, w), dtype=torch.int32, device=dev)
+    for c0 in range(0, n, step_views):   # labels are generated on the device from the ids, chunk by chunk
+        c1 = min(c0 + step_views, n)
+        hip.raster_face_ids(recs[c0:c1], h, w, out=ids[: c1 - c0], check=True)
+        for k in range(c1 - c0):
+            labels[c0 + k] = device_labels(ids[k], c0 + k, C)
+    del ids
+    votes, counts = hip.new_vote_buffers(C)
+    hip.raster_project_labels(recs, labels, C, votes, counts, check=True)   # sizes the segments (fused call), learns micro lists
+    hip.raster_project_labels(recs, labels, C, votes, counts, check=True)
+    st_sized = dict(hip.last_stats)
+    reps, elapsed = 0, 0.0
+    while reps == 0 or (elapsed < wl.min_leg_s and reps < 400):
+        rig.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            votes.zero_()
+            counts.zero_()
+            hip.raster_project_labels(recs, labels, C, votes, counts, check=False)
+        rig.synchronize(dev)
+        elapsed += time.perf_counter() - t0
+        reps += 5
+    f_vis = float(counts.to(torch.int64).sum().item()) / max(n, 1)
+    hip.set_profiling(True)
+    hip.raster_project_labels(recs, labels, C, votes, counts, check=False)
+    stg = hip.stage_times()
+    hip.set_profiling(False)
+    check_view = min(7, n - 1)
+    v1, c1 = hip.new_vote_buffers(C)
+    hip.raster_project_labels(recs[check_view:check_view + 1], labels[check_view:check_view + 1], C, v1, c1, check=True)
+    want = oracle_c.raster(points, faces, recs_np[check_view], h, w)
+    want_v = np.zeros((F, C), dtype=np.uint32)
+    want_c = np.zeros(F, dtype=np.uint32)
+    oracle_c.project_labels(want, labels[check_view].cpu().numpy(), F, C, want_v, want_c)
+    same = bool(np.array_equal(v1.cpu().numpy().view(np.uint32), want_v) and np.array_equal(c1.cpu().numpy().view(np.uint32), want_c))
+    assert same, "quarter-scale fused leg: votes differ from the CPU oracle"
+    views = max(stg["views"], 1)
+    res = {
+        "workload": f"BASELINE config 3 at aggregate_img_scale 0.25: {n} views {w}x{h} of the {F}-face C2 mesh, {C} classes, fused "
+                    "raster + projection + votes in one call per step",
+        "views_per_s": round(n * reps / elapsed, 1),
+        "ms_per_step": round(elapsed / reps * 1e3, 3),
+        "timed_s": round(elapsed, 4),
+        "us_per_view": {"setup": round(stg["setup_ms"] / views * 1e3, 2), "raster_fused": round(stg["raster_ms"] / views * 1e3, 2),
+                        "vote": round(stg["vote_ms"] / views * 1e3, 2)},
+        "faces_seen_per_view": round(f_vis, 1),
+        "entries_per_view": round(st_sized.get("entries", 0) / max(n, 1), 1),
+        "chunk_visits_per_view": round(st_sized.get("chunk_visits", 0) / max(n, 1), 1),
+        "oracle_check": f"votes and counts of view {check_view} (fused call) equal the CPU oracle's: {same}",
+    }
+    del labels, votes, counts, hip
     return res
 
 

@@ -57,9 +57,12 @@ def _compile(src: Path, force: bool) -> Path:
 def build_variant(tag: str, defines) -> Path:
     """A diagnostic build beside the product library: csrc/libgeograster_<tag>.so compiled with extra -D flags (e.g.
     GR_STAMPS: in-kernel phase stamps of the tile kernel, tools/tile_phases.py).  Load it with GEOGRAYPHER_AMD_LIB=<path>."""
+    import tempfile
+
     out = CSRC / f"libgeograster_{tag}.so"
-    obj_dir = CSRC / f"_obj_{tag}"
-    obj_dir.mkdir(exist_ok=True)
+    # objects of diagnostic builds live outside the tree: everything under the repo travels to the GPU box with every run
+    obj_dir = Path(tempfile.gettempdir()) / f"geograster_obj_{tag}"
+    obj_dir.mkdir(parents=True, exist_ok=True)
     flags = [f for f in HIPCC_FLAGS if f != "-shared"] + [f"-D{d}" for d in defines]
 
     def one(src):

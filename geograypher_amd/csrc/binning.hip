@@ -48,7 +48,7 @@ __device__ __forceinline__ Vtx project_vertex(const float *__restrict__ p, const
 // K1  transform + cull + per-tile counts (+ compiled entries in single-pass mode).   grid (<= 1024, views)
 //     (a) work list: the 64-face blocks whose bounding sphere passed k_cull_blocks (~87 % of a survey mesh is rejected
 //         per view before a single face is read); every wave takes its own blocks;
-//     (b) the face's three vertices are read from the de-indexed soup (36 coalesced bytes per lane);
+//     (b) R1 once per DISTINCT vertex of the block (bvert / bidx of the upload), every face picks its three by position;
 //     (c) exact path: survivors compacted with wave ballot + popcount, ONE atomicAdd per wave; record planes written
 //         as consecutive 16-byte slots (full-rate coalesced stores);
 //     (d) tile counting is aggregated per wave as well: neighbouring lanes that hit the same tile share one returning
@@ -174,8 +174,7 @@ __device__ __forceinline__ void store_entry(const BinArgs &a, uint32_t *__restri
 
 // R1 / R2 / R4 for one face of the soup: the record (three int4) that compile_entry turns into per-tile entries, and the
 // range of tiles its pixel bounding box touches.  Returns false for faces that draw nothing in this view; clip_me: the face
-// straddles the near plane or the guard band (R7).  Used by K1 and, for faces over more than 2 x 2 tiles, by k_bin_big:
-// same code, same bits.
+// straddles the near plane or the guard band (R7).
 __device__ __forceinline__ bool face_setup_tail(const BinArgs &a, int face_id, Vtx v0, Vtx v1, Vtx v2, int4 &r0, int4 &r1,
                                                 int4 &r2, int &tx0, int &tx1, int &ty0, int &ty1, bool &clip_me) {
   clip_me = !(v0.valid && v1.valid && v2.valid) && (v0.front || v1.front || v2.front) && v0.finite && v1.finite && v2.finite;
@@ -194,34 +193,20 @@ __device__ __forceinline__ bool face_setup_tail(const BinArgs &a, int face_id, V
   jmax = min(jmax, a.w - 1); imax = min(imax, a.h - 1);
   if (jmin > jmax || imin > imax) return false;
   // R4: gradients of 1/z in double, rounded once to float
-  float A = 0.f, B = 0.f;
-  if (!(GR_DBG(a) & 256)) {
-    const double d1 = (double)v1.iz - (double)v0.iz;
-    const double d2 = (double)v2.iz - (double)v0.iz;
-    const double a2 = (double)area2;
-    double n1, n2;
-    n1 = d1 * (double)(v2.Y - v0.Y); n2 = d2 * (double)(v1.Y - v0.Y);
-    A = (float)((n1 - n2) / a2);
-    n1 = d2 * (double)(v1.X - v0.X); n2 = d1 * (double)(v2.X - v0.X);
-    B = (float)((n1 - n2) / a2);
-  }
+  const double d1 = (double)v1.iz - (double)v0.iz;
+  const double d2 = (double)v2.iz - (double)v0.iz;
+  const double a2 = (double)area2;
+  double n1, n2;
+  n1 = d1 * (double)(v2.Y - v0.Y); n2 = d2 * (double)(v1.Y - v0.Y);
+  const float A = (float)((n1 - n2) / a2);
+  n1 = d2 * (double)(v1.X - v0.X); n2 = d1 * (double)(v2.X - v0.X);
+  const float B = (float)((n1 - n2) / a2);
   r0 = make_int4(v0.X, v0.Y, v1.X, v1.Y);
   r1 = make_int4(v2.X, v2.Y, __float_as_int(v0.iz), face_id);
   r2 = make_int4(__float_as_int(A), __float_as_int(B), jmin | (jmax << 16), imin | (imax << 16));
   tx0 = jmin >> a.twl; tx1 = jmax >> a.twl;
   ty0 = imin >> a.thl; ty1 = imax >> a.thl;
   return true;
-}
-
-__device__ __forceinline__ bool face_setup(const BinArgs &a, const float *__restrict__ cam, int64_t f, int4 &r0, int4 &r1,
-                                           int4 &r2, int &tx0, int &tx1, int &ty0, int &ty1, bool &clip_me) {
-  // the face's three vertices sit side by side in the soup: one coalesced 36-byte read per lane (k_bin_big: rare faces; K1
-  // takes the block's DISTINCT vertices instead, each transformed once -- same function, same bits)
-  const float *sp = a.soup + 9 * f;
-  const Vtx v0 = project_vertex(sp, cam);
-  const Vtx v1 = project_vertex(sp + 3, cam);
-  const Vtx v2 = project_vertex(sp + 6, cam);
-  return face_setup_tail(a, a.orig[f], v0, v1, v2, r0, r1, r2, tx0, tx1, ty0, ty1, clip_me);
 }
 
 // a transformed vertex as the waves of K1 keep it in LDS: {X, Y, 1/z, valid | front << 1 | finite << 2}
@@ -313,14 +298,8 @@ __device__ __forceinline__ void bin_big_pairs(const BinArgs &a, uint32_t *__rest
 #endif
 template <bool DIRECT>
 __global__ __launch_bounds__(256)
-#if GR_EXP & 16  // boundness probe: at most 3 waves per SIMD
-__attribute__((amdgpu_waves_per_eu(1, 3)))
-#elif GR_EXP & 256  // A/B build: six waves per SIMD (80 VGPRs, 44 bytes of scratch)
-__attribute__((amdgpu_waves_per_eu(6, 6)))
-#else
-__attribute__((amdgpu_waves_per_eu(5, 5)))  // at most 96 VGPRs: five waves per SIMD (three: +14.5 %, the kernel lives on latency hiding)
-#endif
-void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
+__attribute__((amdgpu_waves_per_eu(5, 5)))  // at most 96 VGPRs: five waves per SIMD (three: +14.5 %, six -- 80 VGPRs, scratch -- +7 %: the kernel lives on latency hiding)
+void k_setup_cull(const float *__restrict__ cams, BinArgs a) {
   const int lane = threadIdx.x & 63;
   uint32_t n_rec = 0;                    // single-pass binning: the wave's record count (a statistic), added when the wave leaves a view
   uint32_t n_mic = 0;                    // ... and its count of micro faces (pixel box at most 4 x 4)
@@ -330,8 +309,6 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
 #endif
   __shared__ int4 vt_s[4][GR_BLOCK_VERTS];  // the block's transformed vertices, one set of rows per wave (12 KiB per workgroup)
   int4 *const vt = vt_s[threadIdx.x >> 6];
-#if !(GR_EXP & 32)  // the grid of rounds 1-4 -- (workgroups, views), every wave strides over ITS view's list (A/B bit 32: the joint list below)
-  (void)nb;
   const int slot = blockIdx.y;
   const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
   uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
@@ -366,68 +343,13 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
   const uint32_t blk_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk_next);
   const int64_t f = (int64_t)blk_cur * GR_BLOCK + lane;
   if (wi + wstep < n_work) blk_next = work[wi + wstep];
-#else
-  // (a) ONE work list for the launch group: the views' lists of surviving blocks (k_cull_blocks) laid end to end.  A survey
-  //     view over the edge of the mesh keeps half as many blocks as one over its middle; with a (workgroups, views) grid the
-  //     waves of the heavy views ran twice as long and the launch ended in a tail (13-16 of 20 possible waves resident per CU
-  //     on average, tools/setup_phases.py).  Now the grid is ONE generation of workgroups (what the chip holds, bin_batch) and
-  //     every wave takes the same number of consecutive items of the joint list, +-1: lane v holds the count of view v, a
-  //     wave prefix sum gives the views' ranges, a wave crosses a view boundary at most a few times in its life (the camera
-  //     and the view's pointers are reloaded there).
-  // (the wave's index through readfirstlane: the compiler cannot see that threadIdx.x >> 6 is wave-uniform, and everything below
-  // -- the item range, the view, the camera pointer -- would be treated as divergent: vector loads of the camera, masked branches)
-  const uint32_t wave_id = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), n_waves = gridDim.x * 4;
-  const uint32_t vcnt = lane < nb ? a.ctrl[(int64_t)lane * a.ctrl_stride + 3] : 0u;
-  const uint32_t vincl = (uint32_t)wave_incl_scan((int)vcnt);
-  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)vincl, 63);
-#if GR_EXP & 64  // A/B build: items dealt round-robin (the waves in flight share a window of the joint list, like the old grid)
-  const uint32_t g0 = wave_id, g1 = total, gstep = n_waves;
-#else
-  const uint32_t per = (total + n_waves - 1) / n_waves;
-  const uint32_t g0 = wave_id * per, g1 = min(g0 + per, total), gstep = 1;
-#endif
-  if (g0 >= g1) return;                  // wave-uniform; the kernel has no workgroup barrier
-  int slot = 0;
-  uint32_t v_beg = 0, v_end = 0, blk_next = 0;
-  const float *cam = cams;
-  uint32_t *ctrl = a.ctrl;
-  const uint32_t *work = a.work;
-  for (uint32_t g = g0; g < g1; g += gstep) {
-  if (g >= v_end) {                      // the view item g lies in: the first whose inclusive prefix exceeds g
-    if (DIRECT && lane == 0 && n_rec) atomicAdd(&ctrl[0], n_rec);
-    if (DIRECT && lane == 0 && n_mic) atomicAdd(&ctrl[6], n_mic);
-    n_rec = 0; n_mic = 0;
-    slot = __popcll(__ballot(vincl <= g));
-    v_end = (uint32_t)__builtin_amdgcn_readlane((int)vincl, slot);
-    v_beg = v_end - (uint32_t)__builtin_amdgcn_readlane((int)vcnt, slot);
-    cam = cams + (int64_t)slot * GR_CAM_FLOATS;
-    ctrl = a.ctrl + slot * a.ctrl_stride;
-    work = a.work + (int64_t)slot * a.work_stride;
-    blk_next = work[g - v_beg];
-  }
-  const uint32_t blk_cur = blk_next;
-  const int64_t f = (int64_t)blk_cur * GR_BLOCK + lane;
-  if (g + gstep < v_end) blk_next = work[g + gstep - v_beg];
-#endif
 
   bool keep = false, clip_me = false;
   int4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0};
   int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
-#if GR_EXP & 8  // boundness probe: 100 dependent-free slow-class VALU instructions (410 SIMD cycles) per block, results unused
-  {
-    int d0 = lane, d1 = lane + 1, d2 = lane + 2, d3 = lane + 3;
-#pragma unroll
-    for (int i = 0; i < 25; ++i)
-      asm volatile("v_max_i32 %0, %0, %1\n\tv_max_i32 %1, %1, %2\n\tv_max_i32 %2, %2, %3\n\tv_max_i32 %3, %3, %0" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
-  }
-#endif
 #ifdef GR_STAMPS
   st_ = __builtin_amdgcn_s_memtime(); ++siter;
 #endif
-#if GR_EXP & 2  // A/B build: three transforms per face from the soup (rounds 1-4)
-  if (f < a.F) keep = face_setup(a, cam, f, r0, r1, r2, tx0, tx1, ty0, ty1, clip_me);
-  (void)vt;
-#else
   {
     // (b) R1 once per DISTINCT vertex of the block (k_block_vertices: about 48 for the 192 corners of a manifold patch, one
     //     round of the wave; a face soup takes three), results through the wave's own LDS rows -- LDS operations of one wave
@@ -460,7 +382,6 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
     const int4 q0 = vt[bi & 255u], q1 = vt[(bi >> 8) & 255u], q2 = vt[(bi >> 16) & 255u];
     if (f < a.F) keep = face_setup_tail(a, face_id, unpack_vtx(q0), unpack_vtx(q1), unpack_vtx(q2), r0, r1, r2, tx0, tx1, ty0, ty1, clip_me);
   }
-#endif
   GR_SSTAMP(1);
   // R7: faces that straddle the near plane or the guard band go to the view's clip list (k_clip_faces)
   const unsigned long long mc = __ballot(clip_me);
@@ -543,17 +464,15 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
   GR_SSTAMP(3);
   if (DIRECT) {
     // faces over at most 2x2 tiles: positions came from the wave-aggregated counters; the lanes of a group hold
-    // consecutive positions of the same tile segment, so their entries are written side by side.  The tile-independent half
-    // of an entry (face_form) is computed once per face; every such face has a FIRST tile -- one dense round of tile_entry --,
-    // second to fourth tiles are the exception (0.5 per face) and take three more rounds in the face's OWN lane, most lanes
-    // idle but each round a quarter of a whole build_entry.  (Rounds 2-4 compacted those (face, tile) pairs instead -- prefix
-    // sum, 6-step search for the owning lane, 15 ds_bpermute to pull its records, all of build_entry again: 338 static VALU
-    // instructions for the one compacted round against 3 x ~70 here.)
+    // consecutive positions of the same tile segment, so their entries are written side by side.  Every such face has a
+    // FIRST tile -- one dense round of compile_entry --; second to fourth tiles are the exception (0.5 per face): those
+    // (face, tile) pairs are compacted -- prefix sum, 6-step search for the owning lane, its records pulled by ds_bpermute
+    // -- and compiled in one more round.  (Three mostly idle rounds in the face's own lane from one FaceForm measured +4 %:
+    // profiles/r05_ab/setup_own_lane_tiles_vs_compaction.log.)
     int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
     uint8_t *nr8 = a.nrow8 + slot * a.ent_cap;
     const int TW = 1 << a.twl, TH = 1 << a.thl;
-#if !(GR_EXP & 4)  // the compacted extra-tile round of rounds 2-4 (A/B bit 4: own-lane rounds from one FaceForm, measured +4 %)
-    if (small_fp && !(GR_DBG(a) & 32)) {
+    if (small_fp) {
       if ((uint32_t)r3.x < (uint32_t)a.cap_tile) {
         compile_entry(a, ctrl, comp, nr8, slot_of(t00, (uint32_t)r3.x), r0, r1, r2, tx0 << a.twl, ty0 << a.thl, TW, TH, (mcls & 1) != 0);
       } else atomicOr(&ctrl[2], 1u);
@@ -561,7 +480,7 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
     const int shape = small_fp ? ((tx1 > tx0 ? 1 : 0) | (ty1 > ty0 ? 2 : 0)) : 0;  // which neighbours exist: 1 right, 2 below
     const int ne = shape == 3 ? 3 : (shape ? 1 : 0);
     const int incl_e = wave_incl_scan(ne);
-    const int total_e = (GR_DBG(a) & (32 | 64)) ? 0 : __builtin_amdgcn_readlane(incl_e, 63);
+    const int total_e = __builtin_amdgcn_readlane(incl_e, 63);
     const int geo = tx0 | (ty0 << 12) | (shape << 24) | (mcls << 26);
     for (int k0 = 0; k0 < total_e; k0 += 64) {
       const int q = k0 + lane;
@@ -587,48 +506,14 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a, int nb) {
         } else atomicOr(&ctrl[2], 1u);
       }
     }
-#else
-    if (__ballot(small_fp) && !(GR_DBG(a) & 32)) {
-      const FaceForm ff = face_form(r0, r1, r2, TW, TH);
-      const int shape = small_fp ? ((tx1 > tx0 ? 1 : 0) | (ty1 > ty0 ? 2 : 0)) : 0;  // which neighbours exist: 1 right, 2 below
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const bool has = small_fp && (shape & k) == k;       // tile slot k: 0 first, 1 right, 2 below, 3 below right
-        if (k > 0 && (!__ballot(has) || (GR_DBG(a) & 64))) continue;
-        if (has) {
-          const uint32_t pos = (uint32_t)(k == 0 ? r3.x : k == 1 ? r3.y : k == 2 ? r3.z : r3.w);
-          const int tx = tx0 + (k & 1), ty = ty0 + (k >> 1);
-          if (pos < (uint32_t)a.cap_tile) {
-            int4 e0, e1, e2;
-            int rows;
-            int xinfo = -1;
-            const bool mic = ((mcls >> k) & 1) != 0;
-            tile_entry(ff, tx << a.twl, ty << a.thl, TW, TH, e0, e1, e2, rows, &xinfo);
-            store_entry(a, ctrl, comp, nr8, slot_of((ty * a.TX + tx) | (mic ? GR_MICRO_BIT : 0), pos), e0, e1, e2, rows, mic ? xinfo : -1);
-          } else atomicOr(&ctrl[2], 1u);
-        }
-      }
-    }
-#endif
   }
   GR_SSTAMP(4);
   if (DIRECT) {
     // faces over more than 2 x 2 tiles: the wave expands their (face, tile) pairs right here, from the records it holds
-    // (bin_big_pairs).  Variant bit 64: they go to the view's big list instead (the back of the clip buffer, ctrl[5] = count)
-    // and k_bin_big sets them up again, 64 per wave -- one returning atomic per block on ONE address per view.
+    // (bin_big_pairs).  (Round 2 sent them through a per-view list and a second kernel -- one returning atomic per block on
+    // ONE address per view: forest set-up 51.5 vs 39.0 us per view.)
     const bool big_fp = keep && !small_fp;
-    const unsigned long long mb = __ballot(big_fp);
-    if (mb) {
-      if (!(a.var & 64)) {
-        bin_big_pairs(a, ctrl, slot, lane, big_fp, r0, r1, r2, tx0, tx1, ty0, ty1);
-      } else {
-        const int lead = __ffsll((long long)mb) - 1;
-        uint32_t bb = 0;
-        if (lane == lead) bb = atomicAdd(&ctrl[5], (uint32_t)__popcll(mb));
-        bb = __shfl(bb, lead);
-        if (big_fp) a.clip[(int64_t)slot * a.F + (a.F - 1 - (int64_t)(bb + __popcll(mb & ((1ull << lane) - 1ull))))] = (uint32_t)f;
-      }
-    }
+    if (__ballot(big_fp)) bin_big_pairs(a, ctrl, slot, lane, big_fp, r0, r1, r2, tx0, tx1, ty0, ty1);
   }
   if (keep && !DIRECT) {
     int4 *rec = a.rec + slot * a.rec_stride;
@@ -860,7 +745,7 @@ __device__ __forceinline__ bool tile_entry(const FaceForm &ff, int px0, int py0,
   }
   // The bounding box reaches this tile; the triangle itself may not (the far corner of a diagonal face).  An edge whose
   // value is negative even at the tile corner most in its favour, C' + (TW/2)|a| + (TH/2)|b| < 0, excludes every pixel of
-  // the tile: the entry is DEAD (0 rows: the tile kernel never looks at it); k_bin_big asks before it takes a list slot.
+  // the tile: the entry is DEAD (0 rows: the tile kernel never looks at it); bin_big_pairs asks before it takes a list slot.
   const bool touches = nr > 0 && cf + ff.rf >= 0 && cm + ff.rm >= 0 && cl + ff.rl >= 0;
   if (!touches) nr = 0;
   rows = nr;
@@ -1149,26 +1034,6 @@ __global__ __launch_bounds__(256) void k_bin_init(uint4 *__restrict__ ctrl16, in
   if (stats && i0 < 10) stats[i0] = i0 == 4 ? ~0ull : 0ull;
 }
 
-// K1b  (variant bit 64 only: the default expands big faces inside K1) single-pass binning of the view's big list: a wave takes
-//      64 big faces, one per lane (records recomputed from the soup: same code as K1, same bits) and expands their
-//      (face, tile) pairs with bin_big_pairs.
-__global__ __launch_bounds__(256) void k_bin_big(const float *__restrict__ cams, BinArgs a) {
-  const int slot = blockIdx.y;
-  const float *cam = cams + (int64_t)slot * GR_CAM_FLOATS;
-  uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
-  const int64_t n_big = min((int64_t)ctrl[5], a.F);
-  const int lane = threadIdx.x & 63;
-  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), wstep = (int64_t)gridDim.x * 4;
-  if (wave0 * 64 >= n_big) return;  // the usual case for terrain: nothing to do
-  for (int64_t i0 = wave0 * 64; i0 < n_big; i0 += wstep * 64) {
-    int4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0};
-    int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
-    bool clip_me, keep = false;
-    if (i0 + lane < n_big) keep = face_setup(a, cam, a.clip[(int64_t)slot * a.F + (a.F - 1 - (i0 + lane))], r0, r1, r2, tx0, tx1, ty0, ty1, clip_me);
-    bin_big_pairs(a, ctrl, slot, lane, keep, r0, r1, r2, tx0, tx1, ty0, ty1);
-  }
-}
-
 }  // namespace
 
 namespace grimpl {
@@ -1200,33 +1065,15 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int
     const int nblk = (int)ceil_div(c->F, GR_BLOCK);
     hipLaunchKernelGGL(k_cull_blocks, dim3((unsigned)ceil_div(nblk, 256), nb), dim3(256), a.touched ? sizeof(uint32_t) * a.tw : 0, s,
                        cams, a, nblk);
-#if !(GR_EXP & 32)
     // about nblk / 32 waves per view take a few blocks each -- but never fewer than 16 k waves per launch, so that a call with
     // a few views still fills the machine.
     const int gmax = std::min((nblk + 3) / 4, 1024);
     const dim3 gsetup((unsigned)std::max(1, std::min(gmax, std::max(nblk / 128, 4096 / std::max(nb, 1)))), nb);
-#else
-    // A/B build (measured, round 5: C5 -17 %, C2 +16 %, not the default) -- k_setup_cull: ONE generation of workgroups -- as many as the chip holds at the kernel's register count (asked of the
-    // runtime once per context) --, every wave an equal share of the launch group's joint work list; fewer when the group is
-    // small (at least four blocks per wave if nothing were culled).  A wave per surviving block would mostly pay for starting
-    // waves (rounds 1-4: C2 7.5 -> 6.1 us per view with an eighth of the workgroups).
-    if (c->setup_wgs[0] == 0) {
-      int per_cu[2] = {0, 0}, cus = 0;
-      GR_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[0], k_setup_cull<true>, 256, 0));
-      GR_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu[1], k_setup_cull<false>, 256, 0));
-      GR_HIP(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-      c->setup_wgs[0] = std::max(1, per_cu[0] * cus);
-      c->setup_wgs[1] = std::max(1, per_cu[1] * cus);
-    }
-    const int64_t cap_wgs = c->setup_wgs[a.cap_tile > 0 ? 0 : 1];
-    const dim3 gsetup((unsigned)std::max<int64_t>(1, std::min<int64_t>(cap_wgs, ceil_div((int64_t)nb * nblk, 16))));
-#endif
     if (a.cap_tile > 0) {
-      hipLaunchKernelGGL(k_setup_cull<true>, gsetup, dim3(256), 0, s, cams, a, nb);
-      if (a.var & 64) hipLaunchKernelGGL(k_bin_big, dim3(256, nb), dim3(256), 0, s, cams, a);
+      hipLaunchKernelGGL(k_setup_cull<true>, gsetup, dim3(256), 0, s, cams, a);
       GR_LAUNCH_EV((hipEvent_t) nullptr, chain_stop(c, ST_SETUP), k_clip_faces<true>, dim3(8, nb), dim3(64), 0, s, cams, a);
     } else {
-      hipLaunchKernelGGL(k_setup_cull<false>, gsetup, dim3(256), 0, s, cams, a, nb);
+      hipLaunchKernelGGL(k_setup_cull<false>, gsetup, dim3(256), 0, s, cams, a);
       GR_LAUNCH_EV((hipEvent_t) nullptr, chain_stop(c, ST_SETUP), k_clip_faces<false>, dim3(8, nb), dim3(64), 0, s, cams, a);
     }
   }

@@ -166,9 +166,6 @@ void learn_slots(gr_ctx *c, int T, int64_t max_tile, bool full, bool micro) {
   else learn(c, T, GR_LEARNED_EXACT, full, micro);   // this (mesh, image size) bins exactly from now on
 }
 
-#ifndef GR_CPERM_LARGE
-#define GR_CPERM_LARGE 0
-#endif
 int ensure_bins(gr_ctx *c, int n_slots, int T) {
   const int64_t F = c->F > 0 ? c->F : 1;
   const int dcap = c->cur_cap;  // resolved once per call (resolve_binning)
@@ -185,9 +182,6 @@ int ensure_bins(gr_ctx *c, int n_slots, int T) {
   int clg = -1;
   if (direct && !(c->opt_var & 131072)) {
     if (T <= 1024) { clg = 0; while ((1 << clg) < T + 3) ++clg; }          // a line per tile
-#if GR_CPERM_LARGE
-    else { clg = 0; while ((32 << clg) < T + 3) ++clg; }                   // A/B: neighbouring tiles in different lines, no more lines than needed
-#endif
   }
   const int Tcap = clg < 0 ? ((T + 3) & ~3) : (32 << clg);  // words per counter array; the arrays start 16-byte aligned (a chain reads four counters at once)
   const int64_t ctrl_stride = ((GR_CTRL_HDR + (direct ? 2 : 4) * (int64_t)Tcap) + 63) / 64 * 64;   // (exact binning: + offsets and cursors)
@@ -235,7 +229,7 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   // chunk bitmaps for the vote kernel (k_block_chunks / k_cull_blocks): one per launch group in flight; meshes beyond
   // 33 M faces do without (the bitmap of a view would not fit the cull kernel's LDS)
   const int tw = (int)(ceil_div(ceil_div(F, 256), 32) + 1);
-  const bool use_touched = labels && tw <= 4096 && !(c->opt_var & 32);
+  const bool use_touched = labels && tw <= 4096;
   if (labels) {
     rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F * B * (overlap ? 2 : 1));
     if (rc) return rc;
@@ -255,8 +249,7 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   note_stream(c, s);
   c->stats_pending = true;   // the call's statistics are reset by the first launch group's init kernel (bin_batch: k_bin_init)
   c->stats_deferred = false;
-  // (variant bit 32768: never deferred -- A/B and tests of the eager form)
-  c->defer_stats = !labels && n_views <= B && !(c->cur_look && again < 2) && !(c->opt_var & 32768);
+  c->defer_stats = !labels && n_views <= B && !(c->cur_look && again < 2);
   c->last_n_views = n_views;
   int g = 0;
   for (int v0 = 0; v0 < n_views; v0 += B, ++g) {

@@ -28,24 +28,11 @@
 #define GR_TILE_LOG2 6
 #define GR_MAX_BATCH 64     // views per launch group (amortises kernel boundaries and per-launch tails)
 #define GR_ENT_Q 3          // int4 per compiled (face, tile) entry: 48 bytes, 12 words
-#define GR_CTRL_HDR 8       // ctrl words before the tile arrays: rec_count, total_entries, overflow, work_count, clip_count, big_count
+#define GR_CTRL_HDR 8       // ctrl words before the tile arrays: rec_count, total_entries, overflow, work_count, clip_count, -, micro_count
 #define GR_MAX_DIM 16384    // h, w limit (guard band and 16-bit bbox packing)
 #define GR_BLOCK 64         // faces per block of the Morton-ordered soup: one wave, one bounding sphere
 #define GR_BLOCK_VERTS 192  // distinct vertices a block can have (3 per face); a patch of a manifold mesh has about 48
-#define GR_CHUNK_LIST 16
-// The timing-only ablation masks (GR_OPT_DEBUG: skip the scanline loop, the epilogue, the triangles, ...) exist in the
-// DIAGNOSTIC build only (-DGR_ABLATE: tools/ab_kernel.py builds and loads it when a variant asks for a mask): the product's
-// kernels carry none of those branches.  (Bit 512, the scratch-poisoning test hook, is host code and stays.)
-#ifdef GR_ABLATE
-#define GR_DBG(a) ((a).dbg)
-#else
-#define GR_DBG(a) 0
-#endif    // chunks of 256 caller face ids listed per block (k_block_chunks)
-
-#ifndef GR_EXP
-#define GR_EXP 0   // experiment bits of A/B builds (geograypher_amd.build.build_variant, tools/ab_libs.py); 0 in the product
-#endif
-
+#define GR_CHUNK_LIST 16      // chunks of 256 caller face ids listed per block (k_block_chunks)
 namespace grimpl {
 
 struct BinArgs {
@@ -63,8 +50,7 @@ struct BinArgs {
   uint32_t *touched;     // [slot][tw] bit per 256-face chunk of caller ids that a surviving block reaches (+ last word: all), or null
   int tw;                // words per slot of `touched`
   uint32_t *work;        // [slot][work_stride] blocks of this view that passed the frustum test (ctrl[3] = count)
-  uint32_t *clip;        // [slot][F] from the front: soup faces that straddle the near plane / guard band (R7; ctrl[4] = count);
-                         //           from the back: faces over more than 2 x 2 tiles (single-pass binning; ctrl[5] = count)
+  uint32_t *clip;        // [slot][F] soup faces that straddle the near plane / guard band (R7; ctrl[4] = count)
   int64_t work_stride;
   int4 *comp;            // [slot][ent_cap][GR_ENT_Q]  compiled (face, tile) entries grouped by tile, 48 bytes each (ent40: 40 bytes
                          //                            each at the front of the same slot memory)
@@ -85,14 +71,12 @@ struct BinArgs {
   int ent40;             // 1: entries are written in the SHORT form (40 bytes, store_entry below); single-pass binning only
   int count_micro;       // 1: K1 counts the view's micro faces (pixel box at most 4 x 4) for gr_raster_stats: calls that can still learn micro lists
   int micro;             // 1: (face, tile) pairs of at most 4 x 4 pixels go to the tile's second list (K1 / raster_one_tile); needs ent40
-  int var;               // variant bits (GR_OPT_VARIANT): 1 = one tile per workgroup instead of four, 4 = votes on the caller's stream, 8 = no speculative first chunk, 16 = chains of four whatever the launch looks like, 32 = votes without chunk bitmaps
+  int var;               // variant bits (GR_OPT_VARIANT, include/geograster.h)
 #ifdef GR_STAMPS
   unsigned long long *stamps;  // diagnostic build: [16] cycles per tile-kernel phase, summed over waves (raster_tile.hip)
 #endif
-  int dbg;               // timing-only ablation mask (GR_OPT_DEBUG): 1 skip scanline loop, 2 skip id stores, 4 skip triangles,
-                         // fused epilogue: 8 skip winner atomics, 16 skip label loads; set-up: 32 no entry compilation, 64 no
-                         // second-to-fourth tiles of small faces, 256 no depth gradients; 512 (a TEST hook, results stay right):
-                         // entry slots and row counts are poisoned with 0xFF before every launch group is binned
+  int dbg;               // GR_OPT_DEBUG: 512 (a TEST hook, results stay right): entry slots and row counts are poisoned with 0xFF
+                         // before every launch group is binned
 };
 
 // word of tile t's counter inside a counter array (BinArgs::clg)
@@ -178,7 +162,6 @@ struct gr_ctx {
   int last_n_views = 0;
   bool direct_ok = true;     // cleared when a tile overflowed its slots: later calls take the exact path
   bool last_direct = false;
-  int64_t setup_wgs[2] = {0, 0};  // workgroups of k_setup_cull<true / false> the device holds at once (one generation: bin_batch)
   // winner scratch
   void *winner = nullptr;
   size_t winner_bytes = 0;

@@ -27,9 +27,6 @@ using namespace grimpl;
 #ifndef GR_ROLL_KT
 #define GR_ROLL_KT 16   // tiles per workgroup of the rolling-chain kernel
 #endif
-#ifndef GR_EXP
-#define GR_EXP 0   // experiment bits of A/B builds (geograypher_amd.build.build_variant, tools/ab_libs.py); 0 in the product
-#endif
 
 namespace {
 
@@ -296,12 +293,11 @@ __device__ __forceinline__ void micro_item(unsigned long long *keys, const int4 
 template <int TWL, int TH, int NW, int PAD, bool SHORT>
 __device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, const int tab_base, const int tab_self, uint32_t &gen,
                                                    const int4 *ent, const int nrows, const int lane,
-                                                   const int first_b, const int dbg) {
+                                                   const int first_b) {
   char *const lds = reinterpret_cast<char *>(keys);
   const int incl = wave_incl_scan(nrows);
   int total = __builtin_amdgcn_readlane(incl, 63);
   const int excl = incl - nrows;
-  if (dbg & 1) total = 0;
   for (int k0 = first_b * 64; k0 < total; k0 += 64 * NW) {
     const int q = k0 + lane;
     const int slot = excl - k0;
@@ -352,7 +348,6 @@ __device__ __forceinline__ void store_ids(const unsigned long long *keys, const 
     if (gx4 >= a.w) return;
     int32_t *dst = ids_plane + (int64_t)(py0 + rr) * a.w + gx4;
     const int64_t dstep = (int64_t)(NT / 16) * a.w;
-#if !(GR_EXP & 1)
     // Whole keys through ds_read_b64.  The four low dwords of a lane's pixels sit 8 bytes apart and the 16 lanes of a row
     // 32 bytes apart: as ds_read2_b32 (32 banks of 4 bytes; low dwords only ever touch the 16 even ones) every access is a
     // 4-way bank conflict, 32 LDS cycles per wave and pass.  ds_read_b64 uses all 64 banks, two per lane, in groups of 32
@@ -384,12 +379,6 @@ __device__ __forceinline__ void store_ids(const unsigned long long *keys, const 
         *reinterpret_cast<int4 *>(dst) = ids_of(k);
       }
     }
-#else
-    for (int row = rr; row < rows_here; row += NT / 16, dst += dstep) {
-      const uint32_t *kr = klo + 2 * lds_idx<TWL, PAD>(row, c4);
-      *reinterpret_cast<int4 *>(dst) = make_int4((int)~kr[0], (int)~kr[2], (int)~kr[4], (int)~kr[6]);
-    }
-#endif
   } else if (!PLAIN) {
     constexpr int TW = 1 << TWL;
     const int col = te & (TW - 1), gx = px0 + col;
@@ -415,11 +404,8 @@ __device__ __forceinline__ void store_ids(const unsigned long long *keys, const 
 // Unknown neighbours count as "differs": 1 across a tile edge, 2 outside the image (EDGE tiles only).
 template <int TWL, int TH, int NT, int PAD, bool EDGE>
 __device__ __forceinline__ void fused_winners(const unsigned long long *keys, const BinArgs &a, uint32_t *__restrict__ win,
-                                              int te, int px0, int py0, int dbg) {
+                                              int te, int px0, int py0) {
   static_assert(TWL == 6 && NT == 256 && TH % 32 == 0, "16 lanes x 4 pixels per tile row, 16 row pairs per pass");
-#if GR_EXP & 1
-  const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
-#endif
   const int c4 = (te & 15) * 4, rp = te >> 4;  // row pair 0 .. 15 of a pass
 #pragma unroll
   for (int pass = 0; pass < TH / 32; ++pass) {
@@ -428,7 +414,6 @@ __device__ __forceinline__ void fused_winners(const unsigned long long *keys, co
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       if (k < 2 || r0 + 2 < TH) {
-#if !(GR_EXP & 1)
         // whole keys through ds_read_b64 (see store_ids): the 4-way bank conflict of the dword reads becomes a 2-way one
         const uint32_t kbase = (uint32_t)(uintptr_t)(reinterpret_cast<const char *>(keys) + 8 * lds_idx<TWL, PAD>(r0 + k, c4));
         unsigned long long k0, k1, k2, k3;
@@ -436,11 +421,6 @@ __device__ __forceinline__ void fused_winners(const unsigned long long *keys, co
                      "s_waitcnt lgkmcnt(0)"
                      : "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3) : "v"(kbase) : "memory");
         c[k][1] = (int)(uint32_t)k0; c[k][2] = (int)(uint32_t)k1; c[k][3] = (int)(uint32_t)k2; c[k][4] = (int)(uint32_t)k3;
-#else
-        const uint32_t *kr = klo + 2 * lds_idx<TWL, PAD>(r0 + k, c4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c[k][j + 1] = (int)kr[2 * j];
-#endif
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) c[k][j + 1] = 1;  // the tile below: unknown
@@ -477,7 +457,7 @@ __device__ __forceinline__ void fused_winners(const unsigned long long *keys, co
         } else {
           cand = cand & (c[k][j + 2] != f) & (c[k + 1][j + 2] != f);
         }
-        if (cand && !(dbg & 8)) atomicMax(win + ~f, p1 + (uint32_t)(k * a.w + j));
+        if (cand) atomicMax(win + ~f, p1 + (uint32_t)(k * a.w + j));
       }
     }
   }
@@ -581,14 +561,14 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
     if (ROLL) asm volatile("" : "+v"(ring->e0), "+v"(ring->n0));
     if (PLAIN) {  // 16-byte stores: a lane owns 4 consecutive pixels of a row, 16 rows per pass
       const int gx4 = px0 + (tid & 15) * 4;
-      if (gx4 < a.w && !(GR_DBG(a) & 2))
+      if (gx4 < a.w)
         for (int row = tid >> 4; row < TH && py0 + row < a.h; row += NT / 16)
           *reinterpret_cast<int4 *>(out.ids + plane + (int64_t)(py0 + row) * a.w + gx4) = make_int4(-1, -1, -1, -1);
       GR_STAMP(8);
       return;
     }
     const int col = tid & (TW - 1), gx = px0 + col;
-    if (gx < a.w && !(GR_DBG(a) & 2)) {
+    if (gx < a.w) {
       for (int row = tid >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
         const int64_t p = plane + (int64_t)(py0 + row) * a.w + gx;
         if (out.ids) out.ids[p] = -1;
@@ -618,7 +598,6 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
     __syncthreads();  // keys filled, chunk visible
     GR_STAMP(2);
     GR_PRIO_ITEMS();
-#if !(GR_EXP & 2048)
     // LATER CHUNKS ARE REQUESTED ONE CHUNK AHEAD (round 5).  A tile with more than 64 entries -- every tile of a down-scaled
     // or a hostile view: 3-6 chunks at 1000 x 750 on the terrain, dozens under the forest -- used to load each later chunk and
     // its row counts right where it staged them, behind the barrier that frees the chunk buffer: two exposed round trips
@@ -637,12 +616,10 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
     };
     uint32_t nrn = 0u;
     request_chunk(64u, ex, nrn);
-#endif
     const int nrows = (uint32_t)lane < cnt ? (int)nr_first : 0;
-    const int nb = raster_chunk_gather<TWL, TH, NW, PAD, SHORT>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot, GR_DBG(a));
+    const int nb = raster_chunk_gather<TWL, TH, NW, PAD, SHORT>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot);
     rot = (rot - nb) & (NW - 1);
     GR_STAMP(3);
-#if !(GR_EXP & 2048)
 #pragma unroll 1
     for (uint32_t c0 = 64; c0 < cnt; c0 += 64) {
       GR_PRIO_MEM();
@@ -653,32 +630,11 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
       request_chunk(c0 + 64u, ex, nrn);   // into the registers just staged: in flight through this chunk's items
       __syncthreads();
       GR_PRIO_ITEMS();
-      const int nbc = raster_chunk_gather<TWL, TH, NW, PAD, SHORT>(keys, tab_base, tab_self, gen, ent_lds, nrows_c, lane, rot, GR_DBG(a));
+      const int nbc = raster_chunk_gather<TWL, TH, NW, PAD, SHORT>(keys, tab_base, tab_self, gen, ent_lds, nrows_c, lane, rot);
       rot = (rot - nbc) & (NW - 1);
       GR_STAMP(4);
     }
-#endif
   }
-#if GR_EXP & 2048  // A/B build: every later chunk loaded where it is staged (rounds 1-4)
-#pragma unroll 1
-  for (uint32_t c0 = 64; c0 < cnt; c0 += 64) {
-    GR_PRIO_MEM();
-    __syncthreads();  // every wave is done with the previous chunk before it is overwritten
-    if (lane < EL) {
-      const uint32_t qc = wv * EL + lane;  // piece of the chunk
-      const uint32_t q = (SHORT ? (c0 >> 1) * 5 : c0 * GR_ENT_Q) + qc;
-      if (SHORT ? short_piece_needed(qc, min(cnt - c0, 64u)) : q < cnt * GR_ENT_Q) ex = reinterpret_cast<const v4i *>(comp)[q];
-      ent_st[wv * EL + lane] = ex;
-    }
-    __syncthreads();
-    GR_PRIO_ITEMS();
-    const uint32_t e = c0 + (uint32_t)lane;
-    const int nrows = e < cnt ? (int)nr8[e] : 0;
-    const int nb = raster_chunk_gather<TWL, TH, NW, PAD, SHORT>(keys, tab_base, tab_self, gen, ent_lds, nrows, lane, rot, GR_DBG(a));
-    rot = (rot - nb) & (NW - 1);
-    GR_STAMP(4);
-  }
-#endif
   if (SHORT && MICRO && cntm > 0) {
     // micro entries: every wave reads ITS chunks of 64 straight from the segment (no staging, no barrier), one face per lane.
     // Entry k of the list sits in slot cap - 1 - k: block (slot / 64) of 2560 bytes, 32 + 8 bytes at position slot % 64.
@@ -706,12 +662,11 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
   __syncthreads();              // keys complete
   if (GR_PRIO_E != GR_PRIO_M) __builtin_amdgcn_s_setprio(GR_PRIO_E);
   GR_STAMP(5);
-  if (GR_DBG(a) & 2) return;
   if (FUSE) {
     uint32_t *win = out.winner + slot * out.F;
     const bool edge = px0 + TW > a.w || py0 + TH + 1 > a.h;
-    if (edge) fused_winners<TWL, TH, NT, PAD, true>(keys, a, win, te, px0, py0, GR_DBG(a));
-    else fused_winners<TWL, TH, NT, PAD, false>(keys, a, win, te, px0, py0, GR_DBG(a));
+    if (edge) fused_winners<TWL, TH, NT, PAD, true>(keys, a, win, te, px0, py0);
+    else fused_winners<TWL, TH, NT, PAD, false>(keys, a, win, te, px0, py0);
     if (out.ids) {  // the id image as well (rare): background is where no fragment landed (depth bits 0)
       const int col = te & (TW - 1), gx = px0 + col;
       if (gx < a.w)
@@ -774,7 +729,7 @@ __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile(BinArgs a, Rast
   // one tile per workgroup: the first chunk is requested before the count is known (one round trip less).  A chain waits
   // for the exact requests of its tiles 1 - 3 anyway before it starts: requesting its first tile's chunk early saves
   // nothing there (14.9 us per C2 view either way) and fetches 1.6 MB of stale slots per view -- not done
-  const bool spec = KT == 1 && a.cap_tile >= 64 && !(a.var & 8);
+  const bool spec = KT == 1 && a.cap_tile >= 64;
   const int tile0 = KT * (int)blockIdx.x;
   const int n_tiles = min(KT, a.T - tile0);
   constexpr int EL = SHORT ? 40 : 48;
@@ -836,7 +791,6 @@ __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile(BinArgs a, Rast
       if (n_tiles > 3) tile_list(a, ctrl, tile0 + 3, cnt3, beg3);
     }
   }
-  if (GR_DBG(a) & 4) cnt0 = cnt1 = cnt2 = cnt3 = cm0 = cm1 = cm2 = cm3 = 0;
   const int64_t sbase = slot * a.ent_cap;
   if (!spec) {  // exact binning (or segments under 64 slots): the first chunk can only be requested now
     if ((uint32_t)lane < cnt0) nr0 = a.nrow8[sbase + beg0 + lane];
@@ -855,24 +809,6 @@ __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile(BinArgs a, Rast
   // memory counter has nothing left to wait for in the loop over tiles 1 .. 3 -- where a wait means waiting for the
   // previous tile's id stores (tests/test_isa_waits.py)
   if (KT > 1) asm volatile("" : "+v"(ex0), "+v"(ex1), "+v"(ex2), "+v"(ex3), "+v"(nr0), "+v"(nr1), "+v"(nr2), "+v"(nr3));
-#if GR_EXP & 1024
-  // Upper-bound probe for "hide the chain prologue" (round 5): the prologue's two dependent round trips are paid TWICE -- the
-  // counters and the four first chunks are loaded again, each behind a full wait, results folded into the ones in use (same
-  // values) -- so that what a prefetch could at best remove is measured as what doubling it costs.
-  if (KT > 1 && a.cap_tile > 0) {
-    const volatile uint32_t *vc = ctrl + GR_CTRL_HDR + tile0;
-    uint32_t again = vc[0];
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(again));
-    again = min(again, (uint32_t)a.cap_tile) ^ cnt0;   // 0
-    v4i e0b = ex0, e1b = ex1, e2b = ex2, e3b = ex3;
-    if ((lane < EL) & needed(q, cnt0 + again)) e0b = __builtin_nontemporal_load(pieces(beg0) + q);
-    if ((lane < EL) & needed(q, cnt1 + again)) e1b = __builtin_nontemporal_load(pieces(beg1) + q);
-    if ((lane < EL) & needed(q, cnt2 + again)) e2b = __builtin_nontemporal_load(pieces(beg2) + q);
-    if ((lane < EL) & needed(q, cnt3 + again)) e3b = __builtin_nontemporal_load(pieces(beg3) + q);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(e0b), "+v"(e1b), "+v"(e2b), "+v"(e3b));
-    ex0 = e0b; ex1 = e1b; ex2 = e2b; ex3 = e3b;
-  }
-#endif
   GR_STAMP(0);
   static_assert(!(FUSE && PLAIN), "the plain kernel writes ids only");
   raster_one_tile<TWL, THL, NT, FUSE, PAD, SHORT, KT == 1, PLAIN, false, MICRO>(a, out, keys, slot, tile0, cnt0, beg0, nr0, ex0 GR_STAMP_PASS, nullptr, cm0);
@@ -930,9 +866,6 @@ __attribute__((amdgpu_num_sgpr(GR_NUM_SGPR))) void k_raster_tile_roll(BinArgs a,
   constexpr int EL = SHORT ? 40 : 48;
   const uint32_t q = wv * EL + lane;
   const v4i *base = reinterpret_cast<const v4i *>(a.comp + (int64_t)slot * a.ent_cap * GR_ENT_Q);
-  auto pieces = [&](int64_t first) {
-    return SHORT ? reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(base) + first * 40) : base + first * GR_ENT_Q;
-  };
   auto needed = [](uint32_t qq, uint32_t n) { return SHORT ? short_piece_needed(qq, min(n, 64u)) : qq < n * GR_ENT_Q; };
   const uint32_t *ctrl = a.ctrl + slot * a.ctrl_stride;
   if (FUSE && ctrl[2] != 0u) return;
@@ -1023,19 +956,15 @@ int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStr
     const bool chain = (a.var & 1) == 0 && ((a.var & 16) != 0 || (a.cap_tile > 0 && a.cap_tile <= 512 && (int64_t)a.T * nb >= 16384));
     // Rolling chains of GR_ROLL_KT tiles (k_raster_tile_roll) where a chain of four would run -- for the FUSED kernel, whose
     // epilogue stores nothing: C2 15.07 -> 14.22 us per view, C5 29.99 -> 28.67 (profiles/r05_ab/rolling_chains.log).  The ids
-    // kernel loses with them (C2 13.21 -> 13.94, C5 28.5 -> 33.3): the wait for the next tile's request, placed before the
+    // kernels lose with them (C2 13.21 -> 13.94, C5 28.5 -> 33.3): the wait for the next tile's request, placed before the
     // tile's id stores, is also a wait for the PREVIOUS tile's stores (one in-order counter), so a wave never has more than
-    // one tile's stores in flight -- a chain of four has up to four.  Variant bit 1024: rolling chains for the ids kernels as
-    // well (A/B); bit 2048: none at all.
-    const bool roll = chain && a.cap_tile > 0 && a.thl == 5 && !(a.var & 2048) && (out.winner != nullptr || (a.var & 1024) != 0);
+    // one tile's stores in flight -- a chain of four has up to four.  They keep chains of four.
+    const bool roll = chain && a.cap_tile > 0 && a.thl == 5 && out.winner != nullptr;
     const dim3 grid(roll ? (unsigned)((a.T + GR_ROLL_KT - 1) / GR_ROLL_KT) : chain ? (unsigned)((a.T + 3) >> 2) : (unsigned)a.T, nb), block(256);
     const size_t pad = (size_t)c->opt_lds_pad;
 #define GR_LAUNCH_TILE_M(THL_, FUSE_, PLAIN_, MICRO_)                                                                 \
   do {                                                                                                                \
-    if (roll && THL_ == 5) {                                                                                          \
-      if (a.ent40) GR_LAUNCH_EV(ev_none, ev_stop, (k_raster_tile_roll<6, 5, 256, FUSE_, GR_LDS_PAD, true, PLAIN_, GR_ROLL_KT, MICRO_>), grid, block, pad, s, a, out);  \
-      else GR_LAUNCH_EV(ev_none, ev_stop, (k_raster_tile_roll<6, 5, 256, FUSE_, GR_LDS_PAD48, false, PLAIN_, GR_ROLL_KT, false>), grid, block, pad, s, a, out);        \
-    } else if (a.ent40) {                                                                                             \
+    if (a.ent40) {                                                                                                    \
       if (chain) GR_LAUNCH_EV(ev_none, ev_stop, (k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD, true, PLAIN_, MICRO_>), grid, block, pad, s, a, out);  \
       else GR_LAUNCH_EV(ev_none, ev_stop, (k_raster_tile<6, THL_, 256, FUSE_, 1, GR_LDS_PAD, true, PLAIN_, MICRO_>), grid, block, pad, s, a, out);        \
     } else if (chain) GR_LAUNCH_EV(ev_none, ev_stop, (k_raster_tile<6, THL_, 256, FUSE_, 4, GR_LDS_PAD48, false, PLAIN_, false>), grid, block, pad, s, a, out);  \
@@ -1047,9 +976,14 @@ int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStr
     else GR_LAUNCH_TILE_M(THL_, FUSE_, PLAIN_, false);                                                                \
   } while (0)
     // the usual ids-only call: rows of whole 16-byte pieces, every view's plane 16-byte aligned, no depth image
+    // (variant bit 512: the general ids kernel also where the plain one would run)
     const bool plain = !out.winner && out.ids && !out.depth && (w & 3) == 0 && (reinterpret_cast<uintptr_t>(out.ids) & 15) == 0 &&
                        !(a.var & 512);
-    if (out.winner) {
+    if (roll) {  // fused, 64 x 32 tiles, single-pass binning
+      if (a.ent40 && a.micro) GR_LAUNCH_EV(ev_none, ev_stop, (k_raster_tile_roll<6, 5, 256, true, GR_LDS_PAD, true, false, GR_ROLL_KT, true>), grid, block, pad, s, a, out);
+      else if (a.ent40) GR_LAUNCH_EV(ev_none, ev_stop, (k_raster_tile_roll<6, 5, 256, true, GR_LDS_PAD, true, false, GR_ROLL_KT, false>), grid, block, pad, s, a, out);
+      else GR_LAUNCH_EV(ev_none, ev_stop, (k_raster_tile_roll<6, 5, 256, true, GR_LDS_PAD48, false, false, GR_ROLL_KT, false>), grid, block, pad, s, a, out);
+    } else if (out.winner) {
       if (a.thl == 6) GR_LAUNCH_TILE(6, true, false);
       else GR_LAUNCH_TILE(5, true, false);
     } else if (plain) {

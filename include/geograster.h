@@ -117,28 +117,23 @@ enum {
                                set by hand -- process-wide, so that another context for the same mesh and image size
                                starts with segments that fit) or, beyond 65536 slots, or 24 GB of entry memory for ONE
                                view, bins exactly.  Setting the option forgets what the context learned          */
-  GR_OPT_VARIANT = 7,       /* variant bits for A/B runs (results identical): 1 = one tile per workgroup instead of a
-                               chain of four; 4 = fused votes on the caller's stream instead of a side stream; 8 = no
-                               first chunk requested ahead of the tile's count; 16 = chains of four tiles whatever the
-                               size of the launch (default: large launches of light tiles only); 32 = fused votes scan
-                               every view's winners (default: only views whose cull pass reached the 256-face chunk);
-                               64 = faces over more than 2 x 2 tiles go through a per-view list and a second kernel
-                               (default: expanded inside the set-up kernel); 128 = 48-byte entries always (default:
-                               the single-pass binning writes 40-byte entries and falls back to 48 bytes -- one
-                               GR_EOVERFLOW retry, remembered like the slots per tile -- for images with faces of
-                               93 pixels and more); 512 = the general ids kernel (depth output, any width) also for calls
-                               the plain one would take (ids only, rows of whole 16-byte pieces); 1024 = rolling chains of
-                               16 tiles (the next tile's first chunk requested while the current one is rasterized) for the
-                               ids kernels too (default: the fused kernel only); 2048 = no rolling chains; 8192 = micro
-                               lists always, 4096 = never (default: a call whose views show mostly faces of at most 4 x 4
-                               pixels -- a mesh rendered at a fraction of its photos' resolution -- teaches the library to
-                               keep, for that mesh and image size, a second list per tile for such faces, which the tile
-                               kernel point-samples one face per lane; remembered like the slots per tile); 16384 = no
-                               look at the first launch group's counts (every overflow goes through gr_raster_status);
-                               32768 = the view totals behind gr_raster_status are added up inside every call (default: a
-                               call of one launch group that is not fused leaves them to the status call); 131072 = tile
-                               counters packed side by side whatever the image size (default: images of at most 1024 tiles
-                               keep one counter per 128-byte line -- atomics on one line are served one after the other) */
+  GR_OPT_VARIANT = 7,       /* mode bits (results identical; the parity tests run every one against the oracle):
+                                    1 = one tile per workgroup of the tile kernel (default: chains of four consecutive tiles in
+                                        large launches of light tiles, rolling chains of 16 for the fused kernel);
+                                    4 = fused votes on the caller's stream (default: a side stream beside the next group's binning;
+                                        the profiling scripts use it: rocprofv3 counter passes do not survive the side stream);
+                                   16 = chains whatever the size of the launch (tests: small images through the chain kernels);
+                                  128 = 48-byte entries always (default: 40-byte entries; images with faces of 93 pixels and more
+                                        fall back to 48 bytes, remembered like the slots per tile);
+                                  512 = the general ids kernel (depth output, any width) also where the plain one would run;
+                                 4096 = micro lists never, 8192 = always (default: a call whose views show mostly faces of at most
+                                        4 x 4 pixels -- a mesh rendered at a fraction of its photos' resolution -- teaches the
+                                        library to keep, for that mesh and image size, a second list per tile for such faces,
+                                        which the tile kernel point-samples one face per lane);
+                                16384 = no look at the first launch group's counts (every overflow goes through gr_raster_status);
+                               131072 = tile counters packed side by side whatever the image size (default: images of at most
+                                        1024 tiles keep one counter per 128-byte line -- atomics on one line are served one after
+                                        the other) */
   GR_OPT_SHARE_LEARNED = 8, /* 1 (default): consult and feed the process-wide table of learned slots per tile / entry forms
                                (and its file, gr_learned_cache_file); 0: this context learns for itself only.  Setting
                                GR_OPT_DIRECT_CAP by hand switches it off; this option switches it back on            */
@@ -148,7 +143,8 @@ enum {
                                an image whose learned slots would not fit even ONE view bins exactly instead (remembered
                                per mesh and image size like the slots themselves; other image sizes are not affected)   */
   GR_OPT_DEBUG_LDS = 98,    /* extra dynamic LDS bytes per tile workgroup: lowers occupancy (timing experiments)     */
-  GR_OPT_DEBUG = 99         /* timing-only ablation mask for tools/ab_kernel.py: OUTPUTS BECOME WRONG          */
+  GR_OPT_DEBUG = 99         /* test hook: 512 = entry slots and row counts are poisoned with 0xFF before every launch group is
+                               binned (results stay right: tests/test_overflow_protocol.py)                      */
 };
 int gr_set_option(gr_ctx *ctx, int key, int value);
 

@@ -13,33 +13,18 @@ from oracle import oracle_c, oracle_np
 
 pytestmark = pytest.mark.gpu
 
-# every raster test runs against each setting of the tuning knobs (include/geograster.h GR_OPT_*): (tile height log2,
-# slots per tile [0 = exact two-pass binning], GR_OPT_VARIANT bits: 1 = one tile per workgroup, 4 = votes on the caller's
-# stream, 8 = no speculative first chunk, 16 = chains of four tiles even in small launches, 32 = fused votes without the
-# chunk bitmaps, 64 = big faces through the view's big list and k_bin_big, 128 = 48-byte entries always instead of 40-byte
-# entries with a fallback) -- every combination must give identical results
-VARIANTS = {"tile32_chain": (5, 512, 16), "tile64_single_full": (6, 512, 129), "tile32_exact_single": (5, 0, 5),
-            "tile64_exact_chain": (6, 0, 16), "tile32_single_nospec_full": (5, 512, 141), "tile32_chain_nospec_nobitmap": (5, 512, 56),
-            "tile32_chain_biglist": (5, 512, 80), "tile64_single": (6, 512, 1),
-            # 512: the general ids kernel (depth / odd widths) also where the plain one (16-byte id stores only) would run
-            "tile32_chain_general_ids": (5, 512, 528), "tile64_single_general_ids": (6, 512, 513),
-            # 1024: rolling chains of 16 tiles (k_raster_tile_roll) for the ids kernels too (the fused kernel's default wherever a
-            # chain of four would run); 2048: none
-            "tile32_roll": (5, 512, 1040), "tile32_roll_full_general": (5, 512, 1040 + 128 + 512),
-            "tile32_chain_no_roll": (5, 512, 16 + 2048),
-            # 8192: micro lists always (faces of at most 4 x 4 pixels on a second list per tile, one face per lane); the default
-            # keeps them only where an earlier call found such faces to be the rule
-            "tile32_micro_chain": (5, 512, 16 + 8192), "tile32_micro_single": (5, 512, 1 + 8192), "tile64_micro": (6, 512, 8192),
-            "tile32_micro_roll_ids": (5, 512, 16 + 1024 + 8192),
-            # 16384: no look at the first launch group's counts (a call for a mesh / image size nothing has been learned about
-            # reads them before the group's tile kernel runs and starts over by itself): every overflow through gr_raster_status
-            "tile32_chain_no_look": (5, 512, 16 + 16384), "tile64_single_no_look": (6, 512, 1 + 16384),
-            # 32768: the view totals behind gr_raster_status added up inside every call (default: left to the status call when
-            # nothing on the device waits for them)
-            "tile32_chain_eager_stats": (5, 512, 16 + 32768),
-            # 131072: tile counters packed side by side (default for images of at most 1024 tiles -- every image of this file but
-            # the full-size ones: one counter per 128-byte line)
-            "tile32_chain_packed_counters": (5, 512, 16 + 131072), "tile64_single_packed_counters": (6, 512, 1 + 131072)}
+# every raster test runs against each of these settings of the tuning knobs (include/geograster.h GR_OPT_*): (tile height log2,
+# slots per tile [0 = exact two-pass binning], GR_OPT_VARIANT mode bits: 1 = one tile per workgroup, 4 = votes on the caller's
+# stream, 16 = chains of tiles even in small launches, 128 = 48-byte entries always, 512 = the general ids kernel where the plain
+# one would run, 4096 / 8192 = micro lists never / always, 16384 = no look at the first launch group (status-call protocol),
+# 131072 = packed tile counters) -- every combination must give identical results (tools/fuzz_parity.py draws random ones)
+VARIANTS = {"default": (5, 512, 0), "tile32_chain": (5, 512, 16), "tile64_single_full": (6, 512, 1 + 128),
+            "tile32_exact_single_inline_votes": (5, 0, 1 + 4), "tile64_exact_chain": (6, 0, 16),
+            "tile32_chain_full_general_ids": (5, 512, 16 + 128 + 512), "tile64_single_general_ids": (6, 512, 1 + 512),
+            "tile32_micro_chain": (5, 512, 16 + 8192), "tile32_micro_single": (5, 512, 1 + 8192),
+            "tile64_micro_chain": (6, 512, 16 + 8192),
+            "tile32_chain_no_look_packed_counters": (5, 512, 16 + 16384 + 131072),
+            "tile64_single_no_look_no_micro": (6, 512, 1 + 16384 + 4096)}
 
 
 @pytest.fixture(params=list(VARIANTS), autouse=True)

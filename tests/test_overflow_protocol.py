@@ -349,18 +349,19 @@ def test_clipped_faces_outgrow_the_record_planes_of_exact_binning(hip):
 
 def test_view_totals_left_to_the_status_call(hip):
     """A call of one launch group that is not fused does not add up its view totals itself (nothing on the device waits for
-    them): gr_raster_status does, when asked.  The numbers must be those of the eager form (variant bit 32768), also when other
-    work ran on the stream in between, and an overflow must still be reported -- by the status call of an unchecked call too."""
-    EAGER = 32768
+    them): gr_raster_status does, when asked.  The numbers must be those of the eager form (a call of several launch groups adds
+    them up itself: three views per group here), also when other work ran on the stream in between, and an overflow must still
+    be reported -- by the status call of an unchecked call too."""
     (points, faces), cams = synthetic.config1_scene()
     recs = _records(cams)
     hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
     keys = ("records", "entries", "max_entries", "overflow", "views_done", "blocks")
-    hip.set_option(7, EAGER)
+    hip.set_option(7, 0)
     hip.set_option(6, 512)
+    hip.set_option(3, 3)
     want_ids = hip.raster_face_ids(recs, 480, 640)
     want = {k: hip.last_stats[k] for k in keys}
-    hip.set_option(7, 0)
+    hip.set_option(3, 64)
     hip.set_option(6, 512)
     hip.raster_face_ids(recs, 480, 640)                       # learns (the look): the next call is an ordinary one
     ids = hip.raster_face_ids(recs, 480, 640, check=False)

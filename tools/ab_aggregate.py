@@ -19,7 +19,7 @@ H, W, C = 3000, 4000, 4
 def main():
     nv = int(sys.argv[1]) if len(sys.argv) > 1 else 500
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-    variants = [int(x) for x in sys.argv[3:]] or [0, 32, 4]
+    variants = [int(x) for x in sys.argv[3:]] or [0, 4]
     points, faces = synthetic.terrain_mesh()
     cams = synthetic.config3_cameras() if hasattr(synthetic, "config3_cameras") else synthetic.config2_cameras(nv)
     recs = torch.from_numpy(cams.get_raster_records(1.0, near=1.0)[:nv]).cuda()

@@ -2,7 +2,7 @@
 """tools/ab_kernel.py [views] [reps] [variant ...] -- interleaved A/B of tile-kernel variants on the C2 workload, plain
 (pix2face) and fused (raster + label projection), in ONE process.  GPU box only.
 
-A variant is `name:var[:dbg[:thl[:cap[:ldspad[:kt[:batch[:pfd]]]]]]]` (GR_OPT_VARIANT bits, GR_OPT_DEBUG mask, tile height log2, slots per tile).
+A variant is `name:var[:dbg[:thl[:cap[:ldspad[:kt[:batch[:pfd]]]]]]]` (GR_OPT_VARIANT bits, GR_OPT_DEBUG test-hook mask, tile height log2, slots per tile).
 Every variant with dbg == 0 must reproduce the first variant's ids and votes bit for bit.  Prints one JSON line per
 variant: median HIP-event stage times in microseconds per view.
 """
@@ -16,19 +16,11 @@ import numpy as np
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
-# a variant with an ablation mask (third field) needs the DIAGNOSTIC build: the product's kernels carry no ablation branches
-if any(len(sp.split(":")) > 2 and sp.split(":")[2] not in ("", "0") for sp in sys.argv[3:]) and not os.environ.get("GEOGRAYPHER_AMD_LIB"):
-    from geograypher_amd import build as _gbuild
-
-    _lib = _gbuild.CSRC / "libgeograster_ablate.so"
-    if not _lib.is_file() or _lib.stat().st_mtime < max(p.stat().st_mtime for p in _gbuild.SOURCES + _gbuild.HEADERS):
-        _gbuild.build_variant("ablate", ["GR_ABLATE"])
-    os.environ["GEOGRAYPHER_AMD_LIB"] = str(_lib)
 from geograypher_amd._hip import HipRaster
 from geograypher_amd.utils import synthetic
 
 H, W, C = 3000, 4000, 4
-DEFAULT = ["base:0", "xcd:64"]
+DEFAULT = ["base:0"]
 # c2: 1.2 M faces, 4000 x 3000; c5: 5 M faces, 6000 x 4000 (20 views); c2q: c2 at render_img_scale 0.25 (1000 x 750);
 # forest / forestq: the hostile workload (terrain + 20 000 trees, 20 oblique views) at scale 1 / 0.25
 WORKLOAD = os.environ.get("AB_WORKLOAD", "c2")

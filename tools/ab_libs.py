@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""tools/ab_libs.py <rounds> <workloads: c2,c5> <tag[:GR_EXP bits[:GR_OPT_VARIANT bits]]> ... -- A/B of library BUILDS on one
+"""tools/ab_libs.py <rounds> <workloads: c2,c5> <tag[:-D defines, comma separated[:GR_OPT_VARIANT bits]]> ... -- A/B of library BUILDS on one
 box.  GPU box only.
 
 Every tag is a build of the library: `base` = the product's libgeograster.so, anything else libgeograster_<tag>.so (built here
-with -DGR_EXP=<bits> when missing).  Rounds x builds x workloads, alternating (box-to-box spread is larger than most kernel
+with the given -D defines when missing, e.g. `wide:GR_SETUP_BPW=6u`; a library saved from an earlier tree under that name is used as it is).  Rounds x builds x workloads, alternating (box-to-box spread is larger than most kernel
 changes): each cell is one run of tools/ab_kernel.py in a child process with GEOGRAYPHER_AMD_LIB pointing at the build.  The
 FIRST build's ids and votes are hashed; every other build must reproduce them (bit-exact A/B).  Prints the medians."""
 import json
@@ -31,7 +31,7 @@ def main():
             continue
         path = gbuild.CSRC / f"libgeograster_{tag}.so"
         if not path.is_file():
-            gbuild.build_variant(tag, [f"GR_EXP={bits or 0}"])
+            gbuild.build_variant(tag, [d for d in bits.split(",") if d])
         libs.append((name, path, var or "0"))
     acc = {(t, w): [] for t, _, _ in libs for w in workloads}
     sums = {}

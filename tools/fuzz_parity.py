@@ -25,9 +25,9 @@ from geograypher_amd._hip import HipRaster
 from geograypher_amd.utils import synthetic
 from oracle import oracle_c
 
-# round 5: 1024 / 2048 rolling chains for the ids kernels / never, 4096 / 8192 micro lists never / always, 16384 no look at the first
+# the mode bits of GR_OPT_VARIANT (include/geograster.h): 4096 / 8192 micro lists never / always, 16384 no look at the first
 # launch group's counts (the overflow protocol of rounds 1-4)
-VARIANT_BITS = [1, 4, 8, 16, 32, 64, 128, 512, 1024, 2048, 4096, 8192, 16384, 32768, 131072]
+VARIANT_BITS = [1, 4, 16, 128, 512, 4096, 8192, 16384, 131072]
 
 
 BIG = False

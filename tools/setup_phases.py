@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""tools/setup_phases.py [c2|c2q|c5|forest|forestq] [views] [GR_EXP bits] -- where a wave of k_setup_cull spends its life.  GPU box only.
+"""tools/setup_phases.py [c2|c2q|c5|forest|forestq] [views] [-D defines, comma separated] -- where a wave of k_setup_cull spends its life.  GPU box only.
 
-Runs a DIAGNOSTIC build of the library (csrc/libgeograster_sstamps<bits>.so: -DGR_STAMPS [-DGR_EXP=bits], built here if
-missing), whose set-up kernel reads the shader clock at its phase boundaries (binning.hip, GR_SSTAMP: every stamp first
+Runs a DIAGNOSTIC build of the library (csrc/libgeograster_sstamps.so: -DGR_STAMPS [+ the given defines], built here if
+missing or stale), whose set-up kernel reads the shader clock at its phase boundaries (binning.hip, GR_SSTAMP: every stamp first
 waits for the wave's outstanding memory operations, so a latency is charged to the phase that waited for it) and sums the
 cycles per phase over all waves.  Prints one JSON line: cycles per block iteration and share per phase, block iterations
 per view, mean resident waves per CU.  The stamps serialise the wave's memory operations: use the shares as a map of where
@@ -17,11 +17,12 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 from geograypher_amd import build as gbuild
 
-bits = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-tag = f"sstamps{bits}"
+defs = [d for d in (sys.argv[3] if len(sys.argv) > 3 else "").split(",") if d and d != "0"]
+bits = ",".join(defs)
+tag = "sstamps" + "".join(c if c.isalnum() else "_" for c in bits)
 lib_path = gbuild.CSRC / f"libgeograster_{tag}.so"
 if not lib_path.is_file() or lib_path.stat().st_mtime < max(p.stat().st_mtime for p in gbuild.SOURCES + gbuild.HEADERS):
-    gbuild.build_variant(tag, ["GR_STAMPS", f"GR_EXP={bits}"])
+    gbuild.build_variant(tag, ["GR_STAMPS"] + defs)
 os.environ["GEOGRAYPHER_AMD_LIB"] = str(lib_path)
 
 import numpy as np
@@ -72,7 +73,7 @@ def main():
     total = sum(cyc[:6])
     kernel_s = st["setup_ms"] * 1e-3
     out = {
-        "workload": wl, "views": nv, "image": f"{W}x{H}", "GR_EXP": bits, "setup_us_per_view": round(st["setup_ms"] / st["views"] * 1e3, 2),
+        "workload": wl, "views": nv, "image": f"{W}x{H}", "defines": bits, "setup_us_per_view": round(st["setup_ms"] / st["views"] * 1e3, 2),
         "waves_per_view": round(waves / (reps * nv), 1), "block_iterations_per_view": round(iters / (reps * nv), 1),
         "cycles_per_block_iteration": {PHASES[k]: round(cyc[k] / max(iters, 1), 1) for k in range(6)},
         "share": {PHASES[k]: round(cyc[k] / max(total, 1), 4) for k in range(6)},
