@@ -74,6 +74,27 @@ __device__ __forceinline__ void wave_group(int t, int lane, int &leader, int &ra
   }
 }
 
+// The same with WEIGHTS: lane i asks for w_i in {1, 2, 4} consecutive list positions (a micro pair cut into 4 x 4 boxes); rank =
+// the weights of the group's lanes below this one, size = the weights of the whole group.  w - 1 is 0, 1 or 3: two ballots of
+// its bits turn the weighted sums into population counts.
+__device__ __forceinline__ void wave_group_weighted(int t, int w, int lane, int &leader, int &rank, int &size) {
+  leader = lane; rank = 0; size = 0;
+  unsigned long long rem = __ballot(t >= 0);
+  const unsigned long long b0 = __ballot(((w - 1) & 1) != 0), b1 = __ballot(((w - 1) & 2) != 0);
+  const unsigned long long low = (1ull << lane) - 1ull;
+  while (rem) {
+    const int l = __ffsll((long long)rem) - 1;
+    const int tl = __builtin_amdgcn_readlane(t, l);
+    const unsigned long long m = __ballot(t == tl);
+    if (t == tl) {
+      leader = l;
+      rank = __popcll(m & low) + __popcll(m & low & b0) + 2 * __popcll(m & low & b1);
+      size = __popcll(m) + __popcll(m & b0) + 2 * __popcll(m & b1);
+    }
+    rem &= ~m;
+  }
+}
+
 // The same with at most `max_groups` groups looked for: lanes that are left over stand alone (leader = itself, size 1).
 // For the (face, tile) pairs of big faces, where a step of 64 pairs can name 64 different tiles.
 __device__ __forceinline__ void wave_group_capped(int t, int lane, int &leader, int &rank, int &size, int max_groups) {
@@ -162,15 +183,19 @@ struct FaceForm {
 
 __device__ __forceinline__ FaceForm face_form(const int4 p0, const int4 p1, const int4 p2, int TW, int TH);
 __device__ __forceinline__ bool tile_entry(const FaceForm &ff, int px0, int py0, int TW, int TH, int4 &e0, int4 &e1, int4 &e2,
-                                           int &rows, int *xinfo = nullptr);
+                                           int &rows);
 __device__ __forceinline__ bool compile_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
                                               uint8_t *__restrict__ nr8, int64_t idx, const int4 p0, const int4 p1,
-                                              const int4 p2, int px0, int py0, int TW, int TH, bool micro = false);
+                                              const int4 p2, int px0, int py0, int TW, int TH);
 __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const int4 p2, int px0, int py0, int TW, int TH,
-                                            int4 &e0, int4 &e1, int4 &e2, int &rows, int *xinfo = nullptr);
+                                            int4 &e0, int4 &e1, int4 &e2, int &rows);
 __device__ __forceinline__ void store_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
                                             uint8_t *__restrict__ nr8, int64_t idx, const int4 e0, const int4 e1, const int4 e2,
-                                            int rows, int xinfo = -1);
+                                            int rows);
+// Faces whose snapped bounding box is smaller than GR_FAST_EXT sub-pixels (93 px) take a short form of the set-up (build_entry),
+// fit the 40-byte entry (store_entry) and the 32-byte micro record (k_setup_cull)
+#define GR_FAST_EXT 24000
+__device__ __forceinline__ int pack16(int lo, int hi) { return (lo & 0xFFFF) | (hi << 16); }
 
 // R1 / R2 / R4 for one face of the soup: the record (three int4) that compile_entry turns into per-tile entries, and the
 // range of tiles its pixel bounding box touches.  Returns false for faces that draw nothing in this view; clip_me: the face
@@ -296,7 +321,9 @@ __device__ __forceinline__ void bin_big_pairs(const BinArgs &a, uint32_t *__rest
 #ifndef GR_SETUP_BPW_MAX
 #define GR_SETUP_BPW_MAX 8u   // ... and at most (where the blocks outnumber the tiles)
 #endif
-template <bool DIRECT>
+// MICRO: the kernel of a call that keeps micro lists (a build of its own, like the tile kernel's: the ordinary kernel carries none
+// of it)
+template <bool DIRECT, bool MICRO = false>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(5, 5)))  // at most 96 VGPRs: five waves per SIMD (three: +14.5 %, six -- 80 VGPRs, scratch -- +7 %: the kernel lives on latency hiding)
 void k_setup_cull(const float *__restrict__ cams, BinArgs a) {
@@ -404,46 +431,60 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a) {
   const bool small_fp = keep && (tx1 - tx0 <= 1) && (ty1 - ty0 <= 1);
   uint32_t *cntS = ctrl + GR_CTRL_HDR;
   uint32_t *cntB = cntS + a.Tcap;
-  // MICRO entries (round 5; single-pass binning with 40-byte entries): the (face, tile) pairs of a face whose pixel bounding
-  // box is at most 4 x 4 pixels -- nearly every face of a survey mesh at render_img_scale 0.25, the reference's operating
-  // point -- go to a SECOND list of their tile, filled from the back of the tile's segment and
-  // counted in the otherwise unused cntB array; the tile kernel takes it one lane per FACE (sixteen point-sampled pixels, no
-  // span solver, no mailboxes, no staging barriers: raster_tile.hip).  Bit 30 of a tile id marks the class, so that
-  // wave_group keeps the two lists' positions apart.
+  // MICRO records (round 5: lists; round 6: lean records).  In a view whose faces are mostly a few pixels wide -- a survey mesh at
+  // render_img_scale 0.25, the reference's operating point (examples/aggregate_predictions.ipynb:61) -- every (face, tile) pair
+  // whose part of the pixel bounding box in its tile is at most 8 x 8 goes to a SECOND list of the tile, filled from the back of
+  // the tile's segment and counted in the otherwise unused cntB array, as one record per 4 x 4 box of that part (1, 2 or 4
+  // records; 90 % of such pairs: one).  The tile kernel takes the list one record per LANE: sixteen point-sampled pixels, no span
+  // solver, no mailboxes, no staging barriers (raster_tile.hip: micro_item).  A record is 32 bytes and costs this kernel about
+  // thirty instructions -- three snapped vertices relative to the tile's centre pixel, the plane of 1/z, the key, the box --
+  // where a compiled entry (build_entry: edge constants at the tile centre, edge order, slope packing, correction flags, 40
+  // bytes + a row count) costs three hundred: the tile kernel derives its three edge functions from the vertices itself, once
+  // per record, exactly (round 5 stored a compiled entry for every micro pair: 36 % of a wave's life in this kernel at 1000 x
+  // 750, profiles/r05_ab/setup_phases_c2q.log).  Bit 30 of a tile id marks the class, so that the wave's groups keep the two
+  // lists' positions apart.
   constexpr int GR_MICRO_BIT = 1 << 30;
-  int mcls = 0;  // bit k: tile slot k (0 first, 1 right, 2 below, 3 below right) is a micro entry
-  if (DIRECT && (a.count_micro | a.micro)) {   // (wave-uniform: a call that neither counts micro faces nor keeps micro lists skips all of it)
-    const int jmin = r2.z & 0xFFFF, jmax = (int)((uint32_t)r2.z >> 16), imin = r2.w & 0xFFFF, imax = (int)((uint32_t)r2.w >> 16);
+  int mcls = 0;  // bit k: tile slot k (0 first, 1 right, 2 below, 3 below right) is a micro pair
+  int mrec = 0;  // its records, 3 bits per slot (0, 1, 2 or 4)
+  if (DIRECT && a.count_micro) {
     // how many faces of the view are micro faces (whole box at most 4 x 4): the statistic that switches micro lists on for
     // the NEXT call on this mesh and image size (gr_raster_status).  At full size only the clipped corners of ordinary faces
     // would qualify (2 % of the pairs) and give nearly every tile a list of a handful of entries -- a whole extra phase per
     // tile: ids kernel +7 % on C2 and C5 (profiles/r05_ab/micro_lists_per_tile_part.log) -- so the lists exist only where
-    // micro FACES are the rule; there every pair is classed by its own part of the box in its tile.
-    // Counted only by the calls that can still learn from it (BinArgs::count_micro: the call that looks at its first launch group
-    // -- the first for this mesh and image size --, or every call under the status-call protocol of variant bit 16384; not with
-    // 48-byte entries, not once the lists are on): four compares, a ballot and a population count per block were 2 % of the
-    // set-up stage on C2, 5 % at 1000 x 750, for a number nobody read.
-    if (a.count_micro) n_mic += (uint32_t)__popcll(__ballot(small_fp && jmax - jmin < 4 && imax - imin < 4));
-    if (a.micro && small_fp) {
-      const int xb = (tx0 + 1) << a.twl, yb = (ty0 + 1) << a.thl;   // first column / row of the right / lower tiles
-      const bool wl = min(jmax, xb - 1) - jmin < 4, wr = jmax - xb < 4, ht = min(imax, yb - 1) - imin < 4, hb = imax - yb < 4;
-      mcls = (wl && ht ? 1 : 0) | (wr && ht ? 2 : 0) | (wl && hb ? 4 : 0) | (wr && hb ? 8 : 0);
-    }
+    // micro FACES are the rule.  Counted only by the calls that can still learn from it (BinArgs::count_micro: the call that
+    // looks at its first launch group -- the first for this mesh and image size --, or every call under the status-call protocol
+    // of variant bit 16384; not with 48-byte entries, not once the lists are on).
+    const int jmin = r2.z & 0xFFFF, jmax = (int)((uint32_t)r2.z >> 16), imin = r2.w & 0xFFFF, imax = (int)((uint32_t)r2.w >> 16);
+    n_mic += (uint32_t)__popcll(__ballot(small_fp && jmax - jmin < 4 && imax - imin < 4));
+  }
+  if (DIRECT && MICRO && small_fp) {
+    const int jmin = r2.z & 0xFFFF, jmax = (int)((uint32_t)r2.z >> 16), imin = r2.w & 0xFFFF, imax = (int)((uint32_t)r2.w >> 16);
+    const int xb = (tx0 + 1) << a.twl, yb = (ty0 + 1) << a.thl;   // first column / row of the right / lower tiles
+    const int wl = min(jmax, xb - 1) - jmin + 1, wr = jmax - xb + 1, ht = min(imax, yb - 1) - imin + 1, hb = imax - yb + 1;
+    const int cl = wl <= 8 ? (wl + 3) >> 2 : 0, cr = wr <= 8 ? (wr + 3) >> 2 : 0;   // 4-pixel columns of the parts (0: not micro)
+    const int rt = ht <= 8 ? (ht + 3) >> 2 : 0, rb = hb <= 8 ? (hb + 3) >> 2 : 0;
+    const int m0 = cl * rt, m1 = tx1 > tx0 ? cr * rt : 0, m2 = ty1 > ty0 ? cl * rb : 0, m3 = (tx1 > tx0 && ty1 > ty0) ? cr * rb : 0;
+    mrec = m0 | (m1 << 3) | (m2 << 6) | (m3 << 9);
+    mcls = (m0 ? 1 : 0) | (m1 ? 2 : 0) | (m2 ? 4 : 0) | (m3 ? 8 : 0);
   }
   const int t00 = small_fp ? (ty0 * a.TX + tx0) | ((mcls & 1) ? GR_MICRO_BIT : 0) : -1;
   const int t01 = (small_fp && tx1 > tx0) ? (ty0 * a.TX + tx1) | ((mcls & 2) ? GR_MICRO_BIT : 0) : -1;
   const int t10 = (small_fp && ty1 > ty0) ? (ty1 * a.TX + tx0) | ((mcls & 4) ? GR_MICRO_BIT : 0) : -1;
   const int t11 = (small_fp && tx1 > tx0 && ty1 > ty0) ? (ty1 * a.TX + tx1) | ((mcls & 8) ? GR_MICRO_BIT : 0) : -1;
-  // a tile's counter: cntS, or cntB for its micro list; an entry's slot: from the front of the segment, or from its back
+  // a tile's counter: cntS, or cntB for its micro list
   auto counter_of = [&](int t) { return (t & GR_MICRO_BIT) ? &cntB[cidx(a, t & ~GR_MICRO_BIT)] : &cntS[cidx(a, t)]; };
-  auto slot_of = [&](int t, uint32_t pos) {
-    return (t & GR_MICRO_BIT) ? (int64_t)(t & ~GR_MICRO_BIT) * a.cap_tile + ((uint32_t)a.cap_tile - 1u - pos) : (int64_t)t * a.cap_tile + pos;
-  };
   int l0, k0, n0, l1 = lane, k1 = 0, n1 = 0, l2 = lane, k2 = 0, n2 = 0, l3 = lane, k3 = 0, n3 = 0;
-  wave_group(t00, lane, l0, k0, n0);
-  if (__ballot(t01 >= 0)) wave_group(t01, lane, l1, k1, n1);
-  if (__ballot(t10 >= 0)) wave_group(t10, lane, l2, k2, n2);
-  if (__ballot(t11 >= 0)) wave_group(t11, lane, l3, k3, n3);
+  if (DIRECT && MICRO) {   // a micro pair takes as many positions as it has records, any other pair one
+    wave_group_weighted(t00, max(mrec & 7, 1), lane, l0, k0, n0);
+    if (__ballot(t01 >= 0)) wave_group_weighted(t01, max((mrec >> 3) & 7, 1), lane, l1, k1, n1);
+    if (__ballot(t10 >= 0)) wave_group_weighted(t10, max((mrec >> 6) & 7, 1), lane, l2, k2, n2);
+    if (__ballot(t11 >= 0)) wave_group_weighted(t11, max((mrec >> 9) & 7, 1), lane, l3, k3, n3);
+  } else {
+    wave_group(t00, lane, l0, k0, n0);
+    if (__ballot(t01 >= 0)) wave_group(t01, lane, l1, k1, n1);
+    if (__ballot(t10 >= 0)) wave_group(t10, lane, l2, k2, n2);
+    if (__ballot(t11 >= 0)) wave_group(t11, lane, l3, k3, n3);
+  }
   GR_SSTAMP(2);
   uint32_t base = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
   // record count: a list position for the exact path; a statistic otherwise, kept in a register until the wave is done (one
@@ -462,26 +503,71 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a) {
   r3.z = (int)(__shfl(b2, l2) + (uint32_t)k2);
   r3.w = (int)(__shfl(b3, l3) + (uint32_t)k3);
   GR_SSTAMP(3);
+  if (DIRECT && MICRO && __ballot(mcls != 0)) {
+    // the micro records, in the face's own lane: slot by slot (second to fourth tiles are the exception: rounds that few lanes
+    // take part in, thirty instructions each), box by box
+    const int X0 = r0.x, Y0 = r0.y, X1 = r0.z, Y1 = r0.w, X2 = r1.x, Y2 = r1.y;
+    const int jmin = r2.z & 0xFFFF, jmax = (int)((uint32_t)r2.z >> 16), imin = r2.w & 0xFFFF, imax = (int)((uint32_t)r2.w >> 16);
+    // the record holds the vertices as 16-bit offsets from the tile's centre pixel: a face whose snapped bounding box reaches
+    // GR_FAST_EXT (93 px) does not fit -- the condition under which a compiled entry misses the 40-byte form (store_entry):
+    // the same overflow bit, the same retry with 48-byte entries (and without micro lists)
+    const int ext = max(imax3(X0, X1, X2) - imin3(X0, X1, X2), imax3(Y0, Y1, Y2) - imin3(Y0, Y1, Y2));
+    char *const segs = reinterpret_cast<char *>(a.comp + slot * a.ent_cap * GR_ENT_Q);
+    const int TWh = 1 << (a.twl - 1), THh = 1 << (a.thl - 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int nk = (mrec >> (3 * k)) & 7;
+      if (!__ballot(nk != 0)) continue;
+      if (nk != 0) {
+        const int tx = tx0 + (k & 1), ty = ty0 + (k >> 1);
+        const int px0 = tx << a.twl, py0 = ty << a.thl;
+        const int jlo = max(jmin - px0, 0), jhi = min(jmax - px0, (1 << a.twl) - 1);
+        const int ilo = max(imin - py0, 0), ihi = min(imax - py0, (1 << a.thl) - 1);
+        const int Pxc = (px0 + TWh) * 256 + 128, Pyc = (py0 + THh) * 256 + 128;   // centre of the tile's centre pixel
+        const uint32_t pos = (uint32_t)(k == 0 ? r3.x : k == 1 ? r3.y : k == 2 ? r3.z : r3.w);
+        const int ncx = (jhi - jlo + 4) >> 2;   // 4-pixel columns of the part: 1 or 2
+        if (ext >= GR_FAST_EXT) atomicOr(&ctrl[2], 2u);
+        else if ((pos + (uint32_t)nk) * 4u <= (uint32_t)a.cap_tile * 5u) {   // inside the segment (cap slots of 40 bytes; whether the two lists met: k_bin_stats)
+          // record p of the tile's list: the 32 bytes that end 32 p bytes before the end of the tile's segment
+          char *const rec_end = segs + ((int64_t)(ty * a.TX + tx) + 1) * a.cap_tile * 40 - (int64_t)pos * 32;
+          const int4 va = make_int4(pack16(X0 - Pxc, Y0 - Pyc), pack16(X1 - Pxc, Y1 - Pyc), pack16(X2 - Pxc, Y2 - Pyc), r1.z);
+          for (int sb = 0; sb < nk; ++sb) {
+            const int sx = sb & (ncx - 1), sy = sb >> (ncx - 1);
+            const int c0 = jlo + 4 * sx, c1 = min(c0 + 3, jhi), q0 = ilo + 4 * sy, q1 = min(q0 + 3, ihi);
+            int4 *dst = reinterpret_cast<int4 *>(rec_end - 32 * (sb + 1));
+            dst[0] = va;
+            dst[1] = make_int4(r2.x, r2.y, (int)~(uint32_t)r1.w, c0 | ((c1 - c0) << 6) | (q0 << 8) | ((q1 - q0 + 1) << 14));
+          }
+        } else atomicOr(&ctrl[2], 1u);
+      }
+    }
+  }
   if (DIRECT) {
     // faces over at most 2x2 tiles: positions came from the wave-aggregated counters; the lanes of a group hold
     // consecutive positions of the same tile segment, so their entries are written side by side.  Every such face has a
     // FIRST tile -- one dense round of compile_entry --; second to fourth tiles are the exception (0.5 per face): those
     // (face, tile) pairs are compacted -- prefix sum, 6-step search for the owning lane, its records pulled by ds_bpermute
     // -- and compiled in one more round.  (Three mostly idle rounds in the face's own lane from one FaceForm measured +4 %:
-    // profiles/r05_ab/setup_own_lane_tiles_vs_compaction.log.)
+    // profiles/r05_ab/setup_own_lane_tiles_vs_compaction.log.)  With micro lists both rounds see only the pairs that are no
+    // micro pairs -- in a view of micro faces none: the wave skips them.
     int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
     uint8_t *nr8 = a.nrow8 + slot * a.ent_cap;
     const int TW = 1 << a.twl, TH = 1 << a.thl;
-    if (small_fp) {
-      if ((uint32_t)r3.x < (uint32_t)a.cap_tile) {
-        compile_entry(a, ctrl, comp, nr8, slot_of(t00, (uint32_t)r3.x), r0, r1, r2, tx0 << a.twl, ty0 << a.thl, TW, TH, (mcls & 1) != 0);
-      } else atomicOr(&ctrl[2], 1u);
+    const bool first_general = small_fp && !(mcls & 1);
+    if (!MICRO || __ballot(first_general)) {
+      if (first_general) {
+        if ((uint32_t)r3.x < (uint32_t)a.cap_tile) {
+          compile_entry(a, ctrl, comp, nr8, (int64_t)t00 * a.cap_tile + (uint32_t)r3.x, r0, r1, r2, tx0 << a.twl, ty0 << a.thl, TW, TH);
+        } else atomicOr(&ctrl[2], 1u);
+      }
     }
     const int shape = small_fp ? ((tx1 > tx0 ? 1 : 0) | (ty1 > ty0 ? 2 : 0)) : 0;  // which neighbours exist: 1 right, 2 below
-    const int ne = shape == 3 ? 3 : (shape ? 1 : 0);
+    // the face's extra tile slots that take a compiled entry: bit k - 1 for slot k (1 right, 2 below, 3 below right)
+    const int extra = (shape == 3 ? 7 : shape) & ~(mcls >> 1);
+    const int ne = __popc((unsigned)extra);
     const int incl_e = wave_incl_scan(ne);
     const int total_e = __builtin_amdgcn_readlane(incl_e, 63);
-    const int geo = tx0 | (ty0 << 12) | (shape << 24) | (mcls << 26);
+    const int geo = tx0 | (ty0 << 12) | (extra << 24);
     for (int k0 = 0; k0 < total_e; k0 += 64) {
       const int q = k0 + lane;
       int t = 0;  // the face of pair q: the first lane whose inclusive sum exceeds q
@@ -489,9 +575,11 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a) {
       for (int step = 32; step >= 1; step >>= 1) t += (__shfl(incl_e, t + step - 1) <= q) ? step : 0;
       t = min(t, 63);
       const int g = __shfl(geo, t);
-      const int sh = (g >> 24) & 3;
-      const int which = q - (__shfl(incl_e, t) - (sh == 3 ? 3 : 1));  // 0 .. 2: the face's extra tile
-      const int k = sh == 3 ? which + 1 : sh;                          // tile slot 1 (right), 2 (below), 3 (below right)
+      int ex = (g >> 24) & 7;
+      const int which = q - (__shfl(incl_e, t) - __popc((unsigned)ex));  // 0 .. 2: the face's which-th extra tile
+      if (which >= 1) ex &= ex - 1;
+      if (which >= 2) ex &= ex - 1;
+      const int k = __ffs(ex);                                         // tile slot 1 (right), 2 (below), 3 (below right)
       const int4 p0 = make_int4(__shfl(r0.x, t), __shfl(r0.y, t), __shfl(r0.z, t), __shfl(r0.w, t));
       const int4 p1 = make_int4(__shfl(r1.x, t), __shfl(r1.y, t), __shfl(r1.z, t), __shfl(r1.w, t));
       const int4 p2 = make_int4(__shfl(r2.x, t), __shfl(r2.y, t), __shfl(r2.z, t), __shfl(r2.w, t));
@@ -499,10 +587,8 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a) {
       if (q < total_e) {
         const uint32_t pos = (uint32_t)(k == 1 ? py : k == 2 ? pz : pw);
         const int tx = (g & 0xFFF) + (k & 1), ty = ((g >> 12) & 0xFFF) + (k >> 1);
-        const bool mic = ((g >> (26 + k)) & 1) != 0;
         if (pos < (uint32_t)a.cap_tile) {
-          const int64_t idx = slot_of((ty * a.TX + tx) | (mic ? GR_MICRO_BIT : 0), pos);
-          compile_entry(a, ctrl, comp, nr8, idx, p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH, mic);
+          compile_entry(a, ctrl, comp, nr8, (int64_t)(ty * a.TX + tx) * a.cap_tile + pos, p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH);
         } else atomicOr(&ctrl[2], 1u);
       }
     }
@@ -551,8 +637,14 @@ __global__ __launch_bounds__(1024) void k_bin_stats(BinArgs a) {
   const uint32_t *cnt = ctrl + GR_CTRL_HDR;
   unsigned long long sum = 0;
   uint32_t mx = 0;
-  // (with micro lists a tile's segment holds both lists, one from each end: the two counts together must fit)
-  for (int t = threadIdx.x; t < a.T; t += 1024) { const int64_t i = cidx(a, t); const uint32_t c = cnt[i] + (a.micro ? cnt[a.Tcap + i] : 0u); sum += c; mx = max(mx, c); }
+  // (with micro lists a tile's segment holds both lists, one from each end: compiled entries in whole chunks of 64 x 40 bytes
+  // from the front, 32-byte micro records from the back -- together, in 40-byte slots, they must fit)
+  for (int t = threadIdx.x; t < a.T; t += 1024) {
+    const int64_t i = cidx(a, t);
+    uint32_t c = cnt[i];
+    if (a.micro) { const uint32_t cm = cnt[a.Tcap + i]; if (cm) c = ((c + 63u) & ~63u) + (cm * 32u + 39u) / 40u; }
+    sum += c; mx = max(mx, c);
+  }
   for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); }
   if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = sum; pmax[threadIdx.x >> 6] = mx; }
   __syncthreads();
@@ -653,10 +745,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(BinArgs a) {
 //   |E| <= (|dx| + |dy|) * reach + 1 < 48000 * 41152 < 2^31   and   |A|, |B| = 256 * |d| < 2^23:
 // every product has 24-bit factors and every value fits int32 -- no 64-bit arithmetic, no per-tile range test.
 // Larger faces take the general form below (identical coverage: both forms are exact).
-#define GR_FAST_EXT 24000
 #define GR_FLOOR_NOCORR_MAX 16000  // largest slope magnitude for which edge_floor<false> is exact (see there)
-__device__ __forceinline__ int pack16(int lo, int hi) { return (lo & 0xFFFF) | (hi << 16); }
-
 // build_entry in two halves.  face_form: everything about an entry that does not depend on the tile -- the three edges in the
 // order the tile kernel wants them (each with its origin vertex, direction, fill-rule bias and "reach"), the slope words, the
 // flag bits, the plane of 1/z -- computed ONCE per face; tile_entry: the part that does -- the three edge constants at the
@@ -710,7 +799,7 @@ __device__ __forceinline__ FaceForm face_form(const int4 p0, const int4 p1, cons
 }
 
 __device__ __forceinline__ bool tile_entry(const FaceForm &ff, int px0, int py0, int TW, int TH, int4 &e0, int4 &e1, int4 &e2,
-                                           int &rows, int *xinfo) {
+                                           int &rows) {
   const int Pxo = px0 * 256 + 128, Pyo = py0 * 256 + 128;  // centre of the tile's first pixel
   const int jlo = max(ff.jmin - px0, 0), jhi = min(ff.jmax - px0, TW - 1);
   const int ilo = max(ff.imin - py0, 0), ihi = min(ff.imax - py0, TH - 1);
@@ -749,9 +838,6 @@ __device__ __forceinline__ bool tile_entry(const FaceForm &ff, int px0, int py0,
   const bool touches = nr > 0 && cf + ff.rf >= 0 && cm + ff.rm >= 0 && cl + ff.rl >= 0;
   if (!touches) nr = 0;
   rows = nr;
-  // a MICRO entry (clipped bounding box of at most 4 x 4 pixels, K1) also says where its columns are: first column in the
-  // tile (6 bits) | columns - 1 (2 bits)
-  if (xinfo) *xinfo = (jlo & 63) | ((min(max(jhi - jlo, 0), 3)) << 6);
   // float(P_x - X0) of the pixel with CENTRED column x_c = x - TW/2 is float(256 x_c + Xw)
   const int xw = ((Pxo - ff.X0 + (TW / 2) * 256) & 0xFFFFFF) | (nr << 24);
   e0 = make_int4(cf, cm, cl, ff.w3);
@@ -763,9 +849,9 @@ __device__ __forceinline__ bool tile_entry(const FaceForm &ff, int px0, int py0,
 }
 
 __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const int4 p2, int px0, int py0, int TW, int TH,
-                                            int4 &e0, int4 &e1, int4 &e2, int &rows, int *xinfo) {
+                                            int4 &e0, int4 &e1, int4 &e2, int &rows) {
   const FaceForm ff = face_form(p0, p1, p2, TW, TH);
-  return tile_entry(ff, px0, py0, TW, TH, e0, e1, e2, rows, xinfo);
+  return tile_entry(ff, px0, py0, TW, TH, e0, e1, e2, rows);
 }
 
 // The SHORT form of an entry, 40 bytes (single-pass binning, a.ent40): what a face whose snapped bounding box stays below
@@ -781,7 +867,7 @@ __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const 
 // for a tile that outgrew its segment, remembers that this (mesh, image) needs 48-byte entries, and the caller repeats.
 __device__ __forceinline__ void store_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
                                             uint8_t *__restrict__ nr8, int64_t idx, const int4 e0, const int4 e1, const int4 e2,
-                                            int rows, int xinfo) {
+                                            int rows) {
   if (a.ent40) {
     // e1.y (the third slope word) is zero for 16-bit slopes; bit 0 of it is build_entry's "too large for the short form"
     // (the slot was handed out already: it must not keep stale bytes -- an older view's entry, or 48-byte data read as a
@@ -792,10 +878,7 @@ __device__ __forceinline__ void store_entry(const BinArgs &a, uint32_t *__restri
     char *chunk = reinterpret_cast<char *>(comp) + (idx >> 6) * 2560;
     const int t = (int)(idx & 63);
     int4 *d4 = reinterpret_cast<int4 *>(chunk) + t * 2;
-    // a micro entry (xinfo >= 0; short form only, K1 hands such entries to the tile's SECOND list) carries its column range in
-    // the top byte of c_mid, whose value needs 24 bits there (|c| < 2^23 for a face of a few pixels)
-    const int cmid = xinfo >= 0 ? (int)(((uint32_t)e0.y & 0xFFFFFFu) | ((uint32_t)xinfo << 24)) : e0.y;
-    d4[0] = make_int4(e0.x, cmid, (int)(((uint32_t)e0.z & 0xFFFFFFu) | ((uint32_t)e2.w & 0x3F000000u) | (((uint32_t)e2.w << 1) & 0x80000000u)),
+    d4[0] = make_int4(e0.x, e0.y, (int)(((uint32_t)e0.z & 0xFFFFFFu) | ((uint32_t)e2.w & 0x3F000000u) | (((uint32_t)e2.w << 1) & 0x80000000u)),
                       (int)(((uint32_t)e2.y & 0xFFFFu) | ((uint32_t)e2.w << 16)));
     d4[1] = make_int4(e0.w, e1.x, e1.z, e1.w);
     reinterpret_cast<uint2 *>(chunk + 2048)[t] = make_uint2((uint32_t)e2.z, (uint32_t)e2.x);
@@ -808,11 +891,11 @@ __device__ __forceinline__ void store_entry(const BinArgs &a, uint32_t *__restri
 
 __device__ __forceinline__ bool compile_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
                                               uint8_t *__restrict__ nr8, int64_t idx, const int4 p0, const int4 p1,
-                                              const int4 p2, int px0, int py0, int TW, int TH, bool micro) {
+                                              const int4 p2, int px0, int py0, int TW, int TH) {
   int4 e0, e1, e2;
-  int rows, xinfo = -1;
-  const bool touches = build_entry(p0, p1, p2, px0, py0, TW, TH, e0, e1, e2, rows, &xinfo);
-  store_entry(a, ctrl, comp, nr8, idx, e0, e1, e2, rows, micro ? xinfo : -1);
+  int rows;
+  const bool touches = build_entry(p0, p1, p2, px0, py0, TW, TH, e0, e1, e2, rows);
+  store_entry(a, ctrl, comp, nr8, idx, e0, e1, e2, rows);
   return touches;
 }
 
@@ -1070,10 +1153,11 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int
     const int gmax = std::min((nblk + 3) / 4, 1024);
     const dim3 gsetup((unsigned)std::max(1, std::min(gmax, std::max(nblk / 128, 4096 / std::max(nb, 1)))), nb);
     if (a.cap_tile > 0) {
-      hipLaunchKernelGGL(k_setup_cull<true>, gsetup, dim3(256), 0, s, cams, a);
+      if (a.micro) hipLaunchKernelGGL((k_setup_cull<true, true>), gsetup, dim3(256), 0, s, cams, a);
+      else hipLaunchKernelGGL((k_setup_cull<true, false>), gsetup, dim3(256), 0, s, cams, a);
       GR_LAUNCH_EV((hipEvent_t) nullptr, chain_stop(c, ST_SETUP), k_clip_faces<true>, dim3(8, nb), dim3(64), 0, s, cams, a);
     } else {
-      hipLaunchKernelGGL(k_setup_cull<false>, gsetup, dim3(256), 0, s, cams, a);
+      hipLaunchKernelGGL((k_setup_cull<false, false>), gsetup, dim3(256), 0, s, cams, a);
       GR_LAUNCH_EV((hipEvent_t) nullptr, chain_stop(c, ST_SETUP), k_clip_faces<false>, dim3(8, nb), dim3(64), 0, s, cams, a);
     }
   }

@@ -234,40 +234,48 @@ __device__ __forceinline__ void raster_item(unsigned long long *keys, const Entr
   }
 }
 
-// MICRO entries (round 5): one lane = one FACE.  K1 sends a (face, tile) pair whose part of the pixel bounding box in the tile
-// is at most 4 x 4 pixels to the tile's second list (binning.hip); such a face is not worth scanline items -- three rows of
-// two pixels at render_img_scale 0.25, each paying the span solver's three reciprocals, the mailbox look-up and its share of
-// two barriers per chunk.  Here the lane point-samples the (at most) sixteen pixel centres of the box with the entry's own
-// edge functions E'_k = C'_k + a_k x_c + b_k y_c >= 0 (three adds per pixel) and the same 1/z expression as raster_item, op
-// for op (R4): identical coverage and identical depth bits, whichever list a face was put in.  The entry is the 40-byte form
-// as it stands plus the box's first column and width in the top byte of c_mid (store_entry).  nrows: rows of the box (0: a
-// lane without an entry).  Rows and columns outside the tile can only come from a torn entry of an overflowed pass (the view
-// is repeated): they are masked, never written.
+// MICRO records (round 5: lists; round 6: lean records): one lane = one record = a box of at most 4 x 4 pixels of one face.  K1
+// sends a (face, tile) pair whose part of the pixel bounding box in the tile is at most 8 x 8 pixels to the tile's second list
+// (binning.hip), one record per 4 x 4 box; such a face is not worth scanline items -- three rows of two pixels at render_img_scale
+// 0.25, each paying the span solver's three reciprocals, the mailbox look-up and its share of two barriers per chunk.  The record
+// holds what R2 - R4 produced and nothing derived from it: the three snapped vertices as 16-bit offsets from the centre of the
+// tile's centre pixel (positive orientation, vertex 0 first), 1/z at vertex 0 and its gradients, ~face, and the box.  Here the lane
+// forms the three edge functions of R3 at the box's first pixel, exactly, in int32 (|d| < 24 000, |P - V| < 41 000: products
+// below 2^30) -- E_k = dx_k (P_y - Y_k) - dy_k (P_x - X_k) + t_k with the top-left rule as the bias t_k, covered <=> all E_k >= 0 --
+// and point-samples the sixteen pixel centres (three adds per pixel) with the same 1/z expression as raster_item, op for op (R4):
+// identical coverage and identical depth bits, whichever list a face was put in.  Rows and columns outside the tile can only come
+// from a torn record of an overflowed pass (the view is repeated): they are masked, never written.
 template <int TWL, int TH, int PAD>
-__device__ __forceinline__ void micro_item(unsigned long long *keys, const int4 ea, const int4 eb, const uint2 s89, const int nrows) {
+__device__ __forceinline__ void micro_item(unsigned long long *keys, const int4 ea, const int4 eb, const bool valid) {
   constexpr int TW = 1 << TWL;
-  const int c0 = ea.x, c1 = __builtin_amdgcn_sbfe(ea.y, 0, 24), c2 = __builtin_amdgcn_sbfe(ea.z, 0, 24);
-  const int xinfo = (int)((uint32_t)ea.y >> 24);
-  const int y_first = __builtin_amdgcn_sbfe(ea.z, 24, 6);
-  const int X0rel = __builtin_amdgcn_sbfe(ea.w, 0, 16), Y0rel = ea.w >> 16;
-  const int a0 = __builtin_amdgcn_sbfe(eb.x, 0, 16), a1 = eb.x >> 16, b0 = __builtin_amdgcn_sbfe(eb.y, 0, 16), b1 = eb.y >> 16;
-  const int a2 = -(a0 + a1), b2 = -(b0 + b1);                 // the last edge's slopes are not stored (they sum to zero)
-  const float iz0 = __int_as_float(eb.z), A = __int_as_float(eb.w), B = __uint_as_float(s89.y);
-  const uint32_t key = s89.x;
-  const int xc0 = (xinfo & 63) - TW / 2;                      // centred first column
-  const int last_col = xinfo >> 6;                            // columns - 1
-  const float fx0 = (float)(xc0 * 256 + X0rel);
+  const int X0 = __builtin_amdgcn_sbfe(ea.x, 0, 16), Y0 = ea.x >> 16, X1 = __builtin_amdgcn_sbfe(ea.y, 0, 16), Y1 = ea.y >> 16;
+  const int X2 = __builtin_amdgcn_sbfe(ea.z, 0, 16), Y2 = ea.z >> 16;
+  const float iz0 = __int_as_float(ea.w), A = __int_as_float(eb.x), B = __int_as_float(eb.y);
+  const uint32_t key = (uint32_t)eb.z;
+  const int box = eb.w;
+  const int xc0 = (box & 63) - TW / 2, last_col = (box >> 6) & 3;          // centred first column; columns - 1
+  const int yc0 = ((box >> 8) & 63) - TH / 2;                              // centred first row
+  const int nrows = valid ? min((box >> 14) & 7, 4) : 0;
+  const int dx0 = X1 - X0, dy0 = Y1 - Y0, dx1 = X2 - X1, dy1 = Y2 - Y1, dx2 = X0 - X2, dy2 = Y0 - Y2;
+  const int t0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;           // R3 top-left rule as a bias
+  const int t1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
+  const int t2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
+  const int Px = xc0 * 256, Py = yc0 * 256;                                // the box's first pixel centre, same frame as the vertices
+  int r0 = __mul24(dx0, Py - Y0) - __mul24(dy0, Px - X0) + t0;             // edge values at that pixel
+  int r1 = __mul24(dx1, Py - Y1) - __mul24(dy1, Px - X1) + t1;
+  int r2 = __mul24(dx2, Py - Y2) - __mul24(dy2, Px - X2) + t2;
+  const int ax0 = -dy0 * 256, ax1 = -dy1 * 256, ax2 = -dy2 * 256;         // a step of one pixel along the row
+  const int ay0 = dx0 * 256, ay1 = dx1 * 256, ay2 = dx2 * 256;            // ... down the column
+  const float fx0 = (float)(Px - X0);
 #pragma unroll 1   // (unrolled, the sixteen pixels' temporaries cost the chain kernels their 64-register budget)
   for (int r = 0; r < 4; ++r) {
     const bool rl = r < nrows;
     if (!__ballot(rl)) break;
-    const int yc = y_first + r;
-    int e0 = c0 + __mul24(b0, yc) + __mul24(a0, xc0);
-    int e1 = c1 + __mul24(b1, yc) + __mul24(a1, xc0);
-    int e2 = c2 + __mul24(b2, yc) + __mul24(a2, xc0);
+    const int yc = yc0 + r;
+    int e0 = r0, e1 = r1, e2 = r2;
     // a fourth "edge": columns left in the box (negative beyond it, and for a row this lane does not have or that lies outside the tile)
     int e3 = (rl && (uint32_t)(yc + TH / 2) < (uint32_t)TH) ? last_col : -1;
-    const float m1 = B * (float)(yc * 256 + Y0rel);
+    const float m1 = B * (float)(yc * 256 - Y0);
     unsigned long long *row = keys + (__mul24(yc + TH / 2, TW + PAD) + xc0 + TW / 2);
     float fx = fx0;
 #pragma unroll
@@ -278,9 +286,10 @@ __device__ __forceinline__ void micro_item(unsigned long long *keys, const int4 
       const float z = iz0 + t;
       const int zb = max(__float_as_int(z), 1);
       if (in) atomicMax(row + j, ((unsigned long long)(uint32_t)zb << 32) | key);
-      e0 += a0; e1 += a1; e2 += a2; e3 -= 1;
+      e0 += ax0; e1 += ax1; e2 += ax2; e3 -= 1;
       fx += 256.0f;
     }
+    r0 += ay0; r1 += ay1; r2 += ay2;
   }
 }
 
@@ -551,9 +560,9 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
   // the tile's MICRO list (single-pass binning with 40-byte entries): cntm entries from the back of the segment; the scanline
   // list must not reach into it (the two can only collide in a pass whose tile outgrew its segment: the view is repeated)
   if (!(SHORT && MICRO)) cntm = 0u;
-  if (SHORT && MICRO) {
-    cntm = min(cntm, (uint32_t)a.cap_tile);
-    cnt = min(cnt, (uint32_t)a.cap_tile - cntm);
+  if (SHORT && MICRO) {   // both lists inside the segment (a view whose lists met is repeated: k_bin_stats)
+    cntm = min(cntm, (uint32_t)a.cap_tile * 5u / 4u);
+    cnt = min(cnt, (uint32_t)a.cap_tile);
   }
   if (!FUSE && cnt == 0 && cntm == 0) {  // empty tile (a view that overhangs the mesh): background, without the LDS round trip
     // (a rolling chain waits for its ring here as well, before the stores: a path that left the function with a request in
@@ -636,20 +645,16 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
     }
   }
   if (SHORT && MICRO && cntm > 0) {
-    // micro entries: every wave reads ITS chunks of 64 straight from the segment (no staging, no barrier), one face per lane.
-    // Entry k of the list sits in slot cap - 1 - k: block (slot / 64) of 2560 bytes, 32 + 8 bytes at position slot % 64.
-    const char *segb = reinterpret_cast<const char *>(comp);
-    const uint32_t top = (uint32_t)a.cap_tile - 1u;
+    // micro records: every wave reads ITS chunks of 64 straight from the segment (no staging, no barrier), one record per lane.
+    // Record k of the list: the 32 bytes that end 32 k bytes before the end of the tile's segment -- a wave's chunk is 2 KiB of
+    // consecutive memory.
+    const char *seg_end = reinterpret_cast<const char *>(comp) + (size_t)a.cap_tile * 40;
 #pragma unroll 1
     for (uint32_t c = (uint32_t)wv; c * 64u < cntm; c += NW) {
       const uint32_t k = c * 64u + (uint32_t)lane;
-      const uint32_t sl = top - min(k, top);
-      const char *blk = segb + (sl >> 6) * 2560u;
-      const uint32_t tp = sl & 63u;
-      const int4 ea = *reinterpret_cast<const int4 *>(blk + tp * 32u), eb = *reinterpret_cast<const int4 *>(blk + tp * 32u + 16u);
-      const uint2 s89 = *reinterpret_cast<const uint2 *>(blk + 2048u + tp * 8u);
-      const int nrows = k < cntm ? min((int)nr8[sl], 4) : 0;
-      micro_item<TWL, TH, PAD>(keys, ea, eb, s89, nrows);
+      const int4 *rec = reinterpret_cast<const int4 *>(seg_end - 32u * (min(k, cntm - 1u) + 1u));
+      const int4 ea = rec[0], eb = rec[1];
+      micro_item<TWL, TH, PAD>(keys, ea, eb, k < cntm);
     }
   }
   int te = tid;
