@@ -612,9 +612,11 @@ def run(args, rig=None) -> int:
 
     # ---- hostile workload (N == 1): terrain + 20 000 trees, cameras tilted 30-45 degrees; full and quarter resolution -------
     workload_2 = None
+    workload_3 = None
     quarter = None
     if rank == 0 and world == 1 and not args.no_workload2 and rig.side_legs():
         workload_2 = leg_workload2(rig, local_rank, dev)
+        workload_3 = leg_workload3(rig, local_rank, dev, wl)
         quarter = leg_quarter_scale(rig, local_rank, dev, points, faces, wl)
         if not args.no_aggregate:
             quarter["fused"] = leg_quarter_scale_fused(rig, local_rank, dev, points, faces, wl)
@@ -718,6 +720,11 @@ def run(args, rig=None) -> int:
             roofline["hostile_gpix_scale_0.25"] = round(workload_2["scale_0.25"]["mpix_per_s"] / 1e3, 2)
             roofline["hostile_overflow_retries_cold"] = workload_2["scale_1"].get("overflow_retries_cold")
             roofline["hostile_first_group_rebinned_cold"] = workload_2["scale_1"].get("first_group_rebinned_cold")
+        if workload_3:
+            roofline["tin_gpix_scale_1"] = round(workload_3["scale_1"]["mpix_per_s"] / 1e3, 2)
+            roofline["tin_gpix_scale_0.25"] = round(workload_3["scale_0.25"]["mpix_per_s"] / 1e3, 2)
+            roofline["tin_fused_views_per_s_scale_1"] = workload_3["scale_1"]["fused_views_per_s"]
+            roofline["tin_fused_views_per_s_scale_0.25"] = workload_3["scale_0.25"]["fused_views_per_s"]
         if quarter:
             roofline["c2_quarter_scale_gpix"] = round(quarter["mpix_per_s"] / 1e3, 2)
             roofline["c2_quarter_scale_views_per_s"] = quarter["views_per_s"]
@@ -752,6 +759,7 @@ def run(args, rig=None) -> int:
                 "vertices": V,
                 "parallelism": f"views sharded, mesh replicated, dp{world}",
                 "workload_2": None if workload_2 is None else workload_2["workload"],
+                "workload_3": None if workload_3 is None else workload_3["workload"],
             },
             "views_per_s": round(views_per_s, 2),
             "records_per_view": round(stats["records"] / max(nv, 1), 1),
@@ -763,6 +771,7 @@ def run(args, rig=None) -> int:
             "c4": c4,
             "c5": c5,
             "workload_2": workload_2,
+            "workload_3": workload_3,
             "quarter_scale": quarter,
             "api": api,
             "io": io,
@@ -1128,6 +1137,112 @@ def leg_workload2(rig, local_rank, dev):
     lib.gr_learned_cache_file(None)
     _hip._attach_learned_cache(lib)
     shutil.rmtree(cache_dir, ignore_errors=True)
+    return out
+
+
+def leg_workload3(rig, local_rank, dev, wl):
+    """A realistic third workload between the friendliest (C2 height field: every triangle 13 px, depth complexity 1.0) and the
+    most hostile (forest) one: an irregular TIN of 1.2 M faces (synthetic.tin_mesh: log-normal vertex density, Delaunay slivers,
+    folded bumps on 5 % of the area -- what BASELINE config 2 calls the "Example-data Metashape mesh") under the 50 C2 cameras,
+    ids-only and fused (4 classes), at full size and at the reference's aggregate_img_scale 0.25; one view per scale against the
+    CPU oracle."""
+    import torch
+
+    from geograypher_amd.utils import synthetic
+
+    oracle_c = rig.checker()
+    C = wl.n_classes
+    pts, faces = synthetic.tin_mesh()
+    F = faces.shape[0]
+    cams = synthetic.config2_cameras(50, **wl.cam_kw())
+    n = len(cams)
+    hip = rig.make_raster(local_rank)
+    hip.upload_mesh(pts.astype(np.float32), faces.astype(np.int32))
+    tri = pts[faces]
+    area = 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+    out = {"workload": f"irregular TIN, {F} faces (V={pts.shape[0]}): Delaunay of blue-noise points with log-normal density over the C2 "
+                       f"terrain spectrum (log-area sigma {float(np.log(area).std()):.2f}, area p1 / p50 / p99 = "
+                       f"{np.percentile(area, 1):.3f} / {np.percentile(area, 50):.3f} / {np.percentile(area, 99):.3f} m2) + folded "
+                       f"bumps on 5 % of the area; {n} C2 cameras"}
+    for scale in (1.0, 0.25):
+        h, w = cams[0].get_image_size(scale)
+        recs_np = cams.get_raster_records(scale, near=1.0)
+        recs = torch.from_numpy(recs_np).to(dev)
+        ids = torch.empty((n, h, w), dtype=torch.int32, device=dev)
+        hip.raster_face_ids(recs, h, w, out=ids, check=True)
+        retries = int(hip.last_retries)
+        hip.raster_face_ids(recs, h, w, out=ids, check=True)      # (a second checked call: micro lists, once learned, are on)
+        st = dict(hip.last_stats)
+        for _ in range(3):
+            hip.raster_face_ids(recs, h, w, out=ids, check=False)
+        hip.set_profiling(True)
+        reps, dt = 0, 0.0
+        while reps == 0 or (dt < wl.min_leg_s and reps < 400):
+            rig.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                hip.raster_face_ids(recs, h, w, out=ids, check=False)
+            rig.synchronize(dev)
+            dt += time.perf_counter() - t0
+            reps += 5
+        stg = hip.stage_times()
+        hip.set_profiling(False)
+        check_view = 23
+        want = oracle_c.raster(pts, faces, recs_np[check_view], h, w)
+        same = bool(np.array_equal(ids[check_view].cpu().numpy(), want))
+        assert same, f"workload_3 scale {scale}: GPU ids differ from the CPU oracle"
+        labels = torch.empty((n, h, w), dtype=torch.uint8, device=dev)
+        for k in range(n):
+            labels[k] = device_labels(ids[k], k, C)
+        del ids
+        votes, counts = hip.new_vote_buffers(C)
+        hip.raster_project_labels(recs, labels, C, votes, counts, check=True)
+        hip.raster_project_labels(recs, labels, C, votes, counts, check=True)
+        freps, fdt = 0, 0.0
+        while freps == 0 or (fdt < wl.min_leg_s and freps < 400):
+            rig.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                votes.zero_()
+                counts.zero_()
+                hip.raster_project_labels(recs, labels, C, votes, counts, check=False)
+            rig.synchronize(dev)
+            fdt += time.perf_counter() - t0
+            freps += 5
+        hip.set_profiling(True)
+        hip.raster_project_labels(recs, labels, C, votes, counts, check=False)
+        fst = hip.stage_times()
+        hip.set_profiling(False)
+        v1, c1 = hip.new_vote_buffers(C)
+        hip.raster_project_labels(recs[check_view:check_view + 1], labels[check_view:check_view + 1], C, v1, c1, check=True)
+        want_v = np.zeros((F, C), dtype=np.uint32)
+        want_c = np.zeros(F, dtype=np.uint32)
+        oracle_c.project_labels(want, labels[check_view].cpu().numpy(), F, C, want_v, want_c)
+        same_votes = bool(np.array_equal(v1.cpu().numpy().view(np.uint32), want_v) and np.array_equal(c1.cpu().numpy().view(np.uint32), want_c))
+        assert same_votes, f"workload_3 scale {scale}: fused votes differ from the CPU oracle"
+        T = ((w + 63) // 64) * ((h + 31) // 32)
+        views, fviews = max(stg["views"], 1), max(fst["views"], 1)
+        out[f"scale_{scale:g}"] = {
+            "image": f"{w}x{h}",
+            "mpix_per_s": round(reps * n * h * w / dt / 1e6, 1),
+            "views_per_s": round(reps * n / dt, 1),
+            "us_per_view": {"setup": round(stg["setup_ms"] / views * 1e3, 2), "raster": round(stg["raster_ms"] / views * 1e3, 2)},
+            "fused_views_per_s": round(freps * n / fdt, 1),
+            "fused_us_per_view": {"setup": round(fst["setup_ms"] / fviews * 1e3, 2), "raster_fused": round(fst["raster_ms"] / fviews * 1e3, 2),
+                                  "vote": round(fst["vote_ms"] / fviews * 1e3, 2)},
+            "records_per_view": round(st["records"] / n, 1),
+            "entries_per_view": round(st["entries"] / n, 1),
+            "entries_per_tile": round(st["entries"] / n / T, 1),
+            "max_entries_per_tile": int(st["max_entries"]),
+            "overflow_retries_first_call": retries,
+            "depth_complexity_view_23": round(synthetic.depth_complexity(pts, faces, recs_np[check_view], h, w), 3),
+            "covered_fraction_view_23": round(float((want >= 0).mean()), 4),
+            "faces_visible_view_23": int(np.unique(want[want >= 0]).size),
+            "oracle_parity_view_23": same,
+            "oracle_votes_view_23": same_votes,
+        }
+        del labels, votes, counts
+    del hip
     return out
 
 

@@ -123,6 +123,7 @@ class TexturedPhotogrammetryMesh:
         device: typing.Optional[int] = None,
         backend=None,
         neg1_is_last_face: bool = True,
+        devices: typing.Optional[typing.Sequence[int]] = None,
     ):
         """A textured mesh that renders to / aggregates from camera views on an MI355X.
 
@@ -134,7 +135,12 @@ class TexturedPhotogrammetryMesh:
 
         Extra keyword arguments (defaults keep reference behaviour):
             device: GPU index for the HIP backend (default: current torch device).
-            backend: test hook -- an object with the `HipRaster` interface.
+            devices: several GPU indices, e.g. `[0, 1, 2, 3, 4, 5, 6, 7]`: `aggregate_projected_images` deals its views round-robin to
+                one libgeograster context + host thread per entry (the mesh is uploaded to each), adds the per-device partial
+                votes (or float sums + counts) on the first device and finalises there -- the unchanged single-process caller
+                (entrypoints/aggregate_images.py:146-184) uses the whole node.  Everything else runs on `devices[0]`.  The same
+                index may appear more than once (contexts are independent).  Default None: one device, `device`.
+            backend: test hook -- an object with the `HipRaster` interface (or a list of them: one per entry of `devices`).
             neg1_is_last_face: reproduce meshes.py:1998-2001, where background pixels (-1) index the LAST face
                 during projection.  True matches the reference's aggregated textures on every face.
         """
@@ -167,9 +173,24 @@ class TexturedPhotogrammetryMesh:
         self.points = points
         self.faces = faces
 
+        if devices is not None:
+            devices = [int(d) for d in devices]
+            if len(devices) == 0:
+                raise ValueError("devices must name at least one GPU")
+            if device is not None and int(device) != devices[0]:
+                raise ValueError(f"device={device} contradicts devices[0]={devices[0]}")
+            device = devices[0]
+        backends = None
+        if isinstance(backend, (list, tuple)):
+            backends = list(backend)
+            if devices is not None and len(backends) != len(devices):
+                raise ValueError(f"{len(backends)} backends for {len(devices)} devices")
+            backend = backends[0]
         self._device_index = device
+        self._devices = devices
         self._backend = backend
-        self._uploaded_key = None
+        self._backends = backends
+        self._uploaded = {}   # id(backend) -> (points, faces) it holds
 
         self.logger.info("Loading texture")
         if isinstance(IDs_to_labels, (str, Path)):
@@ -193,6 +214,18 @@ class TexturedPhotogrammetryMesh:
 
             self._backend = HipRaster(self._device_index)  # raises when the extension or the GPU is missing
         return self._backend
+
+    @property
+    def backends(self):
+        """One backend per entry of `devices` (the first is `self.backend`); a single-device mesh has one."""
+        if self._backends is None:
+            if not self._devices or len(self._devices) == 1:
+                self._backends = [self.backend]
+            else:
+                from geograypher_amd._hip import HipRaster
+
+                self._backends = [self.backend] + [HipRaster(d) for d in self._devices[1:]]
+        return self._backends
 
     # -- texture (reference: meshes.py:325-531) ------------------------------------------------------------------
     def standardize_texture(self, texture_array: np.ndarray):
@@ -307,21 +340,23 @@ class TexturedPhotogrammetryMesh:
             return None
         return mesh
 
-    def _ensure_uploaded(self, mesh: LocalMesh):
-        """Upload `mesh` unless the device already holds exactly these arrays.  The cache holds strong references and
-        compares identity (`is`) of the point and face arrays: a different array -- also one that happens to reuse the
-        id() of a freed temporary -- is always uploaded again."""
-        held = self._uploaded_key
+    def _ensure_uploaded(self, mesh: LocalMesh, backend=None):
+        """Upload `mesh` to `backend` (default: the first) unless that device already holds exactly these arrays.  The cache
+        holds strong references and compares identity (`is`) of the point and face arrays: a different array -- also one
+        that happens to reuse the id() of a freed temporary -- is always uploaded again."""
+        backend = self.backend if backend is None else backend
+        held = self._uploaded.get(id(backend))
         if held is None or held[0] is not mesh.points or held[1] is not mesh.faces:
             origin = mesh.origin()
             pts = np.asarray(mesh.points, dtype=np.float64)
             if np.any(origin != 0.0):
                 pts = pts - origin
-            self.backend.upload_mesh(pts.astype(np.float32), mesh.faces.astype(np.int32))
-            self._uploaded_key = (mesh.points, mesh.faces)
+            backend.upload_mesh(pts.astype(np.float32), mesh.faces.astype(np.int32))
+            self._uploaded[id(backend)] = (mesh.points, mesh.faces)
 
     # -- pix2face ------------------------------------------------------------------------------------------------
-    def _raster_records(self, cameras, mesh, render_img_scale, near=None, principal_point="center", focal_scaling="scaled"):
+    def _raster_records(self, cameras, mesh, render_img_scale, near=None, principal_point="center", focal_scaling="scaled",
+                        backend=None):
         """Upload the local mesh if needed and pack the (N,16) camera records; returns (records, (h, w))."""
         if isinstance(cameras, PhotogrammetryCamera):
             cameras = PhotogrammetryCameraSet([cameras], local_to_epsg_4978_transform=cameras._local_to_epsg_4978_transform)
@@ -330,7 +365,7 @@ class TexturedPhotogrammetryMesh:
         elif not isinstance(mesh, LocalMesh):
             pts, fcs = _parse_mesh(mesh)
             mesh = LocalMesh(np.asarray(pts, dtype=np.float64), fcs)
-        self._ensure_uploaded(mesh)
+        self._ensure_uploaded(mesh, backend)
         if near is None:
             near = vtk_like_near_planes(
                 np.stack([np.asarray(c.cam_to_world_transform, dtype=np.float64) for c in cameras.cameras]), mesh.bounds()
@@ -704,83 +739,28 @@ class TexturedPhotogrammetryMesh:
             my_inds = view_inds[rank::world]
             mesh = self.get_mesh_in_cameras_coords(cameras)
             C = int(cameras.n_image_channels())
-            self._ensure_uploaded(mesh)
-            votes, counts = self.backend.new_vote_buffers(C)
-            # launch groups of up to 32 views; a short run is still cut into at least four chunks, so that the loader stages
-            # chunk i + 1 while chunk i crosses the link (16 views in ONE chunk ran staging, copy and kernels back to back)
-            chunk = max(int(batch_size), min(32, max(1, -(-len(my_inds) // 4))))
-            chunks = [my_inds[c0 : c0 + chunk] for c0 in range(0, len(my_inds), chunk)]
+            backends = self.backends
+            labels_known = {view_inds[0]: first_label}
 
-            # Input pipeline (row f4).  The label images of a chunk are decoded straight into ONE pinned (n,h,w) uint8
-            # staging tensor (no stack / pin copies), by `loader_threads` workers when the segmentor says its lookups
-            # are thread safe (file look-ups and in-memory arrays are; an arbitrary model may not be), while the GPU
-            # works on the previous chunk.
-            import os
-            from concurrent.futures import ThreadPoolExecutor
+            def run(k):
+                return self._aggregate_label_views(backends[k], cameras, my_inds[k::len(backends)], mesh, C, label_fn, labels_known,
+                                                   batch_size, aggregate_img_scale, loader_threads, fused_ok, kwargs,
+                                                   progress=(k == 0), own_stream=len(backends) > 1)
 
-            thread_safe = bool(getattr(getattr(cameras, "segmentor", None), "thread_safe_lookup", False))
-            n_workers = int(loader_threads if loader_threads is not None else (min(16, os.cpu_count() or 1) if thread_safe else 1))
-            # the label images must have the size the camera records are built for (the reference fails with a shape
-            # error in `textured_faces[flat_pix2face] = flat_img` otherwise, meshes.py:1998-2001)
-            h0, w0 = cameras.cameras[view_inds[0]].get_image_size(aggregate_img_scale)
-            on_gpu = self.backend.device.type == "cuda"
+            if len(backends) == 1:
+                votes, counts = run(0)
+            else:
+                # one host thread per device (the C calls and torch's copies release the interpreter lock); the partial votes
+                # come home to the first device -- peer copies -- and are added there: integer sums, so the result is the
+                # single-device one bit for bit, whatever the number of devices
+                from concurrent.futures import ThreadPoolExecutor
 
-            def check_shape(shape, i):
-                if tuple(shape[:2]) != (h0, w0):
-                    raise ValueError(
-                        f"label image of view {i} has shape {tuple(shape[:2])}, but the camera renders {(h0, w0)} at "
-                        f"aggregate_img_scale={aggregate_img_scale}"
-                    )
-
-            def one_label(i):
-                return first_label if i == view_inds[0] else label_fn(i, aggregate_img_scale)
-
-            def load_chunk(inds, img_pool):
-                if isinstance(first_label, torch.Tensor):  # the segmentor already produces tensors
-                    labs = [one_label(i) for i in inds]
-                    for i, lab in zip(inds, labs):
-                        check_shape(lab.shape, i)
-                    labs = [torch.where((lab < 0) | (lab > 255), torch.full_like(lab, 255), lab)
-                            if lab.dtype != torch.uint8 else lab for lab in labs]
-                    return torch.stack([lab.to(self.backend.device, torch.uint8) for lab in labs], dim=0)
-                stage = torch.empty((len(inds), h0, w0), dtype=torch.uint8, pin_memory=on_gpu)
-                view = stage.numpy()
-
-                def fill(k):
-                    lab = np.asarray(one_label(inds[k]))
-                    check_shape(lab.shape, inds[k])
-                    if lab.dtype != np.uint8:  # an index outside [0, 255] is no class: the ignore value, not a wrapped class
-                        lab = np.where((lab < 0) | (lab > 255), 255, lab)
-                    view[k] = lab  # casts to uint8 while copying
-
-                list(img_pool.map(fill, range(len(inds))))
-                return stage
-
-            with ThreadPoolExecutor(max_workers=1) as pool, ThreadPoolExecutor(max_workers=max(n_workers, 1)) as img_pool:
-                pending = pool.submit(load_chunk, chunks[0], img_pool) if chunks else None
-                for ci in tqdm(range(len(chunks)), total=len(chunks), desc="Aggregating projected viewpoints"):
-                    lab = pending.result()
-                    pending = pool.submit(load_chunk, chunks[ci + 1], img_pool) if ci + 1 < len(chunks) else None
-                    # the chunk's cameras only: a subset of the segmentor wrapper would deep-copy the segmentor with it
-                    # (segmentor.py:49-55) -- every in-memory label image of an ArrayLabelSegmentor, per chunk
-                    sub = getattr(cameras, "base_camera_set", cameras).get_subset_cameras(chunks[ci])
-                    if lab.device.type != self.backend.device.type:
-                        lab = lab.to(self.backend.device, non_blocking=True)
-                    if fused_ok:
-                        # fused: face ids stay in the rasterizer's LDS tiles, only per-face winners reach HBM
-                        records, _ = self._raster_records(sub, mesh, aggregate_img_scale, **_raster_kwargs(kwargs))
-                        self.backend.raster_project_labels(
-                            records, lab, C, votes, counts, neg1_is_last_face=self.neg1_is_last_face
-                        )
-                    else:
-                        p2f_kwargs = {k: v for k, v in kwargs.items() if k in _PIX2FACE_KWARGS}
-                        p2f_kwargs.setdefault("mesh", mesh)
-                        ids = self.pix2face(cameras=sub, render_img_scale=aggregate_img_scale, return_tensor=True, **p2f_kwargs)
-                        if isinstance(ids, np.ndarray):
-                            ids = self.backend._dev(ids.astype(np.int32), torch.int32)
-                        if tuple(ids.shape[-2:]) != (h0, w0):
-                            raise ValueError(f"pix2face returned {tuple(ids.shape[-2:])} ids for {(h0, w0)} label images")
-                        self.backend.project_labels(ids, lab, C, votes, counts, neg1_is_last_face=self.neg1_is_last_face)
+                with ThreadPoolExecutor(max_workers=len(backends)) as dev_pool:
+                    parts = list(dev_pool.map(run, range(len(backends))))
+                votes, counts = parts[0]
+                for v_k, c_k in parts[1:]:
+                    votes += v_k.to(votes.device)
+                    counts += c_k.to(counts.device)
             if distributed and world > 1:
                 dist_utils.all_reduce_votes(votes, counts)
             avg, summed, cnt = self.backend.finalize_votes(votes, counts)
@@ -796,15 +776,64 @@ class TexturedPhotogrammetryMesh:
             raise NotImplementedError("return_all keeps every view's projection: not available with distributed=True")
         all_projections = [] if return_all else None
         sums = counts = first = None
-        if shard:  # this rank's views; the per-view arithmetic does not depend on the other views
+        n_channels = None
+        multi = len(self.backends) > 1 and not return_all and not single_view
+        if multi:
+            # devices=[...]: this rank's views dealt round-robin to the devices, each running the per-view recurrence over its own
+            # views on a host thread of its own; the partial sums and counts are added on the first device.  The float contract
+            # is that of views sharded over processes (include/geograster.h, gr_project_values_f64): counts exact, sums of finite
+            # inputs within 1e-12 relative of the serial result
+            import copy
+            from concurrent.futures import ThreadPoolExecutor
+
+            mine = view_inds[rank::world] if shard else view_inds
+            self.get_mesh_in_cameras_coords(cameras)   # the local mesh, cached before the workers ask for it
+
+            def run(k):
+                inds_k = mine[k::len(self.backends)]
+                if not inds_k:
+                    return None
+                worker = copy.copy(self)   # same arrays, caches and upload table; its own backend
+                worker._backend, worker._backends = self.backends[k], [self.backends[k]]
+                bk = self.backends[k]
+                ctx = contextlib.nullcontext()
+                if bk.device.type == "cuda":
+                    torch.cuda.set_device(bk.device)
+                    ctx = torch.cuda.stream(torch.cuda.Stream(bk.device))
+                with ctx:
+                    s_k = c_k = None
+                    nch = None
+                    for _, ids, img, nch in worker._iter_view_inputs(cameras.get_subset_cameras(inds_k), 1, aggregate_img_scale,
+                                                                     check_null_image, dict(kwargs), loader_threads):
+                        if s_k is None:
+                            s_k = torch.zeros((n_faces, nch), dtype=torch.float64, device=bk.device)
+                            c_k = torch.zeros((n_faces,), dtype=torch.int32, device=bk.device)
+                        if img is not None:
+                            bk.project_values(ids, img, s_k, c_k, neg1_is_last_face=self.neg1_is_last_face)
+                        else:
+                            torch.nan_to_num_(s_k, nan=0.0, posinf=float("inf"), neginf=float("-inf"))
+                    if bk.device.type == "cuda":
+                        torch.cuda.current_stream(bk.device).synchronize()
+                return s_k, c_k, nch
+
+            with ThreadPoolExecutor(max_workers=len(self.backends)) as dev_pool:
+                parts = [p for p in dev_pool.map(run, range(len(self.backends))) if p is not None and p[0] is not None]
+            for s_k, c_k, nch in parts:
+                n_channels = nch
+                if sums is None:
+                    sums, counts = s_k.to(self.backend.device), c_k.to(self.backend.device)
+                else:
+                    sums += s_k.to(sums.device)
+                    counts += c_k.to(counts.device)
+            gen, total = iter(()), 0
+        elif shard:  # this rank's views; the per-view arithmetic does not depend on the other views
             my_cams = cameras.get_subset_cameras(view_inds[rank::world])
             gen = self._iter_view_inputs(my_cams, 1, aggregate_img_scale, check_null_image, kwargs, loader_threads) if len(my_cams) else iter(())
             total = len(my_cams)
         else:
             gen = self._iter_view_inputs(cameras, batch_size, aggregate_img_scale, check_null_image, kwargs, loader_threads)
             total = len(cameras)
-        n_channels = None
-        for _, ids, img, n_channels in tqdm(gen, total=total, desc="Aggregating projected viewpoints"):
+        for _, ids, img, n_channels in (gen if multi else tqdm(gen, total=total, desc="Aggregating projected viewpoints")):
             if sums is None:
                 sums = torch.zeros((n_faces, n_channels), dtype=torch.float64, device=self.backend.device)
                 counts = torch.zeros((n_faces,), dtype=torch.int32, device=self.backend.device)
@@ -841,6 +870,106 @@ class TexturedPhotogrammetryMesh:
         if return_all:
             info["all_projections"] = all_projections
         return avg, info
+
+    def _aggregate_label_views(self, backend, cameras, inds, mesh, C, label_fn, labels_known, batch_size, aggregate_img_scale,
+                               loader_threads, fused_ok, kwargs, progress=True, own_stream=False):
+        """The index-label fast path of aggregate_projected_images for the views `inds` on ONE backend: returns that device's
+        (votes (F,C), counts (F,)) int32 tensors.  Called once for a single-device mesh, once per device -- each on a host
+        thread of its own -- for `devices=[...]`."""
+        torch = _torch()
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+
+        on_gpu = backend.device.type == "cuda"
+        stream_ctx = contextlib.nullcontext()
+        if on_gpu:
+            torch.cuda.set_device(backend.device)   # the current device is a property of the host thread
+            if own_stream:   # contexts that share a device would otherwise queue on its one default stream
+                stream_ctx = torch.cuda.stream(torch.cuda.Stream(backend.device))
+        with stream_ctx:
+            self._ensure_uploaded(mesh, backend)
+            votes, counts = backend.new_vote_buffers(C)
+            if len(inds) == 0:
+                return votes, counts
+            # launch groups of up to 32 views; a short run is still cut into at least four chunks, so that the loader stages
+            # chunk i + 1 while chunk i crosses the link (16 views in ONE chunk ran staging, copy and kernels back to back)
+            chunk = max(int(batch_size), min(32, max(1, -(-len(inds) // 4))))
+            chunks = [inds[c0 : c0 + chunk] for c0 in range(0, len(inds), chunk)]
+
+            # Input pipeline (row f4).  The label images of a chunk are decoded straight into ONE pinned (n,h,w) uint8
+            # staging tensor (no stack / pin copies), by `loader_threads` workers when the segmentor says its lookups
+            # are thread safe (file look-ups and in-memory arrays are; an arbitrary model may not be), while the GPU
+            # works on the previous chunk.
+            thread_safe = bool(getattr(getattr(cameras, "segmentor", None), "thread_safe_lookup", False))
+            n_workers = int(loader_threads if loader_threads is not None else (min(16, os.cpu_count() or 1) if thread_safe else 1))
+            # the label images must have the size the camera records are built for (the reference fails with a shape
+            # error in `textured_faces[flat_pix2face] = flat_img` otherwise, meshes.py:1998-2001)
+            h0, w0 = cameras.cameras[inds[0]].get_image_size(aggregate_img_scale)
+
+            def check_shape(shape, i):
+                if tuple(shape[:2]) != (h0, w0):
+                    raise ValueError(
+                        f"label image of view {i} has shape {tuple(shape[:2])}, but the camera renders {(h0, w0)} at "
+                        f"aggregate_img_scale={aggregate_img_scale}"
+                    )
+
+            def one_label(i):
+                return labels_known[i] if i in labels_known else label_fn(i, aggregate_img_scale)
+
+            probe = next(iter(labels_known.values()))
+
+            def load_chunk(chunk_inds, img_pool):
+                if isinstance(probe, torch.Tensor):  # the segmentor already produces tensors
+                    labs = [one_label(i) for i in chunk_inds]
+                    for i, lab in zip(chunk_inds, labs):
+                        check_shape(lab.shape, i)
+                    labs = [torch.where((lab < 0) | (lab > 255), torch.full_like(lab, 255), lab)
+                            if lab.dtype != torch.uint8 else lab for lab in labs]
+                    return torch.stack([lab.to(backend.device, torch.uint8) for lab in labs], dim=0)
+                stage = torch.empty((len(chunk_inds), h0, w0), dtype=torch.uint8, pin_memory=on_gpu)
+                view = stage.numpy()
+
+                def fill(k):
+                    lab = np.asarray(one_label(chunk_inds[k]))
+                    check_shape(lab.shape, chunk_inds[k])
+                    if lab.dtype != np.uint8:  # an index outside [0, 255] is no class: the ignore value, not a wrapped class
+                        lab = np.where((lab < 0) | (lab > 255), 255, lab)
+                    view[k] = lab  # casts to uint8 while copying
+
+                list(img_pool.map(fill, range(len(chunk_inds))))
+                return stage
+
+            steps = range(len(chunks))
+            if progress:
+                steps = tqdm(steps, total=len(chunks), desc="Aggregating projected viewpoints")
+            with ThreadPoolExecutor(max_workers=1) as pool, ThreadPoolExecutor(max_workers=max(n_workers, 1)) as img_pool:
+                pending = pool.submit(load_chunk, chunks[0], img_pool)
+                for ci in steps:
+                    lab = pending.result()
+                    pending = pool.submit(load_chunk, chunks[ci + 1], img_pool) if ci + 1 < len(chunks) else None
+                    # the chunk's cameras only: a subset of the segmentor wrapper would deep-copy the segmentor with it
+                    # (segmentor.py:49-55) -- every in-memory label image of an ArrayLabelSegmentor, per chunk
+                    sub = getattr(cameras, "base_camera_set", cameras).get_subset_cameras(chunks[ci])
+                    if lab.device.type != backend.device.type:
+                        lab = lab.to(backend.device, non_blocking=True)
+                    if fused_ok:
+                        # fused: face ids stay in the rasterizer's LDS tiles, only per-face winners reach HBM
+                        records, _ = self._raster_records(sub, mesh, aggregate_img_scale, backend=backend, **_raster_kwargs(kwargs))
+                        backend.raster_project_labels(records, lab, C, votes, counts, neg1_is_last_face=self.neg1_is_last_face)
+                    else:
+                        p2f_kwargs = {k: v for k, v in kwargs.items() if k in _PIX2FACE_KWARGS}
+                        p2f_kwargs.setdefault("mesh", mesh)
+                        ids = self.pix2face(cameras=sub, render_img_scale=aggregate_img_scale, return_tensor=True, **p2f_kwargs)
+                        if isinstance(ids, np.ndarray):
+                            ids = backend._dev(ids.astype(np.int32), torch.int32)
+                        elif ids.device != backend.device:
+                            ids = ids.to(backend.device)
+                        if tuple(ids.shape[-2:]) != (h0, w0):
+                            raise ValueError(f"pix2face returned {tuple(ids.shape[-2:])} ids for {(h0, w0)} label images")
+                        backend.project_labels(ids, lab, C, votes, counts, neg1_is_last_face=self.neg1_is_last_face)
+            if on_gpu and own_stream:
+                torch.cuda.current_stream(backend.device).synchronize()   # the partial is complete when the thread hands it back
+        return votes, counts
 
     # the north star's name for the same method
     aggregate_viewpoints = aggregate_projected_images

@@ -290,6 +290,90 @@ def forest_scene(n_trees: int = 20000, n_side: int = 776, extent: float = 400.0,
     return all_points, all_faces
 
 
+# ---- a realistic third workload: an irregular TIN (what BASELINE config 2 calls "Example-data Metashape mesh") ------------------
+def tin_mesh(seed: int = 11, extent: float = 400.0, n_points: int = 600_000, sigma: float = 1.0, overhang_share: float = 0.05,
+             cell: float = 2.0):
+    """A photogrammetric-style triangulated irregular network over the C2 terrain spectrum: about `2 n_points` faces
+    (1.2 M by default), vertex density varying log-normally (sigma = `sigma` of the log) over a smooth random field -- a
+    dense-cloud mesh is fine where the scene has texture and coarse where it has none --, Delaunay connectivity (slivers,
+    valences from 3 to 12, triangle areas over two orders of magnitude), and leaning bumps on `overhang_share` of the area
+    whose downhill side folds under itself (depth complexity 2-3 from above: building eaves, canopy edges).  Blue-noise-like
+    points: every `cell` x `cell` m cell holds an n x n jittered sub-grid, n from the density field (a white-noise point set
+    would make every second Delaunay triangle a sliver; Metashape's are not).  Face order: Delaunay's (spatially incoherent,
+    like a file written by a mesher).  Deterministic in `seed`.  Returns (points (V,3) float64, faces (F,3) int64)."""
+    from scipy.spatial import Delaunay
+
+    rng = np.random.default_rng(seed)
+    n_cells = int(round(extent / cell))
+    cx = (np.arange(n_cells) + 0.5) * cell - extent / 2
+    gx, gy = np.meshgrid(cx, cx)
+    # smooth log-density field: four random plane waves of 60-250 m wavelength, normalised to unit variance
+    g = np.zeros_like(gx)
+    for _ in range(4):
+        lam, ang, ph = rng.uniform(60.0, 250.0), rng.uniform(0, 2 * np.pi), rng.uniform(0, 2 * np.pi)
+        g += np.sin(2 * np.pi / lam * (gx * np.cos(ang) + gy * np.sin(ang)) + ph)
+    g = (g - g.mean()) / g.std()
+    dens = np.exp(sigma * g)
+    dens *= n_points / dens.sum()                          # expected points per cell
+    n_sub = np.clip(np.rint(np.sqrt(dens)), 1, 12).astype(np.int64)
+    # rescale once so that the total lands near n_points despite the rounding
+    n_sub = np.clip(np.rint(np.sqrt(dens * n_points / float((n_sub ** 2).sum()))), 1, 12).astype(np.int64)
+    pts = []
+    for n in np.unique(n_sub):
+        ci, cj = np.nonzero(n_sub == n)
+        k = np.arange(n)
+        ox, oy = np.meshgrid((k + 0.5) / n, (k + 0.5) / n)
+        jit = rng.uniform(-0.35 / n, 0.35 / n, size=(ci.size, n * n, 2))
+        x = cx[cj][:, None] - cell / 2 + (ox.ravel()[None, :] + jit[..., 0]) * cell
+        y = cx[ci][:, None] - cell / 2 + (oy.ravel()[None, :] + jit[..., 1]) * cell
+        pts.append(np.stack([x.ravel(), y.ravel()], axis=1))
+    uv = np.concatenate(pts, axis=0)
+    uv = uv[rng.permutation(uv.shape[0])]                  # vertex order: a mesher's, not the generator's
+    faces = Delaunay(uv).simplices.astype(np.int64)
+    z = _spectrum(1)(uv[:, 0], uv[:, 1]) + rng.normal(0.0, 0.03, uv.shape[0])
+    xyz = np.stack([uv[:, 0], uv[:, 1], z], axis=1)
+    # leaning bumps: height h exp(-r^2 / 2 s^2), the whole bump sheared sideways by 1.6 x its height -- where the shear's
+    # gradient along the lean direction is below -1 the surface folds under itself
+    area, covered = extent * extent, 0.0
+    while covered < overhang_share * area:
+        c = rng.uniform(-0.45 * extent, 0.45 * extent, 2)
+        s_b, ang = rng.uniform(2.0, 6.0), rng.uniform(0, 2 * np.pi)
+        h_b = s_b * rng.uniform(1.0, 2.5)                  # steep enough to fold: the shear's gradient reaches -0.97 h / s
+        d = uv - c
+        r2 = (d * d).sum(axis=1)
+        near = r2 < (3.0 * s_b) ** 2
+        b = h_b * np.exp(-r2[near] / (2 * s_b * s_b))
+        xyz[near, 2] += b
+        xyz[near, 0] += 1.6 * b * np.cos(ang)
+        xyz[near, 1] += 1.6 * b * np.sin(ang)
+        covered += np.pi * (2.0 * s_b) ** 2
+    return xyz, faces
+
+
+def depth_complexity(points, faces, rec, h, w):
+    """Mean number of mesh layers under a covered pixel of one view (camera record `rec`): the summed screen
+    area of the faces that lie wholly inside the image over the number of pixels they can cover (float64, no clipping: an
+    estimate for reporting, not part of any parity claim)."""
+    R = np.asarray(rec[:9], dtype=np.float64).reshape(3, 3)
+    t = np.asarray(rec[9:12], dtype=np.float64)
+    q = (np.asarray(points, dtype=np.float64) - t) @ R
+    ok = q[:, 2] > max(float(rec[15]), 1e-9)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sx = rec[13] + rec[12] * q[:, 0] / q[:, 2]
+        sy = rec[14] + rec[12] * q[:, 1] / q[:, 2]
+    inside = ok & (sx >= 0) & (sx <= w) & (sy >= 0) & (sy <= h)
+    f = np.asarray(faces)
+    keep = inside[f].all(axis=1)
+    a, b, c = f[keep, 0], f[keep, 1], f[keep, 2]
+    area2 = np.abs((sx[b] - sx[a]) * (sy[c] - sy[a]) - (sx[c] - sx[a]) * (sy[b] - sy[a]))
+    g = 64   # coverage at 64-pixel granularity (every covered cell of that size holds a vertex) is enough for a ratio
+    cover = np.zeros((h // g + 1, w // g + 1), dtype=bool)
+    for k in (a, b, c):
+        cover[np.clip((sy[k] // g).astype(np.int64), 0, h // g), np.clip((sx[k] // g).astype(np.int64), 0, w // g)] = True
+    covered_px = min(cover.sum() * float(g * g), float(h) * w)
+    return float(0.5 * area2.sum() / max(covered_px, 1.0))
+
+
 def oblique_cameras(n_views: int = 20, tilt_range=(30.0, 45.0), agl: float = 120.0, f: float = 3000.0, width: int = 4000,
                     height: int = 3000, seed: int = 8, extent: float = 400.0) -> PhotogrammetryCameraSet:
     """Cameras over the central part of the terrain, tilted 30-45 degrees off nadir with random headings."""
