@@ -145,27 +145,19 @@ __global__ __launch_bounds__(256) void k_cull_blocks(const float *__restrict__ c
     base = __shfl(base, leader);
     if (keep) a.work[(int64_t)slot * a.work_stride + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)b;
   }
-  // fused aggregation: which 256-face chunks of caller ids can receive winners in this view.  The workgroup's 256 blocks
-  // are neighbours on the Morton curve and share most of their chunks: the bits are collected in LDS and every non-zero
-  // word leaves the workgroup as one atomicOr.
-  if (a.touched) {
-    extern __shared__ uint32_t bits[];
-    for (int i = threadIdx.x; i < a.tw; i += 256) bits[i] = 0u;
-    __syncthreads();
-    if (keep) {
-      const uint32_t *cl = a.blk_chunks + (int64_t)b * (GR_CHUNK_LIST + 1);
-      const uint32_t n = cl[0];
-      if (n == 0xFFFFFFFFu) atomicOr(&bits[a.tw - 1], 1u);
-      else
-        for (uint32_t i = 0; i < n; ++i) {
-          const uint32_t ch = cl[1 + i];
-          atomicOr(&bits[ch >> 5], 1u << (ch & 31u));
-        }
-    }
-    __syncthreads();
-    uint32_t *dst = a.touched + (int64_t)slot * a.tw;
-    for (int i = threadIdx.x; i < a.tw; i += 256)
-      if (bits[i]) atomicOr(&dst[i], bits[i]);
+  // fused aggregation: which 256-face chunks of CALLER ids can receive winners in this view: ONE BYTE per chunk (zeroed by the
+  // group's init kernel), set with plain stores by the surviving blocks from their chunk lists (k_block_chunks at upload: at most
+  // 16 per block; a block scattered over more raises the view's "all" byte).  Every writer writes the same 1: no atomics, and
+  // stores to one line do not queue the way atomics do -- round 5 kept a BIT per chunk, collected in LDS and merged with one
+  // global atomicOr per non-zero word: all of a view's words lie in five 128-byte lines, and the pass took 66-120 us per 64-view
+  // launch against 7 without the bitmap (atomics on one line are served one after the other).
+  if (a.touched && keep) {
+    uint8_t *dst = reinterpret_cast<uint8_t *>(a.touched + (int64_t)slot * a.tw);
+    const uint32_t *cl = a.blk_chunks + (int64_t)b * (GR_CHUNK_LIST + 1);
+    const uint32_t n = cl[0];
+    if (n == 0xFFFFFFFFu) dst[4 * a.tw - 1] = 1;
+    else
+      for (uint32_t i = 0; i < n; ++i) dst[cl[1 + i]] = 1;
   }
 }
 
@@ -648,19 +640,19 @@ __global__ __launch_bounds__(1024) void k_bin_stats(BinArgs a) {
   for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); }
   if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = sum; pmax[threadIdx.x >> 6] = mx; }
   __syncthreads();
-  // fused aggregation: the 256-face chunks of caller ids this view's vote pass will visit (bits of the view's chunk bitmap; the
-  // "all" word stands for every chunk) -- what prices k_vote_labels' algorithmic bytes (gr_raster_stats.chunk_visits)
+  // fused aggregation: the 256-face chunks of caller ids this view's vote pass will visit (bytes of the view's chunk map; the
+  // "all" byte -- the last of the map -- stands for every chunk) -- what prices k_vote_labels' algorithmic bytes
+  // (gr_raster_stats.chunk_visits)
   unsigned long long chunks = 0;
   if (a.touched) {
     const uint32_t *tv = a.touched + (int64_t)slot * a.tw;
-    if (tv[a.tw - 1]) chunks = threadIdx.x == 0 ? (unsigned long long)((a.F + 255) >> 8) : 0ull;
-    else
-      for (int i = threadIdx.x; i < a.tw - 1; i += 1024) chunks += (unsigned long long)__popc(tv[i]);
+    const bool all = (tv[a.tw - 1] >> 24) != 0u;
+    for (int i = threadIdx.x; i < a.tw; i += 1024) chunks += (unsigned long long)__popc(tv[i] & (i == a.tw - 1 ? 0x00FFFFFFu : 0xFFFFFFFFu));
     for (int o = 32; o > 0; o >>= 1) chunks += __shfl_xor(chunks, o);
     __syncthreads();  // part[] is reused below
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = chunks;
     __syncthreads();
-    if (threadIdx.x == 0) { chunks = 0; for (int k = 0; k < 16; ++k) chunks += part[k]; }
+    if (threadIdx.x == 0) { chunks = 0; for (int k = 0; k < 16; ++k) chunks += part[k]; if (all) chunks = (unsigned long long)((a.F + 255) >> 8); }
     __syncthreads();
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
     __syncthreads();
@@ -1146,7 +1138,7 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int
   {
     // (the stage's span: from the end of k_bin_init to the end of k_clip_faces -- chain_stop)
     const int nblk = (int)ceil_div(c->F, GR_BLOCK);
-    hipLaunchKernelGGL(k_cull_blocks, dim3((unsigned)ceil_div(nblk, 256), nb), dim3(256), a.touched ? sizeof(uint32_t) * a.tw : 0, s,
+    hipLaunchKernelGGL(k_cull_blocks, dim3((unsigned)ceil_div(nblk, 256), nb), dim3(256), 0, s,
                        cams, a, nblk);
     // about nblk / 32 waves per view take a few blocks each -- but never fewer than 16 k waves per launch, so that a call with
     // a few views still fills the machine.

@@ -226,12 +226,12 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   // runs on a side stream beside the binning of group g + 1 (also light); the tile kernels in between fill the machine on
   // their own.  Two winner buffers alternate; votes are still added group by group, in order (one side stream).
   const bool overlap = labels && n_views > B && !(c->opt_var & 4);
-  // chunk bitmaps for the vote kernel (k_block_chunks / k_cull_blocks): one per launch group in flight; meshes beyond
-  // 33 M faces do without (the bitmap of a view would not fit the cull kernel's LDS)
-  const int tw = (int)(ceil_div(ceil_div(F, 256), 32) + 1);
-  const bool use_touched = labels && tw <= 4096;
+  // chunk maps for the vote kernel (k_block_chunks / k_cull_blocks): a byte per 256-face chunk of caller ids + the "all" byte,
+  // in words; one map per view of the launch groups in flight
+  const int tw = (int)ceil_div(ceil_div(F, 256) + 1, 4);
+  const bool use_touched = labels != nullptr;
   if (labels) {
-    rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F * B * (overlap ? 2 : 1));
+    rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F * B * (overlap ? 2 : 1), s);
     if (rc) return rc;
     if (use_touched) {
       rc = grow(c, c->touched, c->touched_have, (int64_t)2 * B * tw, "chunk bitmaps");
@@ -333,6 +333,7 @@ int gr_ctx_create(int device, gr_ctx **out) {
     return GR_ENOMEM;
   }
   (void)hipMemset(c->stats, 0, sizeof(unsigned long long) * 16);
+  (void)hipDeviceSynchronize();   // (the null stream's memset: a non-blocking stream of the first call would not wait for it)
 #ifdef GR_STAMPS
   if (hipMalloc(&c->stamps, sizeof(unsigned long long) * 32 * 1024) == hipSuccess) (void)hipMemset(c->stamps, 0, sizeof(unsigned long long) * 32 * 1024);
 #endif

@@ -47,7 +47,7 @@ struct BinArgs {
   const int32_t *orig;   // [F] soup position -> face id of the caller's mesh
   const float4 *blk;     // [ceil(F/64)] bounding sphere (centre, radius) of each block of GR_BLOCK faces, local frame
   const uint32_t *blk_chunks;  // [ceil(F/64)][17] count (or ~0: more than 16) + the 256-face chunks of CALLER ids the block's faces lie in
-  uint32_t *touched;     // [slot][tw] bit per 256-face chunk of caller ids that a surviving block reaches (+ last word: all), or null
+  uint32_t *touched;     // [slot][tw] a BYTE per 256-face chunk of caller ids that a surviving block reaches (+ last byte: all), or null
   int tw;                // words per slot of `touched`
   uint32_t *work;        // [slot][work_stride] blocks of this view that passed the frustum test (ctrl[3] = count)
   uint32_t *clip;        // [slot][F] soup faces that straddle the near plane / guard band (R7; ctrl[4] = count)
@@ -111,7 +111,7 @@ struct gr_ctx {
   int64_t clip_have = 0;
   float4 *blk = nullptr;
   uint32_t *blk_chunks = nullptr;  // [blk_cap][GR_CHUNK_LIST + 1]
-  uint32_t *touched = nullptr;     // fused aggregation: [2][slots][tw] chunk bitmaps of the launch groups in flight
+  uint32_t *touched = nullptr;     // fused aggregation: [2][slots][tw] chunk maps (a byte per chunk) of the launch groups in flight
   int64_t touched_have = 0;
   uint32_t *cur_touched = nullptr; // the bitmap the next bin_batch fills (null: none)
   int cur_tw = 0;
@@ -291,13 +291,16 @@ int grow(gr_ctx *c, T *&ptr, int64_t &have, int64_t want, const char *what) {
   return GR_OK;
 }
 
-inline int ensure_winner(gr_ctx *c, size_t bytes) {
+// (the zeroes go out on the CALL's stream: a plain hipMemset runs on the null stream, which a non-blocking stream -- torch's
+// side streams, one per device thread of a devices=[...] mesh -- does not wait for: the first view's winners could be wiped
+// after they were written; found by tests/test_devices_kwarg.py with three contexts on one GPU)
+inline int ensure_winner(gr_ctx *c, size_t bytes, hipStream_t s) {
   if (c->winner && c->winner_bytes >= bytes) return GR_OK;
   if (c->winner) quiesce(c);
   if (c->winner) (void)hipFree(c->winner);
   c->winner = nullptr; c->winner_bytes = 0;
   if (hipMalloc(&c->winner, bytes) != hipSuccess) return fail(c, GR_ENOMEM, "winner scratch allocation failed");
-  if (hipMemset(c->winner, 0, bytes) != hipSuccess) return fail(c, GR_EHIP, "winner memset failed");
+  if (hipMemsetAsync(c->winner, 0, bytes, s) != hipSuccess) return fail(c, GR_EHIP, "winner memset failed");
   c->winner_bytes = bytes;
   return GR_OK;
 }

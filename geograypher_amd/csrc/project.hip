@@ -79,16 +79,16 @@ __global__ __launch_bounds__(256) void k_vote_labels(uint32_t *__restrict__ winn
                                                      const unsigned long long *__restrict__ stats, int group,
                                                      const uint32_t *__restrict__ touched, int tw, int last_face_aliases_bg) {
   const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  // which views of the group can hold a winner for this workgroup's 256 faces (chunk = blockIdx.x): the bit the cull pass
-  // set for the chunk, or the view's "all" word; without the bitmap (ids given by the caller) every view can.  Lane v of
+  // which views of the group can hold a winner for this workgroup's 256 faces (chunk = blockIdx.x): the byte the cull pass
+  // set for the chunk, or the view's "all" byte; without the chunk map (ids given by the caller) every view can.  Lane v of
   // every wave looks at view v: the ballot is the same in all four waves.
   unsigned long long dirty = ~0ull;
   if (touched) {
     const int v = threadIdx.x & 63;
     bool d = false;
     if (v < n_views) {
-      const uint32_t *tv = touched + (int64_t)v * tw;
-      d = (((tv[blockIdx.x >> 5] >> (blockIdx.x & 31u)) | tv[tw - 1]) & 1u) != 0u;
+      const uint8_t *tv = reinterpret_cast<const uint8_t *>(touched + (int64_t)v * tw);
+      d = (tv[blockIdx.x] | tv[4 * tw - 1]) != 0;
     }
     dirty = __ballot(d);
     if (last_face_aliases_bg && (int64_t)blockIdx.x == ((F - 1) >> 8)) dirty = ~0ull;  // background pixels vote for face F - 1
@@ -313,7 +313,7 @@ int project_labels(gr_ctx *c, const int32_t *ids, const uint8_t *labels, int n_v
                    uint32_t *counts, int flags, hipStream_t s) {
   const int64_t P = (int64_t)h * w, F = c->F;
   const int B = n_views < GR_MAX_BATCH ? n_views : GR_MAX_BATCH;
-  int rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F * B);
+  int rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F * B, s);
   if (rc) return rc;
   note_stream(c, s);
   uint32_t *win = (uint32_t *)c->winner;
@@ -382,7 +382,7 @@ int gr_project_values_f64(gr_ctx *c, const int32_t *ids, const double *img, int 
   GR_HIP(c, hipSetDevice(c->device));
   const int64_t P = (int64_t)h * w, F = c->F;
   const int B = n_views < GR_MAX_BATCH ? n_views : GR_MAX_BATCH;
-  rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F * B);
+  rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F * B, s);
   if (rc) return rc;
   note_stream(c, s);
   uint32_t *win = (uint32_t *)c->winner;
@@ -412,7 +412,7 @@ int gr_project_view_f64(gr_ctx *c, const int32_t *ids, const double *img, int h,
   hipStream_t s = (hipStream_t)stream;
   GR_HIP(c, hipSetDevice(c->device));
   const int64_t F = c->F;
-  rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F);
+  rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F, s);
   if (rc) return rc;
   note_stream(c, s);
   uint32_t *win = (uint32_t *)c->winner;
@@ -458,7 +458,7 @@ int gr_project_index_pairs(gr_ctx *c, const int32_t *ids, const double *img, int
   GR_HIP(c, hipSetDevice(c->device));
   const int64_t P = (int64_t)h * w, F = c->F;
   const int B = n_views < GR_MAX_BATCH ? n_views : GR_MAX_BATCH;
-  rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F * B);
+  rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F * B, s);
   if (rc) return rc;
   note_stream(c, s);
   uint32_t *win = (uint32_t *)c->winner;

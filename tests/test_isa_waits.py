@@ -21,7 +21,7 @@ from geograypher_amd import build as gbuild
 #           body (the request of the next tile stays in flight over the epilogue: that is the point of the kernel).
 #   With micro lists (the MICRO builds, used only for meshes the learned table marks) a wave also reads its own micro chunks.
 KNOWN_GOOD = {("ids", False, False): 5, ("ids", True, False): 5, ("fused", False, False): 5, ("fused", True, False): 5,
-              ("ids", True, True): 11, ("fused", True, True): 9}
+              ("ids", True, True): 9, ("fused", True, True): 9}
 
 
 def _device_asm(src, out):
