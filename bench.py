@@ -488,7 +488,7 @@ def run(args, rig=None) -> int:
             return hip.finalize_votes(votes, counts)
 
         hip.raster_project_labels(recs3, labels, N_CLASSES, votes, counts, check=True)  # sizing / warm-up pass
-        chunk_visits_per_view = hip.last_stats.get("chunk_visits", 0) / max(n3, 1)  # 256-face chunks the vote pass visits per view
+        chunk_visits_per_view = hip.last_stats.get("chunk_visits", 0) / max(n3, 1)  # 64-face groups the vote pass visits per view
         agg_step()
         # windows of 5 steps until at least 0.3 s of GPU time lie inside timed regions (decided on the MAX-reduced times)
         agg_steps, agg_elapsed = 0, 0.0
@@ -530,13 +530,13 @@ def run(args, rig=None) -> int:
             "k_raster_tile_fused", note="4 F_vis per view: the winners it writes (ids are never written); the entries it reads "
                                         "are a binning tax, not algorithmic bytes")
         rooflines["k_raster_tile_fused"]["valu"] = valu_bound("k_raster_tile_fused", ast["raster_ms"] / a_launches, a_vpl)
-        # the vote kernel reads and resets the winners only of the 256-face chunks a view's block cull reached
-        # (gr_raster_stats.chunk_visits: popcount of the view's chunk bitmap): 256 x 8 B per visited chunk, not 8 F
-        vote_bytes = 256.0 * 8.0 * chunk_visits_per_view + 9.0 * f_vis
+        # the vote kernel reads and resets the winners only of the 64-face groups in which the view's tile pass produced a winner
+        # (gr_raster_stats.chunk_visits: the byte map the fused epilogue fills): 64 x 8 B per visited group, not 8 F
+        vote_bytes = 64.0 * 8.0 * chunk_visits_per_view + 9.0 * f_vis
         rooflines["k_vote_labels"] = hbm_roofline(
             "k_vote_labels", vote_bytes * a_vpl, ast["vote_ms"] / a_launches, a_vpl, "k_vote_labels",
-            note=f"256 x 8 B per visited chunk (winner read + reset; {chunk_visits_per_view:.0f} of {(F + 255) // 256} chunks per view by "
-                 "the chunk bitmaps) + 9 F_vis (label byte, vote and count read-modify-write) per view; SURVEY 8d's 8 F + 9 F_vis "
+            note=f"64 x 8 B per visited group of 64 faces (winner read + reset; {chunk_visits_per_view:.0f} of {(F + 63) // 64} groups per view by "
+                 "the winner map) + 9 F_vis (label byte, vote and count read-modify-write) per view; SURVEY 8d's 8 F + 9 F_vis "
                  f"is the upper bound {(8.0 * F + 9.0 * f_vis) / 1e6:.2f} MB per view")
         rooflines["k_vote_labels"]["chunk_visits_per_view"] = round(chunk_visits_per_view, 1)
         rooflines["k_vote_labels"]["valu"] = valu_bound("k_vote_labels", ast["vote_ms"] / a_launches, a_vpl)

@@ -145,20 +145,6 @@ __global__ __launch_bounds__(256) void k_cull_blocks(const float *__restrict__ c
     base = __shfl(base, leader);
     if (keep) a.work[(int64_t)slot * a.work_stride + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)b;
   }
-  // fused aggregation: which 256-face chunks of CALLER ids can receive winners in this view: ONE BYTE per chunk (zeroed by the
-  // group's init kernel), set with plain stores by the surviving blocks from their chunk lists (k_block_chunks at upload: at most
-  // 16 per block; a block scattered over more raises the view's "all" byte).  Every writer writes the same 1: no atomics, and
-  // stores to one line do not queue the way atomics do -- round 5 kept a BIT per chunk, collected in LDS and merged with one
-  // global atomicOr per non-zero word: all of a view's words lie in five 128-byte lines, and the pass took 66-120 us per 64-view
-  // launch against 7 without the bitmap (atomics on one line are served one after the other).
-  if (a.touched && keep) {
-    uint8_t *dst = reinterpret_cast<uint8_t *>(a.touched + (int64_t)slot * a.tw);
-    const uint32_t *cl = a.blk_chunks + (int64_t)b * (GR_CHUNK_LIST + 1);
-    const uint32_t n = cl[0];
-    if (n == 0xFFFFFFFFu) dst[4 * a.tw - 1] = 1;
-    else
-      for (uint32_t i = 0; i < n; ++i) dst[cl[1 + i]] = 1;
-  }
 }
 
 struct FaceForm {
@@ -640,29 +626,11 @@ __global__ __launch_bounds__(1024) void k_bin_stats(BinArgs a) {
   for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); }
   if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = sum; pmax[threadIdx.x >> 6] = mx; }
   __syncthreads();
-  // fused aggregation: the 256-face chunks of caller ids this view's vote pass will visit (bytes of the view's chunk map; the
-  // "all" byte -- the last of the map -- stands for every chunk) -- what prices k_vote_labels' algorithmic bytes
-  // (gr_raster_stats.chunk_visits)
-  unsigned long long chunks = 0;
-  if (a.touched) {
-    const uint32_t *tv = a.touched + (int64_t)slot * a.tw;
-    const bool all = (tv[a.tw - 1] >> 24) != 0u;
-    for (int i = threadIdx.x; i < a.tw; i += 1024) chunks += (unsigned long long)__popc(tv[i] & (i == a.tw - 1 ? 0x00FFFFFFu : 0xFFFFFFFFu));
-    for (int o = 32; o > 0; o >>= 1) chunks += __shfl_xor(chunks, o);
-    __syncthreads();  // part[] is reused below
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = chunks;
-    __syncthreads();
-    if (threadIdx.x == 0) { chunks = 0; for (int k = 0; k < 16; ++k) chunks += part[k]; if (all) chunks = (unsigned long long)((a.F + 255) >> 8); }
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
-    __syncthreads();
-  }
   if (threadIdx.x == 0) {
     unsigned long long total = 0; uint32_t m = 0;
     for (int k = 0; k < 16; ++k) { total += part[k]; m = max(m, pmax[k]); }
     ctrl[1] = (uint32_t)total;
     atomicAdd(&a.stats[6], (unsigned long long)ctrl[3]);   // 64-face blocks that passed the frustum cull
-    if (chunks) atomicAdd(&a.stats[7], chunks);
     const bool ovf = m > (uint32_t)a.cap_tile || ctrl[2] != 0;
     atomicAdd(&a.stats[0], (unsigned long long)ctrl[0]);
     atomicAdd(&a.stats[1], total);
@@ -1109,6 +1077,15 @@ __global__ __launch_bounds__(256) void k_bin_init(uint4 *__restrict__ ctrl16, in
   if (stats && i0 < 10) stats[i0] = i0 == 4 ? ~0ull : 0ull;
 }
 
+// (view, 64-face group) pairs the vote passes of the last fused call visited, added up for gr_raster_status (k_vote_labels keeps a
+// slot per group: no contention there; this runs once per status call)
+__global__ __launch_bounds__(256) void k_sum_visits(const uint32_t *__restrict__ visits, int64_t n, unsigned long long *__restrict__ out) {
+  unsigned long long sum = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) sum += visits[i];
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if ((threadIdx.x & 63) == 0 && sum) atomicAdd(out, sum);
+}
+
 }  // namespace
 
 namespace grimpl {
@@ -1118,8 +1095,8 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int
   BinArgs a = make_args(c, h, w, slot0);
   a.group = group;
   {
-    // ONE kernel zeroes what the group's bin pass counts in -- the control words of its views, the fused path's chunk bitmaps
-    // and, in the call's first group, the call's statistics -- where rounds 1-5 issued four to five fills: a fill of 40 bytes
+    // ONE kernel zeroes what the group's passes count in -- the control words of its views, the fused path's group maps (bytes
+    // the tile kernel's epilogue sets) and, in the call's first group, the call's statistics -- where rounds 1-5 issued four to five fills: a fill of 40 bytes
     // costs as much as a kernel launch (4.9 us each in the rocprof trace of a C2 step of 940 us; the step: -0.9 %, at quarter
     // scale -2 %: profiles/r05_ab/step_deferred_stats_vs_init_kernel_vs_fills.log, builds in rotated order).  (Folding k_bin_stats into the last k_clip_faces block of each view, to
     // save that launch too, measured no gain: one wave adding up a view's counters takes as long as the launch it saves --
@@ -1172,6 +1149,15 @@ int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int
       GR_LAUNCH_EV((hipEvent_t) nullptr, chain_stop(c, ST_FILL), k_fill_compile, dim3(g, nb), dim3(256), 0, s, a);
     }
   }
+  GR_HIP(c, hipGetLastError());
+  return GR_OK;
+}
+
+// gr_raster_stats.chunk_visits of the last fused call: the vote passes' visit counters, summed into the call's statistics
+int sum_visits(gr_ctx *c, hipStream_t s) {
+  if (!c->visits_pending) return GR_OK;
+  c->visits_pending = false;
+  hipLaunchKernelGGL(k_sum_visits, dim3(64), dim3(256), 0, s, c->visits, ceil_div(c->F, 64), c->stats + 7);
   GR_HIP(c, hipGetLastError());
   return GR_OK;
 }

@@ -226,16 +226,19 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   // runs on a side stream beside the binning of group g + 1 (also light); the tile kernels in between fill the machine on
   // their own.  Two winner buffers alternate; votes are still added group by group, in order (one side stream).
   const bool overlap = labels && n_views > B && !(c->opt_var & 4);
-  // chunk maps for the vote kernel (k_block_chunks / k_cull_blocks): a byte per 256-face chunk of caller ids + the "all" byte,
-  // in words; one map per view of the launch groups in flight
-  const int tw = (int)ceil_div(ceil_div(F, 256) + 1, 4);
+  // group maps for the vote kernel: a byte per 64 consecutive caller face ids, set by the tile kernel's epilogue where it
+  // issues a winner (zeroed by the launch group's init kernel); in words; one map per view of the launch groups in flight
+  const int tw = (int)ceil_div(ceil_div(F, 64), 4);
   const bool use_touched = labels != nullptr;
   if (labels) {
     rc = ensure_winner(c, sizeof(uint32_t) * (size_t)F * B * (overlap ? 2 : 1), s);
     if (rc) return rc;
     if (use_touched) {
-      rc = grow(c, c->touched, c->touched_have, (int64_t)2 * B * tw, "chunk bitmaps");
+      rc = grow(c, c->touched, c->touched_have, (int64_t)2 * B * tw, "winner group maps");
+      if (!rc) rc = grow(c, c->visits, c->visits_have, ceil_div(F, 64) + 4, "visit counters");
       if (rc) return rc;
+      if (again == 0) GR_HIP(c, hipMemsetAsync(c->visits, 0, sizeof(uint32_t) * (size_t)(ceil_div(F, 64) + 4), s));
+      c->visits_pending = true;
     }
     if (overlap && !c->side) {
       GR_HIP(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
@@ -249,6 +252,7 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
   note_stream(c, s);
   c->stats_pending = true;   // the call's statistics are reset by the first launch group's init kernel (bin_batch: k_bin_init)
   c->stats_deferred = false;
+  if (!labels) c->visits_pending = false;
   c->defer_stats = !labels && n_views <= B && !(c->cur_look && again < 2);
   c->last_n_views = n_views;
   int g = 0;
@@ -288,6 +292,8 @@ int raster_views(gr_ctx *c, const float *cams, int n_views, int h, int w, int32_
     out.ids = ids ? ids + v0 * P : nullptr;
     out.depth = depth ? depth + v0 * P : nullptr;
     out.winner = win;
+    out.touched = reinterpret_cast<uint8_t *>(tch);
+    out.tb = 4 * (int64_t)tw;
     out.F = F;
     out.compat = (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0;
     if (overlap && g >= 2) GR_HIP(c, hipStreamWaitEvent(s, c->ev_vote[buf], 0));  // the votes of group g - 2 have read this buffer
@@ -362,7 +368,7 @@ int gr_ctx_destroy(gr_ctx *c) {
   if (c->sort_tmp) (void)hipFree(c->sort_tmp);
   if (c->resize_tmp) (void)hipFree(c->resize_tmp);
   if (c->blk) (void)hipFree(c->blk);
-  if (c->blk_chunks) (void)hipFree(c->blk_chunks);
+  if (c->visits) (void)hipFree(c->visits);
   if (c->touched) (void)hipFree(c->touched);
   if (c->soup) (void)hipFree(c->soup);
   if (c->bvert) (void)hipFree(c->bvert);
@@ -489,7 +495,8 @@ int gr_raster_status(gr_ctx *c, gr_raster_stats *o) {
   if (!c || !o) return GR_EINVAL;
   unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   {
-    const int rc = bin_stats_deferred(c, c->last_stream);   // the view totals of a call that left them for now
+    int rc = bin_stats_deferred(c, c->last_stream);   // the view totals of a call that left them for now
+    if (!rc) rc = sum_visits(c, c->last_stream);      // ... and the visit counters of a fused call's vote passes
     if (rc) return rc;
   }
   GR_HIP(c, hipMemcpyAsync(st, c->stats, sizeof(st), hipMemcpyDeviceToHost, c->last_stream));

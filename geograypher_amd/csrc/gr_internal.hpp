@@ -32,7 +32,6 @@
 #define GR_MAX_DIM 16384    // h, w limit (guard band and 16-bit bbox packing)
 #define GR_BLOCK 64         // faces per block of the Morton-ordered soup: one wave, one bounding sphere
 #define GR_BLOCK_VERTS 192  // distinct vertices a block can have (3 per face); a patch of a manifold mesh has about 48
-#define GR_CHUNK_LIST 16      // chunks of 256 caller face ids listed per block (k_block_chunks)
 namespace grimpl {
 
 struct BinArgs {
@@ -46,8 +45,8 @@ struct BinArgs {
   const uint32_t *bidx;  // [F] positions of the face's three vertices in its block's list (8 bits each) | (distinct vertices - 1) << 24
   const int32_t *orig;   // [F] soup position -> face id of the caller's mesh
   const float4 *blk;     // [ceil(F/64)] bounding sphere (centre, radius) of each block of GR_BLOCK faces, local frame
-  const uint32_t *blk_chunks;  // [ceil(F/64)][17] count (or ~0: more than 16) + the 256-face chunks of CALLER ids the block's faces lie in
-  uint32_t *touched;     // [slot][tw] a BYTE per 256-face chunk of caller ids that a surviving block reaches (+ last byte: all), or null
+  uint32_t *touched;     // fused aggregation: [slot][tw] a BYTE per group of 64 consecutive CALLER face ids that received a winner in the
+                         // view (set by the tile kernel's epilogue beside its winner atomic; zeroed by the group's init kernel), or null
   int tw;                // words per slot of `touched`
   uint32_t *work;        // [slot][work_stride] blocks of this view that passed the frustum test (ctrl[3] = count)
   uint32_t *clip;        // [slot][F] soup faces that straddle the near plane / guard band (R7; ctrl[4] = count)
@@ -88,6 +87,8 @@ struct RasterOut {
   int32_t *ids;      // [slot][h][w] or null
   float *depth;      // [slot][h][w] or null
   uint32_t *winner;  // fused projection: [slot][F] keys = (last pixel of the face in the view) + 1, or null
+  uint8_t *touched;  // ... and [slot][4 tw] the byte map of the 64-face groups that hold a winner (BinArgs::touched)
+  int64_t tb;        // bytes per slot of `touched`
   int64_t F;
   int compat;        // GR_FLAG_NEG1_IS_LAST_FACE
 };
@@ -110,8 +111,10 @@ struct gr_ctx {
   uint32_t *clip = nullptr;   // [slot][F] clip lists (R7)
   int64_t clip_have = 0;
   float4 *blk = nullptr;
-  uint32_t *blk_chunks = nullptr;  // [blk_cap][GR_CHUNK_LIST + 1]
-  uint32_t *touched = nullptr;     // fused aggregation: [2][slots][tw] chunk maps (a byte per chunk) of the launch groups in flight
+  uint32_t *touched = nullptr;     // fused aggregation: [2][slots][tw] group maps (a byte per 64 faces) of the launch groups in flight
+  uint32_t *visits = nullptr;      // ... [F / 64] (view, group) pairs the vote passes of the current call visited (gr_raster_stats.chunk_visits)
+  int64_t visits_have = 0;
+  bool visits_pending = false;     // ... not added into the call's statistics yet (gr_raster_status does)
   int64_t touched_have = 0;
   uint32_t *cur_touched = nullptr; // the bitmap the next bin_batch fills (null: none)
   int cur_tw = 0;
@@ -313,7 +316,7 @@ inline BinArgs make_args(gr_ctx *c, int h, int w, int slot0) {
   a.comp = c->comp + slot0 * a.ent_cap * GR_ENT_Q; a.work = c->work + slot0 * a.work_stride;
   a.nrow8 = c->nrow8 + slot0 * a.ent_cap;
   a.stats = c->stats; a.blk = c->blk; a.soup = c->soup; a.orig = c->orig; a.bvert = c->bvert; a.bidx = c->bidx;
-  a.blk_chunks = c->blk_chunks; a.touched = c->cur_touched; a.tw = c->cur_tw;
+  a.touched = c->cur_touched; a.tw = c->cur_tw;
   a.clip = c->clip + slot0 * c->F;
   a.twl = GR_TILE_LOG2; a.thl = c->opt_thl;
   a.TX = (w + (1 << a.twl) - 1) >> a.twl; a.TY = (h + (1 << a.thl) - 1) >> a.thl; a.T = a.TX * a.TY; a.Tcap = c->Tcap; a.clg = c->clg;
@@ -340,6 +343,7 @@ inline int check_common(gr_ctx *c, int n_views, int h, int w) {
 int bin_batch(gr_ctx *c, const float *cams, int nb, int h, int w, int slot0, int group, hipStream_t s);   // binning.hip
 int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStream_t s);                 // raster_tile.hip
 int bin_stats_deferred(gr_ctx *c, hipStream_t s);                                                         // binning.hip
+int sum_visits(gr_ctx *c, hipStream_t s);                                                                 // binning.hip
 int project_labels(gr_ctx *c, const int32_t *ids, const uint8_t *labels, int n_views, int h, int w, int C, uint32_t *votes,
                    uint32_t *counts, int flags, hipStream_t s);                                           // project.hip
 void launch_vote_labels(gr_ctx *c, hipStream_t vs, uint32_t *win, const uint8_t *labels, int nb, int64_t F, int64_t P, int C,

@@ -109,27 +109,6 @@ __global__ __launch_bounds__(256) void k_block_bounds(const float *__restrict__ 
   }
 }
 
-// K0a  (once per upload) for every block of 64 soup faces: the 256-face chunks of the CALLER's face ids its faces lie in
-//      (at most 16 listed; a block whose faces are scattered over more says so).  The fused aggregation marks, per view,
-//      the chunks that surviving blocks reach, and its vote kernel -- one workgroup per chunk -- reads the winners of the
-//      views that can have any.  One wave per block.
-__global__ __launch_bounds__(256) void k_block_chunks(const int32_t *__restrict__ orig, int64_t F, uint32_t *__restrict__ out) {
-  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int64_t f = b * GR_BLOCK + lane;
-  if (b * GR_BLOCK >= F) return;
-  const int ch = f < F ? (orig[f] >> 8) : -1;
-  unsigned long long rem = __ballot(ch >= 0);
-  int n = 0;
-  while (rem && n < GR_CHUNK_LIST) {
-    const int cl = __builtin_amdgcn_readlane(ch, __ffsll((long long)rem) - 1);
-    if (lane == 0) out[b * (GR_CHUNK_LIST + 1) + 1 + n] = (uint32_t)cl;
-    rem &= ~__ballot(ch == cl);
-    ++n;
-  }
-  if (lane == 0) out[b * (GR_CHUNK_LIST + 1)] = rem ? 0xFFFFFFFFu : (uint32_t)n;
-}
-
 // K0c  (once per upload) the DISTINCT vertices of every block of 64 soup faces.  The set-up kernel transforms a vertex once
 //      per block and view instead of once per face corner: a patch of a manifold mesh has about 48 distinct vertices for its
 //      192 corners (a face soup has 192: no worse than before).  One wave per block: the 192 corner indices go to LDS, every
@@ -243,10 +222,6 @@ int gr_mesh_upload(gr_ctx *c, const float *verts, const int32_t *faces, int64_t 
     if (c->blk) (void)hipFree(c->blk);
     c->blk = nullptr; c->blk_cap = 0;
     if (hipMalloc(&c->blk, sizeof(float4) * nblk) != hipSuccess) return fail(c, GR_ENOMEM, "block bounds allocation failed");
-    if (c->blk_chunks) (void)hipFree(c->blk_chunks);
-    c->blk_chunks = nullptr;
-    if (hipMalloc(&c->blk_chunks, sizeof(uint32_t) * (GR_CHUNK_LIST + 1) * nblk) != hipSuccess)
-      return fail(c, GR_ENOMEM, "block chunk list allocation failed");
     c->blk_cap = nblk;
   }
   if (c->soup_cap < F) {
@@ -286,7 +261,6 @@ int gr_mesh_upload(gr_ctx *c, const float *verts, const int32_t *faces, int64_t 
   GR_HIP(c, hipcub::DeviceRadixSort::SortPairs(tmp, tb, code_in, code_out, idx_in, c->orig, (int)F, 0, 32, s));
   hipLaunchKernelGGL(k_build_soup, dim3((unsigned)ceil_div(3 * F, 256)), dim3(256), 0, s, verts, faces, c->orig, F, c->soup);
   hipLaunchKernelGGL(k_block_bounds, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s, c->soup, F, c->blk);
-  hipLaunchKernelGGL(k_block_chunks, dim3((unsigned)ceil_div(nblk, 4)), dim3(256), 0, s, c->orig, F, c->blk_chunks);
   hipLaunchKernelGGL(k_block_vertices, dim3((unsigned)ceil_div(nblk, 4)), dim3(256), 0, s, verts, faces, c->orig, F, c->bvert, c->bidx);
   GR_HIP(c, hipGetLastError());
   c->verts = verts; c->faces = faces; c->V = V; c->F = F;

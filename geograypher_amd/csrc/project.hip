@@ -73,31 +73,39 @@ __global__ __launch_bounds__(256) void k_winner(const int32_t *__restrict__ ids,
 //     face and view; neighbouring faces win neighbouring pixels): votes[f][label] += 1, counts[f] += 1; a label >= C
 //     (255 = ignore) is an all-zero one-hot row that still counts (predictors/segmentor.py:37-69).  Winners are
 //     cleared for reuse (only the faces a view shows were written: a tenth of the array).
+//     Fused aggregation: a wave reads the winners of its 64 faces only for the views in which the tile kernel marked the group
+//     (round 5: a bit per 256-face chunk from the cull pass's block lists -- half of the winners it made the pass read were empty).
 __global__ __launch_bounds__(256) void k_vote_labels(uint32_t *__restrict__ winner, const uint8_t *__restrict__ labels,
                                                      int n_views, int64_t F, int64_t P, int C,
                                                      uint32_t *__restrict__ votes, uint32_t *__restrict__ counts,
                                                      const unsigned long long *__restrict__ stats, int group,
-                                                     const uint32_t *__restrict__ touched, int tw, int last_face_aliases_bg) {
+                                                     const uint32_t *__restrict__ touched, int tw, uint32_t *__restrict__ visits) {
   const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  // which views of the group can hold a winner for this workgroup's 256 faces (chunk = blockIdx.x): the byte the cull pass
-  // set for the chunk, or the view's "all" byte; without the chunk map (ids given by the caller) every view can.  Lane v of
-  // every wave looks at view v: the ballot is the same in all four waves.
+  // which views of the group hold a winner for this WAVE's 64 faces: the byte the tile kernel's epilogue set for the group
+  // beside its winner atomic (exact: a group no pixel of the view voted into is not read at all; background pixels that alias
+  // the last face mark its group like any other winner); without the map (ids given by the caller) every view can.  Lane v
+  // looks at view v.
   unsigned long long dirty = ~0ull;
   if (touched) {
     const int v = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     bool d = false;
-    if (v < n_views) {
-      const uint8_t *tv = reinterpret_cast<const uint8_t *>(touched + (int64_t)v * tw);
-      d = (tv[blockIdx.x] | tv[4 * tw - 1]) != 0;
-    }
+    if (v < n_views && g * 64 < F) d = reinterpret_cast<const uint8_t *>(touched + (int64_t)v * tw)[g] != 0;
     dirty = __ballot(d);
-    if (last_face_aliases_bg && (int64_t)blockIdx.x == ((F - 1) >> 8)) dirty = ~0ull;  // background pixels vote for face F - 1
+    // (view, group) pairs visited, for gr_raster_stats.chunk_visits: a slot per group, no contention
+    if (visits && v == 0 && dirty) visits[g] += (uint32_t)__popcll(dirty);
   }
   if (f >= F) return;
   // a launch group whose binning overflowed (and every group after it) must not vote: its winners are incomplete.  The
   // caller learns how many views were folded in (gr_raster_status: views_done) and repeats the call for the rest.
   const bool skip = stats != nullptr && stats[4] <= (unsigned long long)group;
   uint32_t c = 0;
+  // up to eight classes: the face's votes of the whole launch group are collected in ONE register, a byte per class (a group has
+  // at most 64 views), and folded into votes[] once at the end -- loads first, then stores.  (`votes[f][label] += 1` view by view
+  // is a chain of dependent read-modify-writes on one array: the compiler must finish each before the next may start, eight
+  // memory round trips per batch of eight views, and the kernel is nothing but latency: round 5, 1.9 us per C2 view.)
+  const bool packed = C <= 8;
+  unsigned long long acc = 0ull;
   // eight views' winners are requested together (the kernel is a stream over winner[views][F]: memory-level
   // parallelism, not arithmetic, sets its speed), then their labels, then the votes in view order
   for (int v0 = 0; v0 < n_views; v0 += 8) {
@@ -114,8 +122,21 @@ __global__ __launch_bounds__(256) void k_vote_labels(uint32_t *__restrict__ winn
       if (key[k] == 0) continue;
       winner[(int64_t)(v0 + k) * F + f] = 0;
       if (skip) continue;
-      if ((int)lab[k] < C) votes[f * C + lab[k]] += 1u;
+      if ((int)lab[k] < C) {
+        if (packed) acc += 1ull << (8u * lab[k]);
+        else votes[f * C + lab[k]] += 1u;
+      }
       ++c;
+    }
+  }
+  if (acc) {
+    uint32_t cur[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cur[k] = k < C ? votes[f * C + k] : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t add = (uint32_t)(acc >> (8 * k)) & 0xFFu;
+      if (k < C && add) votes[f * C + k] = cur[k] + add;
     }
   }
   if (c) counts[f] += c;
@@ -327,7 +348,7 @@ int project_labels(gr_ctx *c, const int32_t *ids, const uint8_t *labels, int n_v
     {
       Timed t(c, s, ST_VOTE);
       hipLaunchKernelGGL(k_vote_labels, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, s, win, labels + v0 * P, nb, F, P, C,
-                         votes, counts, (const unsigned long long *)nullptr, 0, (const uint32_t *)nullptr, 0, 0);
+                         votes, counts, (const unsigned long long *)nullptr, 0, (const uint32_t *)nullptr, 0, (uint32_t *)nullptr);
     }
   }
   GR_HIP(c, hipGetLastError());
@@ -339,7 +360,8 @@ void launch_vote_labels(gr_ctx *c, hipStream_t vs, uint32_t *win, const uint8_t 
                         uint32_t *votes, uint32_t *counts, int group, const uint32_t *touched, int tw, int flags) {
   Timed t(c, vs, ST_VOTE);
   hipLaunchKernelGGL(k_vote_labels, dim3((unsigned)ceil_div(F, 256)), dim3(256), 0, vs, win, labels, nb, F, P, C, votes, counts,
-                     (const unsigned long long *)c->stats, group, touched, tw, (flags & GR_FLAG_NEG1_IS_LAST_FACE) ? 1 : 0);
+                     (const unsigned long long *)c->stats, group, touched, tw, touched ? c->visits : (uint32_t *)nullptr);
+  (void)flags;
 }
 
 }  // namespace grimpl

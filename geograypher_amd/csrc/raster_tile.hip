@@ -413,7 +413,7 @@ __device__ __forceinline__ void store_ids(const unsigned long long *keys, const 
 // Unknown neighbours count as "differs": 1 across a tile edge, 2 outside the image (EDGE tiles only).
 template <int TWL, int TH, int NT, int PAD, bool EDGE>
 __device__ __forceinline__ void fused_winners(const unsigned long long *keys, const BinArgs &a, uint32_t *__restrict__ win,
-                                              int te, int px0, int py0) {
+                                              uint8_t *__restrict__ mark, int te, int px0, int py0) {
   static_assert(TWL == 6 && NT == 256 && TH % 32 == 0, "16 lanes x 4 pixels per tile row, 16 row pairs per pass");
   const int c4 = (te & 15) * 4, rp = te >> 4;  // row pair 0 .. 15 of a pass
 #pragma unroll
@@ -466,7 +466,10 @@ __device__ __forceinline__ void fused_winners(const unsigned long long *keys, co
         } else {
           cand = cand & (c[k][j + 2] != f) & (c[k + 1][j + 2] != f);
         }
-        if (cand) atomicMax(win + ~f, p1 + (uint32_t)(k * a.w + j));
+        if (cand) {
+          atomicMax(win + ~f, p1 + (uint32_t)(k * a.w + j));
+          if (mark) mark[(uint32_t)~f >> 6] = 1;   // the face's group of 64 holds a winner in this view: what the vote pass reads
+        }
       }
     }
   }
@@ -669,9 +672,10 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
   GR_STAMP(5);
   if (FUSE) {
     uint32_t *win = out.winner + slot * out.F;
+    uint8_t *mark = out.touched ? out.touched + slot * out.tb : nullptr;
     const bool edge = px0 + TW > a.w || py0 + TH + 1 > a.h;
-    if (edge) fused_winners<TWL, TH, NT, PAD, true>(keys, a, win, te, px0, py0);
-    else fused_winners<TWL, TH, NT, PAD, false>(keys, a, win, te, px0, py0);
+    if (edge) fused_winners<TWL, TH, NT, PAD, true>(keys, a, win, mark, te, px0, py0);
+    else fused_winners<TWL, TH, NT, PAD, false>(keys, a, win, mark, te, px0, py0);
     if (out.ids) {  // the id image as well (rare): background is where no fragment landed (depth bits 0)
       const int col = te & (TW - 1), gx = px0 + col;
       if (gx < a.w)

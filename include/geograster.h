@@ -81,8 +81,9 @@ typedef struct gr_raster_stats {
   int32_t views_done;   /* leading views of the last call whose outputs / votes are complete    */
   int64_t blocks;       /* 64-face blocks that passed the per-view frustum cull, summed over views (single-pass binning):
                            what a culled pass has to read of the mesh is blocks x 64 x 36 B + 16 B per block tested   */
-  int64_t chunk_visits; /* fused aggregation: 256-face chunks of caller ids the vote pass visits, summed over views
-                           (each visit reads and resets 256 winners: 256 x 8 B of k_vote_labels' algorithmic bytes)   */
+  int64_t chunk_visits; /* fused aggregation: (view, group of 64 consecutive caller face ids) pairs the vote passes visited, summed over
+                           the call (a group is visited in the views whose tile pass produced a winner in it; each visit reads and
+                           resets 64 winners: 64 x 8 B of k_vote_labels' algorithmic bytes)                               */
   int64_t rebinned_groups; /* times the last call binned its FIRST launch group again: a call for a mesh and image size the
                            library has learned nothing about reads that group's counts before its tile kernel runs (one host
                            round trip, once per mesh and image size) and, if a tile outgrew its slots, a face needs 48-byte
