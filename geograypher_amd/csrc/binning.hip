@@ -716,9 +716,9 @@ __device__ __forceinline__ FaceForm face_form(const int4 p0, const int4 p1, cons
   FaceForm ff;
   const int X0 = p0.x, Y0 = p0.y, X1 = p0.z, Y1 = p0.w, X2 = p1.x, Y2 = p1.y;
   const int dx0 = X1 - X0, dy0 = Y1 - Y0, dx1 = X2 - X1, dy1 = Y2 - Y1, dx2 = X0 - X2, dy2 = Y0 - Y2;
-  const int t0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;  // R3 top-left rule as a bias
-  const int t1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
-  const int t2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
+  const int t0 = ((dy0 < 0) || (dy0 == 0 && dx0 < 0)) ? 0 : -1;  // R3 tie rule as a bias: left and bottom edges own their pixels
+  const int t1 = ((dy1 < 0) || (dy1 == 0 && dx1 < 0)) ? 0 : -1;
+  const int t2 = ((dy2 < 0) || (dy2 == 0 && dx2 < 0)) ? 0 : -1;
   const int ext = max(imax3(X0, X1, X2) - imin3(X0, X1, X2), imax3(Y0, Y1, Y2) - imin3(Y0, Y1, Y2));
   ff.fast = ext < GR_FAST_EXT;
   const int a0 = -dy0, a1 = -dy1, a2 = -dy2;

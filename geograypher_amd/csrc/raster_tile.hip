@@ -241,7 +241,7 @@ __device__ __forceinline__ void raster_item(unsigned long long *keys, const Entr
 // holds what R2 - R4 produced and nothing derived from it: the three snapped vertices as 16-bit offsets from the centre of the
 // tile's centre pixel (positive orientation, vertex 0 first), 1/z at vertex 0 and its gradients, ~face, and the box.  Here the lane
 // forms the three edge functions of R3 at the box's first pixel, exactly, in int32 (|d| < 24 000, |P - V| < 41 000: products
-// below 2^30) -- E_k = dx_k (P_y - Y_k) - dy_k (P_x - X_k) + t_k with the top-left rule as the bias t_k, covered <=> all E_k >= 0 --
+// below 2^30) -- E_k = dx_k (P_y - Y_k) - dy_k (P_x - X_k) + t_k with the tie rule of R3 (left and bottom edges own their pixels) as the bias t_k, covered <=> all E_k >= 0 --
 // and point-samples the sixteen pixel centres (three adds per pixel) with the same 1/z expression as raster_item, op for op (R4):
 // identical coverage and identical depth bits, whichever list a face was put in.  Rows and columns outside the tile can only come
 // from a torn record of an overflowed pass (the view is repeated): they are masked, never written.
@@ -257,9 +257,9 @@ __device__ __forceinline__ void micro_item(unsigned long long *keys, const int4 
   const int yc0 = ((box >> 8) & 63) - TH / 2;                              // centred first row
   const int nrows = valid ? min((box >> 14) & 7, 4) : 0;
   const int dx0 = X1 - X0, dy0 = Y1 - Y0, dx1 = X2 - X1, dy1 = Y2 - Y1, dx2 = X0 - X2, dy2 = Y0 - Y2;
-  const int t0 = ((dy0 < 0) || (dy0 == 0 && dx0 > 0)) ? 0 : -1;           // R3 top-left rule as a bias
-  const int t1 = ((dy1 < 0) || (dy1 == 0 && dx1 > 0)) ? 0 : -1;
-  const int t2 = ((dy2 < 0) || (dy2 == 0 && dx2 > 0)) ? 0 : -1;
+  const int t0 = ((dy0 < 0) || (dy0 == 0 && dx0 < 0)) ? 0 : -1;           // R3 tie rule as a bias (left and bottom edges own)
+  const int t1 = ((dy1 < 0) || (dy1 == 0 && dx1 < 0)) ? 0 : -1;
+  const int t2 = ((dy2 < 0) || (dy2 == 0 && dx2 < 0)) ? 0 : -1;
   const int Px = xc0 * 256, Py = yc0 * 256;                                // the box's first pixel centre, same frame as the vertices
   int r0 = __mul24(dx0, Py - Y0) - __mul24(dy0, Px - X0) + t0;             // edge values at that pixel
   int r1 = __mul24(dx1, Py - Y1) - __mul24(dy1, Px - X1) + t1;

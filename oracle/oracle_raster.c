@@ -232,10 +232,10 @@ static inline int64_t orc_edge(const orc_tri *t, int k, int64_t Px, int64_t Py) 
   int64_t dx = (int64_t)t->X[b] - t->X[a], dy = (int64_t)t->Y[b] - t->Y[a];
   return dx * (Py - t->Y[a]) - dy * (Px - t->X[a]);
 }
-static inline int orc_owns(const orc_tri *t, int k) { /* top-left rule, y down */
+static inline int orc_owns(const orc_tri *t, int k) { /* left and BOTTOM edges own their pixels (rows top-down): the tie convention of Mesa's GL, DESIGN.md R3 */
   int a = k, b = (k + 1) % 3;
   int32_t dx = t->X[b] - t->X[a], dy = t->Y[b] - t->Y[a];
-  return (dy < 0) || (dy == 0 && dx > 0);
+  return (dy < 0) || (dy == 0 && dx < 0);
 }
 
 /* R4: fragment depth key */

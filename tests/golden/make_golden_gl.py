@@ -14,6 +14,8 @@ Fixtures (all ids int32, -1 = background, rows top-down like the reference's scr
                           both implementations
   reference_gl_clip.npz   the near-plane / guard-band scenes of tests/test_hip_parity.py::test_clipping_near_plane_and_
                           guard_band with the clipping range VTK's ResetCameraClippingRange would pick
+  reference_gl_c2_full.npz  ONE BASELINE-size view: C2 (1 201 250 faces), view 23, 4000 x 3000, llvmpipe -- the whole id image,
+                          run-length encoded (rle_encode below: 1 MB)
 --full-size additionally renders C2 / C5 / forest views at full size and LOGS the comparison with the oracle
 (profiles/r05_gl_pin.log); nothing of that is stored.
 """
@@ -35,6 +37,20 @@ from gl_raster import GLRasterizer  # noqa: E402
 
 from geograypher_amd.utils import synthetic  # noqa: E402
 from tests.gl_pin_scenes import clip_scenes, vtk_ranges  # noqa: E402
+
+
+def rle_encode(ids):
+    """(h, w) int32 ids -> run lengths (uint16, runs longer than 65535 split) and the id of every run as the difference to the
+    run before (int32): a face-id image is piecewise constant along its rows."""
+    flat = np.asarray(ids, dtype=np.int64).reshape(-1)
+    start = np.flatnonzero(np.diff(flat, prepend=flat[0] - 1))
+    lengths = np.diff(np.append(start, flat.size))
+    reps = (lengths + 65534) // 65535                       # pieces of at most 65535 per run
+    vals = np.repeat(flat[start], reps)
+    piece = np.full(vals.size, 65535, dtype=np.int64)
+    last = np.cumsum(reps) - 1
+    piece[last] = lengths - (reps - 1) * 65535
+    return piece.astype(np.uint16), np.diff(vals, prepend=0).astype(np.int32)
 
 
 def info_array(glr):
@@ -100,7 +116,14 @@ def main():
         out[f"{scene}_records"] = crecs
         out[f"{scene}_far"] = np.array([r[1] for r in ranges])
     np.savez_compressed(HERE / "reference_gl_clip.npz", **out)
-    for f in ("reference_gl_c1.npz", "reference_gl_scaled.npz", "reference_gl_clip.npz"):
+    # ---- one BASELINE-size view: C2 view 23 at 4000 x 3000, llvmpipe (the reference Dockerfile's GL) ----------------------------
+    glr = backends["llvmpipe"]
+    glr.upload_mesh(tpoints, tfaces)
+    rec = synthetic.config2_cameras(50).get_raster_records(1.0, near=1.0)[23]
+    run_len, val_delta = rle_encode(glr.render_ids(rec, 3000, 4000))
+    np.savez_compressed(HERE / "reference_gl_c2_full.npz", run_len=run_len, val_delta=val_delta, record=rec, view=np.int32(23),
+                        h=np.int32(3000), w=np.int32(4000), llvmpipe_info=info_array(glr))
+    for f in ("reference_gl_c1.npz", "reference_gl_scaled.npz", "reference_gl_clip.npz", "reference_gl_c2_full.npz"):
         print(f, (HERE / f).stat().st_size // 1024, "KiB")
 
     if args.full_size:

@@ -127,7 +127,7 @@ def _spec_python(verts, faces, cam, h, w):
                     (xa, ya), (xb, yb) = P[k], P[(k + 1) % 3]
                     dx, dy = xb - xa, yb - ya
                     e = dx * (py - ya) - dy * (px - xa)
-                    owns = dy < 0 or (dy == 0 and dx > 0)
+                    owns = dy < 0 or (dy == 0 and dx < 0)
                     if not (e > 0 or (e == 0 and owns)):
                         ok = False
                 if not ok:
