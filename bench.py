@@ -696,6 +696,12 @@ def run(args, rig=None) -> int:
         cpu_baseline["single_thread"] = {"value": round(P / t1 / 1e6, 2), "unit": "Mpix/s", "cores": 1,
                                          "sample": f"1 C2 view at {W}x{H} in {t1:.2f} s"}
         cpu_baseline["host_cores"] = cores
+        # the real reference's rasterizer, for scale: a quoted constant with its source, NOT measured in this run (and not on this host)
+        cpu_baseline["reference_gl"] = {
+            "value": 22.0, "unit": "Mpix/s", "cores": 8, "kind": "mesa-llvmpipe", "where": "build container",
+            "sample": "Mesa 23.2.1 llvmpipe (the software OpenGL of the reference's Dockerfile:6-13) draws the id image of one C2 view "
+                      "(1 201 250 faces, 4000x3000) in 0.5-0.6 s on 8 cores: profiles/r05_gl_pin.log, tests/golden/gl_raster.py; the "
+                      "draw alone, before VTK's per-view mesh upload, read-back and decode (meshes.py:1776-1836)"}
         cpu_baseline["cgroup_cpu_quota_cores"] = quota
         try:
             cpu_baseline["affinity_cores"] = len(os.sched_getaffinity(0))

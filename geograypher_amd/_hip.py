@@ -372,6 +372,7 @@ class HipRaster:
         self.last_stats = {}
         self.n_faces = 0
         self.n_verts = 0
+        self.vertex_order = "r1"
 
     # -- plumbing ------------------------------------------------------------------------------------------------
     def close(self):
@@ -414,6 +415,15 @@ class HipRaster:
         """Tuning knobs of include/geograster.h (GR_OPT_*): 2 tile height log2, 3 views per launch group, 6 single-pass
         slots per tile (0 = exact binning), 7 variant bits (see GR_OPT_VARIANT in the header)."""
         self._check(self.lib.gr_set_option(self._ctx, int(key), int(value)), "gr_set_option")
+
+    def set_vertex_order(self, name: str):
+        """"r1" (default): rule R1 of DESIGN.md; "gl": the perspective divide, viewport transform and snap in an OpenGL
+        pipeline's order of operations (GR_OPT_VERTEX_ORDER: what Mesa's llvmpipe executes; the principal point must be the
+        window centre).  The only option results depend on."""
+        if name not in ("r1", "gl"):
+            raise ValueError(f"vertex_order must be 'r1' or 'gl', got {name!r}")
+        self.set_option(10, 1 if name == "gl" else 0)
+        self.vertex_order = name
 
     def stage_times(self) -> dict:
         st = StageTimes()

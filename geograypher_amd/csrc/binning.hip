@@ -16,8 +16,35 @@ struct Vtx {
   bool front, finite;  // q_z > near; camera-space point finite (R7: which invalid faces are clipped instead of dropped)
 };
 
+// the second half of R1: perspective divide, principal point, snap to 1/256 px -- in the rule-set's own order of operations, or
+// (gl_order, GR_OPT_VERTEX_ORDER; oracle_raster.c R1-GL) in an OpenGL pipeline's: clip = P q, ndc = clip * (1 / w),
+// window = fma(ndc, size / 2, size / 2), fixed = rint(256 (window - 0.5)), rows bottom-up -- op for op what Mesa's llvmpipe
+// executes (95 % of the pixels on which R1 and llvmpipe disagree are vertices that land on the neighbouring step under that order)
+__device__ __forceinline__ bool snap_vertex(float qx, float qy, float iz, const float *__restrict__ cam, int gl_order, int h, int w,
+                                            int &X, int &Y) {
+  if (!gl_order) {
+    const float fx = cam[12] * qx;
+    const float fy = cam[12] * qy;
+    const float sx = cam[13] + fx * iz;
+    const float sy = cam[14] + fy * iz;
+    X = (int)floorf(sx * 256.0f + 0.5f);
+    Y = (int)floorf(sy * 256.0f + 0.5f);
+    return (fabsf(sx) < 16384.0f) && (fabsf(sy) < 16384.0f);
+  }
+  const float two_f = 2.0f * cam[12];
+  const float px = two_f / (float)w, py = -(two_f / (float)h);   // correctly rounded divisions (-fhip-fp32-correctly-rounded-divide-sqrt)
+  const float hw = 0.5f * (float)w, hh = 0.5f * (float)h;
+  const float xc = px * qx, yc = py * qy;
+  const float xn = xc * iz, yn = yc * iz;
+  const float xw = __builtin_fmaf(xn, hw, hw), yw = __builtin_fmaf(yn, hh, hh);   // the ONE fused operation of the path, on purpose
+  const float fx = (xw - 0.5f) * 256.0f, fy = (yw - 0.5f) * 256.0f;
+  X = (int)rintf(fx) + 128;                    // v_rndne_f32: round half to even, like lrintf
+  Y = 256 * h - 128 - (int)rintf(fy);
+  return (fabsf(xw) < 16384.0f) && (fabsf(yw) < 16384.0f);
+}
+
 // R1 -- vertex transform, fp32, each operation individually rounded
-__device__ __forceinline__ Vtx project_vertex(const float *__restrict__ p, const float *__restrict__ cam) {
+__device__ __forceinline__ Vtx project_vertex(const float *__restrict__ p, const float *__restrict__ cam, int gl_order, int h, int w) {
   Vtx v;
   const float dx = p[0] - cam[9];
   const float dy = p[1] - cam[10];
@@ -33,13 +60,8 @@ __device__ __forceinline__ Vtx project_vertex(const float *__restrict__ p, const
   v.front = v.valid;
   v.finite = isfinite(qx) && isfinite(qy) && isfinite(qz);
   const float iz = 1.0f / qz;  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
-  const float fx = cam[12] * qx;
-  const float fy = cam[12] * qy;
-  const float sx = cam[13] + fx * iz;
-  const float sy = cam[14] + fy * iz;
-  v.valid = v.valid && (fabsf(sx) < 16384.0f) && (fabsf(sy) < 16384.0f);
-  v.X = (int)floorf(sx * 256.0f + 0.5f);
-  v.Y = (int)floorf(sy * 256.0f + 0.5f);
+  const bool inside = snap_vertex(qx, qy, iz, cam, gl_order, h, w, v.X, v.Y);
+  v.valid = v.valid && inside;
   v.iz = iz;
   return v;
 }
@@ -372,7 +394,7 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a) {
 #endif
     {
       const float p0[3] = {vx, vy, vz};
-      if (lane < nv) vt[lane] = pack_vtx(project_vertex(p0, cam));
+      if (lane < nv) vt[lane] = pack_vtx(project_vertex(p0, cam, a.gl_order, a.h, a.w));
     }
     if (nv > 64) {  // a face soup: two more rounds
       // the address is made from an opaque copy of the lane number: left to itself the compiler keeps `a.bvert + 12 * (lane + 64)`
@@ -382,7 +404,7 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a) {
       uint32_t l = lane;
       asm volatile("" : "+v"(l));
       const float *bvi = a.bvert + ((int64_t)blk_cur * GR_BLOCK_VERTS + l) * 3;
-      for (int i = lane + 64; i < nv; i += 64) vt[i] = pack_vtx(project_vertex(bvi += 3 * 64, cam));
+      for (int i = lane + 64; i < nv; i += 64) vt[i] = pack_vtx(project_vertex(bvi += 3 * 64, cam, a.gl_order, a.h, a.w));
     }
     const int4 q0 = vt[bi & 255u], q1 = vt[(bi >> 8) & 255u], q2 = vt[(bi >> 16) & 255u];
     if (f < a.F) keep = face_setup_tail(a, face_id, unpack_vtx(q0), unpack_vtx(q1), unpack_vtx(q2), r0, r1, r2, tx0, tx1, ty0, ty1, clip_me);
@@ -1044,13 +1066,10 @@ __global__ __launch_bounds__(64) void k_clip_faces(const float *__restrict__ cam
       const float qx = (float)px[cur][e][tid], qy = (float)py[cur][e][tid], qz = (float)pz[cur][e][tid];
       if (!(qz > 0.0f)) { bad = true; break; }
       const float iz = 1.0f / qz;
-      const float fx = fe * qx;
-      const float fy = fe * qy;
-      const float sx = cxp + fx * iz;
-      const float sy = cyp + fy * iz;
-      if (!(fabsf(sx) < 16384.0f) || !(fabsf(sy) < 16384.0f)) { bad = true; break; }
-      sX[e][tid] = (int)floorf(sx * 256.0f + 0.5f);
-      sY[e][tid] = (int)floorf(sy * 256.0f + 0.5f);
+      int Xs, Ys;
+      if (!snap_vertex(qx, qy, iz, cam, a.gl_order, a.h, a.w, Xs, Ys)) { bad = true; break; }
+      sX[e][tid] = Xs;
+      sY[e][tid] = Ys;
       sZ[e][tid] = iz;
     }
     if (bad) continue;

@@ -411,6 +411,9 @@ int gr_set_option(gr_ctx *c, int key, int value) {
       c->opt_direct_cap = value; c->direct_ok = true; c->n_learned = 0; c->share_learned = false; return GR_OK;
     case GR_OPT_SHARE_LEARNED:
       c->share_learned = value != 0; return GR_OK;
+    case GR_OPT_VERTEX_ORDER:
+      if (value != 0 && value != 1) return fail(c, GR_EINVAL, "vertex order must be 0 (rule R1) or 1 (OpenGL's order of operations)");
+      c->opt_gl_order = value; return GR_OK;
     case GR_OPT_DIRECT_BUDGET_MB:
       if (value < 1) return fail(c, GR_EINVAL, "entry-memory budget must be at least 1 MiB");
       c->opt_budget_mb = value; return GR_OK;

@@ -71,6 +71,7 @@ struct BinArgs {
   int count_micro;       // 1: K1 counts the view's micro faces (pixel box at most 4 x 4) for gr_raster_stats: calls that can still learn micro lists
   int micro;             // 1: (face, tile) pairs of at most 4 x 4 pixels go to the tile's second list (K1 / raster_one_tile); needs ent40
   int var;               // variant bits (GR_OPT_VARIANT, include/geograster.h)
+  int gl_order;          // GR_OPT_VERTEX_ORDER: 1 = the second half of the vertex stage in an OpenGL pipeline's order of operations
 #ifdef GR_STAMPS
   unsigned long long *stamps;  // diagnostic build: [16] cycles per tile-kernel phase, summed over waves (raster_tile.hip)
 #endif
@@ -136,6 +137,7 @@ struct gr_ctx {
   int opt_batch = GR_MAX_BATCH;
   int opt_dbg = 0;
   int opt_var = 0;
+  int opt_gl_order = 0;  // GR_OPT_VERTEX_ORDER
   int opt_lds_pad = 0;   // extra dynamic LDS bytes per tile workgroup (occupancy experiments, GR_OPT_DEBUG_LDS)
   int opt_direct_cap = 512;  // single-pass binning: entry slots per tile (0 = always use the exact two-pass path)
   struct Learned { uint64_t mesh; int T, cap; bool full; bool micro = false; };
@@ -320,7 +322,7 @@ inline BinArgs make_args(gr_ctx *c, int h, int w, int slot0) {
   a.clip = c->clip + slot0 * c->F;
   a.twl = GR_TILE_LOG2; a.thl = c->opt_thl;
   a.TX = (w + (1 << a.twl) - 1) >> a.twl; a.TY = (h + (1 << a.thl) - 1) >> a.thl; a.T = a.TX * a.TY; a.Tcap = c->Tcap; a.clg = c->clg;
-  a.h = h; a.w = w; a.dbg = c->opt_dbg; a.var = c->opt_var;
+  a.h = h; a.w = w; a.dbg = c->opt_dbg; a.var = c->opt_var; a.gl_order = c->opt_gl_order;
   a.cap_tile = c->cur_cap;          // the call's snapshot: every launch group, bin pass and tile pass alike
   a.ent40 = c->cur_ent40 ? 1 : 0;
   a.micro = c->cur_micro ? 1 : 0;   // resolved once per call (resolve_binning)

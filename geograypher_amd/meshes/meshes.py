@@ -124,6 +124,7 @@ class TexturedPhotogrammetryMesh:
         backend=None,
         neg1_is_last_face: bool = True,
         devices: typing.Optional[typing.Sequence[int]] = None,
+        vertex_order: str = "r1",
     ):
         """A textured mesh that renders to / aggregates from camera views on an MI355X.
 
@@ -141,6 +142,12 @@ class TexturedPhotogrammetryMesh:
                 (entrypoints/aggregate_images.py:146-184) uses the whole node.  Everything else runs on `devices[0]`.  The same
                 index may appear more than once (contexts are independent).  Default None: one device, `device`.
             backend: test hook -- an object with the `HipRaster` interface (or a list of them: one per entry of `devices`).
+            vertex_order: "r1" (default) -- the rule-set's own vertex stage --, or "gl": perspective divide,
+                viewport transform and sub-pixel snap in the order of operations of an OpenGL pipeline, op for op what Mesa's
+                llvmpipe (the software GL of the reference's Dockerfile) executes behind the camera transform
+                (`GR_OPT_VERTEX_ORDER`).  The two put a few per cent of a view's vertices on neighbouring 1/256 px steps, which
+                decides 0.004 % of its pixels; with "gl" a C2 view differs from a real llvmpipe render on 14 of 12 000 000 pixels
+                (`profiles/r06_gl_residue.txt`).  Needs the pyvista camera's principal point (`principal_point="center"`).
             neg1_is_last_face: reproduce meshes.py:1998-2001, where background pixels (-1) index the LAST face
                 during projection.  True matches the reference's aggregated textures on every face.
         """
@@ -191,6 +198,9 @@ class TexturedPhotogrammetryMesh:
         self._backend = backend
         self._backends = backends
         self._uploaded = {}   # id(backend) -> (points, faces) it holds
+        if vertex_order not in ("r1", "gl"):
+            raise ValueError(f"vertex_order must be 'r1' or 'gl', got {vertex_order!r}")
+        self.vertex_order = vertex_order
 
         self.logger.info("Loading texture")
         if isinstance(IDs_to_labels, (str, Path)):
@@ -213,7 +223,14 @@ class TexturedPhotogrammetryMesh:
             from geograypher_amd._hip import HipRaster
 
             self._backend = HipRaster(self._device_index)  # raises when the extension or the GPU is missing
+        self._apply_vertex_order(self._backend)
         return self._backend
+
+    def _apply_vertex_order(self, backend):
+        if getattr(backend, "vertex_order", "r1") != self.vertex_order:
+            if not hasattr(backend, "set_vertex_order"):
+                raise NotImplementedError(f"backend {type(backend).__name__} has no vertex_order switch")
+            backend.set_vertex_order(self.vertex_order)
 
     @property
     def backends(self):
@@ -225,6 +242,8 @@ class TexturedPhotogrammetryMesh:
                 from geograypher_amd._hip import HipRaster
 
                 self._backends = [self.backend] + [HipRaster(d) for d in self._devices[1:]]
+        for b in self._backends:
+            self._apply_vertex_order(b)
         return self._backends
 
     # -- texture (reference: meshes.py:325-531) ------------------------------------------------------------------
@@ -365,6 +384,8 @@ class TexturedPhotogrammetryMesh:
         elif not isinstance(mesh, LocalMesh):
             pts, fcs = _parse_mesh(mesh)
             mesh = LocalMesh(np.asarray(pts, dtype=np.float64), fcs)
+        if self.vertex_order == "gl" and principal_point != "center":
+            raise ValueError('vertex_order="gl" restates an OpenGL viewport: it needs principal_point="center" (the pyvista camera)')
         self._ensure_uploaded(mesh, backend)
         if near is None:
             near = vtk_like_near_planes(

@@ -104,7 +104,8 @@ const char *gr_last_error(const gr_ctx *ctx);
  * timing costs the call 0.2 % this way, where events recorded between the kernels cost it 1.65 % (4.3 % on small images). */
 int gr_set_profiling(gr_ctx *ctx, int enabled);
 
-/* Tuning knobs (results never depend on them; tests run every setting against the oracle). */
+/* Tuning knobs (results never depend on them -- GR_OPT_VERTEX_ORDER excepted, which selects between two documented rule-sets --;
+ * tests run every setting against the oracle). */
 enum {
   GR_OPT_TILE_H_LOG2 = 2,   /* tile height: 5 (64x32, default) or 6 (64x64)                                  */
   GR_OPT_BATCH = 3,         /* views per launch group, 1..64 (default 64)                                    */
@@ -143,6 +144,17 @@ enum {
                                views of 4000 x 3000 at the default 512 slots --; a launch group shrinks until it fits, and
                                an image whose learned slots would not fit even ONE view bins exactly instead (remembered
                                per mesh and image size like the slots themselves; other image sizes are not affected)   */
+  GR_OPT_VERTEX_ORDER = 10, /* 0 (default): rule R1 of DESIGN.md -- s = c + (f q) (1 / q_z), X = floor(256 s + 0.5).  1: the same
+                               perspective divide, viewport transform and snap in the ORDER OF OPERATIONS of an OpenGL pipeline, as
+                               Mesa's llvmpipe -- the software GL of the reference's Dockerfile:6-13 -- executes them behind the camera
+                               transform: clip = P q with P = (2 f / w, -2 f / h), ndc = clip * (1 / q_z), window = fma(ndc, size / 2,
+                               size / 2), fixed = rint(256 (window - 0.5)), rows bottom-up.  The two orders put 3-12 % of the vertices
+                               of a view on neighbouring 1/256 px steps, which decides 0.004 % of its pixels (95 % of the pixels on
+                               which R1 and llvmpipe differ; the rest are faces llvmpipe clips at the image border:
+                               profiles/r06_gl_residue.txt).  With 1 the library differs from llvmpipe on 14 of the 12 000 000 pixels
+                               of a C2 view.  The principal point must be the window centre (cxp = w / 2, cyp = h / 2: the pyvista
+                               camera of cameras.py:446-477); results depend on this option by design -- the oracle has the same
+                               switch (oracle_raster.c R1-GL) and the parity tests run both                              */
   GR_OPT_DEBUG_LDS = 98,    /* extra dynamic LDS bytes per tile workgroup: lowers occupancy (timing experiments)     */
   GR_OPT_DEBUG = 99         /* test hook: 512 = entry slots and row counts are poisoned with 0xFF before every launch group is
                                binned (results stay right: tests/test_overflow_protocol.py)                      */

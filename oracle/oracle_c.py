@@ -35,6 +35,8 @@ def lib():
         f64 = ctypes.c_double
         L.orc_envelope.restype = i32
         L.orc_envelope.argtypes = [vp, vp, i64, vp, i32, i32, f64, f64, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.orc_set_vertex_order.restype = None
+        L.orc_set_vertex_order.argtypes = [i32]
         L.orc_raster_float.restype = i32
         L.orc_raster_float.argtypes = [vp, vp, i64, vp, i32, i32, vp, vp]
         _lib = L
@@ -45,8 +47,23 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def raster(verts, faces, cam, h, w, want_depth=False, spec=False):
-    """One view: (h,w) int32 face ids [, (h,w) float32 depth].  cam: 16-float record (include/geograster.h)."""
+def _vertex_order(name):
+    if name not in ("r1", "gl"):
+        raise ValueError(f"vertex_order must be 'r1' or 'gl', got {name!r}")
+    lib().orc_set_vertex_order(1 if name == "gl" else 0)
+
+
+def raster(verts, faces, cam, h, w, want_depth=False, spec=False, vertex_order="r1"):
+    """One view: (h,w) int32 face ids [, (h,w) float32 depth].  cam: 16-float record (include/geograster.h).
+    vertex_order="gl": the second half of the vertex stage in an OpenGL pipeline's order of operations (oracle_raster.c R1-GL)."""
+    _vertex_order(vertex_order)
+    try:
+        return _raster(verts, faces, cam, h, w, want_depth, spec)
+    finally:
+        lib().orc_set_vertex_order(0)
+
+
+def _raster(verts, faces, cam, h, w, want_depth, spec):
     verts = np.ascontiguousarray(verts, dtype=np.float32)
     faces = np.ascontiguousarray(faces, dtype=np.int32)
     cam = np.ascontiguousarray(cam, dtype=np.float32).reshape(16)

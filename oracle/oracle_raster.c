@@ -51,6 +51,44 @@ typedef struct {
  * cam[0..8]  R = cam_to_world rotation (row-major), cam[9..11] t = camera position,
  * cam[12] f_eff (pixels), cam[13] cxp, cam[14] cyp (principal point in pixels of the rendered image),
  * cam[15] near.   q = R^T (p - t); camera frame +X right, +Y down, +Z forward (cameras.py:446-477). */
+/* R1-GL (round 6, opt-in: orc_set_vertex_order(1)): the second half of the vertex stage in the ORDER OF OPERATIONS of an OpenGL
+ * pipeline, as Mesa 23.2's llvmpipe executes it behind a vertex shader that multiplies the camera-space point with the
+ * projection's diagonal (tests/golden/gl_raster.py; src/gallium/auxiliary/draw/draw_llvm.c generate_viewport;
+ * src/gallium/drivers/llvmpipe/lp_setup_tri.c):  clip = (P_x q_x, P_y q_y, ., q_z) with P_x = 2 f / w, P_y = -2 f / h;
+ * rw = 1 / q_z;  ndc = clip * rw;  win = fma(ndc, size / 2, size / 2) (llvm.fmuladd: fused on every x86 host with FMA3);
+ * fixed = lrintf(256 (win - 0.5)) (round half to even), rows bottom-up.  95 % of the pixels on which rule R1 and llvmpipe
+ * disagree are vertices that land on the neighbouring 1/256 px step under this order (profiles/r06_gl_residue.txt).  The
+ * principal point must be the window centre (the pyvista camera's, cameras.py:446-477). */
+static int orc_vertex_order = 0;
+void orc_set_vertex_order(int gl_order) { orc_vertex_order = gl_order; }
+static int orc_h = 0, orc_w = 0;   /* image size of the running raster call (the GL order needs the viewport) */
+
+static int orc_snap(float qx, float qy, float qz, const float *cam, int32_t *X, int32_t *Y, float *izp) {
+  float iz = 1.0f / qz;
+  *izp = iz;
+  if (!orc_vertex_order) {
+    float fx = cam[12] * qx;
+    float fy = cam[12] * qy;
+    float sx = cam[13] + fx * iz;
+    float sy = cam[14] + fy * iz;
+    if (!(fabsf(sx) < ORC_GUARD) || !(fabsf(sy) < ORC_GUARD)) return 0;
+    *X = (int32_t)floorf(sx * 256.0f + 0.5f);
+    *Y = (int32_t)floorf(sy * 256.0f + 0.5f);
+    return 1;
+  }
+  const float two_f = 2.0f * cam[12];
+  const float px = two_f / (float)orc_w, py = -(two_f / (float)orc_h);
+  const float hw = 0.5f * (float)orc_w, hh = 0.5f * (float)orc_h;
+  float xc = px * qx, yc = py * qy;
+  float xn = xc * iz, yn = yc * iz;
+  float xw = fmaf(xn, hw, hw), yw = fmaf(yn, hh, hh);
+  if (!(fabsf(xw) < ORC_GUARD) || !(fabsf(yw) < ORC_GUARD)) return 0;
+  float fx = (xw - 0.5f) * 256.0f, fy = (yw - 0.5f) * 256.0f;
+  *X = (int32_t)rintf(fx) + ORC_HALF;                      /* rintf: round half to even (default rounding mode), like lrintf / cvtps2dq */
+  *Y = 256 * orc_h - ORC_HALF - (int32_t)rintf(fy);
+  return 1;
+}
+
 static orc_vtx orc_project(const float *p, const float *cam) {
   orc_vtx v;
   float dx = p[0] - cam[9];
@@ -66,14 +104,8 @@ static orc_vtx orc_project(const float *p, const float *cam) {
   v.valid = (qz > cam[15]) ? 1 : 0; /* false for NaN */
   v.X = 0; v.Y = 0; v.iz = 0.0f;
   if (!v.valid) return v;
-  float iz = 1.0f / qz;
-  float fx = cam[12] * qx;
-  float fy = cam[12] * qy;
-  float sx = cam[13] + fx * iz;
-  float sy = cam[14] + fy * iz;
-  if (!(fabsf(sx) < ORC_GUARD) || !(fabsf(sy) < ORC_GUARD)) { v.valid = 0; return v; }
-  v.X = (int32_t)floorf(sx * 256.0f + 0.5f);
-  v.Y = (int32_t)floorf(sy * 256.0f + 0.5f);
+  float iz;
+  if (!orc_snap(qx, qy, qz, cam, &v.X, &v.Y, &iz)) { v.valid = 0; v.X = 0; v.Y = 0; return v; }
   v.iz = iz;
   return v;
 }
@@ -198,14 +230,8 @@ static int orc_clip_face(const float *verts, const int32_t *face, const float *c
   for (int i = 0; i < n; ++i) {
     float qx = (float)a[i].x, qy = (float)a[i].y, qz = (float)a[i].z;
     if (!(qz > 0.0f)) return 0;
-    float iz = 1.0f / qz;
-    float fx = fe * qx;
-    float fy = fe * qy;
-    float sx = cxp + fx * iz;
-    float sy = cyp + fy * iz;
-    if (!(fabsf(sx) < ORC_GUARD) || !(fabsf(sy) < ORC_GUARD)) return 0;
-    out[i].X = (int32_t)floorf(sx * 256.0f + 0.5f);
-    out[i].Y = (int32_t)floorf(sy * 256.0f + 0.5f);
+    float iz;
+    if (!orc_snap(qx, qy, qz, cam, &out[i].X, &out[i].Y, &iz)) return 0;
     out[i].iz = iz;
     out[i].valid = 1;
   }
@@ -271,6 +297,7 @@ static void orc_finish(const int32_t *zbuf, const int32_t *ids, float *depth, in
 int orc_raster_spec(const float *verts, const int32_t *faces, int64_t V, int64_t F, const float *cam, int h, int w,
                     int32_t *ids, float *depth, int32_t *zbuf) {
   (void)V;
+  orc_h = h; orc_w = w;
   int64_t n = (int64_t)h * w;
   for (int64_t p = 0; p < n; ++p) { ids[p] = -1; zbuf[p] = 0; }
   for (int64_t f = 0; f < F; ++f) {
@@ -301,6 +328,7 @@ int orc_raster_spec(const float *verts, const int32_t *faces, int64_t V, int64_t
 int orc_raster_fast(const float *verts, const int32_t *faces, int64_t V, int64_t F, const float *cam, int h, int w,
                     int32_t *ids, float *depth, int32_t *zbuf) {
   (void)V;
+  orc_h = h; orc_w = w;
   int64_t n = (int64_t)h * w;
   for (int64_t p = 0; p < n; ++p) { ids[p] = -1; zbuf[p] = 0; }
   for (int64_t f = 0; f < F; ++f) {
@@ -339,6 +367,7 @@ int orc_raster_views(const float *verts, const int32_t *faces, int64_t V, int64_
                      int h, int w, int32_t *ids, int n_threads) {
   int64_t n = (int64_t)h * w;
   int used = 1;
+  orc_h = h; orc_w = w;
 #ifdef _OPENMP
   if (n_threads < 1) n_threads = 1;
   used = n_threads;

@@ -17,6 +17,12 @@ class OracleBackend:
         self.faces = None
         self.n_faces = 0
         self.uploads = 0
+        self.vertex_order = "r1"
+
+    def set_vertex_order(self, name):
+        if name not in ("r1", "gl"):
+            raise ValueError(name)
+        self.vertex_order = name
 
     def _dev(self, array, dtype):
         if isinstance(array, torch.Tensor):
@@ -33,7 +39,10 @@ class OracleBackend:
 
     def raster_face_ids(self, cams, h, w, out=None, want_depth=False, check=True):
         cams = np.asarray(cams, dtype=np.float32).reshape(-1, 16)
-        ids, _ = oracle_c.raster_views(self.verts, self.faces, cams, h, w, n_threads=1)
+        if self.vertex_order == "gl":
+            ids = np.stack([oracle_c.raster(self.verts, self.faces, cams[v], h, w, vertex_order="gl") for v in range(cams.shape[0])])
+        else:
+            ids, _ = oracle_c.raster_views(self.verts, self.faces, cams, h, w, n_threads=1)
         return torch.from_numpy(ids)
 
     def gather_texture(self, ids, face_texture):

@@ -160,6 +160,42 @@ def _run_c2_full_size(render):
           f"implementation-independent share {indep:.4f}")
 
 
+def _run_gl_vertex_order(render_gl):
+    """vertex_order="gl" (GR_OPT_VERTEX_ORDER, oracle_raster.c R1-GL): with the perspective divide, the viewport transform and the
+    snap in llvmpipe's own order of operations, what is left between this library and the real llvmpipe renders is the faces
+    llvmpipe clips at the image border -- a handful of pixels per view, every one of them inside a face that crosses the border.
+    Measured: C2 4000 x 3000 14 pixels of 12 000 000 (rule R1: 447); C2 at 1000 x 750 1 and 0 (14, 19); C1 0-4 per view (0-5)."""
+    tpoints, tfaces = synthetic.terrain_mesh()
+    g = _load("reference_gl_c2_full.npz")
+    h, w = int(g["h"]), int(g["w"])
+    gl = np.repeat(np.cumsum(g["val_delta"].astype(np.int64)), g["run_len"].astype(np.int64)).astype(np.int32).reshape(h, w)
+    ours = render_gl(tpoints, tfaces, g["record"][None], h, w)[0]
+    assert int((ours != gl).sum()) <= 20, int((ours != gl).sum())
+    _assert_differences_only_in_faces_that_cross_the_border(ours, gl, tpoints, tfaces, g["record"], h, w)
+    g2 = _load("reference_gl_scaled.npz")
+    ours = render_gl(tpoints, tfaces, g2["c2_records"], 750, 1000)
+    for k in range(2):
+        assert int((ours[k] != g2["llvmpipe_c2_ids"][k]).sum()) <= 2
+        _assert_differences_only_in_faces_that_cross_the_border(ours[k], g2["llvmpipe_c2_ids"][k], tpoints, tfaces, g2["c2_records"][k], 750, 1000)
+    points, faces, recs = _c1_case()
+    g1 = _load("reference_gl_c1.npz")
+    ours = render_gl(points, faces, recs, 480, 640)
+    for v in range(len(recs)):
+        assert int((ours[v] != g1["llvmpipe_ids"][v]).sum()) <= 5
+        _assert_differences_only_in_faces_that_cross_the_border(ours[v], g1["llvmpipe_ids"][v], points, faces, recs[v], 480, 640)
+
+
+def _assert_differences_only_in_faces_that_cross_the_border(ours, gl, points, faces, rec, h, w):
+    """every pixel on which `ours` and the GL render differ shows, in one of the two, a face with a vertex outside the image"""
+    cam = np.asarray(rec, dtype=np.float64)
+    q = (np.asarray(points, dtype=np.float32).astype(np.float64) - cam[9:12]) @ cam[:9].reshape(3, 3)
+    sx, sy = cam[13] + cam[12] * q[:, 0] / q[:, 2], cam[14] + cam[12] * q[:, 1] / q[:, 2]
+    outside = (sx < 0) | (sx > w) | (sy < 0) | (sy > h)
+    for i, j in np.argwhere(ours != gl):
+        crossing = any(f >= 0 and outside[np.asarray(faces)[f]].any() for f in (int(ours[i, j]), int(gl[i, j])))
+        assert crossing, (int(i), int(j), int(ours[i, j]), int(gl[i, j]))
+
+
 def _oracle_render(points, faces, recs, h, w):
     return [oracle_c.raster(points, faces, recs[v], h, w) for v in range(recs.shape[0])]
 
@@ -175,6 +211,10 @@ def test_oracle_matches_real_gl_rasterizers_at_quarter_scale():
 
 def test_oracle_matches_llvmpipe_on_config2_at_full_size():
     _run_c2_full_size(_oracle_render)
+
+
+def test_oracle_in_gl_vertex_order_differs_from_llvmpipe_only_where_llvmpipe_clips():
+    _run_gl_vertex_order(lambda p, f, recs, h, w: [oracle_c.raster(p, f, recs[v], h, w, vertex_order="gl") for v in range(recs.shape[0])])
 
 
 def test_oracle_clipping_matches_gl_clipping_under_vtk_like_ranges():
@@ -230,6 +270,16 @@ def test_hip_matches_real_gl_rasterizers_at_quarter_scale(hip):
 @pytest.mark.gpu
 def test_hip_matches_llvmpipe_on_config2_at_full_size(hip):
     _run_c2_full_size(_hip_render(hip))
+
+
+@pytest.mark.gpu
+def test_hip_in_gl_vertex_order_differs_from_llvmpipe_only_where_llvmpipe_clips(hip):
+    render = _hip_render(hip)
+    hip.set_vertex_order("gl")
+    try:
+        _run_gl_vertex_order(render)
+    finally:
+        hip.set_vertex_order("r1")
 
 
 @pytest.mark.gpu

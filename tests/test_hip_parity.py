@@ -67,6 +67,35 @@ def _check_views(hip, points, faces, recs, h, w, depth=False):
     return ids
 
 
+def test_gl_vertex_order_bit_exact_against_the_oracle_in_the_same_order(hip):
+    """GR_OPT_VERTEX_ORDER = 1 (the vertex stage in an OpenGL pipeline's order of operations): ids and depth bits equal the
+    oracle's under the same switch -- C1 (all views, image-border faces), a camera inside the scene (R7 clipping through the same
+    snap) --, and differ from rule R1's somewhere (the switch does something)."""
+    (points, faces), cams = synthetic.config1_scene()
+    recs = _records(cams)
+    hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
+    base = hip.raster_face_ids(recs, 480, 640).cpu().numpy()
+    hip.set_vertex_order("gl")
+    try:
+        ids, dep = hip.raster_face_ids(recs, 480, 640, want_depth=True)
+        ids, dep = ids.cpu().numpy(), dep.cpu().numpy()
+        for v in range(recs.shape[0]):
+            want, wdep = oracle_c.raster(points, faces, recs[v], 480, 640, want_depth=True, vertex_order="gl")
+            np.testing.assert_array_equal(ids[v], want)
+            np.testing.assert_array_equal(dep[v].view(np.int32), wdep.view(np.int32))
+        assert (ids != base).sum() > 0
+        rng = np.random.default_rng(5)
+        verts = rng.uniform(-4, 4, (150, 3)).astype(np.float32)
+        tris = rng.integers(0, 150, (300, 3)).astype(np.int32)
+        inside = synthetic.camera_set_from_poses([synthetic.nadir_pose(0.2, -0.1, 0.3)], f=90.0, width=128, height=96)
+        rec = inside.get_raster_records(1.0, near=0.05)
+        hip.upload_mesh(verts, tris)
+        got = hip.raster_face_ids(rec, 96, 128).cpu().numpy()[0]
+        np.testing.assert_array_equal(got, oracle_c.raster(verts, tris, rec[0], 96, 128, vertex_order="gl"))
+    finally:
+        hip.set_vertex_order("r1")
+
+
 def test_config1_all_views_bit_exact(hip):
     (points, faces), cams = synthetic.config1_scene()
     ids = _check_views(hip, points, faces, _records(cams), 480, 640, depth=True)
