@@ -1320,6 +1320,25 @@ def leg_api(points, faces, wl, n_views=16):
     mesh.aggregate_projected_images(seg)
     _, dt = timed(lambda: mesh.aggregate_projected_images(seg))
     out["aggregate_uint8_labels_from_host_views_per_s"] = round(n / dt, 1)
+    # the same call through devices=[0, 0]: two libgeograster contexts, two host threads, two streams on this ONE GPU, partial votes
+    # added on the first -- the single-process multi-device route of the unchanged caller (no second GPU on this box: what the
+    # number shows is that the threaded route costs nothing; the votes must equal the single-device call's bit for bit)
+    try:
+        mesh2 = TexturedPhotogrammetryMesh((points, faces), texture=tex, IDs_to_labels={i: str(i) for i in range(C)}, log_level="ERROR",
+                                           devices=[0, 0])
+        want_avg, want_info = mesh.aggregate_projected_images(seg)
+        mesh2.aggregate_projected_images(seg)
+        (got_avg, got_info), dt2 = timed(lambda: mesh2.aggregate_projected_images(seg))
+        same = bool(np.array_equal(np.nan_to_num(got_avg, nan=-7.0), np.nan_to_num(want_avg, nan=-7.0))
+                    and np.array_equal(got_info["projection_counts"], want_info["projection_counts"]))
+        out["aggregate_uint8_labels_from_host_devices_0_0_views_per_s"] = round(n / dt2, 1)
+        out["aggregate_devices_0_0_equals_single_device"] = same
+        assert same, "devices=[0, 0] aggregation differs from the single-device result"
+        del mesh2
+    except AssertionError:
+        raise
+    except Exception as exc:  # the leg reports, it does not take the line down
+        out["aggregate_uint8_labels_from_host_devices_0_0_views_per_s"] = f"failed: {exc!r}"
     # the general path of meshes.py:2057-2067, images from host memory: (h, w, 3) uint8 photos (what `aggregate_images` feeds
     # it), (h, w, C) bool one-hot masks (what a segmentor returns) and (h, w, 3) float64 images
     nf = min(n, 8)

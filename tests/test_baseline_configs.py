@@ -261,3 +261,30 @@ def test_cameras_inside_the_canopy_bit_exact(hip):
         assert (want >= 0).mean() > 0.5 and len(np.unique(want)) > (100 if v > 0 else 2)
         if v == 0:  # the trunk 8 cm in front of the lens: faces that cross the near plane are in the picture
             assert wdep[np.isfinite(wdep)].min() < 0.2
+
+
+def test_irregular_tin_workload_full_size_and_quarter_scale(hip):
+    """The bench's workload_3 (synthetic.tin_mesh: 1.2 M faces, log-normal triangle areas, Delaunay slivers, folded bumps; the
+    caller's face order is spatially incoherent) under a C2 camera: ids at 4000 x 3000 and at the reference's aggregate scale
+    0.25, and the fused votes of the view, bit for bit against the oracle."""
+    hip.set_option(2, 5); hip.set_option(6, 512); hip.set_option(7, 0); hip.set_option(3, 64)
+    pts, faces = synthetic.tin_mesh()
+    F, C = faces.shape[0], 4
+    cams = synthetic.config2_cameras(50)
+    hip.upload_mesh(pts.astype(np.float32), faces.astype(np.int32))
+    for scale in (1.0, 0.25):
+        h, w = cams[0].get_image_size(scale)
+        recs = cams.get_raster_records(scale, near=1.0)[[23, 24]]
+        for _ in range(2):   # the second call runs with what the first one taught the library (slots per tile, micro lists)
+            ids = hip.raster_face_ids(recs, h, w).cpu().numpy()
+            for v in range(2):
+                np.testing.assert_array_equal(ids[v], oracle_c.raster(pts, faces, recs[v], h, w))
+        labels = np.stack([synthetic.synthetic_labels(ids[v], v, C) for v in range(2)])
+        votes, counts = hip.new_vote_buffers(C)
+        hip.raster_project_labels(recs, labels, C, votes, counts)
+        want_v, want_c = np.zeros((F, C), dtype=np.uint32), np.zeros(F, dtype=np.uint32)
+        for v in range(2):
+            oracle_c.project_labels(ids[v], labels[v], F, C, want_v, want_c)
+        np.testing.assert_array_equal(votes.cpu().numpy().view(np.uint32), want_v)
+        np.testing.assert_array_equal(counts.cpu().numpy().view(np.uint32), want_c)
+        assert (ids >= 0).mean() > 0.9 and want_c.sum() > 50_000

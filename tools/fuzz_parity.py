@@ -111,8 +111,10 @@ def one(hip, seed):
     else:
         h, w = int(rng.integers(8, 500)), int(rng.integers(8, 700))
     cams = cameras(rng, points, w, h)
-    recs = cams.get_raster_records(1.0, near=float(np.exp(rng.uniform(np.log(0.01), np.log(2.0)))),
-                                   principal_point="intrinsics" if rng.random() < 0.5 else "center")
+    pp = "intrinsics" if rng.random() < 0.5 else "center"
+    recs = cams.get_raster_records(1.0, near=float(np.exp(rng.uniform(np.log(0.01), np.log(2.0)))), principal_point=pp)
+    # round 6: the vertex stage in an OpenGL pipeline's order of operations (GR_OPT_VERTEX_ORDER; needs the centred principal point)
+    order = "gl" if (pp == "center" and rng.random() < 0.3) else "r1"
     thl = int(rng.choice([5, 6]))
     cap = int(rng.choice([0, 64, 128, 512, 512, 512, 2048]))
     var = 0
@@ -121,7 +123,8 @@ def one(hip, seed):
             var |= b
     batch = int(rng.choice([64, 64, 5, 2, 1]))
     hip.set_option(2, thl); hip.set_option(6, cap); hip.set_option(7, var); hip.set_option(3, batch)
-    info = {"seed": seed, "faces": int(faces.shape[0]), "views": int(recs.shape[0]), "image": f"{w}x{h}", "thl": thl, "cap": cap,
+    hip.set_vertex_order(order)
+    info = {"seed": seed, "vertex_order": order, "faces": int(faces.shape[0]), "views": int(recs.shape[0]), "image": f"{w}x{h}", "thl": thl, "cap": cap,
             "var": var, "batch": batch}
     hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
     ids, dep = hip.raster_face_ids(recs, h, w, want_depth=True)
@@ -132,7 +135,7 @@ def one(hip, seed):
     if not torch.equal(ids, ids2):
         bad.append("ids-only call differs from ids + depth call")
     for v in range(recs.shape[0]):
-        want, wdep = oracle_c.raster(points, faces, recs[v], h, w, want_depth=True)
+        want, wdep = oracle_c.raster(points, faces, recs[v], h, w, want_depth=True, vertex_order=order)
         if not np.array_equal(ids_np[v], want):
             bad.append(f"view {v}: {int((ids_np[v] != want).sum())} ids differ")
         elif not np.array_equal(dep_np[v].view(np.int32), wdep.view(np.int32)):
