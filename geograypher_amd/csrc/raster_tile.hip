@@ -962,7 +962,11 @@ int tile_batch(gr_ctx *c, int nb, int h, int w, int slot0, RasterOut out, hipStr
     // Four consecutive tiles per workgroup -- unless the image needed more than the default 512 slots per tile (a scene
     // with heavy tiles: chains of them make a few workgroups very long; hostile workload 57.9 vs 30.4 us per view at
     // 1000x750) or the launch has too few tiles to keep every CU busy with chains.
-    const bool chain = (a.var & 1) == 0 && ((a.var & 16) != 0 || (a.cap_tile > 0 && a.cap_tile <= 512 && (int64_t)a.T * nb >= 16384));
+    // (A view of micro faces has large segments -- hundreds of 32-byte records per tile -- but uniform, light tiles: its ids kernel
+    // takes chains as well, 2.52 -> 2.42 us per C2 view at 1000 x 750; its FUSED kernel does not: rolling chains of 16 leave a
+    // 1000 x 750 launch with 24 workgroups per view, 3.56 -> 4.13 us -- profiles/r06_ab/micro_chains.log.)
+    const bool light = a.cap_tile > 0 && (a.cap_tile <= 512 || (a.micro && out.winner == nullptr));
+    const bool chain = (a.var & 1) == 0 && ((a.var & 16) != 0 || (light && (int64_t)a.T * nb >= 16384));
     // Rolling chains of GR_ROLL_KT tiles (k_raster_tile_roll) where a chain of four would run -- for the FUSED kernel, whose
     // epilogue stores nothing: C2 15.07 -> 14.22 us per view, C5 29.99 -> 28.67 (profiles/r05_ab/rolling_chains.log).  The ids
     // kernels lose with them (C2 13.21 -> 13.94, C5 28.5 -> 33.3): the wait for the next tile's request, placed before the
