@@ -265,6 +265,7 @@ int gr_mesh_upload(gr_ctx *c, const float *verts, const int32_t *faces, int64_t 
   GR_HIP(c, hipGetLastError());
   c->verts = verts; c->faces = faces; c->V = V; c->F = F;
   c->stats_deferred = false;   // (view totals a raster call on the old mesh left for the status call: void)
+  c->visits_pending = false;   // (... and the visit counters of its vote passes: sized for the old mesh)
   return GR_OK;
 }
 

@@ -100,12 +100,12 @@ __global__ __launch_bounds__(256) void k_vote_labels(uint32_t *__restrict__ winn
   // caller learns how many views were folded in (gr_raster_status: views_done) and repeats the call for the rest.
   const bool skip = stats != nullptr && stats[4] <= (unsigned long long)group;
   uint32_t c = 0;
-  // up to eight classes: the face's votes of the whole launch group are collected in ONE register, a byte per class (a group has
+  // up to sixteen classes: the face's votes of the whole launch group are collected in TWO registers, a byte per class (a group has
   // at most 64 views), and folded into votes[] once at the end -- loads first, then stores.  (`votes[f][label] += 1` view by view
   // is a chain of dependent read-modify-writes on one array: the compiler must finish each before the next may start, eight
   // memory round trips per batch of eight views, and the kernel is nothing but latency: round 5, 1.9 us per C2 view.)
-  const bool packed = C <= 8;
-  unsigned long long acc = 0ull;
+  const bool packed = C <= 16;
+  unsigned long long acc0 = 0ull, acc1 = 0ull;
   // eight views' winners are requested together (the kernel is a stream over winner[views][F]: memory-level
   // parallelism, not arithmetic, sets its speed), then their labels, then the votes in view order
   for (int v0 = 0; v0 < n_views; v0 += 8) {
@@ -123,19 +123,20 @@ __global__ __launch_bounds__(256) void k_vote_labels(uint32_t *__restrict__ winn
       winner[(int64_t)(v0 + k) * F + f] = 0;
       if (skip) continue;
       if ((int)lab[k] < C) {
-        if (packed) acc += 1ull << (8u * lab[k]);
-        else votes[f * C + lab[k]] += 1u;
+        if (!packed) votes[f * C + lab[k]] += 1u;
+        else if (lab[k] < 8u) acc0 += 1ull << (8u * lab[k]);
+        else acc1 += 1ull << (8u * (lab[k] - 8u));
       }
       ++c;
     }
   }
-  if (acc) {
-    uint32_t cur[8];
+  if (acc0 | acc1) {
+    uint32_t cur[16];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) cur[k] = k < C ? votes[f * C + k] : 0u;
+    for (int k = 0; k < 16; ++k) cur[k] = k < C ? votes[f * C + k] : 0u;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const uint32_t add = (uint32_t)(acc >> (8 * k)) & 0xFFu;
+    for (int k = 0; k < 16; ++k) {
+      const uint32_t add = (uint32_t)((k < 8 ? acc0 : acc1) >> (8 * (k & 7))) & 0xFFu;
       if (k < C && add) votes[f * C + k] = cur[k] + add;
     }
   }

@@ -377,14 +377,14 @@ def test_running_nan_of_the_float_sums_is_dropped_like_numpy_nansum(hip, calls):
 
 
 @pytest.mark.parametrize("compat", [True, False])
-def test_label_votes_bit_exact_vs_oracle(hip, compat):
+@pytest.mark.parametrize("C", [1, 4, 8, 9, 16, 17, 40])  # the fused vote kernel packs up to 16 classes into two registers
+def test_label_votes_bit_exact_vs_oracle(hip, compat, C):
     (points, faces), cams = synthetic.config1_scene()
     F = faces.shape[0]
     hip.upload_mesh(points.astype(np.float32), faces.astype(np.int32))
     recs = _records(cams)
     ids = hip.raster_face_ids(recs, 480, 640)
     ids_np = ids.cpu().numpy()
-    C = 4
     labels = np.stack([synthetic.synthetic_labels(ids_np[v], v, C) for v in range(len(cams))])
     votes, counts = hip.new_vote_buffers(C)
     hip.project_labels(ids, labels, C, votes, counts, neg1_is_last_face=compat)

@@ -19,7 +19,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from geograypher_amd._hip import HipRaster
 from geograypher_amd.utils import synthetic
 
-H, W, C = 3000, 4000, 4
+H, W, C = 3000, 4000, int(os.environ.get("AB_CLASSES", "4"))   # label classes of the fused leg
 DEFAULT = ["base:0"]
 # c2: 1.2 M faces, 4000 x 3000; c5: 5 M faces, 6000 x 4000 (20 views); c2q: c2 at render_img_scale 0.25 (1000 x 750);
 # forest / forestq: the hostile workload (terrain + 20 000 trees, 20 oblique views) at scale 1 / 0.25
