@@ -17,7 +17,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     n = r["Name"]
-    if any(k in n for k in ("k_setup_cull", "k_cull_blocks", "k_clip_faces", "k_bin_stats", "k_raster_tile")):
+    if any(k in n for k in ("k_setup_cull", "k_cull_blocks", "k_clip_faces", "k_bin_stats", "k_bin_init", "k_vote", "k_raster_tile")):
         print(f"  {n[:70]:70s} calls {r['Calls']:>5s} avg_us {float(r['AverageNs'])/1e3:9.2f} min_us {float(r['MinNs'])/1e3:9.2f} max_us {float(r['MaxNs'])/1e3:9.2f}")
 PY
 done
