@@ -9,7 +9,7 @@ scale from {1, 0.5, 0.37, 0.25, 0.13}, then
   pix2face(cameras, render_img_scale)                          (n, h, w) int64
   render_flat(cameras, render_img_scale)                       per view (h, w, C) float64, NaN background
   aggregate_projected_images(segmentor camera set, scale)      class-index label arrays at NATIVE size (nearest-resized by the
-                                                               segmentor), values >= C and 255 included; 1-9 classes
+                                                               segmentor), values >= C and 255 included; 1-30 classes
   project_images(...)                                          the per-view generator of the same
   aggregate_projected_images(image set, scale)                 float64 / uint8 / bool images of the scaled size (general path)
   TexturedPhotogrammetryMeshIndexPredictions.aggregate_...     sparse (face, class) aggregation
@@ -82,7 +82,7 @@ def one(hip, seed):
     if h < 1 or w < 1:
         scale, (h, w) = 1.0, (h0, w0)
     F = faces.shape[0]
-    C = int(rng.integers(1, 10))
+    C = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 9, 12, 16, 17, 30]))
     tex = rng.random((F, int(rng.integers(1, 4))))
     bs = min(int(rng.choice([1, 1, 2, 3])), len(cams))  # (the reference's batching drops trailing views: mirrored, both sides)
     info = {"seed": seed, "faces": int(F), "views": len(cams), "native": f"{w0}x{h0}", "scale": scale, "C": C, "batch": bs}
