@@ -192,6 +192,8 @@ __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const 
 __device__ __forceinline__ void store_entry(const BinArgs &a, uint32_t *__restrict__ ctrl, int4 *__restrict__ comp,
                                             uint8_t *__restrict__ nr8, int64_t idx, const int4 e0, const int4 e1, const int4 e2,
                                             int rows);
+__device__ __forceinline__ void shifted_entry(const int4 b0, const int4 b1, const int4 b2, int boxx, int boxy, int px0, int py0, int dX,
+                                              int dY, int TW, int TH, int4 &e0, int4 &e1, int4 &e2, int &rows);
 // Faces whose snapped bounding box is smaller than GR_FAST_EXT sub-pixels (93 px) take a short form of the set-up (build_entry),
 // fit the 40-byte entry (store_entry) and the 32-byte micro record (k_setup_cull)
 #define GR_FAST_EXT 24000
@@ -428,7 +430,14 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a) {
   // (d) tile counts.  Faces touching at most 2x2 tiles get their list positions here (wave-aggregated atomics);
   //     larger faces are only counted (cntB) and placed by k_fill_compile.  Groups are found first (registers only),
   //     then ALL atomics of the wave -- record slot + up to four tile counters -- are issued before any is consumed.
-  const bool small_fp = keep && (tx1 - tx0 <= 1) && (ty1 - ty0 <= 1);
+  // (single-pass binning: ... and whose snapped bounding box stays below GR_FAST_EXT -- 93 px; a face of 93 to 128 px over 2 x 2
+  // tiles goes with the big ones --: the entries of their second to fourth tiles are DERIVED from the first tile's, which the
+  // short form of the edge constants allows exactly (shifted_entry))
+  bool small_fp = keep && (tx1 - tx0 <= 1) && (ty1 - ty0 <= 1);
+  if (DIRECT) {
+    const int ext = max(imax3(r0.x, r0.z, r1.x) - imin3(r0.x, r0.z, r1.x), imax3(r0.y, r0.w, r1.y) - imin3(r0.y, r0.w, r1.y));
+    small_fp = small_fp && ext < GR_FAST_EXT;
+  }
   uint32_t *cntS = ctrl + GR_CTRL_HDR;
   uint32_t *cntB = cntS + a.Tcap;
   // MICRO records (round 5: lists; round 6: lean records).  In a view whose faces are mostly a few pixels wide -- a survey mesh at
@@ -508,10 +517,8 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a) {
     // take part in, thirty instructions each), box by box
     const int X0 = r0.x, Y0 = r0.y, X1 = r0.z, Y1 = r0.w, X2 = r1.x, Y2 = r1.y;
     const int jmin = r2.z & 0xFFFF, jmax = (int)((uint32_t)r2.z >> 16), imin = r2.w & 0xFFFF, imax = (int)((uint32_t)r2.w >> 16);
-    // the record holds the vertices as 16-bit offsets from the tile's centre pixel: a face whose snapped bounding box reaches
-    // GR_FAST_EXT (93 px) does not fit -- the condition under which a compiled entry misses the 40-byte form (store_entry):
-    // the same overflow bit, the same retry with 48-byte entries (and without micro lists)
-    const int ext = max(imax3(X0, X1, X2) - imin3(X0, X1, X2), imax3(Y0, Y1, Y2) - imin3(Y0, Y1, Y2));
+    // the record holds the vertices as 16-bit offsets from the tile's centre pixel: they fit because a micro pair belongs to a
+    // face below GR_FAST_EXT (small_fp)
     char *const segs = reinterpret_cast<char *>(a.comp + slot * a.ent_cap * GR_ENT_Q);
     const int TWh = 1 << (a.twl - 1), THh = 1 << (a.thl - 1);
 #pragma unroll
@@ -526,8 +533,7 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a) {
         const int Pxc = (px0 + TWh) * 256 + 128, Pyc = (py0 + THh) * 256 + 128;   // centre of the tile's centre pixel
         const uint32_t pos = (uint32_t)(k == 0 ? r3.x : k == 1 ? r3.y : k == 2 ? r3.z : r3.w);
         const int ncx = (jhi - jlo + 4) >> 2;   // 4-pixel columns of the part: 1 or 2
-        if (ext >= GR_FAST_EXT) atomicOr(&ctrl[2], 2u);
-        else if ((pos + (uint32_t)nk) * 4u <= (uint32_t)a.cap_tile * 5u) {   // inside the segment (cap slots of 40 bytes; whether the two lists met: k_bin_stats)
+        if ((pos + (uint32_t)nk) * 4u <= (uint32_t)a.cap_tile * 5u) {   // inside the segment (cap slots of 40 bytes; whether the two lists met: k_bin_stats)
           // record p of the tile's list: the 32 bytes that end 32 p bytes before the end of the tile's segment
           char *const rec_end = segs + ((int64_t)(ty * a.TX + tx) + 1) * a.cap_tile * 40 - (int64_t)pos * 32;
           const int4 va = make_int4(pack16(X0 - Pxc, Y0 - Pyc), pack16(X1 - Pxc, Y1 - Pyc), pack16(X2 - Pxc, Y2 - Pyc), r1.z);
@@ -545,25 +551,37 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a) {
   if (DIRECT) {
     // faces over at most 2x2 tiles: positions came from the wave-aggregated counters; the lanes of a group hold
     // consecutive positions of the same tile segment, so their entries are written side by side.  Every such face has a
-    // FIRST tile -- one dense round of compile_entry --; second to fourth tiles are the exception (0.5 per face): those
-    // (face, tile) pairs are compacted -- prefix sum, 6-step search for the owning lane, its records pulled by ds_bpermute
-    // -- and compiled in one more round.  (Three mostly idle rounds in the face's own lane from one FaceForm measured +4 %:
-    // profiles/r05_ab/setup_own_lane_tiles_vs_compaction.log.)  With micro lists both rounds see only the pairs that are no
-    // micro pairs -- in a view of micro faces none: the wave skips them.
+    // FIRST tile -- one dense round of build_entry in the face's own lane --; second to fourth tiles are the exception (0.5 per
+    // face): those (face, tile) pairs are compacted -- prefix sum, 6-step search for the owning lane -- and their entries
+    // DERIVED from the owner's first-tile entry, read back from LDS (shifted_entry: three multiply-adds per edge constant
+    // instead of the whole set-up.  Rounds 2-5 pulled the owner's records by ds_bpermute and ran build_entry again: that round
+    // was 23 % of the kernel on C2, profiles/r06_ab/setup_removal_probes.log; three mostly idle rounds in the face's own lane
+    // from one FaceForm had measured +4 %: profiles/r05_ab/setup_own_lane_tiles_vs_compaction.log.)  With micro lists both rounds
+    // see only the pairs that are no micro pairs -- in a view of micro faces none: the wave skips them.
     int4 *comp = a.comp + slot * a.ent_cap * GR_ENT_Q;
     uint8_t *nr8 = a.nrow8 + slot * a.ent_cap;
     const int TW = 1 << a.twl, TH = 1 << a.thl;
     const bool first_general = small_fp && !(mcls & 1);
-    if (!MICRO || __ballot(first_general)) {
-      if (first_general) {
-        if ((uint32_t)r3.x < (uint32_t)a.cap_tile) {
-          compile_entry(a, ctrl, comp, nr8, (int64_t)t00 * a.cap_tile + (uint32_t)r3.x, r0, r1, r2, tx0 << a.twl, ty0 << a.thl, TW, TH);
-        } else atomicOr(&ctrl[2], 1u);
-      }
-    }
     const int shape = small_fp ? ((tx1 > tx0 ? 1 : 0) | (ty1 > ty0 ? 2 : 0)) : 0;  // which neighbours exist: 1 right, 2 below
     // the face's extra tile slots that take a compiled entry: bit k - 1 for slot k (1 right, 2 below, 3 below right)
     const int extra = (shape == 3 ? 7 : shape) & ~(mcls >> 1);
+    // the FIRST tile's entry: stored if that pair is no micro pair, and parked in the wave's LDS rows (the block's vertices are
+    // done with) as the base of the face's other entries
+    const bool base_needed = first_general || extra != 0;
+    if (!MICRO || __ballot(base_needed)) {
+      if (base_needed) {
+        int4 e0, e1, e2;
+        int rows;
+        build_entry(r0, r1, r2, tx0 << a.twl, ty0 << a.thl, TW, TH, e0, e1, e2, rows);
+        if (first_general) {
+          if ((uint32_t)r3.x < (uint32_t)a.cap_tile) store_entry(a, ctrl, comp, nr8, (int64_t)t00 * a.cap_tile + (uint32_t)r3.x, e0, e1, e2, rows);
+          else atomicOr(&ctrl[2], 1u);
+        }
+        vt[lane] = e0;                                          // c_first c_mid c_last | slopes a
+        vt[64 + lane] = make_int4(e1.x, e1.z, e1.w, e2.x);      // slopes b | iz0 A B
+        vt[128 + lane] = make_int4(e2.y, e2.z, e2.w, 0);        // Xw | ~face | Yw + flags
+      }
+    }
     const int ne = __popc((unsigned)extra);
     const int incl_e = wave_incl_scan(ne);
     const int total_e = __builtin_amdgcn_readlane(incl_e, 63);
@@ -580,15 +598,17 @@ void k_setup_cull(const float *__restrict__ cams, BinArgs a) {
       if (which >= 1) ex &= ex - 1;
       if (which >= 2) ex &= ex - 1;
       const int k = __ffs(ex);                                         // tile slot 1 (right), 2 (below), 3 (below right)
-      const int4 p0 = make_int4(__shfl(r0.x, t), __shfl(r0.y, t), __shfl(r0.z, t), __shfl(r0.w, t));
-      const int4 p1 = make_int4(__shfl(r1.x, t), __shfl(r1.y, t), __shfl(r1.z, t), __shfl(r1.w, t));
-      const int4 p2 = make_int4(__shfl(r2.x, t), __shfl(r2.y, t), __shfl(r2.z, t), __shfl(r2.w, t));
+      const int4 b0 = vt[t], b1 = vt[64 + t], b2 = vt[128 + t];        // the owner's first-tile entry (LDS operations of a wave complete in order)
+      const int boxx = __shfl(r2.z, t), boxy = __shfl(r2.w, t);
       const int py = __shfl(r3.y, t), pz = __shfl(r3.z, t), pw = __shfl(r3.w, t);
       if (q < total_e) {
         const uint32_t pos = (uint32_t)(k == 1 ? py : k == 2 ? pz : pw);
         const int tx = (g & 0xFFF) + (k & 1), ty = ((g >> 12) & 0xFFF) + (k >> 1);
         if (pos < (uint32_t)a.cap_tile) {
-          compile_entry(a, ctrl, comp, nr8, (int64_t)(ty * a.TX + tx) * a.cap_tile + pos, p0, p1, p2, tx << a.twl, ty << a.thl, TW, TH);
+          int4 e0, e1, e2;
+          int rows;
+          shifted_entry(b0, b1, b2, boxx, boxy, tx << a.twl, ty << a.thl, (k & 1) ? TW : 0, (k >> 1) ? TH : 0, TW, TH, e0, e1, e2, rows);
+          store_entry(a, ctrl, comp, nr8, (int64_t)(ty * a.TX + tx) * a.cap_tile + pos, e0, e1, e2, rows);
         } else atomicOr(&ctrl[2], 1u);
       }
     }
@@ -830,6 +850,34 @@ __device__ __forceinline__ bool tile_entry(const FaceForm &ff, int px0, int py0,
   return touches;
 }
 
+// The entry of a face below GR_FAST_EXT in the tile dX pixels to the right of / dY pixels below the tile whose entry is given
+// (b0 = {c_first, c_mid, c_last, slopes a}, b1 = {slopes b, iz0, A, B}, b2 = {Xw, ~face, Yw + flags, -}; boxx / boxy: the face's
+// pixel box, px0 / py0: the new tile's first pixel).  Exact: in the short form the edge constants are the unclamped
+// c_k = floor(E_k(centre pixel) / 256) and E_k is linear with slopes 256 a_k, 256 b_k, so the constant at a centre dX, dY pixels
+// away is c_k + a_k dX + b_k dY -- the integer the full set-up (face_form + tile_entry, ten times the instructions) computes;
+// slopes, plane and key do not depend on the tile, the anchors of the row / column words move by the same step.
+__device__ __forceinline__ void shifted_entry(const int4 b0, const int4 b1, const int4 b2, int boxx, int boxy, int px0, int py0, int dX,
+                                              int dY, int TW, int TH, int4 &e0, int4 &e1, int4 &e2, int &rows) {
+  const int af = (b0.w << 16) >> 16, am = b0.w >> 16, bf = (b1.x << 16) >> 16, bm = b1.x >> 16;   // 16-bit slopes (pack16)
+  const int al = -(af + am), bl = -(bf + bm);                                                     // the a_k sum to zero; so do the b_k
+  const int cf = b0.x + __mul24(af, dX) + __mul24(bf, dY);
+  const int cm = b0.y + __mul24(am, dX) + __mul24(bm, dY);
+  const int cl = b0.z + __mul24(al, dX) + __mul24(bl, dY);
+  const int rf = (TW / 2) * abs(af) + (TH / 2) * abs(bf), rm = (TW / 2) * abs(am) + (TH / 2) * abs(bm),
+            rl = (TW / 2) * abs(al) + (TH / 2) * abs(bl);
+  const int jmin = boxx & 0xFFFF, jmax = (int)((uint32_t)boxx >> 16), imin = boxy & 0xFFFF, imax = (int)((uint32_t)boxy >> 16);
+  const int jlo = max(jmin - px0, 0), jhi = min(jmax - px0, TW - 1);
+  const int ilo = max(imin - py0, 0), ihi = min(imax - py0, TH - 1);
+  int nr = (jhi >= jlo) ? max(ihi - ilo + 1, 0) : 0;
+  if (!(nr > 0 && cf + rf >= 0 && cm + rm >= 0 && cl + rl >= 0)) nr = 0;   // a dead entry, as in tile_entry
+  rows = nr;
+  const int xw = ((b2.x + 256 * dX) & 0xFFFFFF) | (nr << 24);
+  const int yw = ((b2.z + 256 * dY) & 0xFFFFFF) | (((ilo - TH / 2) & 0x3F) << 24) | (b2.z & (int)0xC0000000);
+  e0 = make_int4(cf, cm, cl, b0.w);
+  e1 = make_int4(b1.x, 0, b1.y, b1.z);
+  e2 = make_int4(b1.w, xw, b2.y, yw);
+}
+
 __device__ __forceinline__ bool build_entry(const int4 p0, const int4 p1, const int4 p2, int px0, int py0, int TW, int TH,
                                             int4 &e0, int4 &e1, int4 &e2, int &rows) {
   const FaceForm ff = face_form(p0, p1, p2, TW, TH);
@@ -856,7 +904,10 @@ __device__ __forceinline__ void store_entry(const BinArgs &a, uint32_t *__restri
     // 40-byte entry.  Zero rows: no work item of the tile kernel ever looks at it; the view is repeated anyway)
     if (e1.y != 0 || e2.w < 0) { atomicOr(&ctrl[2], 2u); nr8[idx] = 0; return; }
     // a chunk of 64 entries (2560 bytes) holds the 64 x {s0 .. s7} first, then the 64 x {s8, s9}: the tile kernel copies the
-    // chunk to LDS as it is and reads an entry with two 16-byte reads and one 8-byte read, all aligned
+    // chunk to LDS as it is and reads an entry with two 16-byte reads and one 8-byte read, all aligned.  (Three planes -- 64 x
+    // {s0 .. s3}, 64 x {s4 .. s7}, 64 x {s8, s9}: a tile group's lanes write consecutive bytes with every store -- take 4.5 % off
+    // this kernel and add 1.7 % to the tile kernel, 3 % if it re-orders the pieces as it stages them: a wash,
+    // profiles/r06_ab/setup_entry_planes.log)
     char *chunk = reinterpret_cast<char *>(comp) + (idx >> 6) * 2560;
     const int t = (int)(idx & 63);
     int4 *d4 = reinterpret_cast<int4 *>(chunk) + t * 2;
