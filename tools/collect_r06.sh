@@ -7,7 +7,7 @@ cp $P/summary_r06.json $P/traffic.json $P/valu.json profiles/
 cp $P/trace/trace_kernel_stats.csv profiles/r06_kernel_stats.csv
 grep '^{' $F/bench.json | tail -1 > profiles/r06_bench.json
 grep '^{' $P/trace_bench.log | tail -1 > profiles/r06_bench_under_rocprof.json
-tail -13 $F/gpu_tests.log > profiles/r06_gpu_tests.log
+tail -24 $F/gpu_tests.log > profiles/r06_gpu_tests.log
 for w in c2 c5 c2q; do tail -1 $F/phases_$w.log > profiles/r06_ab/tile_phases_$w.log; done
 for w in c2 c2q forest; do tail -1 $F/setup_phases_$w.log > profiles/r06_ab/setup_phases_$w.log; done
 python3 - <<'PY'

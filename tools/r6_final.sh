@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $REPO
 OUT=$REPO/gpurun_out/r6_final
 mkdir -p $OUT
-timeout 1500 python -m pytest tests -m gpu -q > $OUT/gpu_tests.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -q --durations=15 > $OUT/gpu_tests.log 2>&1
 tail -3 $OUT/gpu_tests.log
 bash tools/profile.sh r06 > $OUT/profile.log 2>&1
 grep -E "k_raster_tile|k_setup_cull|k_vote|k_cull" gpurun_out/prof_r06/summary_r06.txt | cut -c1-170
