@@ -67,6 +67,45 @@ def _check_views(hip, points, faces, recs, h, w, depth=False):
     return ids
 
 
+@pytest.mark.parametrize("variant", [0, 128, 8192], ids=["entries40", "entries48", "micro_lists"])
+def test_faces_centred_on_tile_corners_through_the_93_pixel_boundary(hip, variant):
+    """Single-pass binning derives the entries of a small face's second to fourth tiles from its first-tile entry (binning.hip
+    shifted_entry), which the short form of the edge constants allows for faces below 93.75 px; larger faces over 2 x 2 tiles
+    take the big-face path.  Triangles of every size from 1 to 130 px centred on the corners of the 64 x 32 tiles (all three extra
+    slots), on vertical and on horizontal tile borders, at many orientations and depths, overlapping: ids and depth bits equal
+    the oracle's with 40-byte entries (a face of 93 px and more makes the call fall back by itself), 48-byte entries and micro
+    lists."""
+    rng = np.random.default_rng(93)
+    h, w, f = 448, 640, 500.0
+    pts, fcs = [], []
+    k = 0
+    for size in list(range(1, 20)) + list(range(20, 131, 3)) + [91, 92, 93, 94, 95]:
+        for rep in range(3):
+            cx = 64.0 * rng.integers(1, 9) + (rng.random() - 0.5) * (0.0 if rep == 0 else 0.4 * size)
+            cy = 32.0 * rng.integers(1, 13) + (rng.random() - 0.5) * (0.0 if rep == 1 else 0.4 * size)
+            ang = rng.random(3) * 0.6 + np.array([0.0, 2.1, 4.2]) + rng.random() * 6.28
+            r = 0.5 * size * (0.6 + 0.4 * rng.random(3))
+            z = 8.0 + 4.0 * rng.random(3)      # camera-space depth of each corner: tilted faces, overlapping in depth
+            px = cx + r * np.cos(ang) * (1.6 if rep == 2 else 1.0)
+            py = cy + r * np.sin(ang) * (0.4 if rep == 2 else 1.0)
+            for i in range(3):     # pinhole at the origin looking down -z ... the record maps (x, y, z) -> (f x / z + cx0, f y / z + cy0)
+                pts.append([(px[i] - 0.5 * w) * z[i] / f, (py[i] - 0.5 * h) * z[i] / f, z[i]])
+            fcs.append([k, k + 1, k + 2])
+            k += 3
+    points = np.asarray(pts, dtype=np.float64)
+    faces = np.asarray(fcs, dtype=np.int64)
+    rec = np.zeros((1, 16), dtype=np.float32)      # identity rotation, camera at the origin: q = p
+    rec[0, [0, 4, 8]] = 1.0
+    rec[0, 12], rec[0, 13], rec[0, 14], rec[0, 15] = f, 0.5 * w, 0.5 * h, 0.05
+    hip.set_option(7, variant)
+    try:
+        ids = _check_views(hip, points, faces, rec, h, w, depth=True)
+    finally:
+        hip.set_option(7, 0)
+        hip.set_option(6, 512)
+    assert (ids >= 0).mean() > 0.2 and len(np.unique(ids)) > 0.8 * faces.shape[0]
+
+
 def test_gl_vertex_order_bit_exact_against_the_oracle_in_the_same_order(hip):
     """GR_OPT_VERTEX_ORDER = 1 (the vertex stage in an OpenGL pipeline's order of operations): ids and depth bits equal the
     oracle's under the same switch -- C1 (all views, image-border faces), a camera inside the scene (R7 clipping through the same
