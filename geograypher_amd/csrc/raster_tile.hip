@@ -343,6 +343,20 @@ __device__ __forceinline__ int raster_chunk_gather(unsigned long long *keys, con
 // ids-only epilogue.  16-byte stores where the rows allow it: a lane owns 4 consecutive pixels of a row (16 lanes per
 // 64-pixel row, 16 rows per pass); the four low dwords sit 8 bytes apart in LDS (two ds_read2_b32), id = ~low (0 for an
 // empty pixel -> -1).  Images whose width is not a multiple of 4 take one pixel per lane.
+// Stores to the output images are NON-TEMPORAL (global_store ... nt): an image is written once and never read by this kernel, and
+// as ordinary stores its dirty lines sat in L2 and the 256 MB Infinity Cache until the NEXT kernel's traffic pushed them out -- the
+// set-up kernel of the following launch group found the mesh evicted and paid for the write-back (a build of the tile kernel that
+// stores nothing made the SET-UP 15 % faster: profiles/r06_ab/tile_removal_probes.log).  Round 6, builds alternated on one box: C2
+// set-up 4.74 -> 4.23 us per view, ids kernel unchanged; config 5 set-up -6 %, ids kernel -7 %; C2 at 1000 x 750 ids kernel -13 %
+// (profiles/r06_ab/nontemporal_image_stores.log).
+typedef int gr_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_ids16(int32_t *dst, const int4 v) {
+  gr_v4i x = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(x, reinterpret_cast<gr_v4i *>(dst));
+}
+template <typename T>
+__device__ __forceinline__ void store_px(T *dst, const T v) { __builtin_nontemporal_store(v, dst); }
+
 template <int TWL, int TH, int NT, int PAD, bool PLAIN>
 __device__ __forceinline__ void store_ids(const unsigned long long *keys, const BinArgs &a, int32_t *ids_plane, int te,
                                           int px0, int py0) {
@@ -378,14 +392,14 @@ __device__ __forceinline__ void store_ids(const unsigned long long *keys, const 
       read4(rr, k0);
       read4(rr + NT / 16, k1);
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k0[0]), "+v"(k0[1]), "+v"(k0[2]), "+v"(k0[3]), "+v"(k1[0]), "+v"(k1[1]), "+v"(k1[2]), "+v"(k1[3]) : : "memory");
-      *reinterpret_cast<int4 *>(dst) = ids_of(k0);
-      *reinterpret_cast<int4 *>(dst + dstep) = ids_of(k1);
+      store_ids16(dst, ids_of(k0));
+      store_ids16(dst + dstep, ids_of(k1));
     } else {
       for (int row = rr; row < rows_here; row += NT / 16, dst += dstep) {
         unsigned long long k[4];
         read4(row, k);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]) : : "memory");
-        *reinterpret_cast<int4 *>(dst) = ids_of(k);
+        store_ids16(dst, ids_of(k));
       }
     }
   } else if (!PLAIN) {
@@ -394,7 +408,7 @@ __device__ __forceinline__ void store_ids(const unsigned long long *keys, const 
     if (gx >= a.w) return;
     int32_t *dst = ids_plane + (int64_t)(py0 + (te >> TWL)) * a.w + gx;
     const int64_t dstep = (int64_t)(NT / TW) * a.w;
-    for (int row = te >> TWL; row < rows_here; row += NT / TW, dst += dstep) *dst = (int32_t)~klo[2 * lds_idx<TWL, PAD>(row, col)];
+    for (int row = te >> TWL; row < rows_here; row += NT / TW, dst += dstep) store_px(dst, (int32_t)~klo[2 * lds_idx<TWL, PAD>(row, col)]);
   }
 }
 
@@ -575,7 +589,7 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
       const int gx4 = px0 + (tid & 15) * 4;
       if (gx4 < a.w)
         for (int row = tid >> 4; row < TH && py0 + row < a.h; row += NT / 16)
-          *reinterpret_cast<int4 *>(out.ids + plane + (int64_t)(py0 + row) * a.w + gx4) = make_int4(-1, -1, -1, -1);
+          store_ids16(out.ids + plane + (int64_t)(py0 + row) * a.w + gx4, make_int4(-1, -1, -1, -1));
       GR_STAMP(8);
       return;
     }
@@ -583,8 +597,8 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
     if (gx < a.w) {
       for (int row = tid >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
         const int64_t p = plane + (int64_t)(py0 + row) * a.w + gx;
-        if (out.ids) out.ids[p] = -1;
-        if (out.depth) out.depth[p] = INFINITY;
+        if (out.ids) store_px(out.ids + p, (int32_t)-1);
+        if (out.depth) store_px(out.depth + p, INFINITY);
       }
     }
     GR_STAMP(8);
@@ -681,7 +695,7 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
       if (gx < a.w)
         for (int row = te >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
           const unsigned long long key = keys[lds_idx<TWL, PAD>(row, col)];
-          out.ids[plane + (int64_t)(py0 + row) * a.w + gx] = (key >> 32) ? (int32_t)~(uint32_t)key : -1;
+          store_px(out.ids + plane + (int64_t)(py0 + row) * a.w + gx, (key >> 32) ? (int32_t)~(uint32_t)key : (int32_t)-1);
         }
     }
   } else if (PLAIN || (out.ids && !out.depth)) {
@@ -692,8 +706,8 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
       for (int row = te >> TWL; row < TH && py0 + row < a.h; row += ROWS_PER_PASS) {
         const unsigned long long key = keys[lds_idx<TWL, PAD>(row, col)];
         const int64_t p = plane + (int64_t)(py0 + row) * a.w + gx;
-        if (out.ids) out.ids[p] = (int32_t)~(uint32_t)key;  // low dword = ~face, 0 when empty: ~0 = -1
-        if (out.depth) out.depth[p] = key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY;
+        if (out.ids) store_px(out.ids + p, (int32_t)~(uint32_t)key);  // low dword = ~face, 0 when empty: ~0 = -1
+        if (out.depth) store_px(out.depth + p, key ? 1.0f / __int_as_float((int)(key >> 32)) : INFINITY);
       }
   }
   if (GR_PRIO_E != GR_PRIO_M) __builtin_amdgcn_s_setprio(GR_PRIO_M);
