@@ -928,13 +928,15 @@ def leg_quarter_scale(rig, local_rank, dev, points, faces, wl):
     for _ in range(3):
         hip.raster_face_ids(recs, h, w, out=out, check=False)
     hip.set_profiling(True)
-    rig.synchronize(dev)
-    t0 = time.perf_counter()
-    n_rep = 40
-    for _ in range(n_rep):
-        hip.raster_face_ids(recs, h, w, out=out, check=False)
-    rig.synchronize(dev)
-    dt = time.perf_counter() - t0
+    n_rep, windows = 40, []
+    for _ in range(3):   # the median of three windows (11 ms each)
+        rig.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n_rep):
+            hip.raster_face_ids(recs, h, w, out=out, check=False)
+        rig.synchronize(dev)
+        windows.append(time.perf_counter() - t0)
+    dt = sorted(windows)[1]
     stg = hip.stage_times()
     hip.set_profiling(False)
     st = hip.raster_status()
@@ -1106,13 +1108,15 @@ def leg_workload2(rig, local_rank, dev):
         for _ in range(3):
             hip2.raster_face_ids(r2, h2, w2, out=out2, check=False)
         hip2.set_profiling(True)
-        rig.synchronize(dev)
-        t0 = time.perf_counter()
-        n_rep = 10
-        for _ in range(n_rep):
-            hip2.raster_face_ids(r2, h2, w2, out=out2, check=False)
-        rig.synchronize(dev)
-        dt = time.perf_counter() - t0
+        n_rep, windows = 10, []
+        for _ in range(3):   # the median of three windows: one host hiccup in 36 ms of calls moved the figure by 15 % (round 6)
+            rig.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(n_rep):
+                hip2.raster_face_ids(r2, h2, w2, out=out2, check=False)
+            rig.synchronize(dev)
+            windows.append(time.perf_counter() - t0)
+        dt = sorted(windows)[1]
         stg = hip2.stage_times()
         hip2.set_profiling(False)
         want = oracle_c.raster(fpts, ffaces, r2_np[3], h2, w2)
