@@ -489,6 +489,57 @@ __device__ __forceinline__ void fused_winners(const unsigned long long *keys, co
   }
 }
 
+template <int TWL, int TH, int NT, int PAD, bool EDGE>
+__device__ __forceinline__ void fused_winners_rows(const unsigned long long *keys, const BinArgs &a, uint32_t *__restrict__ win,
+                                              uint8_t *__restrict__ mark, int te, int px0, int py0) {
+  static_assert(TWL == 6 && NT == 256 && TH % 32 == 0, "a wave per 64-pixel tile row, TH / 4 consecutive rows per wave");
+  // The same candidates with a LANE PER COLUMN (round 6; the kernels with micro lists use it): a wave owns TH / 4 consecutive rows of
+  // the tile and reads them one row per instruction -- 64 consecutive keys, every key of the tile once (+ one row of the wave below)
+  // --; the neighbours to the right and below-left / below-right come from DPP wave shifts (wave_shl:1 / wave_shr:1: GFX9 has them;
+  // the lane at the end keeps `old` = 1, "unknown across the tile edge").  What it buys is the ATOMICS: the 64 lanes of one
+  // instruction are 64 neighbouring pixels of a row -- in a view of 3-pixel faces some twenty faces next to each other, whose
+  // winner words share a few cache lines -- where the form above spreads an instruction over four row pairs and every fourth pixel.
+  // A view of micro faces has a candidate every 4.7 pixels and its fused kernel was winner traffic (probes: 3.55 us per C2 view at
+  // 1000 x 750, 1.77 with the candidates computed and nothing written, 1.56 without the epilogue): 3.54 -> 2.23 us.  Full-size views
+  // (a candidate every 57 pixels) are 2.5 % slower this way and keep the form above.  profiles/r06_ab/fused_epilogue.log
+  constexpr int RW = TH / 4;
+  const int lane = te & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(te >> 6);
+  const uint32_t *klo = reinterpret_cast<const uint32_t *>(keys);
+  const int gx = px0 + lane;
+#pragma unroll
+  for (int base = 0; base < RW; base += 8) {
+    const int r0 = wv * RW + base;
+    int c[9], cr[9], cl[9];   // raw low dwords (~face; 0: background) of rows r0 .. r0 + 8; their right / left neighbours
+#pragma unroll
+    for (int k = 0; k < 9; ++k) c[k] = (k < 8 || r0 + 8 < TH) ? (int)klo[2 * lds_idx<TWL, PAD>(min(r0 + k, TH - 1), lane)] : 1;
+    if (r0 + 8 >= TH) c[8] = 1;   // the tile below: unknown
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      cr[k] = __builtin_amdgcn_update_dpp(1, c[k], 0x130 /* wave_shl:1: lane + 1 */, 0xf, 0xf, false);
+      cl[k] = k > 0 ? __builtin_amdgcn_update_dpp(1, c[k], 0x138 /* wave_shr:1: lane - 1 */, 0xf, 0xf, false) : 1;
+    }
+    const uint32_t p1 = (uint32_t)((py0 + r0) * a.w + gx + 1);   // linear pixel index + 1 of the lane's pixel in row r0 (h, w <= 16384)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int f = c[k];
+      bool cand;
+      if (EDGE) {   // outside the image: 2 ("differs"), like the rows and columns the old form never read
+        const int gy = py0 + r0 + k;
+        const bool below = gy + 1 < a.h, right = gx + 1 < a.w;
+        cand = (f < 0) & (gx < a.w) & (gy < a.h) & (!below | ((c[k + 1] != f) & (cl[k + 1] != f))) &
+               (!right | ((cr[k] != f) & (!below | (cr[k + 1] != f))));
+      } else {
+        cand = (f < 0) & (c[k + 1] != f) & (cl[k + 1] != f) & (cr[k] != f) & (cr[k + 1] != f);
+      }
+      if (cand) {
+        atomicMax(win + ~f, p1 + (uint32_t)(k * a.w));
+        if (mark) mark[(uint32_t)~f >> 6] = 1;   // the face's group of 64 holds a winner in this view: what the vote pass reads
+      }
+    }
+  }
+}
+
 // the tile's entry list: count and first slot (single-pass binning: the tile's fixed segment; exact binning: the scan's offset)
 __device__ __forceinline__ void tile_list(const BinArgs &a, const uint32_t *__restrict__ ctrl, int tile, uint32_t &cnt, int64_t &beg) {
   if (a.cap_tile > 0) {
@@ -688,7 +739,10 @@ __device__ __forceinline__ void raster_one_tile(const BinArgs &a, const RasterOu
     uint32_t *win = out.winner + slot * out.F;
     uint8_t *mark = out.touched ? out.touched + slot * out.tb : nullptr;
     const bool edge = px0 + TW > a.w || py0 + TH + 1 > a.h;
-    if (edge) fused_winners<TWL, TH, NT, PAD, true>(keys, a, win, mark, te, px0, py0);
+    if (MICRO) {   // views of micro faces: a lane per column (neighbouring faces' winner atomics in one instruction)
+      if (edge) fused_winners_rows<TWL, TH, NT, PAD, true>(keys, a, win, mark, te, px0, py0);
+      else fused_winners_rows<TWL, TH, NT, PAD, false>(keys, a, win, mark, te, px0, py0);
+    } else if (edge) fused_winners<TWL, TH, NT, PAD, true>(keys, a, win, mark, te, px0, py0);
     else fused_winners<TWL, TH, NT, PAD, false>(keys, a, win, mark, te, px0, py0);
     if (out.ids) {  // the id image as well (rare): background is where no fragment landed (depth bits 0)
       const int col = te & (TW - 1), gx = px0 + col;
